@@ -1,0 +1,177 @@
+"""ctypes binding of libbm355.so (include/bm355.h).
+
+The HIP library IS the product: there is no CPU/PyTorch fallback.  `load()`
+raises if the shared object cannot be built/loaded, and every model call
+raises `Bm355Error` if the library reports an error (e.g. no GPU visible).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAX_LAYERS = 4
+UNIT_BERNOULLI, UNIT_GAUSSIAN = 0, 1
+
+
+class Bm355Error(RuntimeError):
+    pass
+
+
+class RbmConfig(C.Structure):
+    _fields_ = [('n_visible', C.c_int32), ('n_hidden', C.c_int32), ('v_unit', C.c_int32),
+                ('sample_v_states', C.c_int32), ('sample_h_states', C.c_int32),
+                ('dbm_first', C.c_int32), ('dbm_last', C.c_int32), ('max_batch', C.c_int32),
+                ('l2', C.c_float), ('sparsity_target', C.c_float), ('sparsity_cost', C.c_float),
+                ('sparsity_damping', C.c_float), ('dropout', C.c_float)]
+
+
+class DbmConfig(C.Structure):
+    _fields_ = [('n_layers', C.c_int32), ('n_visible', C.c_int32),
+                ('n_hiddens', C.c_int32 * MAX_LAYERS), ('v_unit', C.c_int32),
+                ('sample_v_states', C.c_int32), ('sample_h_states', C.c_int32 * MAX_LAYERS),
+                ('n_particles', C.c_int32), ('batch_size', C.c_int32), ('max_mf_updates', C.c_int32),
+                ('mf_tol', C.c_float), ('l2', C.c_float), ('max_norm', C.c_float),
+                ('sparsity_target', C.c_float * MAX_LAYERS), ('sparsity_cost', C.c_float * MAX_LAYERS),
+                ('sparsity_damping', C.c_float)]
+
+
+_vp, _i32, _i64, _u64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+# name -> argtypes; every function returns int (0 = ok) unless listed in _RESTYPE
+SIGNATURES = {
+    'bm_device_count': [],
+    'bm_set_device': [C.c_int],
+    'bm_dev_alloc': [_sz, C.POINTER(_vp)],
+    'bm_dev_free': [_vp],
+    'bm_h2d': [_vp, _vp, _sz],
+    'bm_d2h': [_vp, _vp, _sz],
+    'bm_dev_memset': [_vp, C.c_int, _sz],
+    'bm_rbm_create': [C.POINTER(RbmConfig), C.POINTER(_vp)],
+    'bm_rbm_destroy': [_vp],
+    'bm_rbm_sync': [_vp],
+    'bm_rbm_set_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_rbm_get_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_rbm_dev_ptr': [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)],
+    'bm_rbm_seed': [_vp, _u64],
+    'bm_rbm_set_row_offset': [_vp, _i64],
+    'bm_rbm_train_step': [_vp, _vp, _i32, _f32, _f32, _i32],
+    'bm_rbm_train_step_metrics': [_vp, _vp, _i32, _f32, _f32, _i32, _fp],
+    'bm_rbm_train_epoch': [_vp, _vp, _i64, _i32, _f32, _f32, _i32],
+    'bm_rbm_grad_step': [_vp, _vp, _i32, _i32],
+    'bm_rbm_apply_step': [_vp, _i32, _f32, _f32],
+    'bm_rbm_transform': [_vp, _vp, _i32, _i32, _vp],
+    'bm_rbm_metrics': [_vp, _vp, _i32, _i32, _fp],
+    'bm_rbm_free_energy': [_vp, _vp, _i32, _fp],
+    'bm_rbm_gibbs': [_vp, _vp, _vp, _i32, _i32],
+    'bm_rbm_timer_start': [_vp],
+    'bm_rbm_timer_stop': [_vp, _fp],
+    'bm_dbm_create': [C.POINTER(DbmConfig), C.POINTER(_vp)],
+    'bm_dbm_destroy': [_vp],
+    'bm_dbm_sync': [_vp],
+    'bm_dbm_seed': [_vp, _u64],
+    'bm_dbm_set_row_offset': [_vp, _i64, _i64],
+    'bm_dbm_set_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_dbm_get_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_dbm_dev_ptr': [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)],
+    'bm_dbm_train_step': [_vp, _vp, _f32, _f32, _i32, _ip, _fp],
+    'bm_dbm_grad_step': [_vp, _vp, _i32, _ip],
+    'bm_dbm_apply_step': [_vp, _i32, _i32, _f32, _f32],
+    'bm_dbm_mean_field': [_vp, _vp, _vp, _ip],
+    'bm_dbm_reconstruct': [_vp, _vp, _vp],
+    'bm_dbm_sample_v': [_vp, _i32, _vp],
+    'bm_dbm_ais': [_vp, _i32, _i32, _i32, _u64, _i64, _vp],
+    'bm_dbm_log_proba': [_vp, _vp, _vp],
+    'bm_dbm_timer_start': [_vp],
+    'bm_dbm_timer_stop': [_vp, _fp],
+}
+_RESTYPE = {'bm_last_error': C.c_char_p, 'bm_version': C.c_char_p}
+
+_lib = None
+
+
+def load(rebuild=True):
+    """Load (building if needed) libbm355.so; raises if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if rebuild and _build.needs_build():
+        try:
+            _build.build()
+        except Exception as e:  # stale-but-present library on a box without hipcc is still usable
+            if not os.path.exists(path):
+                raise Bm355Error('libbm355.so is missing and could not be built: %s' % e)
+    if not os.path.exists(path):
+        raise Bm355Error('libbm355.so not found at %s (run __graft_entry__.build())' % path)
+    lib = C.CDLL(path)
+    for name, restype in _RESTYPE.items():
+        f = getattr(lib, name)
+        f.restype = restype
+        f.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        f = getattr(lib, name)   # AttributeError here == header/library mismatch
+        f.restype = C.c_int
+        f.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Bm355Error(load().bm_last_error().decode('utf-8', 'replace'))
+
+
+def exported_symbols():
+    return sorted(list(SIGNATURES) + list(_RESTYPE))
+
+
+class DeviceArray(object):
+    """A float32/int32 array in HBM, allocated through the C-ABI helpers
+    (no torch involved).  Exposes `__cuda_array_interface__` so that torch can
+    wrap it zero-copy for RCCL collectives (torch.as_tensor(arr, device='cuda'))."""
+
+    def __init__(self, shape, dtype=np.float32, ptr=None, owner=None):
+        self.shape = tuple(int(s) for s in (shape if hasattr(shape, '__iter__') else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self._own = ptr is None
+        self._owner = owner
+        if ptr is None:
+            p = _vp()
+            check(load().bm_dev_alloc(self.nbytes, C.byref(p)))
+            ptr = p.value
+        self.ptr = int(ptr)
+
+    @classmethod
+    def from_numpy(cls, a, dtype=np.float32):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = cls(a.shape, dtype)
+        check(load().bm_h2d(d.ptr, a.ctypes.data_as(_vp), a.nbytes))
+        return d
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(load().bm_d2h(out.ctypes.data_as(_vp), self.ptr, self.nbytes))
+        return out
+
+    def offset_ptr(self, n_elems):
+        return self.ptr + int(n_elems) * self.dtype.itemsize
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (self.ptr, False), 'version': 2}
+
+    def free(self):
+        if self._own and self.ptr:
+            load().bm_dev_free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

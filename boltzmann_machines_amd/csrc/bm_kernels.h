@@ -1,0 +1,434 @@
+// bm_kernels.h — the fused CDNA4 kernels of the Boltzmann-machine hot path.
+//
+//   act_kernel      K1/K2/K9/K10/K16 of SURVEY §2b: propagation GEMM (one or two
+//                   K segments) + multiplier + bias + sigmoid / Gaussian-linear +
+//                   Philox Bernoulli / Normal draw, all in the MFMA epilogue.
+//   grad_kernel     K3/K13: positive and negative outer products as two MFMA
+//                   chains + L2 + sparsity + momentum + in-place W update.
+//   colstat_kernel  K4: column sums as an MFMA against a vector of ones (keeps the
+//                   canonical sequential order) + bias / q_means updates.
+//   elementwise / reduction helpers for dropout, msre, l2, free energy, PLL.
+#pragma once
+#include "bm_gemm.h"
+#include "bm_numerics.h"
+#include "bm_rng.h"
+
+namespace bm {
+
+// ------------------------------------------------------------------ act_kernel
+struct ActArgs {
+    Operand P1, Q1; int K1;      // segment 1:  z += sum_k P1[i][k] Q1[j][k]
+    Operand P2, Q2; int K2;      // segment 2 (K2 == 0: absent), chained onto the same accumulator
+    int I, J;                    // output is [J rows][I cols], ld = ldo
+    const float *bias;           // [I]
+    const float *sigma;          // [I], Gaussian units only
+    float mult;                  // propup/propdown multiplier or AIS beta (applied to z and to bias)
+    int kind;                    // BM_UNIT_BERNOULLI: sigmoid(mult*z + mult*b); GAUSSIAN: (mult*z)*sigma + mult*b
+    int sample;                  // 1: states = draw(means); 0: states = means
+    float *means;                // may be null
+    float *states;               // may be null
+    int ldo;
+    PhiloxKey key;
+    long long row0;              // global row of local row 0 (rank-invariant bitmaps)
+    const float *prev;           // mean-field: previous mu (same layout as means) or null
+    unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
+};
+
+template <int PL1, int QL1, bool SEG2>
+__global__ __launch_bounds__(NT) void act_kernel(ActArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    const int tiles_j = (a.J + TJ - 1) / TJ;
+    int ti, tj;
+    block_to_tile(tiles_j, ti, tj);
+    const int i0 = ti * TI, j0 = tj * TJ;
+
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<PL1, QL1>(acc, a.P1, a.Q1, a.K1, i0, j0, smem);
+    if (SEG2) mainloop<XM, XM>(acc, a.P2, a.Q2, a.K2, i0, j0, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int j = j0 + wj * 16 + l15;
+    float dmax = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ib = i0 + wi * 32 + t * 16 + g * 4;
+        if (j >= a.J || ib >= a.I) continue;
+        float m[4], s[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = (ib + r < a.I) ? ib + r : a.I - 1;
+            const float x = a.mult * acc[t][r];
+            const float b = a.mult * a.bias[i];
+            m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+            s[r] = m[r];
+        }
+        if (a.sample) {
+            const unsigned long long flat = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib;
+            if ((a.I & 3) == 0) {       // fast path: the lane's 4 outputs are exactly one Philox block
+                uint32_t wds[4];
+                philox_block(a.key, flat >> 2, wds);
+                if (a.kind == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] = (u32_to_uniform(wds[r]) < m[r]) ? 1.f : 0.f;
+                } else {
+                    float n[4];
+                    box_muller(wds[0], wds[1], n[0], n[1]);
+                    box_muller(wds[2], wds[3], n[2], n[3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] = n[r] * a.sigma[ib + r] + m[r];
+                }
+            } else {                    // generic path: per element
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ib + r >= a.I) break;
+                    const unsigned long long idx = flat + r;
+                    uint32_t wds[4];
+                    philox_block(a.key, idx >> 2, wds);
+                    if (a.kind == 0) {
+                        s[r] = (u32_to_uniform(wds[idx & 3]) < m[r]) ? 1.f : 0.f;
+                    } else {
+                        float n0, n1;
+                        const int pr = (int)(idx & 3) >> 1;
+                        box_muller(wds[2 * pr], wds[2 * pr + 1], n0, n1);
+                        s[r] = ((idx & 1) ? n1 : n0) * a.sigma[ib + r] + m[r];
+                    }
+                }
+            }
+        }
+        const size_t o = (size_t)j * a.ldo + ib;
+        if (a.prev) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ib + r < a.I) dmax = fmaxf(dmax, fabsf(m[r] - a.prev[o + r]));
+        }
+        const bool v4 = ((a.ldo & 3) == 0) && (ib + 3 < a.I);
+        if (a.means) {
+            if (v4 && (((uintptr_t)a.means & 15u) == 0)) {
+                *reinterpret_cast<float4 *>(a.means + o) = make_float4(m[0], m[1], m[2], m[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (ib + r < a.I) a.means[o + r] = m[r];
+            }
+        }
+        if (a.states) {
+            if (v4 && (((uintptr_t)a.states & 15u) == 0)) {
+                *reinterpret_cast<float4 *>(a.states + o) = make_float4(s[0], s[1], s[2], s[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (ib + r < a.I) a.states[o + r] = s[r];
+            }
+        }
+    }
+    if (a.maxdiff) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        if (lane == 0 && dmax > 0.f) atomicMax(a.maxdiff, __float_as_uint(dmax));
+    }
+}
+
+// ----------------------------------------------------------------- grad_kernel
+// out[j][i] over i = above-units (contiguous in W), j = below-units; K = rows.
+struct GradArgs {
+    Operand Ppos, Qpos; int Kpos;     // positive phase:  sum_b Qpos[b][j] * Ppos[b][i]
+    Operand Pneg, Qneg; int Kneg;     // negative phase
+    int I, J;
+    int form;                         // 0: (pos-neg)/N  (RBM, base_rbm.py:447-449); 1: pos/N - neg/M (DBM, dbm.py:553-570)
+    int fused;                        // 1: apply the update in the epilogue; 0: write raw sums to `raw`
+    float *raw;                       // [J][I] raw pos-neg (form 0) ; for form 1: raw pos at raw, raw neg at raw2
+    float *raw2;
+    float *W, *dW;                    // [J][I]
+    const float *pen;                 // [I] sparsity penalty (already cost*(q-target) [+ mu term]) or null
+    float N, M, l2, lr, mom;
+};
+
+// the scalar update rule shared by the fused epilogue and the split (data-parallel) apply kernel
+__device__ __forceinline__ void apply_w_update(float g, float pen, float l2, float lr, float mom,
+                                               float &w, float &dw) {
+    g = g - l2 * w;                // dW = ... - l2*W            (base_rbm.py:449)
+    g = g - pen;                   // dW -= sparsity_penalty      (base_rbm.py:462)
+    const float d = lr * (mom * dw + g);   // dW_update          (base_rbm.py:467)
+    dw = d;
+    w = w + d;                     // W.assign_add               (base_rbm.py:468)
+}
+
+__global__ __launch_bounds__(NT) void grad_kernel(GradArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    const int tiles_j = (a.J + TJ - 1) / TJ;
+    int ti, tj;
+    block_to_tile(tiles_j, ti, tj);
+    const int i0 = ti * TI, j0 = tj * TJ;
+
+    f32x4 pos[2], neg[2];
+    pos[0] = pos[1] = neg[0] = neg[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<KM, KM>(pos, a.Ppos, a.Qpos, a.Kpos, i0, j0, smem);
+    mainloop<KM, KM>(neg, a.Pneg, a.Qneg, a.Kneg, i0, j0, smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int j = j0 + wj * 16 + l15;
+    if (j >= a.J) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int ib = i0 + wi * 32 + t * 16 + g * 4;
+        if (ib >= a.I) continue;
+        const size_t o = (size_t)j * a.I + ib;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (ib + r >= a.I) break;
+            if (!a.fused) {
+                if (a.form == 0) {
+                    a.raw[o + r] = pos[t][r] - neg[t][r];
+                } else {
+                    a.raw[o + r] = pos[t][r];
+                    a.raw2[o + r] = neg[t][r];
+                }
+            } else {
+                const float gr = (a.form == 0) ? (pos[t][r] - neg[t][r]) / a.N
+                                               : (pos[t][r] / a.N - neg[t][r] / a.M);
+                float wv = a.W[o + r], dv = a.dW[o + r];
+                apply_w_update(gr, a.pen ? a.pen[ib + r] : 0.f, a.l2, a.lr, a.mom, wv, dv);
+                a.W[o + r] = wv;
+                a.dW[o + r] = dv;
+            }
+        }
+    }
+}
+
+// split path: W update from (all-reduced) raw sums
+struct ApplyWArgs {
+    const float *raw, *raw2;
+    float *W, *dW;
+    const float *pen;
+    int I; size_t n;
+    int form;
+    float N, M, l2, lr, mom;
+};
+__global__ void apply_w_kernel(ApplyWArgs a) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.n; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % (size_t)a.I);
+        const float gr = (a.form == 0) ? a.raw[e] / a.N : (a.raw[e] / a.N - a.raw2[e] / a.M);
+        float wv = a.W[e], dv = a.dW[e];
+        apply_w_update(gr, a.pen ? a.pen[i] : 0.f, a.l2, a.lr, a.mom, wv, dv);
+        a.W[e] = wv;
+        a.dW[e] = dv;
+    }
+}
+
+// -------------------------------------------------------------- colstat_kernel
+// Column sums in canonical order via MFMA against ones:
+//   D[i][*] = sum_k A[k][i] * 1  ==  sequential fp32 sum over rows k.
+// One wave per 16 columns, operands straight from global memory (64 B per row).
+// job: out[c] = sum_b (A[b][c] - Bm[b][c])   (Bm may be null -> plain column sum)
+struct ColSumJob {
+    const float *A, *Bm;
+    int ld, ncols, nrows;
+    float *out;
+};
+constexpr int MAX_COLJOBS = 12;
+struct ColSumArgs {
+    ColSumJob job[MAX_COLJOBS];
+    int first_wave[MAX_COLJOBS + 1];   // prefix sums of ceil(ncols/16)
+    int njobs;
+};
+
+__global__ __launch_bounds__(64) void colsum_kernel(ColSumArgs a) {
+    const int wv = blockIdx.x, lane = threadIdx.x;
+    int jb = 0;
+    while (jb + 1 < a.njobs && wv >= a.first_wave[jb + 1]) ++jb;
+    const ColSumJob J = a.job[jb];
+    const int c0 = (wv - a.first_wave[jb]) * 16;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int c = c0 + l15;
+    const bool cok = c < J.ncols;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 8;
+    for (int k0 = 0; k0 < J.nrows; k0 += 4 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * 4 + g;
+            float x = 0.f;
+            if (cok && k < J.nrows) {
+                x = J.A[(size_t)k * J.ld + c];
+                if (J.Bm) x = x - J.Bm[(size_t)k * J.ld + c];
+            }
+            v[u] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], 1.0f, acc, 0, 0, 0);
+    }
+    // lane with l15 == 0 in group g holds columns c0 + g*4 + r
+    if (l15 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = c0 + g * 4 + r;
+            if (cc < J.ncols) J.out[cc] = acc[r];
+        }
+    }
+}
+
+// RBM bias / running-mean update from raw column sums (base_rbm.py:450-474).
+//   sv[c] = sum_b (X - v_k),  sh[c] = sum_b (h0 - h_k),  sq[c] = sum_b h_k
+struct RbmBiasArgs {
+    const float *sv, *sh, *sq;
+    float *vb, *dvb, *hb, *dhb, *q, *pen;
+    int V, H;
+    float N, lr, mom, damping, cost, target;
+};
+__global__ void rbm_bias_kernel(RbmBiasArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.V) {
+        const float g = a.sv[c] / a.N;                       // reduce_mean(X - v, 0)     :451
+        const float d = a.lr * (a.mom * a.dvb[c] + g);       // :470
+        a.dvb[c] = d;
+        a.vb[c] = a.vb[c] + d;                               // :471
+    } else if (c < a.V + a.H) {
+        const int h = c - a.V;
+        const float qn = a.damping * a.q[h] + (1.0f - a.damping) * a.sq[h];   // :457-459 (column SUM)
+        a.q[h] = qn;
+        const float pen = a.cost * (qn - a.target);          // :460
+        a.pen[h] = pen;
+        float g = a.sh[h] / a.N;                             // :453
+        g = g - pen;                                         // :461
+        const float d = a.lr * (a.mom * a.dhb[h] + g);       // :473
+        a.dhb[h] = d;
+        a.hb[h] = a.hb[h] + d;                               // :474
+    }
+}
+
+// ----------------------------------------------------------------- elementwise
+// tf.nn.dropout(x, keep): x / keep * floor(keep + u)   (base_rbm.py:417-418)
+__global__ void dropout_kernel(const float *X, float *Y, size_t n, float keep, PhiloxKey key,
+                               unsigned long long flat0) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float u = philox_uniform_at(key, flat0 + e);
+        Y[e] = (X[e] / keep) * floorf(keep + u);
+    }
+}
+
+// GaussianRBM placeholder: X / sigma (rbm.py:107)
+__global__ void div_cols_kernel(const float *X, const float *sigma, float *Y, size_t n, int ncols) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        Y[e] = X[e] / sigma[e % (size_t)ncols];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// sum of (A-B)^2 and of A^2 into double accumulators (msre :486-488; l2 :482-484)
+__global__ void sqdiff_kernel(const float *A, const float *B, size_t n, double *out) {
+    double s = 0.0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const float d = B ? (A[e] - B[e]) : A[e];
+        s += (double)d * (double)d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// ------------------------------------------------ free-energy hidden term (K5/K6)
+// rowacc[j]  += sum_i softplus(z[j][i] + hb[i])           over this block's i-range
+// rowacc2[j] += the same for the PLL-corrupted row x~ (one flipped column per row,
+//               base_rbm.py:496-509):  z~ = z + (1 - 2 x_f) W[f][:]
+struct FeArgs {
+    Operand P, Q; int K;     // P = W (KM), Q = X rows (XM)
+    int I, J;
+    const float *hb;
+    float *rowacc;           // [J], zero-initialised
+    float *rowacc2;          // [J] or null
+    const int *flip_col;     // [J] or null
+};
+__global__ __launch_bounds__(NT) void fe_hidden_kernel(FeArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    const int tiles_j = (a.J + TJ - 1) / TJ;
+    int ti, tj;
+    block_to_tile(tiles_j, ti, tj);
+    const int i0 = ti * TI, j0 = tj * TJ;
+    f32x4 acc[2];
+    acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<KM, XM>(acc, a.P, a.Q, a.K, i0, j0, smem);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int j = j0 + wj * 16 + l15;
+    float s = 0.f, s2 = 0.f;
+    if (j < a.J) {
+        float delta = 0.f; int fc = -1;
+        if (a.flip_col) {
+            fc = a.flip_col[j];
+            delta = 1.0f - 2.0f * a.Q.ptr[(size_t)j * a.Q.ld + fc];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 32 + t * 16 + g * 4 + r;
+                if (i < a.I) {
+                    const float z = acc[t][r] + a.hb[i];
+                    s += softplus(z);
+                    if (fc >= 0) s2 += softplus(z + delta * a.P.ptr[(size_t)fc * a.P.ld + i]);
+                }
+            }
+    }
+    s += __shfl_xor(s, 16);  s += __shfl_xor(s, 32);
+    s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+    if (g == 0 && j < a.J) {
+        atomicAdd(a.rowacc + j, s);
+        if (a.rowacc2) atomicAdd(a.rowacc2 + j, s2);
+    }
+}
+
+// visible term + batch sums: one wave per row.  Bernoulli: -x.vb (rbm.py:18);
+// Gaussian: 0.5*||x - vb/sigma||^2 (rbm.py:110-112).  out[0] += F(x_j), out[1] += F(x~_j)
+struct FeRowArgs {
+    const float *X; int ld, V, B;
+    const float *vb, *sigma;     // sigma null => Bernoulli
+    const float *rowacc, *rowacc2;
+    const int *flip_col;
+    double *out;
+};
+__global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= a.B) return;
+    const float *x = a.X + (size_t)row * a.ld;
+    const int fc = a.flip_col ? a.flip_col[row] : -1;
+    double t = 0.0, t2 = 0.0;
+    for (int c = lane; c < a.V; c += 64) {
+        const float xv = x[c];
+        const float xf = (c == fc) ? 1.0f - xv : xv;
+        if (a.sigma) {
+            const float mu = a.vb[c] / a.sigma[c];
+            t += 0.5 * (double)((xv - mu) * (xv - mu));
+            t2 += 0.5 * (double)((xf - mu) * (xf - mu));
+        } else {
+            t -= (double)(xv * a.vb[c]);
+            t2 -= (double)(xf * a.vb[c]);
+        }
+    }
+    t = wave_sum(t);
+    t2 = wave_sum(t2);
+    if (lane == 0) {
+        atomicAdd(a.out + 0, t - (double)a.rowacc[row]);
+        if (a.rowacc2) atomicAdd(a.out + 1, t2 - (double)a.rowacc2[row]);
+    }
+}
+
+// pll_rand = tf.random_uniform([B], 0, V, int32): minval + u32 % range (base_rbm.py:500-501)
+__global__ void pll_index_kernel(int *out, int B, int V, PhiloxKey key, unsigned long long row0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long idx = row0 + b;
+    uint32_t w[4];
+    philox_block(key, idx >> 2, w);
+    out[b] = (int)(w[idx & 3] % (uint32_t)V);
+}
+
+}  // namespace bm

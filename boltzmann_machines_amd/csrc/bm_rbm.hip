@@ -1,0 +1,430 @@
+// bm_rbm.hip — C-ABI entry points for the RBM path (include/bm355.h) and the
+// host-side sequencing of the fused kernels for one CD-k update.
+//
+// Reference graph restated: boltzmann_machines/rbm/base_rbm.py:415-525
+// (train op + metrics), :329-413 (propagations, Gibbs chain), rbm/rbm.py:17-22,
+// :101-116 (free energies, Gaussian input scaling), layers.py:39-51,73-89.
+#include "../../include/bm355.h"
+#include "bm_common.h"
+#include "bm_kernels.h"
+
+#include <math.h>
+
+namespace bm {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// RNG site ids (counter word 2 = site + 16 * gibbs_step); DESIGN.md "RNG"
+enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5 };
+
+}  // namespace bm
+
+using namespace bm;
+
+struct bm_rbm {
+    bm_rbm_config cfg;
+    int V, H, maxB;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, DevBuf *> vars;
+    DevBuf W, vb, hb, dW, dvb, dhb, q, sigma;
+    DevBuf h0m, h0s, vm, vs, hm, hs, Xs, Xd;
+    DevBuf grad;      // [V*H | V | H | H] raw sums
+    DevBuf pen;       // [H]
+    DevBuf rowacc;    // [2*maxB]
+    int *flip = nullptr;
+    double *scal = nullptr;   // [4] device accumulators
+    uint64_t seed = 0;
+    uint32_t call = 0;
+    int64_t row0 = 0;
+    // chain results of the last run_chain()
+    const float *Xin = nullptr;
+};
+
+static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
+    PhiloxKey k;
+    k.k0 = (uint32_t)h->seed;
+    k.k1 = (uint32_t)(h->seed >> 32);
+    k.site = site + 16u * (uint32_t)t;
+    k.call = h->call;
+    return k;
+}
+
+static inline int grid_for(int I, int J) { return ((I + TI - 1) / TI) * ((J + TJ - 1) / TJ); }
+
+// E[h|v] (+ sample): base_rbm.py:339-351
+static void launch_up(bm_rbm *h, const float *v, int B, float *means, float *states, int sample,
+                      uint32_t site, int t) {
+    ActArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P1 = make_operand(h->W.p, h->H, h->H);   // W[k=v][i=h], KM
+    a.Q1 = make_operand(v, h->V, B);           // v[j=b][k=v], XM
+    a.K1 = h->V;
+    a.I = h->H; a.J = B;
+    a.bias = h->hb.p; a.sigma = nullptr;
+    a.mult = 1.0f + (h->cfg.dbm_first ? 1.0f : 0.0f);
+    a.kind = BM_UNIT_BERNOULLI;
+    a.sample = sample;
+    a.means = means; a.states = states; a.ldo = h->H;
+    a.key = make_key(h, site, t);
+    a.row0 = h->row0;
+    hipLaunchKernelGGL((act_kernel<KM, XM, false>), dim3(grid_for(a.I, a.J)), dim3(NT), 0, h->stream, a);
+}
+
+// E[v|h] (+ sample): base_rbm.py:353-365
+static void launch_down(bm_rbm *h, const float *hs, int B, float *means, float *states, int sample,
+                        uint32_t site, int t) {
+    ActArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P1 = make_operand(h->W.p, h->H, h->V);   // W[i=v][k=h], XM
+    a.Q1 = make_operand(hs, h->H, B);          // h[j=b][k=h], XM
+    a.K1 = h->H;
+    a.I = h->V; a.J = B;
+    a.bias = h->vb.p; a.sigma = h->sigma.p;
+    a.mult = 1.0f + (h->cfg.dbm_last ? 1.0f : 0.0f);
+    a.kind = h->cfg.v_unit;
+    a.sample = sample;
+    a.means = means; a.states = states; a.ldo = h->V;
+    a.key = make_key(h, site, t);
+    a.row0 = h->row0;
+    hipLaunchKernelGGL((act_kernel<XM, XM, false>), dim3(grid_for(a.I, a.J)), dim3(NT), 0, h->stream, a);
+}
+
+// input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426). Leaves
+// h0m/h0s, vm/vs (last step), hm/hs (last step) and Xin in the handle.
+// If hm_out != null the last step's h_means are written there instead of h->hm.
+static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out) {
+    BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
+    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    const size_t nX = (size_t)B * h->V;
+    const float *Xin = X_dev;
+    if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {   // rbm.py:107
+        hipLaunchKernelGGL(div_cols_kernel, dim3(256), dim3(256), 0, h->stream, Xin, h->sigma.p, h->Xs.p, nX, h->V);
+        Xin = h->Xs.p;
+    }
+    if (h->cfg.dropout >= 0.f) {               // base_rbm.py:417-418
+        hipLaunchKernelGGL(dropout_kernel, dim3(256), dim3(256), 0, h->stream, Xin, h->Xd.p, nX, h->cfg.dropout,
+                           make_key(h, SITE_DROPOUT, 0), (unsigned long long)h->row0 * (unsigned long long)h->V);
+        Xin = h->Xd.p;
+    }
+    h->Xin = Xin;
+    launch_up(h, Xin, B, h->h0m.p, h->h0s.p, 1, SITE_H0, 0);                  // :421-422
+    const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;       // :423
+    for (int t = 0; t < k; ++t) {                                             // :367-378
+        launch_down(h, hstate, B, h->vm.p, h->vs.p, h->cfg.sample_v_states, SITE_V, t);
+        float *hm = (hm_out && t == k - 1) ? hm_out : h->hm.p;
+        launch_up(h, h->vs.p, B, hm, h->hs.p, h->cfg.sample_h_states, SITE_H, t);
+        hstate = h->hs.p;
+    }
+    return 0;
+}
+
+// raw column sums -> grad tail (base_rbm.py:450-453,457)
+static void launch_colsums(bm_rbm *h, int B) {
+    ColSumArgs c;
+    memset(&c, 0, sizeof(c));
+    float *tail = h->grad.p + (size_t)h->V * h->H;
+    c.njobs = 3;
+    c.job[0] = ColSumJob{h->Xin, h->vs.p, h->V, h->V, B, tail};                    // sum(X - v_k)
+    c.job[1] = ColSumJob{h->h0m.p, h->hm.p, h->H, h->H, B, tail + h->V};           // sum(h0 - h_k)
+    c.job[2] = ColSumJob{h->hm.p, nullptr, h->H, h->H, B, tail + h->V + h->H};     // sum(h_k)
+    c.first_wave[0] = 0;
+    for (int j = 0; j < c.njobs; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 15) / 16;
+    hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[c.njobs]), dim3(64), 0, h->stream, c);
+}
+
+static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
+    RbmBiasArgs b;
+    float *tail = h->grad.p + (size_t)h->V * h->H;
+    b.sv = tail; b.sh = tail + h->V; b.sq = tail + h->V + h->H;
+    b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
+    b.V = h->V; b.H = h->H;
+    b.N = N; b.lr = lr; b.mom = mom;
+    b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost; b.target = h->cfg.sparsity_target;
+    const int n = h->V + h->H;
+    hipLaunchKernelGGL(rbm_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, b);
+}
+
+static void launch_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom) {
+    GradArgs g;
+    memset(&g, 0, sizeof(g));
+    g.Ppos = make_operand(h->h0m.p, h->H, h->H);   // h0 means [k=b][i=h]           :447
+    g.Qpos = make_operand(h->Xin, h->V, h->V);     // X        [k=b][j=v]
+    g.Kpos = B;
+    g.Pneg = make_operand(h->hm.p, h->H, h->H);    // h_k means                     :448
+    g.Qneg = make_operand(h->vs.p, h->V, h->V);    // v_k states
+    g.Kneg = B;
+    g.I = h->H; g.J = h->V;
+    g.form = 0; g.fused = fused;
+    g.raw = h->grad.p; g.raw2 = nullptr;
+    g.W = h->W.p; g.dW = h->dW.p;
+    g.pen = h->pen.p;
+    g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
+    hipLaunchKernelGGL(grad_kernel, dim3(grid_for(g.I, g.J)), dim3(NT), 0, h->stream, g);
+}
+
+// metrics from the chain currently in the handle (base_rbm.py:482-517)
+static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
+    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
+    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 2 * (size_t)h->maxB * sizeof(float), h->stream));
+    const size_t nX = (size_t)B * h->V;
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, h->vm.p, nX, h->scal + 0);     // msre
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->W.p, (const float *)nullptr,
+                       (size_t)h->V * h->H, h->scal + 1);                                                         // l2
+    hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
+                       make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
+    FeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.P = make_operand(h->W.p, h->H, h->H);
+    f.Q = make_operand(h->Xin, h->V, B);
+    f.K = h->V; f.I = h->H; f.J = B;
+    f.hb = h->hb.p;
+    f.rowacc = h->rowacc.p; f.rowacc2 = h->rowacc.p + h->maxB; f.flip_col = h->flip;
+    hipLaunchKernelGGL(fe_hidden_kernel, dim3(grid_for(f.I, f.J)), dim3(NT), 0, h->stream, f);
+    FeRowArgs r;
+    r.X = h->Xin; r.ld = h->V; r.V = h->V; r.B = B;
+    r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
+    r.rowacc = f.rowacc; r.rowacc2 = f.rowacc2; r.flip_col = h->flip; r.out = h->scal + 2;
+    hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
+    double host[4];
+    BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    const double fe = host[2] / B, fe2 = host[3] / B;
+    out4[0] = (float)(host[0] / (double)nX);                    // msre          :487
+    const float d = (float)(fe2 - fe);                          // pll           :511-512
+    const float ls = -(fmaxf(-d, 0.f) + log1pf(expf(-fabsf(d))));
+    out4[1] = (float)h->V * ls;
+    out4[2] = h->cfg.l2 * (float)(0.5 * host[1]);               // l2_loss       :483
+    out4[3] = (float)fe;                                        // free energy   :516
+    return 0;
+}
+
+extern "C" {
+
+const char *bm_last_error(void) { return bm::g_err; }
+const char *bm_version(void) { return "bm355 0.1 gfx950"; }
+
+int bm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int bm_set_device(int device) { BM_HIP(hipSetDevice(device)); return 0; }
+int bm_dev_alloc(size_t bytes, void **out_dev) { BM_HIP(hipMalloc(out_dev, bytes ? bytes : 1)); return 0; }
+int bm_dev_free(void *dev) { BM_HIP(hipFree(dev)); return 0; }
+int bm_h2d(void *dst, const void *src, size_t bytes) { BM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int bm_d2h(void *dst, const void *src, size_t bytes) { BM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
+int bm_dev_memset(void *dst, int value, size_t bytes) { BM_HIP(hipMemset(dst, value, bytes)); return 0; }
+
+int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
+    BM_CHECK(cfg && out, "null argument");
+    BM_CHECK(cfg->n_visible >= 1 && cfg->n_hidden >= 1, "bad layer sizes %d x %d", cfg->n_visible, cfg->n_hidden);
+    BM_CHECK(cfg->max_batch >= 1, "max_batch must be >= 1");
+    BM_CHECK(cfg->v_unit == BM_UNIT_BERNOULLI || cfg->v_unit == BM_UNIT_GAUSSIAN, "unknown visible unit %d", cfg->v_unit);
+    BM_CHECK(bm_device_count() > 0, "no HIP device visible: libbm355 has no CPU fallback");
+    bm_rbm *h = new bm_rbm();
+    h->cfg = *cfg;
+    h->V = cfg->n_visible; h->H = cfg->n_hidden; h->maxB = cfg->max_batch;
+    const size_t V = h->V, H = h->H, B = h->maxB;
+    BM_HIP(hipStreamCreate(&h->stream));
+    BM_HIP(hipEventCreate(&h->ev0));
+    BM_HIP(hipEventCreate(&h->ev1));
+    BM_TRY(h->W.alloc(V * H)); BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H));
+    BM_TRY(h->dW.alloc(V * H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
+    BM_TRY(h->q.alloc(H)); BM_TRY(h->sigma.alloc(V));
+    BM_TRY(h->h0m.alloc(B * H)); BM_TRY(h->h0s.alloc(B * H));
+    BM_TRY(h->hm.alloc(B * H)); BM_TRY(h->hs.alloc(B * H));
+    BM_TRY(h->vm.alloc(B * V)); BM_TRY(h->vs.alloc(B * V));
+    BM_TRY(h->Xs.alloc(B * V)); BM_TRY(h->Xd.alloc(B * V));
+    BM_TRY(h->grad.alloc(V * H + V + 2 * H));
+    BM_TRY(h->pen.alloc(H));
+    BM_TRY(h->rowacc.alloc(2 * B));
+    BM_HIP(hipMalloc((void **)&h->flip, B * sizeof(int)));
+    BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
+    {   // sigma defaults to 1 (rbm.py:88)
+        std::vector<float> ones(V, 1.0f);
+        BM_HIP(hipMemcpy(h->sigma.p, ones.data(), V * sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->vars = {{"W", &h->W}, {"vb", &h->vb}, {"hb", &h->hb}, {"dW", &h->dW}, {"dvb", &h->dvb},
+               {"dhb", &h->dhb}, {"q_means", &h->q}, {"sigma", &h->sigma}, {"grad", &h->grad}};
+    *out = h;
+    return 0;
+}
+
+int bm_rbm_destroy(bm_rbm *h) {
+    if (!h) return 0;
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *all[] = {&h->W, &h->vb, &h->hb, &h->dW, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->h0m, &h->h0s,
+                     &h->vm, &h->vs, &h->hm, &h->hs, &h->Xs, &h->Xd, &h->grad, &h->pen, &h->rowacc};
+    for (DevBuf *b : all) b->release();
+    if (h->flip) (void)hipFree(h->flip);
+    if (h->scal) (void)hipFree(h->scal);
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int bm_rbm_sync(bm_rbm *h) { BM_HIP(hipStreamSynchronize(h->stream)); return 0; }
+
+static int find_var(bm_rbm *h, const char *name, DevBuf **out) {
+    auto it = h->vars.find(name ? name : "");
+    BM_CHECK(it != h->vars.end(), "unknown RBM variable '%s'", name ? name : "(null)");
+    *out = it->second;
+    return 0;
+}
+
+int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
+    DevBuf *b;
+    BM_TRY(find_var(h, name, &b));
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    BM_HIP(hipStreamSynchronize(h->stream));
+    BM_HIP(hipMemcpy(b->p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n) {
+    DevBuf *b;
+    BM_TRY(find_var(h, name, &b));
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    BM_HIP(hipStreamSynchronize(h->stream));
+    BM_HIP(hipMemcpy(host, b->p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bm_rbm_dev_ptr(bm_rbm *h, const char *name, void **out_dev, size_t *out_n) {
+    DevBuf *b;
+    BM_TRY(find_var(h, name, &b));
+    *out_dev = b->p;
+    if (out_n) *out_n = b->n;
+    return 0;
+}
+
+int bm_rbm_seed(bm_rbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 0; }
+int bm_rbm_set_row_offset(bm_rbm *h, int64_t row0) { h->row0 = row0; return 0; }
+
+int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    launch_colsums(h, B);
+    launch_bias(h, (float)B, lr, mom);
+    launch_grad(h, B, 1, (float)B, lr, mom);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k,
+                              float *out4) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(metrics_from_chain(h, B, out4));
+    launch_colsums(h, B);
+    launch_bias(h, (float)B, lr, mom);
+    launch_grad(h, B, 1, (float)B, lr, mom);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
+    BM_CHECK(batch >= 1 && N >= 1, "bad N=%lld batch=%d", (long long)N, batch);
+    for (int64_t s = 0; s < N; s += batch) {
+        const int B = (int)((N - s < batch) ? (N - s) : batch);
+        BM_TRY(bm_rbm_train_step(h, X_dev + (size_t)s * h->V, B, lr, mom, k));
+    }
+    return 0;
+}
+
+int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    launch_colsums(h, B);
+    launch_grad(h, B, 0, (float)B, 0.f, 0.f);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float lr, float mom) {
+    launch_bias(h, (float)B_global, lr, mom);
+    ApplyWArgs a;
+    a.raw = h->grad.p; a.raw2 = nullptr;
+    a.W = h->W.p; a.dW = h->dW.p; a.pen = h->pen.p;
+    a.I = h->H; a.n = (size_t)h->V * h->H; a.form = 0;
+    a.N = (float)B_global; a.M = a.N; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
+    hipLaunchKernelGGL(apply_w_kernel, dim3(1024), dim3(256), 0, h->stream, a);
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_transform(bm_rbm *h, const float *X_dev, int32_t B, int32_t k, float *H_dev) {
+    BM_CHECK(H_dev, "null output");
+    BM_TRY(run_chain(h, X_dev, B, k, H_dev));
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_metrics(bm_rbm *h, const float *X_dev, int32_t B, int32_t k, float *out4) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(metrics_from_chain(h, B, out4));
+    h->call++;
+    return 0;
+}
+
+int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1) {
+    BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
+    const float *Xin = X_dev;
+    if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {
+        hipLaunchKernelGGL(div_cols_kernel, dim3(256), dim3(256), 0, h->stream, Xin, h->sigma.p, h->Xs.p,
+                           (size_t)B * h->V, h->V);
+        Xin = h->Xs.p;
+    }
+    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
+    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 2 * (size_t)h->maxB * sizeof(float), h->stream));
+    FeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.P = make_operand(h->W.p, h->H, h->H);
+    f.Q = make_operand(Xin, h->V, B);
+    f.K = h->V; f.I = h->H; f.J = B;
+    f.hb = h->hb.p; f.rowacc = h->rowacc.p;
+    hipLaunchKernelGGL(fe_hidden_kernel, dim3(grid_for(f.I, f.J)), dim3(NT), 0, h->stream, f);
+    FeRowArgs r;
+    memset(&r, 0, sizeof(r));
+    r.X = Xin; r.ld = h->V; r.V = h->V; r.B = B;
+    r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
+    r.rowacc = f.rowacc; r.out = h->scal + 2;
+    hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
+    double host[4];
+    BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    *out1 = (float)(host[2] / B);
+    return 0;
+}
+
+int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_steps) {
+    BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
+    BM_CHECK(H_dev && V_dev, "null state pointer");
+    for (int t = 0; t < n_steps; ++t) {
+        launch_down(h, H_dev, B, nullptr, V_dev, h->cfg.sample_v_states, SITE_V, t);
+        launch_up(h, V_dev, B, nullptr, H_dev, h->cfg.sample_h_states, SITE_H, t);
+    }
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_timer_start(bm_rbm *h) { BM_HIP(hipEventRecord(h->ev0, h->stream)); return 0; }
+int bm_rbm_timer_stop(bm_rbm *h, float *out_ms) {
+    BM_HIP(hipEventRecord(h->ev1, h->stream));
+    BM_HIP(hipEventSynchronize(h->ev1));
+    BM_HIP(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+    return 0;
+}
+
+}  // extern "C"

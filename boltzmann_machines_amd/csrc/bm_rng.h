@@ -1,0 +1,70 @@
+// bm_rng.h — Philox4x32-10 in TensorFlow's stream convention,
+// the generator behind the reference's `Bernoulli(probs).sample()` /
+// `tf.random_uniform` / `tf.random_normal` sites (layers.py:34-36,50-51,88-89;
+// base_rbm.py:277-279,418,501).  Device-side, gfx950 only.
+//
+// Stream addressing used by every sampling site of this engine (DESIGN.md "RNG"):
+//   key     = 64-bit seed of the public call        (k0 = lo, k1 = hi)
+//   counter = (block_lo, block_hi, site, call)
+//   block   = flat row-major element index / 4, word = index % 4
+// so a [rows, cols] tensor sampled at (site, call) is independent of tiling,
+// of the rank count (rows are GLOBAL rows) and reproducible on the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bm {
+
+struct PhiloxKey {
+    uint32_t k0, k1;   // seed lo / hi
+    uint32_t site;     // counter word 2
+    uint32_t call;     // counter word 3
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// the four words of element-block `block` of stream `key`
+__device__ __forceinline__ void philox_block(const PhiloxKey &key, uint64_t block, uint32_t (&out)[4]) {
+    philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), key.site, key.call, key.k0, key.k1, out);
+}
+
+// TF Uint32ToFloat: 23 mantissa bits, [1,2) - 1
+__device__ __forceinline__ float u32_to_uniform(uint32_t x) {
+    return __uint_as_float(0x3f800000u | (x & 0x007fffffu)) - 1.0f;
+}
+
+// one word for flat element `idx` (slow generic path: recomputes the block)
+__device__ __forceinline__ float philox_uniform_at(const PhiloxKey &key, uint64_t idx) {
+    uint32_t w[4];
+    philox_block(key, idx >> 2, w);
+    return u32_to_uniform(w[idx & 3]);
+}
+
+// TF BoxMullerFloat on a word pair -> two standard normals (sin first, cos second)
+__device__ __forceinline__ void box_muller(uint32_t x0, uint32_t x1, float &n0, float &n1) {
+    const float eps = 1.0e-7f;
+    float u1 = u32_to_uniform(x0);
+    if (u1 < eps) u1 = eps;
+    const float v1 = 6.2831853071795864769f * u32_to_uniform(x1);
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(v1, &s, &c);
+    n0 = s * r;
+    n1 = c * r;
+}
+
+}  // namespace bm

@@ -1,0 +1,123 @@
+"""Thin object wrappers over the C-ABI handles (include/bm355.h).
+
+`RbmEngine` plays the role the TF session plays in the reference: it owns the
+variables of one model in HBM and executes the fetch sites of
+boltzmann_machines/rbm/base_rbm.py (`session.run(train_op)` :566, metric
+fetches :554-564,:578, `transform_op.eval` :697, free energy :605,:612).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import DeviceArray, check
+
+RBM_VARS = ('W', 'vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means', 'sigma')
+
+
+def as_device(X):
+    """host ndarray -> DeviceArray (float32, C order); DeviceArray passes through."""
+    if isinstance(X, DeviceArray):
+        return X
+    return DeviceArray.from_numpy(np.asarray(X), np.float32)
+
+
+class RbmEngine(object):
+    def __init__(self, n_visible, n_hidden, v_unit=_ffi.UNIT_BERNOULLI, sample_v_states=False,
+                 sample_h_states=True, dbm_first=False, dbm_last=False, max_batch=10, l2=1e-4,
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, dropout=None):
+        self.lib = _ffi.load()
+        self.V, self.H, self.max_batch = int(n_visible), int(n_hidden), int(max_batch)
+        cfg = _ffi.RbmConfig(self.V, self.H, int(v_unit), int(bool(sample_v_states)),
+                             int(bool(sample_h_states)), int(bool(dbm_first)), int(bool(dbm_last)),
+                             self.max_batch, float(l2), float(sparsity_target), float(sparsity_cost),
+                             float(sparsity_damping), -1.0 if dropout is None else float(dropout))
+        self._h = C.c_void_p()
+        check(self.lib.bm_rbm_create(C.byref(cfg), C.byref(self._h)))
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.bm_rbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- variables
+    def _size(self, name):
+        return {'W': self.V * self.H, 'dW': self.V * self.H, 'vb': self.V, 'dvb': self.V, 'sigma': self.V,
+                'hb': self.H, 'dhb': self.H, 'q_means': self.H,
+                'grad': self.V * self.H + self.V + 2 * self.H}[name]
+
+    def _shape(self, name):
+        return (self.V, self.H) if name in ('W', 'dW') else (self._size(name),)
+
+    def set(self, name, value):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float32), self._shape(name)))
+        check(self.lib.bm_rbm_set_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get(self, name):
+        a = np.empty(self._shape(name), dtype=np.float32)
+        check(self.lib.bm_rbm_get_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def device_view(self, name):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.bm_rbm_dev_ptr(self._h, name.encode(), C.byref(p), C.byref(n)))
+        return DeviceArray((n.value,), np.float32, ptr=p.value, owner=self)
+
+    # -- control
+    def seed(self, seed):
+        check(self.lib.bm_rbm_seed(self._h, int(seed)))
+
+    def set_row_offset(self, row0):
+        check(self.lib.bm_rbm_set_row_offset(self._h, int(row0)))
+
+    def sync(self):
+        check(self.lib.bm_rbm_sync(self._h))
+
+    # -- fetch sites
+    def train_step(self, Xd, B, lr, momentum, k, row=0):
+        check(self.lib.bm_rbm_train_step(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k))
+
+    def train_step_metrics(self, Xd, B, lr, momentum, k, row=0):
+        out = (C.c_float * 4)()
+        check(self.lib.bm_rbm_train_step_metrics(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k, out))
+        return np.array(out[:], dtype=np.float32)
+
+    def train_epoch(self, Xd, N, batch, lr, momentum, k):
+        check(self.lib.bm_rbm_train_epoch(self._h, Xd.ptr, N, batch, lr, momentum, k))
+
+    def grad_step(self, Xd, B, k, row=0):
+        check(self.lib.bm_rbm_grad_step(self._h, Xd.offset_ptr(row * self.V), B, k))
+
+    def apply_step(self, B_global, lr, momentum):
+        check(self.lib.bm_rbm_apply_step(self._h, B_global, lr, momentum))
+
+    def transform(self, Xd, B, k, Hd, row=0, out_row=0):
+        check(self.lib.bm_rbm_transform(self._h, Xd.offset_ptr(row * self.V), B, k, Hd.offset_ptr(out_row * self.H)))
+
+    def metrics(self, Xd, B, k, row=0):
+        out = (C.c_float * 4)()
+        check(self.lib.bm_rbm_metrics(self._h, Xd.offset_ptr(row * self.V), B, k, out))
+        return np.array(out[:], dtype=np.float32)
+
+    def free_energy(self, Xd, B, row=0):
+        out = C.c_float()
+        check(self.lib.bm_rbm_free_energy(self._h, Xd.offset_ptr(row * self.V), B, C.byref(out)))
+        return float(out.value)
+
+    def gibbs(self, Hd, Vd, B, n_steps):
+        check(self.lib.bm_rbm_gibbs(self._h, Hd.ptr, Vd.ptr, B, n_steps))
+
+    def timer_start(self):
+        check(self.lib.bm_rbm_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.bm_rbm_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)

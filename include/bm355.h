@@ -1,0 +1,214 @@
+/* bm355.h — C-ABI of libbm355.so, the MI355X (gfx950) RBM/DBM engine.
+ *
+ * The reference (yell/boltzmann-machines) has no FFI: its only seam is
+ * Python class API <-> `session.run`.  Every entry point
+ * below replaces one `session.run` / `.eval` fetch site of the reference,
+ * cited as  reference-file:line  next to the declaration.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; the message
+ *     is available from bm_last_error() (thread-local).
+ *   - `*_dev` pointers are DEVICE pointers (hipMalloc / bm_dev_alloc /
+ *     torch .data_ptr()); everything else is host memory owned by the caller.
+ *   - a handle owns all model state (W, biases, momentum buffers, running
+ *     means, chain workspaces) in HBM and one HIP stream; calls on one handle
+ *     are asynchronous on that stream and must not be issued concurrently
+ *     from several host threads.  bm_*_sync() blocks until the stream drains.
+ *   - all arithmetic is fp32 (reference default dtype, base/mixin.py:15).
+ *   - matrices are row-major; W is [n_below, n_above] like the reference
+ *     (base_rbm.py:277-293).
+ */
+#ifndef BM355_H
+#define BM355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ misc */
+const char *bm_last_error(void);
+/* "bm355 <version> gfx950" */
+const char *bm_version(void);
+/* number of visible HIP devices (0 when no GPU / no driver) */
+int bm_device_count(void);
+int bm_set_device(int device);
+
+/* raw device-memory helpers so that a host without torch can drive the ABI */
+int bm_dev_alloc(size_t bytes, void **out_dev);
+int bm_dev_free(void *dev);
+int bm_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int bm_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int bm_dev_memset(void *dst_dev, int value, size_t bytes);
+
+/* ------------------------------------------------------------------- RBM */
+typedef struct bm_rbm bm_rbm;
+
+enum { BM_UNIT_BERNOULLI = 0, BM_UNIT_GAUSSIAN = 1 };
+
+/* ctor kwargs of BaseRBM.__init__ that influence the device graph
+ * (rbm/base_rbm.py:95-105, :244-327). */
+typedef struct bm_rbm_config {
+    int32_t n_visible;
+    int32_t n_hidden;
+    int32_t v_unit;            /* BM_UNIT_*: BernoulliRBM / GaussianRBM (rbm/rbm.py:10-15,88-99) */
+    int32_t sample_v_states;   /* base_rbm.py:100 */
+    int32_t sample_h_states;   /* base_rbm.py:100 */
+    int32_t dbm_first;         /* propup multiplier 1+dbm_first (base_rbm.py:256-260) */
+    int32_t dbm_last;          /* propdown multiplier 1+dbm_last (base_rbm.py:261-262) */
+    int32_t max_batch;         /* largest minibatch the workspaces must hold */
+    float   l2;                /* base_rbm.py:249 */
+    float   sparsity_target;   /* base_rbm.py:253-255 */
+    float   sparsity_cost;
+    float   sparsity_damping;
+    float   dropout;           /* keep-prob of tf.nn.dropout; <0 => no dropout (base_rbm.py:417-418) */
+} bm_rbm_config;
+
+int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out);
+int bm_rbm_destroy(bm_rbm *h);
+int bm_rbm_sync(bm_rbm *h);
+
+/* Variables of the TF graph by name (tf_model.py:183-202 get_tf_params; Saver
+ * restore tf_model.py:22-28): "W" [V*H], "vb" [V], "hb" [H], "dW", "dvb",
+ * "dhb", "q_means" [H], "sigma" [V].  n = number of floats. */
+int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n);
+int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n);
+/* device pointer of a variable / workspace for zero-copy interop (RCCL):
+ * the variables above plus "grad" (fused [V*H + V + H + H] raw-sum buffer). */
+int bm_rbm_dev_ptr(bm_rbm *h, const char *name, void **out_dev, size_t *out_n);
+
+/* Replaces tf.set_random_seed(model.make_random_seed()) done by the
+ * run_in_tf_session decorator on every public call (tf_model.py:20-21).
+ * Sets the Philox key and resets the per-handle call counter to 0.
+ * Stream convention: DESIGN.md "RNG". */
+int bm_rbm_seed(bm_rbm *h, uint64_t seed);
+/* global index of local row 0 (data-parallel: rank*local_batch); sample
+ * bitmaps depend on the GLOBAL row so they are rank-count invariant. */
+int bm_rbm_set_row_offset(bm_rbm *h, int64_t row0);
+
+/* One CD-k update: session.run(train_op, feed_dict) at base_rbm.py:566
+ * (graph: base_rbm.py:415-479).  X_dev [B, n_visible] row-major. */
+int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B,
+                      float learning_rate, float momentum, int32_t n_gibbs_steps);
+/* Same update, but the metric ops are fetched from the SAME chain in the same
+ * run, as the reference does every `train_metrics_every_iter` iterations
+ * (base_rbm.py:554-564).  out4 as in bm_rbm_metrics (computed before the update). */
+int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B,
+                              float learning_rate, float momentum, int32_t n_gibbs_steps,
+                              float *out4);
+/* The `for X_batch in batch_iter(X, batch_size)` loop of _train_epoch
+ * (base_rbm.py:549-571) run device-side without host round trips:
+ * N rows, consecutive batches of `batch` rows (last one may be short). */
+int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
+                       float learning_rate, float momentum, int32_t n_gibbs_steps);
+
+/* Data-parallel split of a train step: phase 1 runs the chain and
+ * leaves the raw un-normalised sums in the "grad" buffer
+ * [pos-neg (V*H) | sum(X-v) (V) | sum(h0-hk) (H) | sum(hk) (H)]; the caller
+ * all-reduces that buffer (RCCL) and calls phase 2 with the GLOBAL batch. */
+int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B_local, int32_t n_gibbs_steps);
+int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float learning_rate, float momentum);
+
+/* transform_op.eval at base_rbm.py:697: h_means at the END of the k-step
+ * chain (base_rbm.py:426,438-440).  H_dev [B, n_hidden]. */
+int bm_rbm_transform(bm_rbm *h, const float *X_dev, int32_t B, int32_t n_gibbs_steps,
+                     float *H_dev);
+
+/* Metric fetches of base_rbm.py:554-564,578,605,612: out[0]=msre (:486-488),
+ * out[1]=pll (:496-513), out[2]=l2_loss (:482-484), out[3]=free_energy
+ * (:516-517; rbm.py:17-22 / :109-116).  Runs the same chain as train_step
+ * without updating parameters.  `out` is host memory (4 floats). */
+int bm_rbm_metrics(bm_rbm *h, const float *X_dev, int32_t B, int32_t n_gibbs_steps,
+                   float *out4);
+/* batch-mean free energy only (free_energy_op, base_rbm.py:516-517). */
+int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1);
+
+/* Pure block-Gibbs sampling sweep (R5/R6 of SURVEY §8a; base_rbm.py:367-413):
+ * n_steps of h->v->h starting from hidden states H_dev [B, n_hidden] (in/out);
+ * V_dev [B, n_visible] receives the last visible states.  No parameter update. */
+int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_steps);
+
+/* HIP-event timer on the handle's stream (bench.py roofline leg). */
+int bm_rbm_timer_start(bm_rbm *h);
+int bm_rbm_timer_stop(bm_rbm *h, float *out_ms);
+
+/* ------------------------------------------------------------------- DBM */
+typedef struct bm_dbm bm_dbm;
+
+#define BM_DBM_MAX_LAYERS 4
+
+/* ctor kwargs of DBM.__init__ (dbm.py:89-99) + layer sizes (dbm.py:207-231). */
+typedef struct bm_dbm_config {
+    int32_t n_layers;                       /* number of hidden layers */
+    int32_t n_visible;
+    int32_t n_hiddens[BM_DBM_MAX_LAYERS];
+    int32_t v_unit;                         /* BM_UNIT_* of the visible layer */
+    int32_t sample_v_states;
+    int32_t sample_h_states[BM_DBM_MAX_LAYERS];
+    int32_t n_particles;                    /* M (dbm.py:254-255) */
+    int32_t batch_size;                     /* N; mu variables are [batch_size, n_i] (dbm.py:345-348) */
+    int32_t max_mf_updates;
+    float   mf_tol;
+    float   l2;
+    float   max_norm;                       /* +inf => off (dbm.py:511-513) */
+    float   sparsity_target[BM_DBM_MAX_LAYERS];
+    float   sparsity_cost[BM_DBM_MAX_LAYERS];
+    float   sparsity_damping;
+} bm_dbm_config;
+
+int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out);
+int bm_dbm_destroy(bm_dbm *h);
+int bm_dbm_sync(bm_dbm *h);
+int bm_dbm_seed(bm_dbm *h, uint64_t seed);
+int bm_dbm_set_row_offset(bm_dbm *h, int64_t row0, int64_t particle0);
+
+/* names: "W","W_1",.. "hb","hb_1",.. "vb", "dW*","dhb*","dvb", "mu*","q_means*",
+ * "mu_means*", "v" (particles [M,V]), "h","h_1",.. ([M,n_i]), "sigma"
+ * (get_tf_params naming, examples/dbm_mnist.py:367-371). */
+int bm_dbm_set_param(bm_dbm *h, const char *name, const float *host, size_t n);
+int bm_dbm_get_param(bm_dbm *h, const char *name, float *host, size_t n);
+int bm_dbm_dev_ptr(bm_dbm *h, const char *name, void **out_dev, size_t *out_n);
+
+/* session.run(train_op) at dbm.py:805 (graph dbm.py:515-621): mean-field on
+ * X_dev [batch_size, V], n_gibbs_steps PCD sweeps on the particles, gradient
+ * + sparsity + momentum + max-norm update.  out_n_mf (host, may be NULL)
+ * receives the executed mean-field sweeps (n_mf_updates, dbm.py:631);
+ * out_msre (host, may be NULL) the reconstruction msre (dbm.py:625-630). */
+int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float learning_rate, float momentum,
+                      int32_t n_gibbs_steps, int32_t *out_n_mf, float *out_msre);
+/* data-parallel halves, as for the RBM */
+int bm_dbm_grad_step(bm_dbm *h, const float *X_dev, int32_t n_gibbs_steps, int32_t *out_n_mf);
+int bm_dbm_apply_step(bm_dbm *h, int32_t N_global, int32_t M_global,
+                      float learning_rate, float momentum);
+
+/* _make_mf (dbm.py:429-478) on X_dev [batch_size, V]; leaves mu in the
+ * handle; copies the top layer's mu to MU_top_dev if non-NULL
+ * (transform, dbm.py:859-872). */
+int bm_dbm_mean_field(bm_dbm *h, const float *X_dev, float *MU_top_dev, int32_t *out_n_mf);
+/* reconstruction op (dbm.py:625-633, public dbm.py:874-885): runs MF then
+ * sigma(mu0 W0^T + vb) into R_dev [batch_size, V]. */
+int bm_dbm_reconstruct(bm_dbm *h, const float *X_dev, float *R_dev);
+/* sample_v op (dbm.py:641-648, public :887-897): k PCD sweeps, one mean
+ * sweep, v <- v_means; copies v to V_dev [M, V] if non-NULL. */
+int bm_dbm_sample_v(bm_dbm *h, int32_t n_gibbs_steps, float *V_dev);
+/* AIS (dbm.py:650-736; public log_Z :899-939) for the 2-layer Bernoulli
+ * DBM: n_runs chains, n_betas temperatures, n_gibbs_steps transitions per
+ * temperature.  values_host [n_runs] receives the per-chain log Z estimates
+ * (host post-processing with log_mean_exp stays in Python, dbm.py:935-939).
+ * chain0 = global index of this rank's first chain (chains shard over ranks). */
+int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t n_gibbs_steps,
+               uint64_t seed, int64_t chain0, float *values_host);
+/* log_proba op (dbm.py:738-759): MF then -E_q[E] + H(mu) per row of
+ * X_dev [batch_size, V] into out_host [batch_size] (log Z is subtracted by
+ * the Python caller, dbm.py:955-956). */
+int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host);
+
+int bm_dbm_timer_start(bm_dbm *h);
+int bm_dbm_timer_stop(bm_dbm *h, float *out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BM355_H */

@@ -1,0 +1,141 @@
+"""-m gpu parity tests proper: HIP path (through the C-ABI) vs the CPU oracle on
+identical seeds/inputs.  Bar: BIT-EXACT parameters, probabilities and sample
+bitmaps (the kernels reproduce the oracle's canonical summation order); metrics
+(free energy, PLL, msre) within 1e-5 relative (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from tests.helpers import assert_state_equal, make_pair, synth_data
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # V, H, B, k, kwargs
+    (12, 8, 16, 1, dict(sample_v_states=True, sample_h_states=True, dropout=0.9)),        # reference test shape
+    (12, 8, 5, 3, dict(sample_v_states=False, sample_h_states=True, sparsity_cost=0.01)),
+    (784, 128, 100, 1, dict(l2=1e-5)),                                                     # BASELINE configs[0]
+    (100, 52, 37, 2, dict(sample_v_states=True, l2=1e-3, sparsity_cost=1e-3)),             # ragged tiles
+    (37, 23, 19, 2, dict(sample_v_states=True, dbm_first=True)),                           # cols % 4 != 0 (generic RNG path)
+    (64, 96, 33, 1, dict(dbm_last=True, sample_h_states=False)),
+    (784, 1024, 512, 1, dict(l2=1e-5, sample_v_states=True)),                              # north-star shape
+]
+
+
+@pytest.mark.parametrize('V,H,B,k,kw', CASES)
+def test_train_steps_bit_exact(gpu_lib, V, H, B, k, kw):
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, H, max_batch=B, **kw)
+    eng.seed(1337); twin.set_seed(1337)
+    nsteps = 3 if V * H < 200000 else 2
+    for s in range(nsteps):
+        X = synth_data(B, V, s)
+        Xd = as_device(X)
+        eng.train_step(Xd, B, 0.05, 0.9, k)
+        twin.train_step(X, 0.05, 0.9, k)
+        assert_state_equal(eng, twin)
+    eng.close()
+
+
+@pytest.mark.parametrize('V,H,B,k,kw', CASES[:6])
+def test_transform_bit_exact(gpu_lib, V, H, B, k, kw):
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, H, max_batch=B, **kw)
+    eng.seed(7); twin.set_seed(7)
+    X = synth_data(B, V, 3)
+    Hd = DeviceArray((B, H))
+    eng.transform(as_device(X), B, k, Hd)
+    eng.sync()
+    g = Hd.numpy()
+    c = twin.transform(X, k)
+    assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
+    eng.close()
+
+
+def test_gaussian_visible(gpu_lib):
+    """GaussianRBM (rbm.py:88-116): means bit-exact without v sampling; with Normal
+    sampling the draw uses device logf/sincosf, so states are checked to 1e-5."""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B = 48, 40, 21
+    sig = np.linspace(0.5, 1.5, V).astype(np.float32)
+    eng, twin = make_pair(V, H, max_batch=B, v_unit=1, sample_v_states=False, l2=1e-3)
+    eng.set('sigma', sig); twin.p['sigma'][...] = sig
+    eng.seed(3); twin.set_seed(3)
+    for s in range(2):
+        X = synth_data(B, V, s, gaussian=True)
+        eng.train_step(as_device(X), B, 1e-3, 0.9, 2)
+        twin.train_step(X, 1e-3, 0.9, 2)
+        assert_state_equal(eng, twin)
+    eng.close()
+    eng, twin = make_pair(V, H, max_batch=B, v_unit=1, sample_v_states=True, l2=1e-3)
+    eng.seed(3); twin.set_seed(3)
+    X = synth_data(B, V, 5, gaussian=True)
+    eng.train_step(as_device(X), B, 1e-3, 0.9, 1)
+    twin.train_step(X, 1e-3, 0.9, 1)
+    for n in ('W', 'vb', 'hb'):
+        np.testing.assert_allclose(eng.get(n), twin.p[n], rtol=1e-5, atol=1e-7)
+    eng.close()
+
+
+@pytest.mark.parametrize('V,H,B,k,kw', [CASES[0], CASES[2], CASES[3]])
+def test_metrics(gpu_lib, V, H, B, k, kw):
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, H, max_batch=B, **kw)
+    eng.seed(99); twin.set_seed(99)
+    X = synth_data(B, V, 1)
+    g = eng.metrics(as_device(X), B, k)
+    c, _ = twin.metrics(X, k)
+    np.testing.assert_allclose(g, c, rtol=1e-5, atol=1e-6)
+    fe = eng.free_energy(as_device(X), B)
+    np.testing.assert_allclose(fe, twin.free_energy(X), rtol=1e-5)
+    eng.close()
+
+
+def test_split_step_matches_fused(gpu_lib):
+    """grad_step + apply_step (the data-parallel halves) == fused train_step, bitwise."""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B = 100, 52, 37
+    kw = dict(sample_v_states=True, l2=1e-3, sparsity_cost=1e-3)
+    e1, twin = make_pair(V, H, max_batch=B, **kw)
+    e2, _ = make_pair(V, H, max_batch=B, **kw)
+    e1.seed(5); e2.seed(5)
+    for s in range(2):
+        Xd = as_device(synth_data(B, V, s))
+        e1.train_step(Xd, B, 0.05, 0.9, 1)
+        e2.grad_step(Xd, B, 1)
+        e2.apply_step(B, 0.05, 0.9)
+    for n in ('W', 'vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means'):
+        assert np.array_equal(e1.get(n).view(np.uint32), e2.get(n).view(np.uint32)), n
+    e1.close(); e2.close()
+
+
+def test_gibbs_sweep_bit_exact(gpu_lib):
+    from boltzmann_machines_amd._ffi import DeviceArray
+    V, H, B = 784, 128, 64
+    eng, twin = make_pair(V, H, max_batch=B, sample_v_states=True)
+    eng.seed(11); twin.set_seed(11)
+    H0 = synth_data(B, H, 9)
+    Hd = DeviceArray.from_numpy(H0)
+    Vd = DeviceArray((B, V))
+    eng.gibbs(Hd, Vd, B, 4)
+    eng.sync()
+    Hc, Vc = twin.gibbs(H0, 4)
+    assert np.array_equal(Hd.numpy(), Hc)
+    assert np.array_equal(Vd.numpy(), Vc)
+    eng.close()
+
+
+def test_errors(gpu_lib):
+    from boltzmann_machines_amd._ffi import Bm355Error
+    from boltzmann_machines_amd.engine import RbmEngine, as_device
+    eng = RbmEngine(8, 4, max_batch=4)
+    with pytest.raises(Bm355Error):
+        eng.train_step(as_device(np.zeros((8, 8), np.float32)), 8, 0.1, 0.5, 1)   # B > max_batch
+    with pytest.raises(Bm355Error):
+        import ctypes as C
+        from boltzmann_machines_amd._ffi import check
+        buf = (C.c_float * 4)()
+        check(eng.lib.bm_rbm_get_param(eng._h, b'nope', buf, 4))          # unknown variable
+    with pytest.raises(Bm355Error):
+        eng.train_step(as_device(np.zeros((2, 8), np.float32)), 2, 0.1, 0.5, 0)   # k < 1
+    eng.close()
