@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric on MI355X: Gibbs-steps/sec of the CD-k loop,
+784x1024 Bernoulli RBM, batch 512 per GPU, fp32 MFMA.
+
+    python bench.py --gpus N --steps K --warmup W [--k 1] [--no-cpu]
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one CD-k update (base_rbm.py:566 `session.run(train_op)`) of one
+512-row minibatch per GPU, already resident in HBM = k Gibbs steps.
+N > 1 is data-parallel, weak scaling (512 rows per GPU): each rank runs the
+chain + raw outer products on its rows, ONE RCCL all-reduce(sum) of the fused
+[dW|dvb|dhb|q] buffer over xGMI, then every rank applies the identical update.
+value = N * k * K / t  (512-row Gibbs steps per second, whole job).
+
+The JSON line also carries
+  roofline     : fp32-MFMA roofline of the CD-k update.  achieved = algorithmic
+                 GEMM flops (2k+3)*2*B*V*H per update / HIP-event time of the
+                 update's kernels on the engine stream; `kernels` holds the
+                 per-kernel-class durations from a second, event-instrumented pass.
+  cpu_baseline : the CPU oracle (restatement of the reference maths, NOT TF1
+                 itself) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V, H, B = 784, 1024, 512
+LR, MOM, L2 = 0.05, 0.9, 1e-5            # examples/rbm_mnist.py:160,166,55
+PEAK_FP32_MFMA = 157.3                    # TFLOP/s, MI355X_MICROARCH.md
+N_BATCHES = 20                            # synthetic batches resident in HBM, cycled
+
+
+def synth(seed, rows):
+    from boltzmann_machines_amd.utils import philox
+    u = philox.uniform(87654321, 42 + seed, 0, rows * V).reshape(rows, V)
+    X = (u < 0.1307).astype(np.float32)   # MNIST mean intensity; MNIST itself is not available offline
+    W = philox.tf_random_normal((V, H), 0.01, 1337)     # reference W_init (base_rbm.py:277-279)
+    return X, W
+
+
+def cpu_baseline(k, budget_s=15.0):
+    from oracle import oracle as orc
+    X, W = synth(0, B)
+    twin = orc.OracleRBM(V, H, l2=L2, sample_v_states=True)
+    twin.p['W'][...] = W
+    twin.set_seed(1337)
+    twin.train_step(X, LR, MOM, k)        # warm-up (thread pool, page faults)
+    n, t0 = 0, time.time()
+    while time.time() - t0 < budget_s:
+        twin.train_step(X, LR, MOM, k)
+        n += 1
+    dt = time.time() - t0
+    cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
+    return {'value': round(n * k / dt, 3), 'unit': 'Gibbs-steps/s (512-row)', 'cores': cores, 'kind': 'port',
+            'sample': '%d CD-%d updates of the same 784x1024 batch-512 workload, %.1f s, OpenMP C oracle '
+                      '(oracle/bm_oracle.c, restatement of base_rbm.py:415-479; TF1.3 cannot run here)' % (n, k, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--k', type=int, default=1, help='n_gibbs_steps of CD-k')
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)'
+                         % (args.gpus, world))
+
+    import torch
+    from boltzmann_machines_amd import _ffi
+    from boltzmann_machines_amd.engine import RbmEngine, as_device
+    lib = _ffi.load()
+    if lib.bm_device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    _ffi.check(lib.bm_set_device(local_rank))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    k = args.k
+    X, W = synth(rank, B * N_BATCHES)
+    eng = RbmEngine(V, H, max_batch=B, l2=L2, sample_v_states=True, sample_h_states=True)
+    eng.set('W', W)
+    eng.seed(1337)
+    eng.set_row_offset(rank * B)
+    Xd = as_device(X)
+
+    if world > 1:
+        ext = torch.cuda.ExternalStream(eng.stream(), device=torch.device('cuda', local_rank))
+        gbuf = torch.as_tensor(eng.device_view('grad'), device=torch.device('cuda', local_rank))
+
+        def step(i):
+            eng.grad_step(Xd, B, k, row=(i % N_BATCHES) * B)
+            with torch.cuda.stream(ext):
+                dist.all_reduce(gbuf)                      # RCCL sum over xGMI, same HIP stream
+            eng.apply_step(B * world, LR, MOM)
+    else:
+        def step(i):
+            eng.train_step(Xd, B, LR, MOM, k, row=(i % N_BATCHES) * B)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for i in range(args.steps):
+        step(i)
+    ev_ms = eng.timer_stop()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # second, instrumented pass: per-kernel-class durations (HIP events on the engine stream)
+    kern = {}
+    if rank == 0:
+        n_prof = min(args.steps, 200)
+        eng.profile(True)
+        if world == 1:
+            for i in range(n_prof):
+                step(i)
+        else:   # kernels only (no collective) so that other ranks need not participate
+            for i in range(n_prof):
+                eng.grad_step(Xd, B, k, row=(i % N_BATCHES) * B)
+                eng.apply_step(B * world, LR, MOM)
+        kt = eng.kernel_times()
+        eng.profile(False)
+        kern = {name: {'avg_us': round(1e3 * ms / n, 3), 'launches_per_step': n // n_prof}
+                for name, (ms, n) in kt.items() if n}
+    barrier()
+
+    if rank == 0:
+        F = 2.0 * B * V * H
+        flops_update = (2 * k + 3) * F
+        ms_step = 1e3 * dt / args.steps
+        achieved = flops_update / (ev_ms / args.steps * 1e-3) / 1e12
+        # dominant kernel = prop-up act_kernel (k+1 launches per update): its own roofline point
+        up_us = kern.get('act_up', {}).get('avg_us')
+        out = {
+            'metric': 'Gibbs-steps/sec (CD-k, 784x1024 RBM, batch 512)',
+            'value': round(world * k * args.steps / dt, 2),
+            'unit': 'Gibbs-steps/s (512-row block sweeps h->v->h incl. CD-%d update)' % k,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_step, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BernoulliRBM 784x1024 CD-%d batch=512 fp32 (BASELINE configs[1])' % k,
+                       'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
+                       'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
+                       'parallelism': 'dp%d' % world},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4), 'traffic': None,
+                         'scope': 'whole CD-%d update = (2k+3)*2*B*V*H = %.3f GFLOP per launch sequence, '
+                                  'HIP events on the engine stream over the timed region' % (k, flops_update / 1e9),
+                         'dominant_kernel': 'act_kernel<KM,XM> (prop-up GEMM + sigmoid + Philox)',
+                         'dominant_kernel_tflops': round(F / (up_us * 1e-6) / 1e12, 3) if up_us else None,
+                         'kernels': kern},
+        }
+        if not args.no_cpu and world == 1:
+            out['cpu_baseline'] = cpu_baseline(k)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -67,6 +67,9 @@ SIGNATURES = {
     'bm_rbm_metrics': [_vp, _vp, _i32, _i32, _fp],
     'bm_rbm_free_energy': [_vp, _vp, _i32, _fp],
     'bm_rbm_gibbs': [_vp, _vp, _vp, _i32, _i32],
+    'bm_rbm_stream': [_vp, C.POINTER(_vp)],
+    'bm_rbm_profile': [_vp, _i32],
+    'bm_rbm_kernel_times': [_vp, _fp, _ip],
     'bm_rbm_timer_start': [_vp],
     'bm_rbm_timer_stop': [_vp, _fp],
     'bm_dbm_create': [C.POINTER(DbmConfig), C.POINTER(_vp)],

@@ -34,7 +34,51 @@ struct ActArgs {
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
 };
 
-template <int PL1, int QL1, bool SEG2>
+// draw for 4 consecutive outputs starting at flat index `flat` (multiple of 4 on the fast path)
+__device__ __forceinline__ void draw4(const ActArgs &a, unsigned long long flat, int ib, int nvalid,
+                                      const float *m, float *s, bool aligned) {
+    if (aligned) {                  // the 4 outputs are exactly one Philox block
+        uint32_t wds[4];
+        philox_block(a.key, flat >> 2, wds);
+        if (a.kind == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = (u32_to_uniform(wds[r]) < m[r]) ? 1.f : 0.f;
+        } else {
+            float n[4];
+            box_muller(wds[0], wds[1], n[0], n[1]);
+            box_muller(wds[2], wds[3], n[2], n[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] = n[r] * a.sigma[ib + r] + m[r];
+        }
+    } else {                        // generic path (I % 4 != 0 or ragged edge): per element
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nvalid) break;
+            const unsigned long long idx = flat + r;
+            uint32_t wds[4];
+            philox_block(a.key, idx >> 2, wds);
+            if (a.kind == 0) {
+                s[r] = (u32_to_uniform(wds[idx & 3]) < m[r]) ? 1.f : 0.f;
+            } else {
+                float n0, n1;
+                const int pr = (int)(idx & 3) >> 1;
+                box_muller(wds[2 * pr], wds[2 * pr + 1], n0, n1);
+                s[r] = ((idx & 1) ? n1 : n0) * a.sigma[ib + r] + m[r];
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int nvalid, bool v4) {
+    if (v4) {
+        *reinterpret_cast<float4 *>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (r < nvalid) dst[o + r] = v[r];
+    }
+}
+
+template <bool SEG2, bool FAST>
 __global__ __launch_bounds__(NT) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const int tiles_j = (a.J + TJ - 1) / TJ;
@@ -45,82 +89,46 @@ __global__ __launch_bounds__(NT) void act_kernel(ActArgs a) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<PL1, QL1>(acc, a.P1, a.Q1, a.K1, i0, j0, smem);
-    if (SEG2) mainloop<XM, XM>(acc, a.P2, a.Q2, a.K2, i0, j0, smem);
+    mainloop<XM, FAST>(acc, a.P1, a.Q1, a.K1, i0, j0, smem);
+    if (SEG2) mainloop<XM, FAST>(acc, a.P2, a.Q2, a.K2, i0, j0, smem);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
     const int j = j0 + wj * 16 + l15;
+    const int ib0 = i0 + wi * 32 + g * 8;          // 8 consecutive outputs i = ib0 + e
+    float z[8];
+    lane_outputs(acc, z);
     float dmax = 0.f;
+    if (j < a.J && ib0 < a.I) {
+        const bool al_out = ((a.ldo & 3) == 0);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ib = i0 + wi * 32 + t * 16 + g * 4;
-        if (j >= a.J || ib >= a.I) continue;
-        float m[4], s[4];
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int ib = ib0 + 4 * hlf;
+            if (ib >= a.I) break;
+            const int nvalid = (a.I - ib < 4) ? a.I - ib : 4;
+            float m[4], s[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = (ib + r < a.I) ? ib + r : a.I - 1;
-            const float x = a.mult * acc[t][r];
-            const float b = a.mult * a.bias[i];
-            m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * a.sigma[i] + b);
-            s[r] = m[r];
-        }
-        if (a.sample) {
-            const unsigned long long flat = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib;
-            if ((a.I & 3) == 0) {       // fast path: the lane's 4 outputs are exactly one Philox block
-                uint32_t wds[4];
-                philox_block(a.key, flat >> 2, wds);
-                if (a.kind == 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r] = (u32_to_uniform(wds[r]) < m[r]) ? 1.f : 0.f;
-                } else {
-                    float n[4];
-                    box_muller(wds[0], wds[1], n[0], n[1]);
-                    box_muller(wds[2], wds[3], n[2], n[3]);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r] = n[r] * a.sigma[ib + r] + m[r];
-                }
-            } else {                    // generic path: per element
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ib + r >= a.I) break;
-                    const unsigned long long idx = flat + r;
-                    uint32_t wds[4];
-                    philox_block(a.key, idx >> 2, wds);
-                    if (a.kind == 0) {
-                        s[r] = (u32_to_uniform(wds[idx & 3]) < m[r]) ? 1.f : 0.f;
-                    } else {
-                        float n0, n1;
-                        const int pr = (int)(idx & 3) >> 1;
-                        box_muller(wds[2 * pr], wds[2 * pr + 1], n0, n1);
-                        s[r] = ((idx & 1) ? n1 : n0) * a.sigma[ib + r] + m[r];
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int i = (r < nvalid) ? ib + r : a.I - 1;
+                const float x = a.mult * z[4 * hlf + r];
+                const float b = a.mult * a.bias[i];
+                m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+                s[r] = m[r];
             }
-        }
-        const size_t o = (size_t)j * a.ldo + ib;
-        if (a.prev) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ib + r < a.I) dmax = fmaxf(dmax, fabsf(m[r] - a.prev[o + r]));
-        }
-        const bool v4 = ((a.ldo & 3) == 0) && (ib + 3 < a.I);
-        if (a.means) {
-            if (v4 && (((uintptr_t)a.means & 15u) == 0)) {
-                *reinterpret_cast<float4 *>(a.means + o) = make_float4(m[0], m[1], m[2], m[3]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (ib + r < a.I) a.means[o + r] = m[r];
+            if (a.sample) {
+                const unsigned long long flat = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib;
+                draw4(a, flat, ib, nvalid, m, s, ((a.I & 3) == 0));
             }
-        }
-        if (a.states) {
-            if (v4 && (((uintptr_t)a.states & 15u) == 0)) {
-                *reinterpret_cast<float4 *>(a.states + o) = make_float4(s[0], s[1], s[2], s[3]);
-            } else {
+            const size_t o = (size_t)j * a.ldo + ib;
+            if (a.prev) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (ib + r < a.I) a.states[o + r] = s[r];
+                for (int r = 0; r < 4; ++r)
+                    if (r < nvalid) dmax = fmaxf(dmax, fabsf(m[r] - a.prev[o + r]));
             }
+            const bool v4 = al_out && nvalid == 4;
+            if (a.means) store4(a.means, o, m, nvalid, v4 && (((uintptr_t)a.means & 15u) == 0));
+            if (a.states) store4(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
         }
     }
     if (a.maxdiff) {
@@ -140,7 +148,9 @@ struct GradArgs {
     int fused;                        // 1: apply the update in the epilogue; 0: write raw sums to `raw`
     float *raw;                       // [J][I] raw pos-neg (form 0) ; for form 1: raw pos at raw, raw neg at raw2
     float *raw2;
-    float *W, *dW;                    // [J][I]
+    float *W, *dW;                    // [J][I], pitch ldw (raw/raw2 share it)
+    float *Wt;                        // [I][J] transpose of W kept in sync (or null), pitch ldwt
+    int ldw, ldwt;
     const float *pen;                 // [I] sparsity penalty (already cost*(q-target) [+ mu term]) or null
     float N, M, l2, lr, mom;
 };
@@ -155,6 +165,7 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
     w = w + d;                     // W.assign_add               (base_rbm.py:468)
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(NT) void grad_kernel(GradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const int tiles_j = (a.J + TJ - 1) / TJ;
@@ -164,37 +175,36 @@ __global__ __launch_bounds__(NT) void grad_kernel(GradArgs a) {
 
     f32x4 pos[2], neg[2];
     pos[0] = pos[1] = neg[0] = neg[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<KM, KM>(pos, a.Ppos, a.Qpos, a.Kpos, i0, j0, smem);
-    mainloop<KM, KM>(neg, a.Pneg, a.Qneg, a.Kneg, i0, j0, smem);
+    mainloop<KM, FAST>(pos, a.Ppos, a.Qpos, a.Kpos, i0, j0, smem);
+    mainloop<KM, FAST>(neg, a.Pneg, a.Qneg, a.Kneg, i0, j0, smem);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
     const int j = j0 + wj * 16 + l15;
-    if (j >= a.J) return;
+    const int ib0 = i0 + wi * 32 + g * 8;
+    if (j >= a.J || ib0 >= a.I) return;
+    float pv[8], nv[8];
+    lane_outputs(pos, pv);
+    lane_outputs(neg, nv);
+    const size_t o = (size_t)j * a.ldw + ib0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int ib = i0 + wi * 32 + t * 16 + g * 4;
-        if (ib >= a.I) continue;
-        const size_t o = (size_t)j * a.I + ib;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (ib + r >= a.I) break;
-            if (!a.fused) {
-                if (a.form == 0) {
-                    a.raw[o + r] = pos[t][r] - neg[t][r];
-                } else {
-                    a.raw[o + r] = pos[t][r];
-                    a.raw2[o + r] = neg[t][r];
-                }
+    for (int e = 0; e < 8; ++e) {
+        if (ib0 + e >= a.I) break;
+        if (!a.fused) {
+            if (a.form == 0) {
+                a.raw[o + e] = pv[e] - nv[e];
             } else {
-                const float gr = (a.form == 0) ? (pos[t][r] - neg[t][r]) / a.N
-                                               : (pos[t][r] / a.N - neg[t][r] / a.M);
-                float wv = a.W[o + r], dv = a.dW[o + r];
-                apply_w_update(gr, a.pen ? a.pen[ib + r] : 0.f, a.l2, a.lr, a.mom, wv, dv);
-                a.W[o + r] = wv;
-                a.dW[o + r] = dv;
+                a.raw[o + e] = pv[e];
+                a.raw2[o + e] = nv[e];
             }
+        } else {
+            const float gr = (a.form == 0) ? (pv[e] - nv[e]) / a.N : (pv[e] / a.N - nv[e] / a.M);
+            float wv = a.W[o + e], dv = a.dW[o + e];
+            apply_w_update(gr, a.pen ? a.pen[ib0 + e] : 0.f, a.l2, a.lr, a.mom, wv, dv);
+            a.W[o + e] = wv;
+            a.dW[o + e] = dv;
+            if (a.Wt) a.Wt[(size_t)(ib0 + e) * a.ldwt + j] = wv;     // maintained transpose (prop-down P operand)
         }
     }
 }
@@ -202,20 +212,23 @@ __global__ __launch_bounds__(NT) void grad_kernel(GradArgs a) {
 // split path: W update from (all-reduced) raw sums
 struct ApplyWArgs {
     const float *raw, *raw2;
-    float *W, *dW;
+    float *W, *dW, *Wt;
     const float *pen;
-    int I; size_t n;
+    int I, J, ldw, ldwt;
     int form;
     float N, M, l2, lr, mom;
 };
 __global__ void apply_w_kernel(ApplyWArgs a) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < a.n; e += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e % (size_t)a.I);
-        const float gr = (a.form == 0) ? a.raw[e] / a.N : (a.raw[e] / a.N - a.raw2[e] / a.M);
-        float wv = a.W[e], dv = a.dW[e];
+    const size_t n = (size_t)a.I * a.J;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e % (size_t)a.I), j = (int)(e / (size_t)a.I);
+        const size_t o = (size_t)j * a.ldw + i;
+        const float gr = (a.form == 0) ? a.raw[o] / a.N : (a.raw[o] / a.N - a.raw2[o] / a.M);
+        float wv = a.W[o], dv = a.dW[o];
         apply_w_update(gr, a.pen ? a.pen[i] : 0.f, a.l2, a.lr, a.mom, wv, dv);
-        a.W[e] = wv;
-        a.dW[e] = dv;
+        a.W[o] = wv;
+        a.dW[o] = dv;
+        if (a.Wt) a.Wt[(size_t)i * a.ldwt + j] = wv;
     }
 }
 
@@ -226,7 +239,7 @@ __global__ void apply_w_kernel(ApplyWArgs a) {
 // job: out[c] = sum_b (A[b][c] - Bm[b][c])   (Bm may be null -> plain column sum)
 struct ColSumJob {
     const float *A, *Bm;
-    int ld, ncols, nrows;
+    int lda, ldb, ncols, nrows;
     float *out;
 };
 constexpr int MAX_COLJOBS = 12;
@@ -246,21 +259,21 @@ __global__ __launch_bounds__(64) void colsum_kernel(ColSumArgs a) {
     const int c = c0 + l15;
     const bool cok = c < J.ncols;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 8;
+    constexpr int U = 16;
     for (int k0 = 0; k0 < J.nrows; k0 += 4 * U) {
-        float v[U];
+        float va[U], vb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < U; ++u) {        // branch-free: out-of-range lanes read g_zero16
             const int k = k0 + u * 4 + g;
-            float x = 0.f;
-            if (cok && k < J.nrows) {
-                x = J.A[(size_t)k * J.ld + c];
-                if (J.Bm) x = x - J.Bm[(size_t)k * J.ld + c];
-            }
-            v[u] = x;
+            const bool ok = cok && k < J.nrows;
+            const float *pa = ok ? J.A + (size_t)k * J.lda + c : g_zero16;
+            const float *pb = (ok && J.Bm) ? J.Bm + (size_t)k * J.ldb + c : g_zero16;
+            va[u] = *pa;
+            vb[u] = *pb;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u], 1.0f, acc, 0, 0, 0);
+        for (int u = 0; u < U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[u] - vb[u], 1.0f, acc, 0, 0, 0);
     }
     // lane with l15 == 0 in group g holds columns c0 + g*4 + r
     if (l15 == 0) {
@@ -303,18 +316,33 @@ __global__ void rbm_bias_kernel(RbmBiasArgs a) {
 
 // ----------------------------------------------------------------- elementwise
 // tf.nn.dropout(x, keep): x / keep * floor(keep + u)   (base_rbm.py:417-418)
-__global__ void dropout_kernel(const float *X, float *Y, size_t n, float keep, PhiloxKey key,
-                               unsigned long long flat0) {
+// X [rows][cols] pitch ldx -> Y pitch ldy; RNG index = flat0 + row*cols + col
+__global__ void dropout_kernel(const float *X, int ldx, float *Y, int ldy, int rows, int cols, float keep,
+                               PhiloxKey key, unsigned long long flat0) {
+    const size_t n = (size_t)rows * cols;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
         const float u = philox_uniform_at(key, flat0 + e);
-        Y[e] = (X[e] / keep) * floorf(keep + u);
+        Y[r * ldy + c] = (X[r * ldx + c] / keep) * floorf(keep + u);
     }
 }
 
 // GaussianRBM placeholder: X / sigma (rbm.py:107)
-__global__ void div_cols_kernel(const float *X, const float *sigma, float *Y, size_t n, int ncols) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
-        Y[e] = X[e] / sigma[e % (size_t)ncols];
+__global__ void div_cols_kernel(const float *X, int ldx, const float *sigma, float *Y, int ldy, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
+        Y[r * ldy + c] = X[r * ldx + c] / sigma[c];
+    }
+}
+
+// strided 2-D copy (dense user buffer <-> padded internal matrix)
+__global__ void copy2d_kernel(const float *X, int ldx, float *Y, int ldy, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
+        Y[r * ldy + c] = X[r * ldx + c];
+    }
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -323,11 +351,14 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// sum of (A-B)^2 and of A^2 into double accumulators (msre :486-488; l2 :482-484)
-__global__ void sqdiff_kernel(const float *A, const float *B, size_t n, double *out) {
+// sum of (A-B)^2 (B may be null) over a [rows][cols] window into a double accumulator
+// (msre :486-488; l2 :482-484)
+__global__ void sqdiff_kernel(const float *A, int lda, const float *B, int ldb, int rows, int cols, double *out) {
+    const size_t n = (size_t)rows * cols;
     double s = 0.0;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const float d = B ? (A[e] - B[e]) : A[e];
+        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
+        const float d = B ? (A[r * lda + c] - B[r * ldb + c]) : A[r * lda + c];
         s += (double)d * (double)d;
     }
     s = wave_sum(s);
@@ -346,6 +377,7 @@ struct FeArgs {
     float *rowacc2;          // [J] or null
     const int *flip_col;     // [J] or null
 };
+template <bool FAST>
 __global__ __launch_bounds__(NT) void fe_hidden_kernel(FeArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const int tiles_j = (a.J + TJ - 1) / TJ;
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(NT) void fe_hidden_kernel(FeArgs a) {
     const int i0 = ti * TI, j0 = tj * TJ;
     f32x4 acc[2];
     acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<KM, XM>(acc, a.P, a.Q, a.K, i0, j0, smem);
+    mainloop<XM, FAST>(acc, a.P, a.Q, a.K, i0, j0, smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
@@ -366,17 +398,17 @@ __global__ __launch_bounds__(NT) void fe_hidden_kernel(FeArgs a) {
             fc = a.flip_col[j];
             delta = 1.0f - 2.0f * a.Q.ptr[(size_t)j * a.Q.ld + fc];
         }
+        float zz[8];
+        lane_outputs(acc, zz);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = i0 + wi * 32 + t * 16 + g * 4 + r;
-                if (i < a.I) {
-                    const float z = acc[t][r] + a.hb[i];
-                    s += softplus(z);
-                    if (fc >= 0) s2 += softplus(z + delta * a.P.ptr[(size_t)fc * a.P.ld + i]);
-                }
+        for (int e = 0; e < 8; ++e) {
+            const int i = i0 + wi * 32 + g * 8 + e;
+            if (i < a.I) {
+                const float z = zz[e] + a.hb[i];
+                s += softplus(z);
+                if (fc >= 0) s2 += softplus(z + delta * a.P.ptr[(size_t)fc * a.P.ld + i]);
             }
+        }
     }
     s += __shfl_xor(s, 16);  s += __shfl_xor(s, 32);
     s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
@@ -429,6 +461,38 @@ __global__ void pll_index_kernel(int *out, int B, int V, PhiloxKey key, unsigned
     uint32_t w[4];
     philox_block(key, idx >> 2, w);
     out[b] = (int)(w[idx & 3] % (uint32_t)V);
+}
+
+// ------------------------------------------------------------- host launchers
+static inline int tile_grid(int I, int J) { return ((I + TI - 1) / TI) * ((J + TJ - 1) / TJ); }
+
+static inline void launch_act(const ActArgs &a, hipStream_t st) {
+    const bool seg2 = a.K2 > 0;
+    const bool fast = operand_fast(a.P1, KM, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
+                      (!seg2 || (operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2)));
+    const dim3 grid(tile_grid(a.I, a.J)), blk(NT);
+    if (seg2) {
+        if (fast) hipLaunchKernelGGL((act_kernel<true, true>), grid, blk, 0, st, a);
+        else      hipLaunchKernelGGL((act_kernel<true, false>), grid, blk, 0, st, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((act_kernel<false, true>), grid, blk, 0, st, a);
+        else      hipLaunchKernelGGL((act_kernel<false, false>), grid, blk, 0, st, a);
+    }
+}
+
+static inline void launch_grad(const GradArgs &g, hipStream_t st) {
+    const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
+                      operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
+    const dim3 grid(tile_grid(g.I, g.J)), blk(NT);
+    if (fast) hipLaunchKernelGGL((grad_kernel<true>), grid, blk, 0, st, g);
+    else      hipLaunchKernelGGL((grad_kernel<false>), grid, blk, 0, st, g);
+}
+
+static inline void launch_fe_hidden(const FeArgs &f, hipStream_t st) {
+    const bool fast = operand_fast(f.P, KM, f.K) && operand_fast(f.Q, XM, f.K);
+    const dim3 grid(tile_grid(f.I, f.J)), blk(NT);
+    if (fast) hipLaunchKernelGGL((fe_hidden_kernel<true>), grid, blk, 0, st, f);
+    else      hipLaunchKernelGGL((fe_hidden_kernel<false>), grid, blk, 0, st, f);
 }
 
 }  // namespace bm

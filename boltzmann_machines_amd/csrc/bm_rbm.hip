@@ -32,10 +32,13 @@ struct bm_rbm {
     int V, H, maxB;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::map<std::string, DevBuf *> vars;
-    DevBuf W, vb, hb, dW, dvb, dhb, q, sigma;
-    DevBuf h0m, h0s, vm, vs, hm, hs, Xs, Xd;
-    DevBuf grad;      // [V*H | V | H | H] raw sums
+    // variables (padded pitch, see pad_ld); Wt = W^T kept in sync by every writer of W
+    Mat W, Wt, dW;                     // [V][H], [H][V], [V][H]
+    DevBuf vb, hb, dvb, dhb, q, sigma;
+    // chain workspaces
+    Mat h0m, h0s, hm, hs;              // [maxB][H]
+    Mat vm, vs, Xs, Xd;                // [maxB][V]
+    DevBuf grad;      // [V*ldH | V | H | H] raw sums (the data-parallel all-reduce buffer)
     DevBuf pen;       // [H]
     DevBuf rowacc;    // [2*maxB]
     int *flip = nullptr;
@@ -43,8 +46,28 @@ struct bm_rbm {
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0;
-    // chain results of the last run_chain()
+    // input of the last run_chain() (after /sigma and dropout) and its pitch
     const float *Xin = nullptr;
+    int Xin_ld = 0;
+    // optional per-kernel-class event timing
+    bool prof = false;
+    struct Rec { int cls; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    size_t grad_tail() const { return (size_t)V * W.ld; }
+};
+
+enum { KC_UP = 0, KC_DOWN = 1, KC_GRAD = 2, KC_COLSUM = 3, KC_BIAS = 4, KC_OTHER = 5 };
+
+struct ProfScope {
+    bm_rbm *h; hipEvent_t b = nullptr;
+    ProfScope(bm_rbm *h_, int cls) : h(h_) {
+        if (!h->prof) return;
+        hipEvent_t a;
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, h->stream);
+        h->recs.push_back({cls, a, b});
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, h->stream); }
 };
 
 static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
@@ -56,70 +79,73 @@ static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
     return k;
 }
 
-static inline int grid_for(int I, int J) { return ((I + TI - 1) / TI) * ((J + TJ - 1) / TJ); }
-
-// E[h|v] (+ sample): base_rbm.py:339-351
-static void launch_up(bm_rbm *h, const float *v, int B, float *means, float *states, int sample,
-                      uint32_t site, int t) {
+// E[h|v] (+ sample): base_rbm.py:339-351.  v [B][V] pitch ldv
+static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, float *states, int ldo,
+                      int sample, uint32_t site, int t) {
+    ProfScope _ps(h, KC_UP);
     ActArgs a;
     memset(&a, 0, sizeof(a));
-    a.P1 = make_operand(h->W.p, h->H, h->H);   // W[k=v][i=h], KM
-    a.Q1 = make_operand(v, h->V, B);           // v[j=b][k=v], XM
+    a.P1 = make_operand(h->W.p, h->W.ld, h->H);   // W[k=v][i=h], KM
+    a.Q1 = make_operand(v, ldv, B);               // v[j=b][k=v], XM
     a.K1 = h->V;
     a.I = h->H; a.J = B;
     a.bias = h->hb.p; a.sigma = nullptr;
     a.mult = 1.0f + (h->cfg.dbm_first ? 1.0f : 0.0f);
     a.kind = BM_UNIT_BERNOULLI;
     a.sample = sample;
-    a.means = means; a.states = states; a.ldo = h->H;
+    a.means = means; a.states = states; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
-    hipLaunchKernelGGL((act_kernel<KM, XM, false>), dim3(grid_for(a.I, a.J)), dim3(NT), 0, h->stream, a);
+    launch_act(a, h->stream);
 }
 
-// E[v|h] (+ sample): base_rbm.py:353-365
-static void launch_down(bm_rbm *h, const float *hs, int B, float *means, float *states, int sample,
-                        uint32_t site, int t) {
+// E[v|h] (+ sample): base_rbm.py:353-365.  hs [B][H] pitch ldh
+static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means, float *states, int ldo,
+                        int sample, uint32_t site, int t) {
+    ProfScope _ps(h, KC_DOWN);
     ActArgs a;
     memset(&a, 0, sizeof(a));
-    a.P1 = make_operand(h->W.p, h->H, h->V);   // W[i=v][k=h], XM
-    a.Q1 = make_operand(hs, h->H, B);          // h[j=b][k=h], XM
+    a.P1 = make_operand(h->Wt.p, h->Wt.ld, h->V);  // Wt[k=h][i=v], KM
+    a.Q1 = make_operand(hs, ldh, B);               // h[j=b][k=h], XM
     a.K1 = h->H;
     a.I = h->V; a.J = B;
     a.bias = h->vb.p; a.sigma = h->sigma.p;
     a.mult = 1.0f + (h->cfg.dbm_last ? 1.0f : 0.0f);
     a.kind = h->cfg.v_unit;
     a.sample = sample;
-    a.means = means; a.states = states; a.ldo = h->V;
+    a.means = means; a.states = states; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
-    hipLaunchKernelGGL((act_kernel<XM, XM, false>), dim3(grid_for(a.I, a.J)), dim3(NT), 0, h->stream, a);
+    launch_act(a, h->stream);
 }
 
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426). Leaves
 // h0m/h0s, vm/vs (last step), hm/hs (last step) and Xin in the handle.
-// If hm_out != null the last step's h_means are written there instead of h->hm.
+// If hm_out != null the last step's h_means are written there (dense, pitch H).
 static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
-    const size_t nX = (size_t)B * h->V;
     const float *Xin = X_dev;
+    int ldx = h->V;
     if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {   // rbm.py:107
-        hipLaunchKernelGGL(div_cols_kernel, dim3(256), dim3(256), 0, h->stream, Xin, h->sigma.p, h->Xs.p, nX, h->V);
-        Xin = h->Xs.p;
+        hipLaunchKernelGGL(div_cols_kernel, dim3(256), dim3(256), 0, h->stream, Xin, ldx, h->sigma.p, h->Xs.p,
+                           h->Xs.ld, B, h->V);
+        Xin = h->Xs.p; ldx = h->Xs.ld;
     }
     if (h->cfg.dropout >= 0.f) {               // base_rbm.py:417-418
-        hipLaunchKernelGGL(dropout_kernel, dim3(256), dim3(256), 0, h->stream, Xin, h->Xd.p, nX, h->cfg.dropout,
-                           make_key(h, SITE_DROPOUT, 0), (unsigned long long)h->row0 * (unsigned long long)h->V);
-        Xin = h->Xd.p;
+        hipLaunchKernelGGL(dropout_kernel, dim3(256), dim3(256), 0, h->stream, Xin, ldx, h->Xd.p, h->Xd.ld, B, h->V,
+                           h->cfg.dropout, make_key(h, SITE_DROPOUT, 0),
+                           (unsigned long long)h->row0 * (unsigned long long)h->V);
+        Xin = h->Xd.p; ldx = h->Xd.ld;
     }
-    h->Xin = Xin;
-    launch_up(h, Xin, B, h->h0m.p, h->h0s.p, 1, SITE_H0, 0);                  // :421-422
-    const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;       // :423
-    for (int t = 0; t < k; ++t) {                                             // :367-378
-        launch_down(h, hstate, B, h->vm.p, h->vs.p, h->cfg.sample_v_states, SITE_V, t);
-        float *hm = (hm_out && t == k - 1) ? hm_out : h->hm.p;
-        launch_up(h, h->vs.p, B, hm, h->hs.p, h->cfg.sample_h_states, SITE_H, t);
+    h->Xin = Xin; h->Xin_ld = ldx;
+    launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0);      // :421-422
+    const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
+    for (int t = 0; t < k; ++t) {                                                 // :367-378
+        launch_down(h, hstate, h->hs.ld, B, h->vm.p, h->vs.p, h->vm.ld, h->cfg.sample_v_states, SITE_V, t);
+        const bool last_out = hm_out && t == k - 1;
+        launch_up(h, h->vs.p, h->vs.ld, B, last_out ? hm_out : h->hm.p, h->hs.p, last_out ? h->H : h->hm.ld,
+                  h->cfg.sample_h_states, SITE_H, t);
         hstate = h->hs.p;
     }
     return 0;
@@ -127,21 +153,23 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out)
 
 // raw column sums -> grad tail (base_rbm.py:450-453,457)
 static void launch_colsums(bm_rbm *h, int B) {
+    ProfScope _ps(h, KC_COLSUM);
     ColSumArgs c;
     memset(&c, 0, sizeof(c));
-    float *tail = h->grad.p + (size_t)h->V * h->H;
+    float *tail = h->grad.p + h->grad_tail();
     c.njobs = 3;
-    c.job[0] = ColSumJob{h->Xin, h->vs.p, h->V, h->V, B, tail};                    // sum(X - v_k)
-    c.job[1] = ColSumJob{h->h0m.p, h->hm.p, h->H, h->H, B, tail + h->V};           // sum(h0 - h_k)
-    c.job[2] = ColSumJob{h->hm.p, nullptr, h->H, h->H, B, tail + h->V + h->H};     // sum(h_k)
+    c.job[0] = ColSumJob{h->Xin, h->vs.p, h->Xin_ld, h->vs.ld, h->V, B, tail};                 // sum(X - v_k)
+    c.job[1] = ColSumJob{h->h0m.p, h->hm.p, h->h0m.ld, h->hm.ld, h->H, B, tail + h->V};        // sum(h0 - h_k)
+    c.job[2] = ColSumJob{h->hm.p, nullptr, h->hm.ld, 0, h->H, B, tail + h->V + h->H};          // sum(h_k)
     c.first_wave[0] = 0;
     for (int j = 0; j < c.njobs; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 15) / 16;
     hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[c.njobs]), dim3(64), 0, h->stream, c);
 }
 
 static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
+    ProfScope _ps(h, KC_BIAS);
     RbmBiasArgs b;
-    float *tail = h->grad.p + (size_t)h->V * h->H;
+    float *tail = h->grad.p + h->grad_tail();
     b.sv = tail; b.sh = tail + h->V; b.sq = tail + h->V + h->H;
     b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
     b.V = h->V; b.H = h->H;
@@ -152,51 +180,59 @@ static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
 }
 
 static void launch_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom) {
+    ProfScope _ps(h, KC_GRAD);
     GradArgs g;
     memset(&g, 0, sizeof(g));
-    g.Ppos = make_operand(h->h0m.p, h->H, h->H);   // h0 means [k=b][i=h]           :447
-    g.Qpos = make_operand(h->Xin, h->V, h->V);     // X        [k=b][j=v]
+    g.Ppos = make_operand(h->h0m.p, h->h0m.ld, h->H);   // h0 means [k=b][i=h]           :447
+    g.Qpos = make_operand(h->Xin, h->Xin_ld, h->V);     // X        [k=b][j=v]
     g.Kpos = B;
-    g.Pneg = make_operand(h->hm.p, h->H, h->H);    // h_k means                     :448
-    g.Qneg = make_operand(h->vs.p, h->V, h->V);    // v_k states
+    g.Pneg = make_operand(h->hm.p, h->hm.ld, h->H);     // h_k means                     :448
+    g.Qneg = make_operand(h->vs.p, h->vs.ld, h->V);     // v_k states
     g.Kneg = B;
     g.I = h->H; g.J = h->V;
     g.form = 0; g.fused = fused;
     g.raw = h->grad.p; g.raw2 = nullptr;
-    g.W = h->W.p; g.dW = h->dW.p;
+    g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p;
+    g.ldw = h->W.ld; g.ldwt = h->Wt.ld;
     g.pen = h->pen.p;
     g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
-    hipLaunchKernelGGL(grad_kernel, dim3(grid_for(g.I, g.J)), dim3(NT), 0, h->stream, g);
+    bm::launch_grad(g, h->stream);
+}
+
+static void launch_fe(bm_rbm *h, const float *Xin, int ldx, int B, bool with_flip) {
+    FeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.P = make_operand(h->W.p, h->W.ld, h->H);
+    f.Q = make_operand(Xin, ldx, B);
+    f.K = h->V; f.I = h->H; f.J = B;
+    f.hb = h->hb.p;
+    f.rowacc = h->rowacc.p;
+    if (with_flip) { f.rowacc2 = h->rowacc.p + h->maxB; f.flip_col = h->flip; }
+    launch_fe_hidden(f, h->stream);
+    FeRowArgs r;
+    memset(&r, 0, sizeof(r));
+    r.X = Xin; r.ld = ldx; r.V = h->V; r.B = B;
+    r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
+    r.rowacc = f.rowacc; r.rowacc2 = f.rowacc2; r.flip_col = f.flip_col; r.out = h->scal + 2;
+    hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
 }
 
 // metrics from the chain currently in the handle (base_rbm.py:482-517)
 static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
     BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
     BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 2 * (size_t)h->maxB * sizeof(float), h->stream));
-    const size_t nX = (size_t)B * h->V;
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, h->vm.p, nX, h->scal + 0);     // msre
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->W.p, (const float *)nullptr,
-                       (size_t)h->V * h->H, h->scal + 1);                                                         // l2
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, h->Xin_ld, h->vm.p, h->vm.ld,
+                       B, h->V, h->scal + 0);                                                             // msre
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->W.p, h->W.ld, (const float *)nullptr, 0,
+                       h->V, h->H, h->scal + 1);                                                          // l2
     hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
                        make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
-    FeArgs f;
-    memset(&f, 0, sizeof(f));
-    f.P = make_operand(h->W.p, h->H, h->H);
-    f.Q = make_operand(h->Xin, h->V, B);
-    f.K = h->V; f.I = h->H; f.J = B;
-    f.hb = h->hb.p;
-    f.rowacc = h->rowacc.p; f.rowacc2 = h->rowacc.p + h->maxB; f.flip_col = h->flip;
-    hipLaunchKernelGGL(fe_hidden_kernel, dim3(grid_for(f.I, f.J)), dim3(NT), 0, h->stream, f);
-    FeRowArgs r;
-    r.X = h->Xin; r.ld = h->V; r.V = h->V; r.B = B;
-    r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
-    r.rowacc = f.rowacc; r.rowacc2 = f.rowacc2; r.flip_col = h->flip; r.out = h->scal + 2;
-    hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
+    launch_fe(h, h->Xin, h->Xin_ld, B, true);
     double host[4];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     const double fe = host[2] / B, fe2 = host[3] / B;
-    out4[0] = (float)(host[0] / (double)nX);                    // msre          :487
+    out4[0] = (float)(host[0] / ((double)B * h->V));            // msre          :487
     const float d = (float)(fe2 - fe);                          // pll           :511-512
     const float ls = -(fmaxf(-d, 0.f) + log1pf(expf(-fabsf(d))));
     out4[1] = (float)h->V * ls;
@@ -231,28 +267,24 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     bm_rbm *h = new bm_rbm();
     h->cfg = *cfg;
     h->V = cfg->n_visible; h->H = cfg->n_hidden; h->maxB = cfg->max_batch;
-    const size_t V = h->V, H = h->H, B = h->maxB;
+    const int V = h->V, H = h->H, B = h->maxB;
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipEventCreate(&h->ev0));
     BM_HIP(hipEventCreate(&h->ev1));
-    BM_TRY(h->W.alloc(V * H)); BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H));
-    BM_TRY(h->dW.alloc(V * H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
+    BM_TRY(h->W.alloc(V, H)); BM_TRY(h->Wt.alloc(H, V)); BM_TRY(h->dW.alloc(V, H));
+    BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
     BM_TRY(h->q.alloc(H)); BM_TRY(h->sigma.alloc(V));
-    BM_TRY(h->h0m.alloc(B * H)); BM_TRY(h->h0s.alloc(B * H));
-    BM_TRY(h->hm.alloc(B * H)); BM_TRY(h->hs.alloc(B * H));
-    BM_TRY(h->vm.alloc(B * V)); BM_TRY(h->vs.alloc(B * V));
-    BM_TRY(h->Xs.alloc(B * V)); BM_TRY(h->Xd.alloc(B * V));
-    BM_TRY(h->grad.alloc(V * H + V + 2 * H));
+    BM_TRY(h->h0m.alloc(B, H)); BM_TRY(h->h0s.alloc(B, H)); BM_TRY(h->hm.alloc(B, H)); BM_TRY(h->hs.alloc(B, H));
+    BM_TRY(h->vm.alloc(B, V)); BM_TRY(h->vs.alloc(B, V)); BM_TRY(h->Xs.alloc(B, V)); BM_TRY(h->Xd.alloc(B, V));
+    BM_TRY(h->grad.alloc(h->grad_tail() + V + 2 * (size_t)H));
     BM_TRY(h->pen.alloc(H));
-    BM_TRY(h->rowacc.alloc(2 * B));
+    BM_TRY(h->rowacc.alloc(2 * (size_t)B));
     BM_HIP(hipMalloc((void **)&h->flip, B * sizeof(int)));
     BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
     {   // sigma defaults to 1 (rbm.py:88)
         std::vector<float> ones(V, 1.0f);
         BM_HIP(hipMemcpy(h->sigma.p, ones.data(), V * sizeof(float), hipMemcpyHostToDevice));
     }
-    h->vars = {{"W", &h->W}, {"vb", &h->vb}, {"hb", &h->hb}, {"dW", &h->dW}, {"dvb", &h->dvb},
-               {"dhb", &h->dhb}, {"q_means", &h->q}, {"sigma", &h->sigma}, {"grad", &h->grad}};
     *out = h;
     return 0;
 }
@@ -260,11 +292,13 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
 int bm_rbm_destroy(bm_rbm *h) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->W, &h->vb, &h->hb, &h->dW, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->h0m, &h->h0s,
-                     &h->vm, &h->vs, &h->hm, &h->hs, &h->Xs, &h->Xd, &h->grad, &h->pen, &h->rowacc};
+    Mat *mats[] = {&h->W, &h->Wt, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->vm, &h->vs, &h->Xs, &h->Xd};
+    for (Mat *m : mats) m->release();
+    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->pen, &h->rowacc};
     for (DevBuf *b : all) b->release();
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
+    for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
     (void)hipStreamDestroy(h->stream);
@@ -274,34 +308,56 @@ int bm_rbm_destroy(bm_rbm *h) {
 
 int bm_rbm_sync(bm_rbm *h) { BM_HIP(hipStreamSynchronize(h->stream)); return 0; }
 
-static int find_var(bm_rbm *h, const char *name, DevBuf **out) {
-    auto it = h->vars.find(name ? name : "");
-    BM_CHECK(it != h->vars.end(), "unknown RBM variable '%s'", name ? name : "(null)");
-    *out = it->second;
-    return 0;
+// name -> vector variable
+static DevBuf *find_vec(bm_rbm *h, const std::string &n) {
+    if (n == "vb") return &h->vb;
+    if (n == "hb") return &h->hb;
+    if (n == "dvb") return &h->dvb;
+    if (n == "dhb") return &h->dhb;
+    if (n == "q_means") return &h->q;
+    if (n == "sigma") return &h->sigma;
+    return nullptr;
 }
 
 int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
-    DevBuf *b;
-    BM_TRY(find_var(h, name, &b));
-    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    const std::string nm(name ? name : "");
     BM_HIP(hipStreamSynchronize(h->stream));
+    if (nm == "W" || nm == "dW") {
+        BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
+        BM_TRY((nm == "W" ? h->W : h->dW).upload(host));
+        if (nm == "W") {   // keep the transposed copy in sync
+            std::vector<float> t(n);
+            for (int v = 0; v < h->V; ++v)
+                for (int c = 0; c < h->H; ++c) t[(size_t)c * h->V + v] = host[(size_t)v * h->H + c];
+            BM_TRY(h->Wt.upload(t.data()));
+        }
+        return 0;
+    }
+    DevBuf *b = find_vec(h, nm);
+    BM_CHECK(b, "unknown RBM variable '%s'", name ? name : "(null)");
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
     BM_HIP(hipMemcpy(b->p, host, n * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 
 int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n) {
-    DevBuf *b;
-    BM_TRY(find_var(h, name, &b));
-    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    const std::string nm(name ? name : "");
     BM_HIP(hipStreamSynchronize(h->stream));
+    if (nm == "W" || nm == "dW" || nm == "Wt") {
+        BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
+        return (nm == "W" ? h->W : nm == "dW" ? h->dW : h->Wt).download(host);
+    }
+    DevBuf *b = find_vec(h, nm);
+    BM_CHECK(b, "unknown RBM variable '%s'", name ? name : "(null)");
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
     BM_HIP(hipMemcpy(host, b->p, n * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
 int bm_rbm_dev_ptr(bm_rbm *h, const char *name, void **out_dev, size_t *out_n) {
-    DevBuf *b;
-    BM_TRY(find_var(h, name, &b));
+    const std::string nm(name ? name : "");
+    DevBuf *b = (nm == "grad") ? &h->grad : find_vec(h, nm);
+    BM_CHECK(b, "no device view for '%s' (matrices are pitched; use get/set_param)", name ? name : "(null)");
     *out_dev = b->p;
     if (out_n) *out_n = b->n;
     return 0;
@@ -352,10 +408,12 @@ int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
 
 int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float lr, float mom) {
     launch_bias(h, (float)B_global, lr, mom);
+    ProfScope _ps(h, KC_BIAS);
     ApplyWArgs a;
+    memset(&a, 0, sizeof(a));
     a.raw = h->grad.p; a.raw2 = nullptr;
-    a.W = h->W.p; a.dW = h->dW.p; a.pen = h->pen.p;
-    a.I = h->H; a.n = (size_t)h->V * h->H; a.form = 0;
+    a.W = h->W.p; a.dW = h->dW.p; a.Wt = h->Wt.p; a.pen = h->pen.p;
+    a.I = h->H; a.J = h->V; a.ldw = h->W.ld; a.ldwt = h->Wt.ld; a.form = 0;
     a.N = (float)B_global; a.M = a.N; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
     hipLaunchKernelGGL(apply_w_kernel, dim3(1024), dim3(256), 0, h->stream, a);
     BM_HIP(hipGetLastError());
@@ -380,26 +438,15 @@ int bm_rbm_metrics(bm_rbm *h, const float *X_dev, int32_t B, int32_t k, float *o
 int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     const float *Xin = X_dev;
+    int ldx = h->V;
     if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {
-        hipLaunchKernelGGL(div_cols_kernel, dim3(256), dim3(256), 0, h->stream, Xin, h->sigma.p, h->Xs.p,
-                           (size_t)B * h->V, h->V);
-        Xin = h->Xs.p;
+        hipLaunchKernelGGL(div_cols_kernel, dim3(256), dim3(256), 0, h->stream, Xin, ldx, h->sigma.p, h->Xs.p,
+                           h->Xs.ld, B, h->V);
+        Xin = h->Xs.p; ldx = h->Xs.ld;
     }
     BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
     BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 2 * (size_t)h->maxB * sizeof(float), h->stream));
-    FeArgs f;
-    memset(&f, 0, sizeof(f));
-    f.P = make_operand(h->W.p, h->H, h->H);
-    f.Q = make_operand(Xin, h->V, B);
-    f.K = h->V; f.I = h->H; f.J = B;
-    f.hb = h->hb.p; f.rowacc = h->rowacc.p;
-    hipLaunchKernelGGL(fe_hidden_kernel, dim3(grid_for(f.I, f.J)), dim3(NT), 0, h->stream, f);
-    FeRowArgs r;
-    memset(&r, 0, sizeof(r));
-    r.X = Xin; r.ld = h->V; r.V = h->V; r.B = B;
-    r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
-    r.rowacc = f.rowacc; r.out = h->scal + 2;
-    hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
+    launch_fe(h, Xin, ldx, B, false);
     double host[4];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
@@ -410,12 +457,39 @@ int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1) {
 int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_steps) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(H_dev && V_dev, "null state pointer");
+    BM_CHECK(n_steps >= 1, "n_steps must be >= 1");
+    // dense user buffers <-> pitched workspaces (hs / vs)
+    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)H_dev, h->H, h->hs.p, h->hs.ld, B, h->H);
     for (int t = 0; t < n_steps; ++t) {
-        launch_down(h, H_dev, B, nullptr, V_dev, h->cfg.sample_v_states, SITE_V, t);
-        launch_up(h, V_dev, B, nullptr, H_dev, h->cfg.sample_h_states, SITE_H, t);
+        launch_down(h, h->hs.p, h->hs.ld, B, nullptr, h->vs.p, h->vs.ld, h->cfg.sample_v_states, SITE_V, t);
+        launch_up(h, h->vs.p, h->vs.ld, B, nullptr, h->hs.p, h->hs.ld, h->cfg.sample_h_states, SITE_H, t);
     }
+    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)h->hs.p, h->hs.ld, H_dev, h->H, B, h->H);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)h->vs.p, h->vs.ld, V_dev, h->V, B, h->V);
     h->call++;
     BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_rbm_stream(bm_rbm *h, void **out_stream) { *out_stream = (void *)h->stream; return 0; }
+
+int bm_rbm_profile(bm_rbm *h, int32_t enable) {
+    BM_HIP(hipStreamSynchronize(h->stream));
+    for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    h->recs.clear();
+    h->prof = enable != 0;
+    return 0;
+}
+
+int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6) {
+    BM_HIP(hipStreamSynchronize(h->stream));
+    for (int c = 0; c < BM_NUM_KERNEL_CLASSES; ++c) { ms6[c] = 0.f; n6[c] = 0; }
+    for (auto &r : h->recs) {
+        float ms = 0.f;
+        BM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        ms6[r.cls] += ms;
+        n6[r.cls] += 1;
+    }
     return 0;
 }
 

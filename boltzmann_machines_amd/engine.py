@@ -114,6 +114,20 @@ class RbmEngine(object):
     def gibbs(self, Hd, Vd, B, n_steps):
         check(self.lib.bm_rbm_gibbs(self._h, Hd.ptr, Vd.ptr, B, n_steps))
 
+    def stream(self):
+        p = C.c_void_p()
+        check(self.lib.bm_rbm_stream(self._h, C.byref(p)))
+        return p.value
+
+    def profile(self, enable):
+        check(self.lib.bm_rbm_profile(self._h, int(bool(enable))))
+
+    def kernel_times(self):
+        ms, n = (C.c_float * 6)(), (C.c_int32 * 6)()
+        check(self.lib.bm_rbm_kernel_times(self._h, ms, n))
+        names = ('act_up', 'act_down', 'grad', 'colsum', 'bias', 'other')
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(names)}
+
     def timer_start(self):
         check(self.lib.bm_rbm_timer_start(self._h))
 

@@ -130,6 +130,20 @@ int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1);
  * V_dev [B, n_visible] receives the last visible states.  No parameter update. */
 int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_steps);
 
+/* the handle's hipStream_t (as void*), so a host can enqueue collectives on
+ * the same stream (torch.cuda.ExternalStream) without host synchronisation. */
+int bm_rbm_stream(bm_rbm *h, void **out_stream);
+
+/* Per-kernel-class HIP-event timing (bench.py roofline leg).  While enabled,
+ * every launch is bracketed by events on the handle's stream;
+ * bm_rbm_kernel_times() synchronises and returns, for class c in
+ * {0: prop-up act_kernel, 1: prop-down act_kernel, 2: grad_kernel,
+ *  3: colsum_kernel, 4: bias/apply kernels, 5: other}, the summed duration
+ * ms[c] and the launch count n[c] since the last enable. */
+#define BM_NUM_KERNEL_CLASSES 6
+int bm_rbm_profile(bm_rbm *h, int32_t enable);
+int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6);
+
 /* HIP-event timer on the handle's stream (bench.py roofline leg). */
 int bm_rbm_timer_start(bm_rbm *h);
 int bm_rbm_timer_stop(bm_rbm *h, float *out_ms);
