@@ -38,13 +38,19 @@
 
 namespace bm {
 
+// VALU side work threaded through the main loop, one call per K step (default: none)
+struct NoSide { __device__ __forceinline__ void step() {} };
+
+// compile-time ablation mask (template parameter ABL, 0 in the product; tools/probe_act.hip
+// instantiates other values to price each pipeline stage)
+#define BM_ABL(bit) ((ABL >> (bit)) & 1)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TI = 64;    // tile extent along i
 constexpr int TJ = 32;    // tile extent along j
-constexpr int BK = 32;    // K chunk
+constexpr int BK = 64;    // K chunk
 constexpr int NT = 256;   // threads per workgroup
-constexpr int PF = 3;     // global->register prefetch distance (chunks)
 
 enum : int { KM = 0, XM = 1 };
 
@@ -53,7 +59,8 @@ constexpr int Q_STRIDE_KM = TJ + 16;   // 48
 constexpr int Q_STRIDE_XM = BK + 2;    // 34
 constexpr int P_BUF = BK * P_STRIDE;                                                              // 3072
 constexpr int Q_BUF = (BK * Q_STRIDE_KM > TJ * Q_STRIDE_XM) ? BK * Q_STRIDE_KM : TJ * Q_STRIDE_XM;  // 1536
-constexpr int SMEM_FLOATS = 2 * (P_BUF + Q_BUF);                                                  // 36 KiB
+constexpr int NBUF = 3;   // LDS ring depth
+constexpr int SMEM_FLOATS = NBUF * (P_BUF + Q_BUF);                                               // 108 KiB at BK = 64
 
 struct Operand {
     const float *ptr;
@@ -100,8 +107,8 @@ __device__ __forceinline__ float4 load4_guard(const float *p, bool row_ok, int c
 // load is unconditional and branch free: an out-of-range lane reads g_zero16.
 // That keeps PF chunks of loads in flight with counted vmcnt waits only.
 template <int L, int TX, bool FAST>
-__device__ __forceinline__ void g2r(float4 (&reg)[TX / 32], const Operand &op, int x0, int k0, int K, int tid) {
-    constexpr int NV = TX / 32;   // float4 per thread
+__device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NT)], const Operand &op, int x0, int k0, int K, int tid) {
+    constexpr int NV = TX * BK / (4 * NT);   // float4 per thread
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int f = tid + n * NT;
@@ -133,8 +140,8 @@ __device__ __forceinline__ void g2r(float4 (&reg)[TX / 32], const Operand &op, i
 // registers -> LDS.  kz = K - k0 (rows/cols of this chunk at k >= K are zeroed; only the
 // FAST path needs it, the guarded loads already returned zeros).
 template <int L, int TX, bool FAST>
-__device__ __forceinline__ void r2s(const float4 (&reg)[TX / 32], float *s, int tid, int kz) {
-    constexpr int NV = TX / 32;
+__device__ __forceinline__ void r2s(const float4 (&reg)[TX * BK / (4 * NT)], float *s, int tid, int kz) {
+    constexpr int NV = TX * BK / (4 * NT);
     constexpr int STRIDE_K = (TX == TI) ? P_STRIDE : Q_STRIDE_KM;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
@@ -154,33 +161,40 @@ __device__ __forceinline__ void r2s(const float4 (&reg)[TX / 32], float *s, int 
     }
 }
 
-// one BK chunk of MFMAs for this wave: acc[t] += P-frag(t) x Q-frag
-template <int QL>
-__device__ __forceinline__ void compute_chunk(f32x4 (&acc)[2], const float *sP, const float *sQ,
-                                              int wi, int wj, int lane) {
+// MFMA operand fragments of one BK chunk for this wave (48 VGPRs at BK = 64)
+struct Frags {
+    float2 p[BK / 4];   // p[kk] = P[k = 4kk+g][i = base + 2*l15 + {0,1}]
+    float q[BK / 4];    // q[kk] = Q[j = l15][k = 4kk+g]
+};
+
+template <int QL, int ABL = 0>
+__device__ __forceinline__ void read_frags(Frags &f, const float *sP, const float *sQ, int wi, int wj, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
     const float *pP = sP + g * P_STRIDE + wi * 32 + 2 * l15;
     const float *pQ = (QL == KM) ? sQ + g * Q_STRIDE_KM + wj * 16 + l15
                                  : sQ + (wj * 16 + l15) * Q_STRIDE_XM + g;
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-        const float q  = (QL == KM) ? pQ[kk * 4 * Q_STRIDE_KM] : pQ[kk * 4];
-        const float2 p = *reinterpret_cast<const float2 *>(pP + kk * 4 * P_STRIDE);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p.x, q, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p.y, q, acc[1], 0, 0, 0);
+        if (BM_ABL(3)) { f.p[kk] = make_float2(1.f, 2.f); f.q[kk] = 1.f; continue; }
+        f.p[kk] = *reinterpret_cast<const float2 *>(pP + kk * 4 * P_STRIDE);
+        f.q[kk] = (QL == KM) ? pQ[kk * 4 * Q_STRIDE_KM] : pQ[kk * 4];
     }
 }
 
-// acc += sum_k P[k][i] * Q[j][k] over k in [0, K), k ascending (canonical order).
-// Software pipeline: register set (c % PF) holds chunk c; at step c the set is
-// refilled with chunk c+PF (loads stay in flight for PF-1 steps), chunk c is
-// consumed from LDS buffer c&1 and chunk c+1 moves registers -> LDS buffer (c+1)&1.
-// No load sits under a branch (chunks past K read g_zero16 / the guarded path
-// returns zeros), so the only waits are counted vmcnt for the set being stored.
-// one register set = one BK chunk of both operand tiles (3 x 16 B per thread)
+template <int ABL = 0>
+__device__ __forceinline__ void mfma_frags(f32x4 (&acc)[2], const Frags &f) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+        if (BM_ABL(1)) { acc[0][0] += f.p[kk].x * f.q[kk]; acc[1][0] += f.p[kk].y; continue; }
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk].x, f.q[kk], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk].y, f.q[kk], acc[1], 0, 0, 0);
+    }
+}
+
+// one register set = one BK chunk of both operand tiles, global -> VGPR staging
 struct ChunkRegs {
-    float4 p[TI / 32];
-    float4 q[TJ / 32];
+    float4 p[TI * BK / (4 * NT)];
+    float4 q[TJ * BK / (4 * NT)];
 };
 
 template <int QL, bool FAST>
@@ -196,40 +210,78 @@ __device__ __forceinline__ void store_chunk(const ChunkRegs &r, float *sP, float
     r2s<QL, TJ, FAST>(r.q, sQ, tid, kz);
 }
 
-template <int QL, bool FAST>
+// acc += sum_k P[k][i] * Q[j][k] over k in [0, K), k ascending (canonical order).
+//
+// One wave per SIMD has nobody to hide behind, so the loop is software-pipelined by
+// hand over a 3-deep LDS ring.  In step c (between barriers B(c-1) and B(c)) a wave
+//   * runs the 32 MFMAs of chunk c on fragments F(c) that are ALREADY in registers,
+//   * reads the fragments F(c+1) from LDS slot (c+1)%3 (published by B(c-1)),
+//   * stores chunk c+2 (global data that arrived in registers) to LDS slot (c+2)%3
+//     (last read for F(c-1), complete before B(c-2)),
+//   * re-issues the global loads of chunk c+4 into the register set just stored.
+// LDS traffic, global loads and the barrier all overlap the MFMA stream of the same
+// wave; the only exposed latency is the barrier skew.  No load sits under a branch
+// (chunks past K are clamped / zero-filled), so all waits are counted.
+template <int QL, bool FAST, int ABL = 0, class Side = NoSide>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[2], const Operand &P, const Operand &Q, int K,
-                                         int i0, int j0, float *smem) {
+                                         int i0, int j0, float *smem, Side &side, long long *stamps = nullptr) {
+#ifdef BM_PROBE
+#define BM_MSTAMP(n) do { if (stamps && threadIdx.x == 0) stamps[n] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BM_MSTAMP(n) do {} while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
-    float *sP = smem, *sQ = smem + 2 * P_BUF;
+    float *sP = smem, *sQ = smem + NBUF * P_BUF;
     const int nch = (K + BK - 1) / BK;
-    static_assert(PF == 3, "the step sequence below is written for PF == 3");
-    ChunkRegs r0, r1, r2;          // named sets (not an array): must stay in VGPRs, never scratch
-    load_chunk<QL, FAST>(r0, P, Q, K, i0, j0, 0, tid);
-    load_chunk<QL, FAST>(r1, P, Q, K, i0, j0, 1, tid);
-    load_chunk<QL, FAST>(r2, P, Q, K, i0, j0, 2, tid);
-    store_chunk<QL, FAST>(r0, sP, sQ, tid, K);
+    ChunkRegs g0, g1;          // named sets (never arrays: must stay in VGPRs)
+    Frags fa, fb;
+    BM_MSTAMP(0);
+    load_chunk<QL, FAST>(g0, P, Q, K, i0, j0, 0, tid);
+    load_chunk<QL, FAST>(g1, P, Q, K, i0, j0, 1, tid);
+    store_chunk<QL, FAST>(g0, sP, sQ, tid, K);
+    load_chunk<QL, FAST>(g0, P, Q, K, i0, j0, 2, tid);
+    store_chunk<QL, FAST>(g1, sP + P_BUF, sQ + Q_BUF, tid, K - BK);
+    load_chunk<QL, FAST>(g1, P, Q, K, i0, j0, 3, tid);
+    BM_MSTAMP(1);
     __syncthreads();
-    int cc = 0, cur = 0;
-#define BM_STEP(RU, RN)                                                                     \
-    {                                                                                       \
-        load_chunk<QL, FAST>(RU, P, Q, K, i0, j0, cc + PF, tid);                            \
-        compute_chunk<QL>(acc, sP + cur * P_BUF, sQ + cur * Q_BUF, wi, wj, lane);           \
-        store_chunk<QL, FAST>(RN, sP + (cur ^ 1) * P_BUF, sQ + (cur ^ 1) * Q_BUF, tid,     \
-                              K - (cc + 1) * BK);                                           \
-        __syncthreads();                                                                    \
-        cur ^= 1;                                                                           \
-        ++cc;                                                                               \
+    read_frags<QL, ABL>(fa, sP, sQ, wi, wj, lane);
+    BM_MSTAMP(2);
+    int cc = 0, b1 = 1, b2 = 2;   // LDS slots of chunk cc+1 / cc+2
+    // Desired issue order inside a step (hipcc otherwise issues the LDS traffic AFTER the
+    // MFMAs and the two phases run back to back): LDS reads of F(c+1) right behind the
+    // barrier, then the stores of chunk c+2, then the global re-loads, each group
+    // threaded between MFMAs so the matrix pipe never waits for the LDS pipe.
+    // masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
+#define BM_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#define BM_SCHED_STEP                                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 2) }     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) }     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 6; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }     \
+    BM_SG(0x008, 6)
+#define BM_STEP(FC, FN, G)                                                                   \
+    {                                                                                        \
+        if (!BM_ABL(3)) read_frags<QL, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
+        if (!BM_ABL(2)) store_chunk<QL, FAST>(G, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid, K - (cc + 2) * BK); \
+        if (!BM_ABL(0)) load_chunk<QL, FAST>(G, P, Q, K, i0, j0, cc + 4, tid);               \
+        side.step();                                                                         \
+        mfma_frags<ABL>(acc, FC);                                                            \
+        BM_SCHED_STEP                                                                        \
+        if (!BM_ABL(5)) __syncthreads();                                                     \
+        b1 = b2;                                                                             \
+        b2 = (b2 == NBUF - 1) ? 0 : b2 + 1;                                                  \
+        ++cc;                                                                                \
     }
-    const int ngroups = nch / PF, rem = nch % PF;
-    for (int gi = 0; gi < ngroups; ++gi) {
-        BM_STEP(r0, r1)
-        BM_STEP(r1, r2)
-        BM_STEP(r2, r0)
+    for (int pi = 0; pi < nch / 2; ++pi) {
+        BM_STEP(fa, fb, g0)
+        BM_STEP(fb, fa, g1)
     }
-    if (rem >= 1) BM_STEP(r0, r1)
-    if (rem >= 2) BM_STEP(r1, r2)
+    BM_MSTAMP(3);
+    if (nch & 1) BM_STEP(fa, fb, g0)
+    BM_MSTAMP(4);
 #undef BM_STEP
+#undef BM_SCHED_STEP
+#undef BM_SG
 }
 
 // the 8 consecutive outputs of a lane: v[e], e = 2r + t  <->  i = ib + e
@@ -244,8 +296,8 @@ __device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[2], float (&v)[8
 // XCD-aware block -> tile map: blocks are dispatched round-robin over the 8 XCDs
 // (block b -> XCD b % 8, MI355X_MICROARCH.md), so consecutive logical tiles
 // t (which share the P panel = same i-tile) are placed on ONE XCD's L2.
-__device__ __forceinline__ void block_to_tile(int tiles_j, int &ti, int &tj) {
-    const int nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ void block_to_tile(int tiles_j, int &ti, int &tj, int skip = 0) {
+    const int nb = gridDim.x - skip, b = blockIdx.x - skip;   // `skip` leading non-tile workgroups
     const int q = nb / 8, r = nb % 8, xcd = b % 8;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     ti = t / tiles_j;

@@ -32,7 +32,15 @@ struct ActArgs {
     long long row0;              // global row of local row 0 (rank-invariant bitmaps)
     const float *prev;           // mean-field: previous mu (same layout as means) or null
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
+#ifdef BM_PROBE
+    long long *dbg;              // [grid][4] s_memtime stamps (tools/probe_act.hip only)
+#endif
 };
+#ifdef BM_PROBE
+#define BM_STAMP(n) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + (n)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BM_STAMP(n) do {} while (0)
+#endif
 
 // draw for 4 consecutive outputs starting at flat index `flat` (multiple of 4 on the fast path)
 __device__ __forceinline__ void draw4(const ActArgs &a, unsigned long long flat, int ib, int nvalid,
@@ -78,29 +86,52 @@ __device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int
     }
 }
 
-template <bool SEG2, bool FAST>
-__global__ __launch_bounds__(NT) void act_kernel(ActArgs a) {
+template <bool SEG2, bool FAST, int ABL = 0>
+__global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const int tiles_j = (a.J + TJ - 1) / TJ;
     int ti, tj;
+    BM_STAMP(0);
     block_to_tile(tiles_j, ti, tj);
     const int i0 = ti * TI, j0 = tj * TJ;
-
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<XM, FAST>(acc, a.P1, a.Q1, a.K1, i0, j0, smem);
-    if (SEG2) mainloop<XM, FAST>(acc, a.P2, a.Q2, a.K2, i0, j0, smem);
-
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
     const int j = j0 + wj * 16 + l15;
     const int ib0 = i0 + wi * 32 + g * 8;          // 8 consecutive outputs i = ib0 + e
+
+    // epilogue inputs fetched before the main loop so their latency is off the tail
+    const bool full8 = (ib0 + 7 < a.I);
+    float bs[8], sg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i = (ib0 + e < a.I) ? ib0 + e : a.I - 1;
+        bs[e] = a.bias[i];
+        sg[e] = a.sigma ? a.sigma[i] : 1.0f;
+    }
+    // the lane's two Philox blocks advance one round per K step inside the main loop
+    const bool rng_fast = ((a.I & 3) == 0);
+    PhiloxPair rng;
+    rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
+
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef BM_PROBE
+    mainloop<XM, FAST, ABL>(acc, a.P1, a.Q1, a.K1, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+#else
+    mainloop<XM, FAST, ABL>(acc, a.P1, a.Q1, a.K1, i0, j0, smem, rng);
+#endif
+    if (SEG2) mainloop<XM, FAST, ABL>(acc, a.P2, a.Q2, a.K2, i0, j0, smem, rng);
+    rng.finish();
+    BM_STAMP(1);
+
     float z[8];
     lane_outputs(acc, z);
     float dmax = 0.f;
-    if (j < a.J && ib0 < a.I) {
+    if (BM_ABL(4)) {
+        if (j < a.J && ib0 < a.I && a.states) a.states[(size_t)j * a.ldo + ib0] = z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7];
+    } else if (j < a.J && ib0 < a.I) {
         const bool al_out = ((a.ldo & 3) == 0);
 #pragma unroll
         for (int hlf = 0; hlf < 2; ++hlf) {
@@ -110,15 +141,28 @@ __global__ __launch_bounds__(NT) void act_kernel(ActArgs a) {
             float m[4], s[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = (r < nvalid) ? ib + r : a.I - 1;
                 const float x = a.mult * z[4 * hlf + r];
-                const float b = a.mult * a.bias[i];
-                m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+                const float b = a.mult * bs[4 * hlf + r];
+                m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * sg[4 * hlf + r] + b);
                 s[r] = m[r];
             }
             if (a.sample) {
-                const unsigned long long flat = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib;
-                draw4(a, flat, ib, nvalid, m, s, ((a.I & 3) == 0));
+                if (rng_fast) {          // the 4 outputs are exactly one (precomputed) Philox block
+                    const uint32_t *wds = hlf ? rng.b : rng.a;
+                    if (a.kind == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[r] = (u32_to_uniform(wds[r]) < m[r]) ? 1.f : 0.f;
+                    } else {
+                        float n[4];
+                        box_muller(wds[0], wds[1], n[0], n[1]);
+                        box_muller(wds[2], wds[3], n[2], n[3]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[r] = n[r] * sg[4 * hlf + r] + m[r];
+                    }
+                } else {
+                    const unsigned long long flat = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib;
+                    draw4(a, flat, ib, nvalid, m, s, false);
+                }
             }
             const size_t o = (size_t)j * a.ldo + ib;
             if (a.prev) {
@@ -136,6 +180,211 @@ __global__ __launch_bounds__(NT) void act_kernel(ActArgs a) {
         for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
         if (lane == 0 && dmax > 0.f) atomicMax(a.maxdiff, __float_as_uint(dmax));
     }
+    (void)full8;
+    BM_STAMP(2);
+}
+
+// -------------------------------------------------------------- colstat_kernel
+// Column sums in canonical order via MFMA against ones:
+//   D[i][*] = sum_k A[k][i] * 1  ==  sequential fp32 sum over rows k.
+// One wave per 16 columns, operands straight from global memory (64 B per row).
+// job: out[c] = sum_b (A[b][c] - Bm[b][c])   (Bm may be null -> plain column sum)
+struct ColSumJob {
+    const float *A, *Bm;
+    int lda, ldb, ncols, nrows;
+    float *out;
+};
+constexpr int MAX_COLJOBS = 12;
+struct ColSumArgs {
+    ColSumJob job[MAX_COLJOBS];
+    int first_wave[MAX_COLJOBS + 1];   // prefix sums of ceil(ncols/16)
+    int njobs;
+};
+
+// Canonical column sums of 16 columns [c0, c0+16) by one 256-thread workgroup.
+//   sum1[c] = sum_k (A - Bm)[k][c]   (wave 0)      sum2[c] = sum_k Bm[k][c]   (wave 1, optional)
+// The MFMA chain D[i][*] += A[k][i] * 1 is sequential in k (that IS the canonical
+// order), so the only parallelism is in the loads: all 4 waves stage CS_ROWS rows of
+// both operands into LDS with 16-byte loads (one memory round trip), then one wave per
+// sum runs the 128-MFMA chain out of LDS (stride 16 floats: lanes 0-15 / 16-31 hit
+// disjoint bank halves).  Returns the sums in lanes with (lane & 15) == 0: acc[r] is
+// column c0 + 4*(lane>>4) + r.
+constexpr int CS_ROWS = 512;
+constexpr int CS_SMEM_FLOATS = 2 * CS_ROWS * 16;    // 64 KiB
+
+__device__ __forceinline__ void block_colsum(const float *A, int lda, const float *Bm, int ldb,
+                                             int c0, int ncols, int nrows, bool want2,
+                                             float *smem, f32x4 &sum1, f32x4 &sum2) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    float *sA = smem, *sB = smem + CS_ROWS * 16;
+    sum1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    sum2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool vecA = (((uintptr_t)A & 15u) == 0) && ((lda & 3) == 0) && (c0 + 16 <= ncols);
+    const bool vecB = !Bm || ((((uintptr_t)Bm & 15u) == 0) && ((ldb & 3) == 0) && (c0 + 16 <= ncols));
+    for (int r0 = 0; r0 < nrows; r0 += CS_ROWS) {
+        const int nr = (nrows - r0 < CS_ROWS) ? nrows - r0 : CS_ROWS;
+        if (vecA && vecB) {
+            const int c4 = tid & 3;
+#pragma unroll
+            for (int n = 0; n < CS_ROWS / 64; ++n) {
+                const int row = (tid >> 2) + 64 * n;
+                const int rc = (row < nr) ? row : nr - 1;            // clamp: always a legal load
+                float4 va = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + rc) * lda + c0 + 4 * c4);
+                float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (Bm) vb = *reinterpret_cast<const float4 *>(Bm + (size_t)(r0 + rc) * ldb + c0 + 4 * c4);
+                if (row >= nr) { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+                *reinterpret_cast<float4 *>(sA + row * 16 + 4 * c4) = va;
+                *reinterpret_cast<float4 *>(sB + row * 16 + 4 * c4) = vb;
+            }
+        } else {
+            for (int e = tid; e < CS_ROWS * 16; e += NT) {
+                const int row = e >> 4, c = c0 + (e & 15);
+                const bool ok = row < nr && c < ncols;
+                sA[e] = ok ? A[(size_t)(r0 + row) * lda + c] : 0.f;
+                sB[e] = (ok && Bm) ? Bm[(size_t)(r0 + row) * ldb + c] : 0.f;
+            }
+        }
+        __syncthreads();
+        // rows >= nr are zero in LDS, so the chain may run to a multiple of 8 steps:
+        // 8 fragment reads are issued ahead of the 8 dependent MFMAs that consume them
+        const int nsteps = (((nr + 3) / 4) + 7) & ~7;
+        if (w == 0) {
+            for (int s = 0; s < nsteps; s += 8) {
+                float d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int o = (4 * (s + u) + g) * 16 + l15;
+                    d[u] = sA[o] - sB[o];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], 1.0f, sum1, 0, 0, 0);
+            }
+        } else if (w == 1 && want2) {
+            for (int s = 0; s < nsteps; s += 8) {
+                float d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d[u] = sB[(4 * (s + u) + g) * 16 + l15];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum2 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], 1.0f, sum2, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(NT) void colsum_kernel(ColSumArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[CS_SMEM_FLOATS];
+    const int wv = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int jb = 0;
+    while (jb + 1 < a.njobs && wv >= a.first_wave[jb + 1]) ++jb;
+    const ColSumJob J = a.job[jb];
+    const int c0 = (wv - a.first_wave[jb]) * 16;
+    f32x4 s1, s2;
+    block_colsum(J.A, J.lda, J.Bm, J.ldb, c0, J.ncols, J.nrows, false, smem, s1, s2);
+    if (w == 0 && (lane & 15) == 0) {
+        const int g = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cc = c0 + g * 4 + r;
+            if (cc < J.ncols) J.out[cc] = s1[r];
+        }
+    }
+}
+
+// RBM bias / running-mean update from raw column sums (base_rbm.py:450-474).
+//   sv[c] = sum_b (X - v_k),  sh[c] = sum_b (h0 - h_k),  sq[c] = sum_b h_k
+struct RbmBiasArgs {
+    const float *sv, *sh, *sq;
+    float *vb, *dvb, *hb, *dhb, *q, *pen;
+    int V, H;
+    float N, lr, mom, damping, cost, target;
+};
+__global__ void rbm_bias_kernel(RbmBiasArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.V) {
+        const float g = a.sv[c] / a.N;                       // reduce_mean(X - v, 0)     :451
+        const float d = a.lr * (a.mom * a.dvb[c] + g);       // :470
+        a.dvb[c] = d;
+        a.vb[c] = a.vb[c] + d;                               // :471
+    } else if (c < a.V + a.H) {
+        const int h = c - a.V;
+        const float qn = a.damping * a.q[h] + (1.0f - a.damping) * a.sq[h];   // :457-459 (column SUM)
+        a.q[h] = qn;
+        const float pen = a.cost * (qn - a.target);          // :460
+        a.pen[h] = pen;
+        float g = a.sh[h] / a.N;                             // :453
+        g = g - pen;                                         // :461
+        const float d = a.lr * (a.mom * a.dhb[h] + g);       // :473
+        a.dhb[h] = d;
+        a.hb[h] = a.hb[h] + d;                               // :474
+    }
+}
+
+// Fused single-GPU form of colsum_kernel + rbm_bias_kernel: the wave that sums a group
+// of 16 columns applies their bias / q_means update directly (identical arithmetic).
+struct RbmBiasFusedArgs {
+    const float *X, *vs, *h0m, *hm;     // [B][V] pitch ldx / ldv, [B][H] pitch ldh0 / ldh
+    int ldx, ldv, ldh0, ldh, B;
+    float *raw_tail;                    // [V | H | H] raw sums are still published (metrics / tests)
+    RbmBiasArgs u;
+};
+// body of one 16-column group (block index wv); smem >= CS_SMEM_FLOATS + 16 floats
+__device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, int wv, float *smem) {
+    float *s_sq = smem + CS_SMEM_FLOATS;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
+    const int nv = (a.u.V + 15) / 16;
+    f32x4 s1, s2;
+    if (wv < nv) {
+        const int c0 = wv * 16;
+        block_colsum(a.X, a.ldx, a.vs, a.ldv, c0, a.u.V, a.B, false, smem, s1, s2);   // sum(X - v_k)
+        if (w == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + g * 4 + r;
+                if (c < a.u.V) {
+                    a.raw_tail[c] = s1[r];
+                    const float gr = s1[r] / a.u.N;
+                    const float d = a.u.lr * (a.u.mom * a.u.dvb[c] + gr);
+                    a.u.dvb[c] = d;
+                    a.u.vb[c] = a.u.vb[c] + d;
+                }
+            }
+        }
+    } else {
+        const int c0 = (wv - nv) * 16;
+        block_colsum(a.h0m, a.ldh0, a.hm, a.ldh, c0, a.u.H, a.B, true, smem, s1, s2);  // sum(h0 - h_k), sum(h_k)
+        if (w == 1 && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_sq[g * 4 + r] = s2[r];
+        }
+        __syncthreads();
+        if (w == 0 && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = c0 + g * 4 + r;
+                if (h < a.u.H) {
+                    const float sq = s_sq[g * 4 + r];
+                    a.raw_tail[a.u.V + h] = s1[r];
+                    a.raw_tail[a.u.V + a.u.H + h] = sq;
+                    const float qn = a.u.damping * a.u.q[h] + (1.0f - a.u.damping) * sq;
+                    a.u.q[h] = qn;
+                    const float pen = a.u.cost * (qn - a.u.target);
+                    a.u.pen[h] = pen;
+                    float gr = s1[r] / a.u.N;
+                    gr = gr - pen;
+                    const float d = a.u.lr * (a.u.mom * a.u.dhb[h] + gr);
+                    a.u.dhb[h] = d;
+                    a.u.hb[h] = a.u.hb[h] + d;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void rbm_bias_fused_kernel(RbmBiasFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[CS_SMEM_FLOATS + 16];
+    rbm_bias_fused_block(a, blockIdx.x, smem);
 }
 
 // ----------------------------------------------------------------- grad_kernel
@@ -153,6 +402,11 @@ struct GradArgs {
     int ldw, ldwt;
     const float *pen;                 // [I] sparsity penalty (already cost*(q-target) [+ mu term]) or null
     float N, M, l2, lr, mom;
+    // RBM single-GPU fusion: the first `nbias` workgroups of the launch run the column-sum
+    // + bias update (rbm_bias_fused_block) concurrently with the tile workgroups.  Legal
+    // only when the W update does not need the penalty they produce (sparsity_cost == 0).
+    int nbias;
+    RbmBiasFusedArgs bias;
 };
 
 // the scalar update rule shared by the fused epilogue and the split (data-parallel) apply kernel
@@ -166,17 +420,23 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
 }
 
 template <bool FAST>
-__global__ __launch_bounds__(NT) void grad_kernel(GradArgs a) {
+__global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    static_assert(SMEM_FLOATS >= CS_SMEM_FLOATS + 16, "bias path reuses the tile LDS");
+    if ((int)blockIdx.x < a.nbias) {
+        rbm_bias_fused_block(a.bias, blockIdx.x, smem);
+        return;
+    }
     const int tiles_j = (a.J + TJ - 1) / TJ;
     int ti, tj;
-    block_to_tile(tiles_j, ti, tj);
+    block_to_tile(tiles_j, ti, tj, a.nbias);
     const int i0 = ti * TI, j0 = tj * TJ;
 
     f32x4 pos[2], neg[2];
     pos[0] = pos[1] = neg[0] = neg[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<KM, FAST>(pos, a.Ppos, a.Qpos, a.Kpos, i0, j0, smem);
-    mainloop<KM, FAST>(neg, a.Pneg, a.Qneg, a.Kneg, i0, j0, smem);
+    NoSide none;
+    mainloop<KM, FAST>(pos, a.Ppos, a.Qpos, a.Kpos, i0, j0, smem, none);
+    mainloop<KM, FAST>(neg, a.Pneg, a.Qneg, a.Kneg, i0, j0, smem, none);
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
@@ -229,88 +489,6 @@ __global__ void apply_w_kernel(ApplyWArgs a) {
         a.W[o] = wv;
         a.dW[o] = dv;
         if (a.Wt) a.Wt[(size_t)i * a.ldwt + j] = wv;
-    }
-}
-
-// -------------------------------------------------------------- colstat_kernel
-// Column sums in canonical order via MFMA against ones:
-//   D[i][*] = sum_k A[k][i] * 1  ==  sequential fp32 sum over rows k.
-// One wave per 16 columns, operands straight from global memory (64 B per row).
-// job: out[c] = sum_b (A[b][c] - Bm[b][c])   (Bm may be null -> plain column sum)
-struct ColSumJob {
-    const float *A, *Bm;
-    int lda, ldb, ncols, nrows;
-    float *out;
-};
-constexpr int MAX_COLJOBS = 12;
-struct ColSumArgs {
-    ColSumJob job[MAX_COLJOBS];
-    int first_wave[MAX_COLJOBS + 1];   // prefix sums of ceil(ncols/16)
-    int njobs;
-};
-
-__global__ __launch_bounds__(64) void colsum_kernel(ColSumArgs a) {
-    const int wv = blockIdx.x, lane = threadIdx.x;
-    int jb = 0;
-    while (jb + 1 < a.njobs && wv >= a.first_wave[jb + 1]) ++jb;
-    const ColSumJob J = a.job[jb];
-    const int c0 = (wv - a.first_wave[jb]) * 16;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int c = c0 + l15;
-    const bool cok = c < J.ncols;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 16;
-    for (int k0 = 0; k0 < J.nrows; k0 += 4 * U) {
-        float va[U], vb[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {        // branch-free: out-of-range lanes read g_zero16
-            const int k = k0 + u * 4 + g;
-            const bool ok = cok && k < J.nrows;
-            const float *pa = ok ? J.A + (size_t)k * J.lda + c : g_zero16;
-            const float *pb = (ok && J.Bm) ? J.Bm + (size_t)k * J.ldb + c : g_zero16;
-            va[u] = *pa;
-            vb[u] = *pb;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[u] - vb[u], 1.0f, acc, 0, 0, 0);
-    }
-    // lane with l15 == 0 in group g holds columns c0 + g*4 + r
-    if (l15 == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int cc = c0 + g * 4 + r;
-            if (cc < J.ncols) J.out[cc] = acc[r];
-        }
-    }
-}
-
-// RBM bias / running-mean update from raw column sums (base_rbm.py:450-474).
-//   sv[c] = sum_b (X - v_k),  sh[c] = sum_b (h0 - h_k),  sq[c] = sum_b h_k
-struct RbmBiasArgs {
-    const float *sv, *sh, *sq;
-    float *vb, *dvb, *hb, *dhb, *q, *pen;
-    int V, H;
-    float N, lr, mom, damping, cost, target;
-};
-__global__ void rbm_bias_kernel(RbmBiasArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < a.V) {
-        const float g = a.sv[c] / a.N;                       // reduce_mean(X - v, 0)     :451
-        const float d = a.lr * (a.mom * a.dvb[c] + g);       // :470
-        a.dvb[c] = d;
-        a.vb[c] = a.vb[c] + d;                               // :471
-    } else if (c < a.V + a.H) {
-        const int h = c - a.V;
-        const float qn = a.damping * a.q[h] + (1.0f - a.damping) * a.sq[h];   // :457-459 (column SUM)
-        a.q[h] = qn;
-        const float pen = a.cost * (qn - a.target);          // :460
-        a.pen[h] = pen;
-        float g = a.sh[h] / a.N;                             // :453
-        g = g - pen;                                         // :461
-        const float d = a.lr * (a.mom * a.dhb[h] + g);       // :473
-        a.dhb[h] = d;
-        a.hb[h] = a.hb[h] + d;                               // :474
     }
 }
 
@@ -378,7 +556,7 @@ struct FeArgs {
     const int *flip_col;     // [J] or null
 };
 template <bool FAST>
-__global__ __launch_bounds__(NT) void fe_hidden_kernel(FeArgs a) {
+__global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const int tiles_j = (a.J + TJ - 1) / TJ;
     int ti, tj;
@@ -386,7 +564,8 @@ __global__ __launch_bounds__(NT) void fe_hidden_kernel(FeArgs a) {
     const int i0 = ti * TI, j0 = tj * TJ;
     f32x4 acc[2];
     acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<XM, FAST>(acc, a.P, a.Q, a.K, i0, j0, smem);
+    NoSide none;
+    mainloop<XM, FAST>(acc, a.P, a.Q, a.K, i0, j0, smem, none);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
@@ -483,7 +662,7 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
 static inline void launch_grad(const GradArgs &g, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
-    const dim3 grid(tile_grid(g.I, g.J)), blk(NT);
+    const dim3 grid(tile_grid(g.I, g.J) + g.nbias), blk(NT);
     if (fast) hipLaunchKernelGGL((grad_kernel<true>), grid, blk, 0, st, g);
     else      hipLaunchKernelGGL((grad_kernel<false>), grid, blk, 0, st, g);
 }

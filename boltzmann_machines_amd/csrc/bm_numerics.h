@@ -37,7 +37,8 @@ __device__ __forceinline__ float sigmoid(float x) {
     if (a > 80.0f) a = 80.0f;
     const float e = exp_neg(a);
     const float d = 1.0f + e;
-    return (x >= 0.0f) ? (1.0f / d) : (e / d);     // correctly rounded IEEE division
+    const float num = (x >= 0.0f) ? 1.0f : e;
+    return num / d;                                // ONE correctly rounded IEEE division
 }
 
 // metrics only (tolerance-checked, not bit-pinned)

@@ -163,7 +163,7 @@ static void launch_colsums(bm_rbm *h, int B) {
     c.job[2] = ColSumJob{h->hm.p, nullptr, h->hm.ld, 0, h->H, B, tail + h->V + h->H};          // sum(h_k)
     c.first_wave[0] = 0;
     for (int j = 0; j < c.njobs; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 15) / 16;
-    hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[c.njobs]), dim3(64), 0, h->stream, c);
+    hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[c.njobs]), dim3(NT), 0, h->stream, c);
 }
 
 static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
@@ -179,7 +179,40 @@ static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
     hipLaunchKernelGGL(rbm_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, b);
 }
 
-static void launch_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom) {
+// single-GPU path: column sums + bias/q update in ONE launch (or inside the grad launch)
+static int fill_bias_fused(bm_rbm *h, int B, float lr, float mom, RbmBiasFusedArgs &a) {
+    memset(&a, 0, sizeof(a));
+    a.X = h->Xin; a.ldx = h->Xin_ld; a.vs = h->vs.p; a.ldv = h->vs.ld;
+    a.h0m = h->h0m.p; a.ldh0 = h->h0m.ld; a.hm = h->hm.p; a.ldh = h->hm.ld; a.B = B;
+    a.raw_tail = h->grad.p + h->grad_tail();
+    RbmBiasArgs &b = a.u;
+    b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
+    b.V = h->V; b.H = h->H;
+    b.N = (float)B; b.lr = lr; b.mom = mom;
+    b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost; b.target = h->cfg.sparsity_target;
+    return (h->V + 15) / 16 + (h->H + 15) / 16;
+}
+
+static void launch_bias_fused(bm_rbm *h, int B, float lr, float mom) {
+    ProfScope _ps(h, KC_COLSUM);
+    RbmBiasFusedArgs a;
+    const int nw = fill_bias_fused(h, B, lr, mom, a);
+    hipLaunchKernelGGL(rbm_bias_fused_kernel, dim3(nw), dim3(NT), 0, h->stream, a);
+}
+
+static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, bool with_bias);
+
+// whole parameter update of the fused single-GPU step (base_rbm.py:443-478)
+static void launch_update_fused(bm_rbm *h, int B, float lr, float mom) {
+    if (h->cfg.sparsity_cost != 0.f) {      // W update needs the penalty: bias kernel first
+        launch_bias_fused(h, B, lr, mom);
+        rbm_grad(h, B, 1, (float)B, lr, mom, false);
+    } else {                                // penalty == 0: run both in one launch
+        rbm_grad(h, B, 1, (float)B, lr, mom, true);
+    }
+}
+
+static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, bool with_bias) {
     ProfScope _ps(h, KC_GRAD);
     GradArgs g;
     memset(&g, 0, sizeof(g));
@@ -194,8 +227,9 @@ static void launch_grad(bm_rbm *h, int B, int fused, float N, float lr, float mo
     g.raw = h->grad.p; g.raw2 = nullptr;
     g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p;
     g.ldw = h->W.ld; g.ldwt = h->Wt.ld;
-    g.pen = h->pen.p;
+    g.pen = with_bias ? nullptr : h->pen.p;
     g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
+    if (with_bias) g.nbias = fill_bias_fused(h, B, lr, mom, g.bias);
     bm::launch_grad(g, h->stream);
 }
 
@@ -368,9 +402,7 @@ int bm_rbm_set_row_offset(bm_rbm *h, int64_t row0) { h->row0 = row0; return 0; }
 
 int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
-    launch_colsums(h, B);
-    launch_bias(h, (float)B, lr, mom);
-    launch_grad(h, B, 1, (float)B, lr, mom);
+    launch_update_fused(h, B, lr, mom);
     h->call++;
     BM_HIP(hipGetLastError());
     return 0;
@@ -380,9 +412,7 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr
                               float *out4) {
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
     BM_TRY(metrics_from_chain(h, B, out4));
-    launch_colsums(h, B);
-    launch_bias(h, (float)B, lr, mom);
-    launch_grad(h, B, 1, (float)B, lr, mom);
+    launch_update_fused(h, B, lr, mom);
     h->call++;
     BM_HIP(hipGetLastError());
     return 0;
@@ -400,7 +430,7 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, 
 int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
     launch_colsums(h, B);
-    launch_grad(h, B, 0, (float)B, 0.f, 0.f);
+    rbm_grad(h, B, 0, (float)B, 0.f, 0.f, false);
     h->call++;
     BM_HIP(hipGetLastError());
     return 0;

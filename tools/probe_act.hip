@@ -1,0 +1,66 @@
+// tools/probe_act.hip — ablation probe for act_kernel (developer tool, not part of the product).
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DBM_PROBE tools/probe_act.hip -o probe_act
+#include "../boltzmann_machines_amd/csrc/bm_common.h"
+#include "../boltzmann_machines_amd/csrc/bm_kernels.h"
+#include <vector>
+#include <algorithm>
+namespace bm { void set_error(const char *, ...) {} }
+using namespace bm;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+__global__ __launch_bounds__(256) void k_empty(float *o) { if (threadIdx.x == 999) o[0] = 1.f; }
+__global__ __launch_bounds__(256, 2) void k_lds(float *o) {
+    __shared__ float sm[SMEM_FLOATS];
+    sm[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    if (sm[(threadIdx.x + 1) & 255] == 999.f) o[0] = 1.f;
+}
+__global__ __launch_bounds__(256, 2) void k_args(ActArgs a) { if (threadIdx.x == 999) a.states[0] = a.mult; }
+template <class F> static float time_it(hipStream_t st, hipEvent_t e0, hipEvent_t e1, F f) {
+    for (int i = 0; i < 20; ++i) f();
+    (void)hipStreamSynchronize(st);
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < 200; ++i) f();
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    return 1e3f * ms / 200;
+}
+int main(int argc, char **argv) {
+    const int V = 784, H = 1024, B = 512;
+    Mat W, X, Hm, Hs;
+    W.alloc(V, H); X.alloc(B, V); Hm.alloc(B, H); Hs.alloc(B, H);
+    std::vector<float> hw((size_t)V * H), hx((size_t)B * V);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.01f * (float)((i * 2654435761u >> 8) % 2001 - 1000) / 1000.f;
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = ((i * 2246822519u >> 7) % 8) == 0 ? 1.f : 0.f;
+    W.upload(hw.data()); X.upload(hx.data());
+    float *hb; CK(hipMalloc((void **)&hb, H * 4)); CK(hipMemset(hb, 0, H * 4));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    ActArgs a; memset(&a, 0, sizeof(a));
+    a.P1 = make_operand(W.p, W.ld, H); a.Q1 = make_operand(X.p, X.ld, B); a.K1 = V;
+    a.I = H; a.J = B; a.bias = hb; a.mult = 1.f; a.kind = 0; a.sample = 1;
+    a.means = Hm.p; a.states = Hs.p; a.ldo = Hm.ld; a.key = PhiloxKey{1, 2, 3, 4};
+    printf("k_empty 256x256      %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, Hs.p); }));
+    printf("k_lds 73KB 256x256   %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_lds, dim3(256), dim3(256), 0, st, Hs.p); }));
+    printf("k_args 256x256       %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_args, dim3(256), dim3(256), 0, st, a); }));
+    long long *dbg; CK(hipMalloc((void **)&dbg, 8192 * 8)); CK(hipMemset(dbg, 0, 8192 * 8));
+    a.dbg = dbg;
+    const dim3 grid(tile_grid(a.I, a.J)), blk(NT);
+#define RUN(MASK, NAME) { \
+        float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<false, true, MASK>), grid, blk, 0, st, a); }); \
+        std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
+        double d[4] = {0, 0, 0, 0}, s1 = 0, s2 = 0; \
+        for (int b = 0; b < 256; ++b) { for (int q = 0; q < 4; ++q) d[q] += hd[2048 + b * 8 + q + 1] - hd[2048 + b * 8 + q]; s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
+        printf("%-26s %6.2f us | prologue-issue %5.0f  wait+store+sync %5.0f  loop %6.0f  tail %5.0f | mainloop %6.0f epilogue %5.0f\n", NAME, us, d[0]/256, d[1]/256, d[2]/256, d[3]/256, s1/256, s2/256); }
+    RUN(0, "full")
+    RUN(16, "no-epilogue")
+    RUN(1, "no-gload")
+    RUN(2, "no-mfma")
+    RUN(4, "no-ldswrite")
+    RUN(8, "no-ldsread")
+    RUN(32, "no-barrier")
+    RUN(37, "no gload+write+barrier")
+    RUN(45, "only mfma (+epilogue)")
+    RUN(63, "nothing")
+    return 0;
+}
