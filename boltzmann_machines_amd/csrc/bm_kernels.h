@@ -114,20 +114,22 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
     PhiloxPair rng;
     rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][1];
+    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    KRange kr;
+    kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
+    kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2; kr.sgn2 = 1.0f;
 #ifdef BM_PROBE
-    mainloop<XM, FAST, ABL>(acc, a.P1, a.Q1, a.K1, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+    mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
 #else
-    mainloop<XM, FAST, ABL>(acc, a.P1, a.Q1, a.K1, i0, j0, smem, rng);
+    mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng);
 #endif
-    if (SEG2) mainloop<XM, FAST, ABL>(acc, a.P2, a.Q2, a.K2, i0, j0, smem, rng);
     rng.finish();
     BM_STAMP(1);
 
     float z[8];
-    lane_outputs(acc, z);
+    lane_outputs<1>(acc, 0, z);
     float dmax = 0.f;
     if (BM_ABL(4)) {
         if (j < a.J && ib0 < a.I && a.states) a.states[(size_t)j * a.ldo + ib0] = z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7];
@@ -402,7 +404,7 @@ struct GradArgs {
     int ldw, ldwt;
     const float *pen;                 // [I] sparsity penalty (already cost*(q-target) [+ mu term]) or null
     float N, M, l2, lr, mom;
-    // RBM single-GPU fusion: the first `nbias` workgroups of the launch run the column-sum
+    // RBM single-GPU fusion: the LAST `nbias` workgroups of the launch run the column-sum
     // + bias update (rbm_bias_fused_block) concurrently with the tile workgroups.  Legal
     // only when the W update does not need the penalty they produce (sparsity_cost == 0).
     int nbias;
@@ -421,50 +423,70 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
 
 template <bool FAST>
 __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    static_assert(SMEM_FLOATS >= CS_SMEM_FLOATS + 16, "bias path reuses the tile LDS");
-    if ((int)blockIdx.x < a.nbias) {
-        rbm_bias_fused_block(a.bias, blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS2];
+    static_assert(SMEM_FLOATS2 >= CS_SMEM_FLOATS + 16, "bias path reuses the tile LDS");
+    // the bias/colsum workgroups sit BEHIND the tile workgroups in dispatch order: 208 tiles
+    // (784x1024) take 208 CUs for the whole launch, the short bias groups cycle through
+    // the CUs that are left and finish inside the tiles' shadow.
+    const int ntile_blocks = (int)gridDim.x - a.nbias;
+    if ((int)blockIdx.x >= ntile_blocks) {
+        rbm_bias_fused_block(a.bias, (int)blockIdx.x - ntile_blocks, smem);
         return;
     }
-    const int tiles_j = (a.J + TJ - 1) / TJ;
+    constexpr int TJ2 = 64;                       // NJ = 2: 64 x 64 tiles
+    const int tiles_j = (a.J + TJ2 - 1) / TJ2;
     int ti, tj;
-    block_to_tile(tiles_j, ti, tj, a.nbias);
-    const int i0 = ti * TI, j0 = tj * TJ;
+    block_to_tile(tiles_j, ti, tj, 0, a.nbias);
+    const int i0 = ti * TI, j0 = tj * TJ2;
 
-    f32x4 pos[2], neg[2];
-    pos[0] = pos[1] = neg[0] = neg[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 pos[2][2], neg[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) pos[t][n] = neg[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     NoSide none;
-    mainloop<KM, FAST>(pos, a.Ppos, a.Qpos, a.Kpos, i0, j0, smem, none);
-    mainloop<KM, FAST>(neg, a.Pneg, a.Qneg, a.Kneg, i0, j0, smem, none);
+    KRange kr;
+    kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
+    if (a.form == 0) {
+        // RBM: ONE chain, positive rows then negative rows with the product negated
+        // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
+        kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = a.Kneg; kr.sgn2 = -1.0f;
+        mainloop<KM, 2, FAST, true>(pos, kr, i0, j0, smem, none);
+    } else {
+        // DBM: pos/N - neg/M with N != M needs the two sums separately
+        kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0; kr.sgn2 = 1.0f;
+        mainloop<KM, 2, FAST, false>(pos, kr, i0, j0, smem, none);
+        kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
+        mainloop<KM, 2, FAST, false>(neg, kr, i0, j0, smem, none);
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
-    const int j = j0 + wj * 16 + l15;
     const int ib0 = i0 + wi * 32 + g * 8;
-    if (j >= a.J || ib0 >= a.I) return;
-    float pv[8], nv[8];
-    lane_outputs(pos, pv);
-    lane_outputs(neg, nv);
-    const size_t o = (size_t)j * a.ldw + ib0;
+    if (ib0 >= a.I) return;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        if (ib0 + e >= a.I) break;
-        if (!a.fused) {
-            if (a.form == 0) {
-                a.raw[o + e] = pv[e] - nv[e];
-            } else {
+    for (int n = 0; n < 2; ++n) {
+        const int j = j0 + wj * 32 + n * 16 + l15;
+        if (j >= a.J) continue;
+        float pv[8], nv[8];
+        lane_outputs<2>(pos, n, pv);
+        lane_outputs<2>(neg, n, nv);
+        const size_t o = (size_t)j * a.ldw + ib0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (ib0 + e >= a.I) break;
+            if (!a.fused) {
                 a.raw[o + e] = pv[e];
-                a.raw2[o + e] = nv[e];
+                if (a.form != 0) a.raw2[o + e] = nv[e];
+            } else {
+                const float gr = (a.form == 0) ? pv[e] / a.N : (pv[e] / a.N - nv[e] / a.M);
+                float wv = a.W[o + e], dv = a.dW[o + e];
+                apply_w_update(gr, a.pen ? a.pen[ib0 + e] : 0.f, a.l2, a.lr, a.mom, wv, dv);
+                a.W[o + e] = wv;
+                a.dW[o + e] = dv;
+                if (a.Wt) a.Wt[(size_t)(ib0 + e) * a.ldwt + j] = wv;     // maintained transpose (prop-down P operand)
             }
-        } else {
-            const float gr = (a.form == 0) ? (pv[e] - nv[e]) / a.N : (pv[e] / a.N - nv[e] / a.M);
-            float wv = a.W[o + e], dv = a.dW[o + e];
-            apply_w_update(gr, a.pen ? a.pen[ib0 + e] : 0.f, a.l2, a.lr, a.mom, wv, dv);
-            a.W[o + e] = wv;
-            a.dW[o + e] = dv;
-            if (a.Wt) a.Wt[(size_t)(ib0 + e) * a.ldwt + j] = wv;     // maintained transpose (prop-down P operand)
         }
     }
 }
@@ -562,10 +584,13 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
     int ti, tj;
     block_to_tile(tiles_j, ti, tj);
     const int i0 = ti * TI, j0 = tj * TJ;
-    f32x4 acc[2];
-    acc[0] = acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[2][1];
+    acc[0][0] = acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     NoSide none;
-    mainloop<XM, FAST>(acc, a.P, a.Q, a.K, i0, j0, smem, none);
+    KRange kr;
+    kr.P1 = a.P; kr.Q1 = a.Q; kr.K1 = a.K;
+    kr.P2 = a.P; kr.Q2 = a.Q; kr.K2 = 0; kr.sgn2 = 1.0f;
+    mainloop<XM, 1, FAST, false>(acc, kr, i0, j0, smem, none);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
@@ -578,7 +603,7 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
             delta = 1.0f - 2.0f * a.Q.ptr[(size_t)j * a.Q.ld + fc];
         }
         float zz[8];
-        lane_outputs(acc, zz);
+        lane_outputs<1>(acc, 0, zz);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int i = i0 + wi * 32 + g * 8 + e;
@@ -662,7 +687,7 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
 static inline void launch_grad(const GradArgs &g, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
-    const dim3 grid(tile_grid(g.I, g.J) + g.nbias), blk(NT);
+    const dim3 grid(((g.I + TI - 1) / TI) * ((g.J + 63) / 64) + g.nbias), blk(NT);
     if (fast) hipLaunchKernelGGL((grad_kernel<true>), grid, blk, 0, st, g);
     else      hipLaunchKernelGGL((grad_kernel<false>), grid, blk, 0, st, g);
 }

@@ -188,14 +188,16 @@ void orc_act(const float *Q1, int K1, const float *P1k,
     }
 }
 
-/* out[j][i] = sum_b Qb[b][j] * Pb[b][i]  — outer-product accumulation over rows b */
-static void outer_chain(float *out, const float *Qb, int J, const float *Pb, int I, int B) {
+/* out[j][i] (+)= sgn * sum_b Qb[b][j] * Pb[b][i]  — outer-product accumulation over rows b,
+ * continuing the chain already in `out` when `accumulate` is set */
+static void outer_chain(float *out, const float *Qb, int J, const float *Pb, int I, int B, float sgn,
+                        int accumulate) {
 #pragma omp parallel for schedule(static)
     for (int j = 0; j < J; ++j) {
         float *acc = out + (size_t)j * I;
-        for (int i = 0; i < I; ++i) acc[i] = 0.0f;
+        if (!accumulate) for (int i = 0; i < I; ++i) acc[i] = 0.0f;
         for (int b = 0; b < B; ++b) {
-            const float q = Qb[(size_t)b * J + j];
+            const float q = sgn * Qb[(size_t)b * J + j];
             const float *p = Pb + (size_t)b * I;
             for (int i = 0; i < I; ++i) acc[i] = fmaf(p[i], q, acc[i]);
         }
@@ -265,12 +267,10 @@ void orc_rbm_chain(const orc_rbm_cfg *c, const orc_rbm_state *s, const float *X,
  * raw = [ X^T h0 - v^T h_k  (V*H) | sum(X - v) (V) | sum(h0 - h_k) (H) | sum(h_k) (H) ] */
 void orc_rbm_raw_grads(const orc_rbm_cfg *c, const orc_rbm_work *w, int B, float *raw) {
     const int V = c->V, H = c->H;
-    float *pos = (float *)malloc((size_t)V * H * sizeof(float));
-    float *neg = (float *)malloc((size_t)V * H * sizeof(float));
-    outer_chain(pos, w->Xin, V, w->h0m, H, B);      /* X^T h0_means          :447 */
-    outer_chain(neg, w->vs, V, w->hm, H, B);        /* v_states^T h_means    :448 */
-    for (size_t e = 0; e < (size_t)V * H; ++e) raw[e] = pos[e] - neg[e];
-    free(pos); free(neg);
+    /* dW_positive - dW_negative (:447-449) as ONE canonical chain: the positive rows
+     * X^T h0_means, then the negative rows with the product negated, -(v_states^T h_means) */
+    outer_chain(raw, w->Xin, V, w->h0m, H, B, 1.0f, 0);
+    outer_chain(raw, w->vs, V, w->hm, H, B, -1.0f, 1);
     float *tail = raw + (size_t)V * H;
     colsum_diff(tail, w->Xin, w->vs, B, V);
     colsum_diff(tail + V, w->h0m, w->hm, B, H);
