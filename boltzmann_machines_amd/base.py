@@ -1,0 +1,265 @@
+"""Model plumbing shared by the RBM and DBM classes.
+
+Mirrors the reference's base/ package with the TensorFlow parts replaced by
+the MI355X engine:
+
+* `BaseMixin` / `DtypeMixin` / `SeedMixin`   reference base/mixin.py:7-35
+* `BaseModel.get_params/set_params`          reference base/base_model.py:12-63
+* `EngineModel` (the reference's `TensorFlowModel`, base/tf_model.py:43-202):
+  working paths, params.json / random_state.json persistence, `init`, `fit`,
+  `get_tf_params`, `load_model`, and `run_on_engine` — the stand-in for the
+  `run_in_tf_session` decorator (tf_model.py:10-40).
+
+Differences that are deliberate (DESIGN.md "boundary"):
+  - variables live in HBM behind a C-ABI handle for the lifetime of the Python
+    object; they are written to `<model_filepath>.npz` where the reference runs
+    the TF Saver, and re-read from there only by `load_model`.
+  - dtype: the device path is fp32 (the reference default).  'float64' models
+    can be constructed/initialised (the W-init known answer of
+    rbm/tests/test_rbm.py:67 holds) but `fit`/`transform` raise.
+"""
+import json
+import os
+from copy import deepcopy
+from functools import wraps
+
+import numpy as np
+
+from .utils import RNG, write_during_training
+
+
+def is_param_name(name):
+    return not name.startswith('_') and not name.endswith('_')
+
+
+def is_attribute_name(name):
+    return not name.startswith('_') and name.endswith('_')
+
+
+class BaseMixin(object):
+    def __init__(self, *args, **kwargs):
+        if args or kwargs:
+            raise AttributeError('Invalid parameters: {0}, {1}'.format(args, kwargs))
+        super(BaseMixin, self).__init__()
+
+
+class DtypeMixin(BaseMixin):
+    def __init__(self, dtype='float32', *args, **kwargs):
+        super(DtypeMixin, self).__init__(*args, **kwargs)
+        self.dtype = dtype
+
+    @property
+    def _np_dtype(self):
+        return getattr(np, self.dtype)
+
+
+class SeedMixin(BaseMixin):
+    def __init__(self, random_seed=None, *args, **kwargs):
+        super(SeedMixin, self).__init__(*args, **kwargs)
+        self.random_seed = random_seed
+        self._rng = RNG(seed=self.random_seed)
+
+    def make_random_seed(self):
+        return self._rng.randint(2 ** 31 - 1)
+
+
+class BaseModel(SeedMixin):
+    def get_params(self, deep=True, include_attributes=True):
+        params = vars(self)
+        p = lambda k: is_param_name(k) or (include_attributes and is_attribute_name(k))
+        params = {k: params[k] for k in params if p(k)}
+        if deep:
+            params = deepcopy(params)
+        return params
+
+    def set_params(self, **params):
+        for k, v in params.items():
+            if (is_param_name(k) or is_attribute_name(k)) and hasattr(self, k):
+                setattr(self, k, v)
+            else:
+                raise ValueError("invalid param name '{0}'".format(k))
+        return self
+
+    def _serialize(self, params):
+        for k, v in params.items():
+            if isinstance(v, np.ndarray):
+                if v.size > 1e6:
+                    msg = "WARNING: parameter `{0}` won't be serialized because it is too large:"
+                    msg += ' ({1:.2f} > 1 Mio elements)'
+                    write_during_training(msg.format(k, 1e-6 * v.size))
+                    params[k] = None
+                else:
+                    params[k] = v.tolist()
+            elif isinstance(v, (np.floating, np.integer)):
+                params[k] = v.item()
+        return params
+
+    def _deserialize(self, params):
+        return params
+
+
+def run_on_engine(check_initialized=True, update_seed=False):
+    """Stand-in for `run_in_tf_session` (reference base/tf_model.py:10-40).
+
+    update_seed : draw the call's graph seed from the host MT stream, as
+        `tf.set_random_seed(model.make_random_seed())` does, and install it as
+        the Philox key of every sampling site of this call.
+    check_initialized : RuntimeError before `fit`/`init`, as the reference.
+    """
+    def wrap(f):
+        @wraps(f)
+        def wrapped_f(model, *args, **kwargs):
+            model._graph_seed = model.make_random_seed() if update_seed else None
+            if not model.initialized_ and check_initialized:
+                raise RuntimeError('`fit` or `init` must be called before calling `{0}`'.format(f.__name__))
+            model._ensure_engine()
+            if update_seed:
+                model._seed_engine(model._graph_seed)
+            return f(model, *args, **kwargs)
+        return wrapped_f
+    return wrap
+
+
+class EngineModel(BaseModel, DtypeMixin):
+    def __init__(self, model_path='tf_model/', paths=None, tf_session_config=None, tf_saver_params=None,
+                 json_params=None, *args, **kwargs):
+        super(EngineModel, self).__init__(*args, **kwargs)
+        # accepted for signature compatibility with the reference (tf_model.py:44-46); unused
+        self.tf_saver_params = tf_saver_params or {}
+        self._model_dirpath = None
+        self._model_filepath = None
+        self._params_filepath = None
+        self._random_state_filepath = None
+        self._train_summary_dirpath = None
+        self._val_summary_dirpath = None
+        self._tf_meta_graph_filepath = None
+        self.update_working_paths(model_path=model_path, paths=paths)
+        self.json_params = json_params or {}
+        self.json_params.setdefault('sort_keys', True)
+        self.json_params.setdefault('indent', 4)
+        self.initialized_ = False
+        self._engine = None
+        self._graph_seed = None
+        self._pending_vars = None      # variables read by load_model, uploaded when the engine is built
+
+    # ---- paths (reference tf_model.py:71-99) -------------------------------------
+    @staticmethod
+    def compute_working_paths(model_path):
+        head, tail = os.path.split(model_path)
+        if not head:
+            head = '.'
+        if not head.endswith('/'):
+            head += '/'
+        if not tail:
+            tail = 'model'
+        paths = {}
+        paths['model_dirpath'] = head
+        paths['model_filepath'] = os.path.join(paths['model_dirpath'], tail)
+        paths['params_filepath'] = os.path.join(paths['model_dirpath'], 'params.json')
+        paths['random_state_filepath'] = os.path.join(paths['model_dirpath'], 'random_state.json')
+        paths['train_summary_dirpath'] = os.path.join(paths['model_dirpath'], 'logs/train')
+        paths['val_summary_dirpath'] = os.path.join(paths['model_dirpath'], 'logs/val')
+        paths['tf_meta_graph_filepath'] = paths['model_filepath'] + '.meta'
+        return paths
+
+    def update_working_paths(self, model_path=None, paths=None):
+        paths = paths or {}
+        if not paths:
+            paths = EngineModel.compute_working_paths(model_path=model_path)
+        for k, v in paths.items():
+            setattr(self, '_{0}'.format(k), v)
+
+    # ---- engine hooks (class specific) -------------------------------------------
+    def _make_engine(self):
+        """Build the device handle and upload the initial variables (the
+        reference's `_make_tf_model` + `global_variables_initializer`)."""
+        raise NotImplementedError
+
+    def _seed_engine(self, seed):
+        raise NotImplementedError
+
+    def _variables(self):
+        """dict name -> ndarray of every checkpointed variable."""
+        raise NotImplementedError
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            if np.dtype(self.dtype) != np.float32 and self._needs_device():
+                raise NotImplementedError("the MI355X engine computes in float32 (dtype='%s' requested)" % self.dtype)
+            self._make_engine()
+            if self._pending_vars is not None:
+                self._upload_variables(self._pending_vars)
+                self._pending_vars = None
+
+    def _needs_device(self):
+        return True
+
+    def _upload_variables(self, d):
+        raise NotImplementedError
+
+    # ---- persistence (reference tf_model.py:117-162) ----------------------------
+    def _save_model(self, global_step=None):
+        for dirpath in (self._train_summary_dirpath, self._val_summary_dirpath):
+            if not os.path.exists(dirpath):
+                os.makedirs(dirpath)
+        params = self.get_params(deep=False)
+        params = self._serialize(dict(params))
+        params['__class_name__'] = self.__class__.__name__
+        with open(self._params_filepath, 'w') as params_file:
+            json.dump(params, params_file, **self.json_params)
+        if self.random_seed is not None:
+            with open(self._random_state_filepath, 'w') as random_state_file:
+                json.dump(self._rng.get_state(), random_state_file)
+        # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
+        np.savez(self._model_filepath + '.npz', **self._variables())
+
+    @classmethod
+    def load_model(cls, model_path):
+        paths = EngineModel.compute_working_paths(model_path)
+        with open(paths['params_filepath'], 'r') as params_file:
+            params = json.load(params_file)
+        class_name = params.pop('__class_name__')
+        if class_name != cls.__name__:
+            raise RuntimeError("attempt to load {0} with class {1}".format(class_name, cls.__name__))
+        model = cls(paths=paths, **{k: params[k] for k in params if is_param_name(k)})
+        params = model._deserialize(params)
+        model.set_params(**params)
+        if os.path.isfile(model._random_state_filepath):
+            with open(model._random_state_filepath, 'r') as random_state_file:
+                model._rng.set_state(json.load(random_state_file))
+        # variables are uploaded once any computation is needed (reference: lazily restored)
+        with np.load(model._model_filepath + '.npz') as z:
+            model._pending_vars = {k: z[k] for k in z.files}
+        return model
+
+    # ---- public API (reference tf_model.py:164-202) ------------------------------
+    def _fit(self, X, X_val=None, *args, **kwargs):
+        raise NotImplementedError('`fit` is not implemented')
+
+    @run_on_engine(check_initialized=False)
+    def init(self):
+        if not self.initialized_:
+            self.initialized_ = True
+            self._save_model()
+        return self
+
+    @run_on_engine(check_initialized=False, update_seed=True)
+    def fit(self, X, X_val=None, *args, **kwargs):
+        self.initialized_ = True
+        self._fit(X, X_val=X_val, *args, **kwargs)
+        self._save_model()
+        return self
+
+    @run_on_engine()
+    def get_tf_params(self, scope=None):
+        """Variables by TF scope, as the reference's get_tf_params (tf_model.py:183-202)."""
+        out = {}
+        for key, (var_scope, value) in self._scoped_variables().items():
+            if scope is None:
+                out['{0}/{1}'.format(var_scope, key)] = value
+            elif scope in var_scope:
+                out[key] = value
+        return out
+
+    def _scoped_variables(self):
+        raise NotImplementedError

@@ -1,0 +1,364 @@
+"""BernoulliRBM / GaussianRBM with the reference's sklearn-like API on the MI355X engine.
+
+Drop-in for boltzmann_machines/rbm/{base_rbm,rbm}.py of the reference:
+same constructor keywords (base_rbm.py:95-105, rbm.py:88-99), `fit`, `init`,
+`transform`, `get_tf_params`, `init_from`, `load_model`, `get_params`/
+`set_params`, attributes `epoch_`, `iter_`; same schedules (1-based epoch index,
+base_rbm.py:535-541), metric cadence (:549-571), validation metrics (:573-590),
+free-energy gap (:592-621) and per-epoch checkpoint (:665-666).  The TF graph
+of `_make_train_op` (:415-525) is executed by libbm355 (csrc/bm_rbm.hip).
+
+MultinomialRBM is out of scope of the hot path.
+"""
+import numpy as np
+
+from . import _ffi
+from .base import EngineModel, is_attribute_name, run_on_engine
+from .engine import RbmEngine, as_device
+from .utils import batch_iter, epoch_iter, make_list_from, write_during_training
+from .utils import philox
+
+
+def assert_shape(obj, name, desired_shape):
+    actual_shape = getattr(obj, name).shape
+    if actual_shape != desired_shape:
+        raise ValueError('`{0}` has invalid shape {1} != {2}'.format(name, actual_shape, desired_shape))
+
+
+def assert_len(obj, name, desired_len):
+    actual_len = len(getattr(obj, name))
+    if actual_len != desired_len:
+        raise ValueError('`{0}` has invalid len {1} != {2}'.format(name, actual_len, desired_len))
+
+
+class _HostVars(object):
+    """float64 models: variables exist on the host only (no fp64 device path)."""
+
+    def __init__(self, variables):
+        self.vars = variables
+
+    def get(self, name):
+        return self.vars[name]
+
+    def set(self, name, value):
+        self.vars[name] = np.asarray(value, dtype=self.vars[name].dtype).reshape(self.vars[name].shape)
+
+    def close(self):
+        pass
+
+
+class BaseRBM(EngineModel):
+    """Restricted Boltzmann machine trained with CD-k (reference base_rbm.py:14-94)."""
+
+    _V_UNIT = _ffi.UNIT_BERNOULLI
+
+    def __init__(self,
+                 n_visible=784, v_layer_cls=None, v_layer_params=None,
+                 n_hidden=256, h_layer_cls=None, h_layer_params=None,
+                 W_init=0.01, vb_init=0., hb_init=0., n_gibbs_steps=1,
+                 learning_rate=0.01, momentum=0.9, max_epoch=10, batch_size=10, l2=1e-4,
+                 sample_v_states=False, sample_h_states=True, dropout=None,
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9,
+                 dbm_first=False, dbm_last=False,
+                 metrics_config=None, verbose=True, save_after_each_epoch=True,
+                 display_filters=0, display_hidden_activations=0, v_shape=(28, 28),
+                 model_path='rbm_model/', *args, **kwargs):
+        super(BaseRBM, self).__init__(model_path=model_path, *args, **kwargs)
+        self.n_visible = n_visible
+        self.n_hidden = n_hidden
+
+        self.W_init = W_init
+        if hasattr(self.W_init, '__iter__'):
+            self.W_init = np.asarray(self.W_init)
+            assert_shape(self, 'W_init', (self.n_visible, self.n_hidden))
+        self.vb_init = vb_init
+        if hasattr(self.vb_init, '__iter__'):
+            self.vb_init = np.asarray(self.vb_init)
+            assert_len(self, 'vb_init', self.n_visible)
+        self.hb_init = hb_init
+        if hasattr(self.hb_init, '__iter__'):
+            self.hb_init = np.asarray(self.hb_init)
+            assert_len(self, 'hb_init', self.n_hidden)
+
+        # these can be set by `init_from`
+        self._dW_init = None
+        self._dvb_init = None
+        self._dhb_init = None
+
+        self.n_gibbs_steps = make_list_from(n_gibbs_steps)
+        self.learning_rate = make_list_from(learning_rate)
+        self.momentum = make_list_from(momentum)
+        self.max_epoch = max_epoch
+        self.batch_size = batch_size
+        self.l2 = l2
+
+        self.sample_h_states = sample_h_states
+        self.sample_v_states = sample_v_states
+        self.dropout = dropout
+
+        self.sparsity_target = sparsity_target
+        self.sparsity_cost = sparsity_cost
+        self.sparsity_damping = sparsity_damping
+
+        self.dbm_first = dbm_first
+        self.dbm_last = dbm_last
+
+        self.metrics_config = metrics_config or {}
+        self.metrics_config.setdefault('l2_loss', False)
+        self.metrics_config.setdefault('msre', False)
+        self.metrics_config.setdefault('pll', False)
+        self.metrics_config.setdefault('feg', False)
+        self.metrics_config.setdefault('l2_loss_fmt', '.2e')
+        self.metrics_config.setdefault('msre_fmt', '.4f')
+        self.metrics_config.setdefault('pll_fmt', '.3f')
+        self.metrics_config.setdefault('feg_fmt', '.2f')
+        self.metrics_config.setdefault('train_metrics_every_iter', 10)
+        self.metrics_config.setdefault('val_metrics_every_epoch', 1)
+        self.metrics_config.setdefault('feg_every_epoch', 2)
+        self.metrics_config.setdefault('n_batches_for_feg', 10)
+        self._train_metrics_names = ('l2_loss', 'msre', 'pll')
+        self._val_metrics_names = ('msre', 'pll')
+
+        self.verbose = verbose
+        self.save_after_each_epoch = save_after_each_epoch
+
+        assert self.n_hidden >= display_filters
+        self.display_filters = display_filters
+        assert self.n_hidden >= display_hidden_activations
+        self.display_hidden_activations = display_hidden_activations
+        self.v_shape = v_shape
+        if len(self.v_shape) == 2:
+            self.v_shape = (self.v_shape[0], self.v_shape[1], 1)
+
+        # current epoch and iteration
+        self.epoch_ = 0
+        self.iter_ = 0
+
+    # ---- variables -----------------------------------------------------------------
+    def _sigma_vector(self):
+        return np.ones(self.n_visible, dtype=self._np_dtype)
+
+    def _initial_variables(self):
+        """The initialisers of `_make_vars` (reference base_rbm.py:271-327).
+
+        W ~ tf.random_normal(stddev=W_init, seed=random_seed): with the graph seed of
+        the enclosing public call when there is one (`fit`), else TF's
+        DEFAULT_GRAPH_SEED (`init()`; pinned by rbm/tests/test_rbm.py:64-67)."""
+        dt = self._np_dtype
+        V, H = self.n_visible, self.n_hidden
+        if hasattr(self.W_init, '__iter__'):
+            W = np.asarray(self.W_init, dtype=dt)
+        else:
+            op_seed = self.random_seed
+            if op_seed is None:      # TF: non-deterministic when no seed is given
+                op_seed = int(np.random.randint(2 ** 31 - 1))
+            graph_seed = self._graph_seed if self._graph_seed is not None else philox.DEFAULT_GRAPH_SEED
+            W = (philox.normal(graph_seed, int(op_seed) & 0xFFFFFFFF, (int(op_seed) >> 32) & 0xFFFFFFFF, V * H, dt)
+                 * dt(self.W_init)).reshape(V, H).astype(dt)
+        vb = np.asarray(self.vb_init, dtype=dt) if hasattr(self.vb_init, '__iter__') \
+            else np.repeat(dt(self.vb_init), V)
+        hb = np.asarray(self.hb_init, dtype=dt) if hasattr(self.hb_init, '__iter__') \
+            else np.repeat(dt(self.hb_init), H)
+        z = lambda a, shape: np.zeros(shape, dtype=dt) if a is None else np.asarray(a, dtype=dt).reshape(shape)
+        return dict(W=W, vb=vb, hb=hb, dW=z(self._dW_init, (V, H)), dvb=z(self._dvb_init, (V,)),
+                    dhb=z(self._dhb_init, (H,)), q_means=np.zeros(H, dtype=dt), sigma=self._sigma_vector())
+
+    _VAR_SCOPES = (('W', 'weights'), ('vb', 'weights'), ('hb', 'weights'),
+                   ('dW', 'grads_accumulators'), ('dvb', 'grads_accumulators'), ('dhb', 'grads_accumulators'),
+                   ('q_means', 'hidden_activations_means'), ('sigma', 'input_data'))
+
+    def _make_engine(self):
+        variables = self._initial_variables()
+        if np.dtype(self.dtype) == np.float32:
+            self._engine = RbmEngine(self.n_visible, self.n_hidden, v_unit=self._V_UNIT,
+                                     sample_v_states=self.sample_v_states, sample_h_states=self.sample_h_states,
+                                     dbm_first=self.dbm_first, dbm_last=self.dbm_last, max_batch=self.batch_size,
+                                     l2=self.l2, sparsity_target=self.sparsity_target,
+                                     sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping,
+                                     dropout=self.dropout)
+            self._upload_variables(variables)
+        else:
+            self._engine = _HostVars(variables)
+
+    def _needs_device(self):
+        return False
+
+    def _on_device(self):
+        if not isinstance(self._engine, RbmEngine):
+            raise NotImplementedError("the MI355X engine computes in float32 (dtype='%s' requested)" % self.dtype)
+        return self._engine
+
+    def _upload_variables(self, d):
+        for name, _ in self._VAR_SCOPES:
+            if name in d:
+                self._engine.set(name, d[name])
+
+    def _seed_engine(self, seed):
+        if isinstance(self._engine, RbmEngine):
+            self._engine.seed(seed)
+
+    def _variables(self):
+        return {name: self._engine.get(name) for name, _ in self._VAR_SCOPES}
+
+    def _scoped_variables(self):
+        return {name: (scope, self._engine.get(name)) for name, scope in self._VAR_SCOPES}
+
+    def set_params(self, **params):
+        # the handle bakes in the graph constants: rebuild it if one of them changes
+        rebuild = {'batch_size', 'l2', 'dropout', 'sample_v_states', 'sample_h_states', 'sparsity_target',
+                   'sparsity_cost', 'sparsity_damping', 'dbm_first', 'dbm_last'}
+        super(BaseRBM, self).set_params(**params)
+        if self._engine is not None and isinstance(self._engine, RbmEngine) and rebuild & set(params):
+            self._pending_vars = self._variables()
+            self._engine.close()
+            self._engine = None
+        return self
+
+    # ---- schedules (reference base_rbm.py:533-547) -----------------------------------
+    def _schedule(self, values):
+        return values[min(self.epoch_, len(values) - 1)]
+
+    def _feed(self):
+        return (float(self._schedule(self.learning_rate)), float(self._schedule(self.momentum)),
+                int(self._schedule(self.n_gibbs_steps)))
+
+    # ---- training loop (reference base_rbm.py:549-666) -------------------------------
+    def _train_epoch(self, Xd, N):
+        eng = self._on_device()
+        names = sorted(m for m in self._train_metrics_names if self.metrics_config[m])
+        results = {m: [] for m in names}
+        lr, mom, k = self._feed()
+        every = self.metrics_config['train_metrics_every_iter']
+        for start in range(0, N, self.batch_size):
+            B = min(self.batch_size, N - start)
+            self.iter_ += 1
+            if self.iter_ % every == 0:
+                out = eng.train_step_metrics(Xd, B, lr, mom, k, row=start)
+                vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
+                for m in names:
+                    results[m].append(vals[m])
+            else:
+                eng.train_step(Xd, B, lr, mom, k, row=start)
+        return {m: (np.mean(r) if r else None) for m, r in results.items()}
+
+    def _run_val_metrics(self, Xvd, N):
+        eng = self._on_device()
+        names = sorted(m for m in self._val_metrics_names if self.metrics_config[m])
+        results = {m: [] for m in names}
+        _, _, k = self._feed()
+        for start in range(0, N, self.batch_size):
+            B = min(self.batch_size, N - start)
+            out = eng.metrics(Xvd, B, k, row=start)
+            vals = dict(msre=out[0], pll=out[1])
+            for m in names:
+                results[m].append(vals[m])
+        return {m: (np.mean(r) if r else None) for m, r in results.items()}
+
+    def _run_feg(self, Xd, N, Xvd, Nv):
+        """Free-energy gap between validation and training subsets (reference base_rbm.py:592-621)."""
+        eng = self._on_device()
+        nb = self.metrics_config['n_batches_for_feg']
+        train_fes, val_fes = [], []
+        for b, start in zip(range(nb), range(0, N, self.batch_size)):
+            train_fes.append(eng.free_energy(Xd, min(self.batch_size, N - start), row=start))
+        for b, start in zip(range(nb), range(0, Nv, self.batch_size)):
+            val_fes.append(eng.free_energy(Xvd, min(self.batch_size, Nv - start), row=start))
+        return np.mean(val_fes) - np.mean(train_fes)
+
+    def _fit(self, X, X_val=None, *args, **kwargs):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        Xd = as_device(X)
+        N = len(X)
+        Xvd, Nv = None, 0
+        if X_val is not None:
+            X_val = np.ascontiguousarray(X_val, dtype=np.float32)
+            Xvd, Nv = as_device(X_val), len(X_val)
+        for self.epoch_ in epoch_iter(start_epoch=self.epoch_, max_epoch=self.max_epoch, verbose=self.verbose):
+            val_results = {}
+            feg = None
+            train_results = self._train_epoch(Xd, N)
+            if X_val is not None and self.epoch_ % self.metrics_config['val_metrics_every_epoch'] == 0:
+                val_results = self._run_val_metrics(Xvd, Nv)
+            if X_val is not None and self.metrics_config['feg'] and \
+                    self.epoch_ % self.metrics_config['feg_every_epoch'] == 0:
+                feg = self._run_feg(Xd, N, Xvd, Nv)
+            if self.verbose:
+                s = "epoch: {0:{1}}/{2}".format(self.epoch_, len(str(self.max_epoch)), self.max_epoch)
+                for m, v in sorted(train_results.items()):
+                    if v is not None:
+                        s += "; {0}: {1:{2}}".format(m, v, self.metrics_config['{0}_fmt'.format(m)])
+                for m, v in sorted(val_results.items()):
+                    if v is not None:
+                        s += "; val.{0}: {1:{2}}".format(m, v, self.metrics_config['{0}_fmt'.format(m)])
+                if feg is not None:
+                    s += " ; feg: {0:{1}}".format(feg, self.metrics_config['feg_fmt'])
+                write_during_training(s)
+            if self.save_after_each_epoch:
+                self._save_model(global_step=self.epoch_)
+        self._engine.sync()
+
+    def init_from(self, rbm):
+        """Start from another RBM's weights and momentum buffers (reference base_rbm.py:668-685)."""
+        if type(self) != type(rbm):
+            raise ValueError('an attempt to initialize `{0}` from `{1}`'.
+                             format(self.__class__.__name__, rbm.__class__.__name__))
+        weights = rbm.get_tf_params(scope='weights')
+        self.W_init = weights['W']
+        self.vb_init = weights['vb']
+        self.hb_init = weights['hb']
+        grads_accumulators = rbm.get_tf_params(scope='grads_accumulators')
+        self._dW_init = grads_accumulators['dW']
+        self._dvb_init = grads_accumulators['dvb']
+        self._dhb_init = grads_accumulators['dhb']
+        for k, v in vars(rbm).items():
+            if is_attribute_name(k):
+                setattr(self, k, v)
+
+    @run_on_engine(update_seed=True)
+    def transform(self, X, np_dtype=None):
+        """Hidden activation probabilities at the END of the k-step chain, stochastic
+        (reference base_rbm.py:687-700 with the op of :438-440)."""
+        np_dtype = np_dtype or self._np_dtype
+        eng = self._on_device()
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        N = len(X)
+        Xd = as_device(X)
+        Hd = _ffi.DeviceArray((N, self.n_hidden))
+        _, _, k = self._feed()
+        for start in range(0, N, self.batch_size):
+            eng.transform(Xd, min(self.batch_size, N - start), k, Hd, row=start, out_row=start)
+        eng.sync()
+        return Hd.numpy().astype(np_dtype)
+
+
+class BernoulliRBM(BaseRBM):
+    """RBM with Bernoulli visible and hidden units (reference rbm/rbm.py:10-22)."""
+
+    def __init__(self, model_path='b_rbm_model/', *args, **kwargs):
+        super(BernoulliRBM, self).__init__(model_path=model_path, *args, **kwargs)
+
+
+class GaussianRBM(BaseRBM):
+    """RBM with Gaussian visible (fixed `sigma`) and Bernoulli hidden units
+    (reference rbm/rbm.py:68-116)."""
+
+    _V_UNIT = _ffi.UNIT_GAUSSIAN
+
+    def __init__(self, learning_rate=1e-3, sigma=1., model_path='g_rbm_model/', *args, **kwargs):
+        self.sigma = sigma
+        super(GaussianRBM, self).__init__(learning_rate=learning_rate, model_path=model_path, *args, **kwargs)
+        if hasattr(self.sigma, '__iter__'):
+            self._sigma_tmp = self.sigma = np.asarray(self.sigma)
+        else:
+            self._sigma_tmp = np.repeat(self.sigma, self.n_visible)
+
+    def _sigma_vector(self):
+        return np.asarray(self._sigma_tmp, dtype=self._np_dtype)
+
+
+def logit_mean(X):
+    """log(p / (1 - p)) of the per-feature mean, clipped (reference rbm/rbm.py:119-123)."""
+    p = np.mean(X, axis=0)
+    p = np.clip(p, 1e-7, 1. - 1e-7)
+    q = np.log(p / (1. - p))
+    return q

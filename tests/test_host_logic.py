@@ -1,0 +1,127 @@
+"""CPU tests (-m "not gpu"): host logic that mirrors the reference without touching
+the device — constructor validation, working paths, utilities, RNG, the W-init known
+answer, and that the C-ABI library loads and exports every declared symbol."""
+import doctest
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_w_init_shape_validation():
+    """reference rbm/tests/test_rbm.py:29-36"""
+    from boltzmann_machines_amd import BernoulliRBM, GaussianRBM
+    for C in (BernoulliRBM, GaussianRBM):
+        for bad in ((4, 2), (3, 3), (3, 2)):
+            with pytest.raises(ValueError):
+                C(n_visible=4, n_hidden=3, W_init=np.zeros(bad))
+        C(n_visible=4, n_hidden=3, W_init=np.zeros((4, 3)))
+        C(n_visible=3, n_hidden=3, W_init=np.zeros((3, 3)))
+        C(n_visible=1, n_hidden=1, W_init=np.zeros((1, 1)))
+        with pytest.raises(ValueError):
+            C(n_visible=4, n_hidden=3, vb_init=np.zeros(5))
+        with pytest.raises(ValueError):
+            C(n_visible=4, n_hidden=3, hb_init=np.zeros(5))
+        with pytest.raises(AttributeError):
+            C(n_visible=4, n_hidden=3, no_such_kwarg=1)      # base/mixin.py:9-10
+
+
+def test_w_init_known_answer():
+    """reference rbm/tests/test_rbm.py:64-67: random_seed=1337, stddev 0.01."""
+    from boltzmann_machines_amd import BernoulliRBM
+    w32 = BernoulliRBM(n_visible=12, n_hidden=8, random_seed=1337)._initial_variables()['W']
+    w64 = BernoulliRBM(n_visible=12, n_hidden=8, random_seed=1337, dtype='float64')._initial_variables()['W']
+    assert w32.dtype == np.float32 and w64.dtype == np.float64
+    assert_almost_equal(w32[0][0], -0.0094548017)
+    assert_almost_equal(w64[0][0], -0.0077341544416)
+
+
+PATHS = [   # reference base/tests/test_tf_model.py:8-93
+    ('model/', ('model/', 'model/model')),
+    ('model/my_model', ('model/', 'model/my_model')),
+    ('a/b/c/', ('a/b/c/', 'a/b/c/model')),
+    ('my_model', ('./', './my_model')),
+    ('./', ('./', './model')),
+]
+
+
+@pytest.mark.parametrize('model_path,expected', PATHS)
+def test_working_paths(model_path, expected):
+    from boltzmann_machines_amd.base import EngineModel
+    p = EngineModel.compute_working_paths(model_path)
+    assert p['model_dirpath'] == expected[0]
+    assert p['model_filepath'] == expected[1]
+    assert p['params_filepath'] == expected[0] + 'params.json'
+    assert p['random_state_filepath'] == expected[0] + 'random_state.json'
+    assert p['train_summary_dirpath'] == expected[0] + 'logs/train'
+    assert p['tf_meta_graph_filepath'] == expected[1] + '.meta'
+
+
+def test_params_roundtrip():
+    from boltzmann_machines_amd import BernoulliRBM
+    rbm = BernoulliRBM(n_visible=4, n_hidden=3, learning_rate=[0.1, 0.01], random_seed=3)
+    p = rbm.get_params()
+    assert p['learning_rate'] == [0.1, 0.01] and p['epoch_'] == 0 and 'n_visible' in p
+    assert not any(k.startswith('_') for k in p)
+    rbm.set_params(max_epoch=7, epoch_=2)
+    assert rbm.max_epoch == 7 and rbm.epoch_ == 2
+    with pytest.raises(ValueError):
+        rbm.set_params(_rng=None)
+    json.dumps(rbm._serialize(rbm.get_params(deep=True)))     # params.json payload is serialisable
+    s1, s2 = BernoulliRBM(random_seed=9).make_random_seed(), BernoulliRBM(random_seed=9).make_random_seed()
+    assert s1 == s2
+
+
+def test_utils_doctests():
+    from boltzmann_machines_amd.utils import rng, utils
+    for m in (utils, rng):
+        assert doctest.testmod(m).failed == 0
+
+
+def test_batch_and_epoch_iter():
+    from boltzmann_machines_amd.utils import batch_iter, epoch_iter, make_list_from
+    X = np.arange(36).reshape(12, 3)
+    assert [b.shape[0] for b in batch_iter(X, 5)] == [5, 5, 2]
+    assert list(epoch_iter(2, 5)) == [3, 4, 5]
+    assert make_list_from(3) == [3] and make_list_from((1, 2)) == [1, 2]
+
+
+def test_host_philox_matches_oracle():
+    from boltzmann_machines_amd.utils import philox
+    from oracle import oracle as orc
+    assert np.array_equal(philox.philox_blocks(123456789012, 7, 9, 5, 33), orc.philox_words(123456789012, 7, 9, 5, 33))
+    assert np.array_equal(philox.uniform(5, 3, 7, 1001, idx0=3), orc.uniform(5, 3, 7, 1001, idx0=3))
+    np.testing.assert_allclose(philox.normal(5, 3, 7, 1001), orc.normal(5, 3, 7, 1001), atol=5e-7)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libbm355.so loads without a GPU and exports exactly what include/bm355.h declares."""
+    from boltzmann_machines_amd import _ffi
+    lib = _ffi.load()
+    header = open(os.path.join(ROOT, 'include', 'bm355.h')).read()
+    declared = set(re.findall(r'\b(bm_[a-z0-9_]+)\s*\(', header))
+    declared -= {'bm_rbm_config', 'bm_dbm_config'}
+    assert declared, 'no declarations parsed'
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libbm355.so does not export %s' % name
+    assert declared == set(_ffi.exported_symbols()), declared ^ set(_ffi.exported_symbols())
+    assert lib.bm_version().startswith(b'bm355')
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a visible GPU the product path must fail loudly, not compute on the CPU."""
+    from boltzmann_machines_amd import _ffi
+    lib = _ffi.load()
+    if lib.bm_device_count() > 0:
+        pytest.skip('GPU visible: covered by the -m gpu tests')
+    from boltzmann_machines_amd.engine import RbmEngine
+    with pytest.raises(_ffi.Bm355Error, match='no HIP device'):
+        RbmEngine(8, 4, max_batch=2)
+    from boltzmann_machines_amd import BernoulliRBM
+    with pytest.raises(_ffi.Bm355Error):
+        BernoulliRBM(n_visible=8, n_hidden=4, verbose=False, model_path='/tmp/bm355_nogpu/').fit(np.zeros((4, 8)))

@@ -1,0 +1,123 @@
+"""Port of the reference's own RBM tests (boltzmann_machines/rbm/tests/test_rbm.py)
+to the MI355X classes — same shapes, seeds and assertions — plus checks that the
+Python fit loop drives the engine exactly like the oracle twin driven by hand."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_almost_equal
+
+from boltzmann_machines_amd import BernoulliRBM, GaussianRBM
+from boltzmann_machines_amd.utils import RNG
+
+pytestmark = pytest.mark.gpu
+
+N_VISIBLE, N_HIDDEN = 12, 8
+X = RNG(seed=1337).rand(16, N_VISIBLE)
+X_VAL = RNG(seed=42).rand(8, N_VISIBLE)
+CONFIG = dict(n_visible=N_VISIBLE, n_hidden=N_HIDDEN, sample_v_states=True, sample_h_states=True,
+              dropout=0.9, verbose=False, display_filters=False, random_seed=1337)
+
+
+@pytest.fixture
+def dirs(tmp_path):
+    d1, d2 = str(tmp_path / 'test_rbm_1') + '/', str(tmp_path / 'test_rbm_2') + '/'
+    yield d1, d2
+    for d in (d1, d2):
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def compare_weights(rbm1, rbm2):
+    w1, w2 = rbm1.get_tf_params(scope='weights'), rbm2.get_tf_params(scope='weights')
+    for k in ('W', 'hb', 'vb'):
+        assert_allclose(w1[k], w2[k])
+
+
+def compare_transforms(rbm1, rbm2):
+    H1, H2 = rbm1.transform(X_VAL), rbm2.transform(X_VAL)
+    assert H1.shape == (len(X_VAL), N_HIDDEN)
+    assert H1.shape == H2.shape
+    assert_allclose(H1, H2)
+
+
+@pytest.mark.parametrize('C,dtype', [(BernoulliRBM, 'float32'), (BernoulliRBM, 'float64'), (GaussianRBM, 'float32')])
+def test_initialization(gpu_lib, dirs, C, dtype):
+    """reference test_rbm.py:52-67 — the W-init known answer after init()."""
+    rbm = C(max_epoch=2, model_path=dirs[0], dtype=dtype, **CONFIG)
+    rbm.init()
+    w = rbm.get_tf_params(scope='weights')['W'][0][0]
+    assert_almost_equal(w, -0.0094548017 if dtype == 'float32' else -0.0077341544416)
+
+
+@pytest.mark.parametrize('C', [BernoulliRBM, GaussianRBM])
+def test_consistency(gpu_lib, dirs, C):
+    """reference test_rbm.py:69-114 — twin models stay identical through fit, +1 epoch,
+    load_model from disk, +1 epoch."""
+    rbm1 = C(max_epoch=2, model_path=dirs[0], **CONFIG)
+    rbm2 = C(max_epoch=2, model_path=dirs[1], **CONFIG)
+    rbm1.fit(X); rbm2.fit(X)
+    compare_weights(rbm1, rbm2); compare_transforms(rbm1, rbm2)
+    rbm1.set_params(max_epoch=rbm1.max_epoch + 1).fit(X)
+    rbm2.set_params(max_epoch=rbm2.max_epoch + 1).fit(X)
+    compare_weights(rbm1, rbm2); compare_transforms(rbm1, rbm2)
+    w_before = rbm1.get_tf_params(scope='weights')
+    rbm1 = C.load_model(dirs[0])
+    rbm2 = C.load_model(dirs[1])
+    assert rbm1.epoch_ == 3 and rbm1.iter_ == 3 * 2
+    assert_allclose(rbm1.get_tf_params(scope='weights')['W'], w_before['W'])      # resume == state before
+    compare_weights(rbm1, rbm2); compare_transforms(rbm1, rbm2)
+    rbm1.set_params(max_epoch=rbm1.max_epoch + 1).fit(X)
+    rbm2.set_params(max_epoch=rbm2.max_epoch + 1).fit(X)
+    compare_weights(rbm1, rbm2); compare_transforms(rbm1, rbm2)
+    assert rbm1.epoch_ == 4
+
+
+def test_consistency_val(gpu_lib, dirs):
+    """reference test_rbm.py:116-131 — same with validation metrics enabled."""
+    mc = dict(msre=True, pll=True, feg=True, l2_loss=True, train_metrics_every_iter=1, feg_every_epoch=1)
+    rbm1 = BernoulliRBM(max_epoch=2, model_path=dirs[0], metrics_config=dict(mc), **CONFIG)
+    rbm2 = BernoulliRBM(max_epoch=2, model_path=dirs[1], metrics_config=dict(mc), **CONFIG)
+    rbm1.fit(X, X_VAL); rbm2.fit(X, X_VAL)
+    compare_weights(rbm1, rbm2); compare_transforms(rbm1, rbm2)
+
+
+def test_fit_matches_oracle_driven_by_hand(gpu_lib, dirs):
+    """fit() == the oracle twin stepped with the same seeds, schedules and batches
+    (1-based schedule index, short last batch, one graph seed per public call)."""
+    from oracle import oracle as orc
+    V, H, N, bs = 20, 12, 37, 10
+    Xd = (RNG(seed=5).rand(N, V) < 0.3).astype(np.float32)
+    kw = dict(n_visible=V, n_hidden=H, batch_size=bs, max_epoch=3, learning_rate=[0.3, 0.05, 0.02], momentum=[0.1, 0.5, 0.9],
+              n_gibbs_steps=[4, 1, 2], l2=1e-3, sample_v_states=True, random_seed=77, verbose=False,
+              sparsity_cost=0.01, model_path=dirs[0])
+    rbm = BernoulliRBM(**kw)
+    rbm.fit(Xd)
+    twin = orc.OracleRBM(V, H, sample_v_states=True, l2=1e-3, sparsity_cost=0.01)
+    host = RNG(seed=77)
+    graph_seed = host.randint(2 ** 31 - 1)                   # the fit() call's seed (tf_model.py:20-21)
+    from boltzmann_machines_amd.utils import philox
+    twin.p['W'][...] = (philox.normal(graph_seed, 77, 0, V * H) * np.float32(0.01)).reshape(V, H)
+    twin.set_seed(graph_seed)
+    for epoch in (1, 2, 3):
+        i = min(epoch, 2)
+        for s in range(0, N, bs):
+            twin.train_step(Xd[s:s + bs], [0.3, 0.05, 0.02][i], [0.1, 0.5, 0.9][i], [4, 1, 2][i])
+    p = rbm.get_tf_params(scope='weights')
+    for k in ('W', 'vb', 'hb'):
+        assert np.array_equal(p[k].view(np.uint32), twin.p[k].view(np.uint32)), k
+    assert rbm.epoch_ == 3 and rbm.iter_ == 12
+
+
+def test_errors(gpu_lib, dirs):
+    rbm = BernoulliRBM(n_visible=4, n_hidden=3, model_path=dirs[0], verbose=False)
+    with pytest.raises(RuntimeError):
+        rbm.transform(np.zeros((2, 4)))                      # before fit/init (tf_model.py:29-30)
+    rbm.init()
+    with pytest.raises(ValueError):
+        rbm.set_params(nope=1)
+    with pytest.raises(RuntimeError):
+        GaussianRBM.load_model(dirs[0])                      # class mismatch (tf_model.py:149-150)
+    r64 = BernoulliRBM(n_visible=4, n_hidden=3, dtype='float64', model_path=dirs[1], verbose=False).init()
+    with pytest.raises(NotImplementedError):
+        r64.fit(np.zeros((4, 4)))
