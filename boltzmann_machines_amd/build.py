@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libbm355.so')
-SOURCES = ['bm_rbm.hip', 'bm_dbm.hip']
+SOURCES = ['bm355.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-ffp-contract=off',          # every fma is an explicit fmaf (DESIGN.md "Numerics")
          '-Wall', '-Wno-unused-function']

@@ -1,24 +1,649 @@
-// bm_dbm.hip — DBM entry points (placeholder until the DBM kernels land).
+// bm_dbm.hip — C-ABI entry points for the DBM path (include/bm355.h): block-Gibbs
+// sweep, mean-field, PCD particles, train op, sample_v, reconstruction, AIS, ELBO.
+//
+// Reference graph restated: boltzmann_machines/dbm.py:385-427 (Gibbs sweep),
+// :429-478 (mean-field), :480-509 (particles), :511-639 (train op + max-norm),
+// :641-648 (sample_v), :650-736 (AIS), :738-759 (ELBO).  Every layer update is one
+// act_kernel launch (two-sided inputs = two K segments of one MFMA pipeline).
 #include "../../include/bm355.h"
 #include "bm_common.h"
-#define NI(name) do { bm::set_error(name ": not implemented yet"); return 99; } while (0)
-extern "C" {
-int bm_dbm_create(const bm_dbm_config *, bm_dbm **) { NI("bm_dbm_create"); }
-int bm_dbm_destroy(bm_dbm *) { return 0; }
-int bm_dbm_sync(bm_dbm *) { NI("bm_dbm_sync"); }
-int bm_dbm_seed(bm_dbm *, uint64_t) { NI("bm_dbm_seed"); }
-int bm_dbm_set_row_offset(bm_dbm *, int64_t, int64_t) { NI("bm_dbm_set_row_offset"); }
-int bm_dbm_set_param(bm_dbm *, const char *, const float *, size_t) { NI("bm_dbm_set_param"); }
-int bm_dbm_get_param(bm_dbm *, const char *, float *, size_t) { NI("bm_dbm_get_param"); }
-int bm_dbm_dev_ptr(bm_dbm *, const char *, void **, size_t *) { NI("bm_dbm_dev_ptr"); }
-int bm_dbm_train_step(bm_dbm *, const float *, float, float, int32_t, int32_t *, float *) { NI("bm_dbm_train_step"); }
-int bm_dbm_grad_step(bm_dbm *, const float *, int32_t, int32_t *) { NI("bm_dbm_grad_step"); }
-int bm_dbm_apply_step(bm_dbm *, int32_t, int32_t, float, float) { NI("bm_dbm_apply_step"); }
-int bm_dbm_mean_field(bm_dbm *, const float *, float *, int32_t *) { NI("bm_dbm_mean_field"); }
-int bm_dbm_reconstruct(bm_dbm *, const float *, float *) { NI("bm_dbm_reconstruct"); }
-int bm_dbm_sample_v(bm_dbm *, int32_t, float *) { NI("bm_dbm_sample_v"); }
-int bm_dbm_ais(bm_dbm *, int32_t, int32_t, int32_t, uint64_t, int64_t, float *) { NI("bm_dbm_ais"); }
-int bm_dbm_log_proba(bm_dbm *, const float *, float *) { NI("bm_dbm_log_proba"); }
-int bm_dbm_timer_start(bm_dbm *) { NI("bm_dbm_timer_start"); }
-int bm_dbm_timer_stop(bm_dbm *, float *) { NI("bm_dbm_timer_stop"); }
+#include "bm_kernels.h"
+
+#include <math.h>
+
+using namespace bm;
+
+namespace {
+// RNG sites (counter word 2 = site + 16 * sweep index); DESIGN.md "RNG"
+enum : uint32_t { SITE_DBM_H = 8 /* + layer */, SITE_DBM_V = 12, SITE_AIS_X0 = 13 };
+constexpr int MAXL = BM_DBM_MAX_LAYERS;
+}  // namespace
+
+struct bm_dbm {
+    bm_dbm_config cfg;
+    int L, V, N, M;
+    int n[MAXL + 1];                       // n[0] = V, n[i+1] = hidden layer i
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // variables
+    Mat W[MAXL], Wt[MAXL], dW[MAXL];       // W[i]: [n[i]][n[i+1]]
+    DevBuf vb, dvb, sigma;
+    DevBuf hb[MAXL], dhb[MAXL], q[MAXL], mm[MAXL], pen[MAXL];
+    Mat mu[MAXL], mu_alt[MAXL], mu_new[MAXL];      // [N][n[i+1]]: result, ping-pong partner, approx-inference init
+    Mat v, v_new, H[MAXL], H_new[MAXL];            // particles [M][*]
+    Mat recon;                                     // [N][V]
+    DevBuf sums;                                   // column sums: [V | V | (n_i | n_i) per layer]
+    DevBuf wnorm[MAXL];
+    unsigned *flag = nullptr;                      // mean-field max-norm cell
+    double *scal = nullptr;
+    // AIS / ELBO workspaces (allocated on demand)
+    int ais_rows = 0;
+    Mat ax, ax2, av, ah2;
+    DevBuf alogw, adot, rowtmp;
+    uint64_t seed = 0;
+    uint32_t call = 0;
+    int64_t row0 = 0, prow0 = 0;
+};
+
+static PhiloxKey dkey(const bm_dbm *h, uint32_t site, int t, uint64_t seed, uint32_t call) {
+    PhiloxKey k;
+    k.k0 = (uint32_t)seed; k.k1 = (uint32_t)(seed >> 32);
+    k.site = site + 16u * (uint32_t)t;
+    k.call = call;
+    return k;
 }
+
+// one layer update: out = act(mult * (below.W_lo [+ above.W_hi^T]) + bmult * bias)
+//   below [J][n_lo] (pitch ldb) with W_lo = W[lo] ([n_lo][I]);  above [J][n_hi] with Wt[lo+1] ([n_hi][I])
+struct LayerIn { const float *p; int ld; };
+static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visible */, int J,
+                         LayerIn below, LayerIn above, float mult, float bmult, int sample,
+                         float *means, float *states, int ldo, const PhiloxKey &key, int64_t row0,
+                         const float *prev = nullptr, unsigned *maxdiff = nullptr, ActArgs *extra = nullptr) {
+    ActArgs a;
+    if (extra) a = *extra; else memset(&a, 0, sizeof(a));
+    if (layer >= 0) {
+        a.I = h->n[layer + 1];
+        a.P1 = make_operand(h->W[layer].p, h->W[layer].ld, a.I);          // W[layer][k = below][i]
+        a.Q1 = make_operand(below.p, below.ld, J);
+        a.K1 = h->n[layer];
+        if (above.p) {
+            a.P2 = make_operand(h->Wt[layer + 1].p, h->Wt[layer + 1].ld, a.I);   // W[layer+1]^T [k = above][i]
+            a.Q2 = make_operand(above.p, above.ld, J);
+            a.K2 = h->n[layer + 2];
+        }
+        a.bias = h->hb[layer].p; a.sigma = nullptr; a.kind = BM_UNIT_BERNOULLI;
+    } else {
+        a.I = h->V;
+        a.P1 = make_operand(h->Wt[0].p, h->Wt[0].ld, a.I);               // W[0]^T [k = h0][i = v]
+        a.Q1 = make_operand(above.p, above.ld, J);
+        a.K1 = h->n[1];
+        a.bias = h->vb.p; a.sigma = h->sigma.p; a.kind = h->cfg.v_unit;
+    }
+    a.J = J;
+    a.mult = mult; a.bmult = bmult;
+    a.sample = sample;
+    a.means = means; a.states = states; a.ldo = ldo;
+    a.key = key; a.row0 = row0;
+    a.prev = prev; a.maxdiff = maxdiff;
+    launch_act(a, h->stream);
+}
+
+// `_make_gibbs_step` (dbm.py:385-427): bottom-up Gauss-Seidel sweep.
+//   vin / Hin  : current states (Hin[i] may alias mu)      vout / Hout : new states
+//   out_means  : Hout receives means (sample == 0) or samples (per-layer flags)
+static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout, Mat *Hout,
+                        bool update_v, bool sample, int t, int64_t row0,
+                        unsigned *maxdiff = nullptr) {
+    const int L = h->L;
+    for (int i = 0; i < L; ++i) {
+        LayerIn below = (i == 0) ? vin : LayerIn{Hout[i - 1].p, Hout[i - 1].ld};       // NEW below   :400-402
+        LayerIn above = (i + 1 < L) ? LayerIn{Hin[i + 1].p, Hin[i + 1].ld} : LayerIn{nullptr, 0};   // OLD above
+        const int smp = sample && h->cfg.sample_h_states[i];
+        // without sampling the layer's value is its mean: write it as `means` only
+        layer_update(h, i, J, below, above, 1.f, 1.f, smp, smp ? nullptr : Hout[i].p, smp ? Hout[i].p : nullptr,
+                     Hout[i].ld, dkey(h, SITE_DBM_H + i, t, h->seed, h->call), row0,
+                     maxdiff ? Hin[i].p : nullptr, maxdiff);
+    }
+    if (update_v) {                                                                       // :419-425
+        const int smp = sample && h->cfg.sample_v_states;
+        layer_update(h, -1, J, LayerIn{nullptr, 0}, LayerIn{Hout[0].p, Hout[0].ld}, 1.f, 1.f, smp,
+                     smp ? nullptr : vout->p, smp ? vout->p : nullptr, vout->ld,
+                     dkey(h, SITE_DBM_V, t, h->seed, h->call), row0);
+    }
+}
+
+static int read_flag(bm_dbm *h, float *out) {
+    unsigned bits = 0;
+    BM_HIP(hipMemcpyAsync(&bits, h->flag, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    memcpy(out, &bits, sizeof(float));
+    return 0;
+}
+
+// `_make_mf` (dbm.py:429-478).  Leaves the result in h->mu; returns executed sweeps.
+static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
+    const int L = h->L, N = h->N;
+    // approximate-inference init into the mu_new VARIABLES (:434-446): doubled bottom-up pass
+    for (int i = 0; i < L; ++i) {
+        LayerIn below = (i == 0) ? LayerIn{X_dev, h->V} : LayerIn{h->mu_new[i - 1].p, h->mu_new[i - 1].ld};
+        const float mult = (i == 0 || i < L - 1) ? 2.f : 1.f;
+        layer_update(h, i, N, below, LayerIn{nullptr, 0}, mult, 1.f, 0, h->mu_new[i].p, nullptr, h->mu_new[i].ld,
+                     dkey(h, 0, 0, h->seed, h->call), 0);
+    }
+    // cond at step 0 compares the persistent mu with the init values (:449-452)
+    BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
+    for (int i = 0; i < L; ++i)
+        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
+                           (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
+    float diff = 0.f;
+    BM_TRY(read_flag(h, &diff));
+    int step = 0;
+    // body (:454-457): mu_new = sweep(X, mu) (values, not the mu_new variables), then swap
+    Mat *cur = h->mu, *alt = h->mu_alt;
+    while (step < h->cfg.max_mf_updates && diff > h->cfg.mf_tol) {
+        BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
+        gibbs_sweep(h, N, LayerIn{X_dev, h->V}, cur, nullptr, alt, false, false, 0, 0, h->flag);
+        BM_TRY(read_flag(h, &diff));
+        Mat *t = cur; cur = alt; alt = t;
+        ++step;
+    }
+    if (cur != h->mu)                  // `self._mu[i].assign(mu[i])` (:477): keep the handle's mu as the result
+        for (int i = 0; i < L; ++i) { Mat t = h->mu[i]; h->mu[i] = h->mu_alt[i]; h->mu_alt[i] = t; }
+    if (out_n) *out_n = step;
+    return 0;
+}
+
+// `_make_particles_update` (dbm.py:480-509)
+static void particles_update(bm_dbm *h, int k, bool sample, bool update_only_v_at_end = false) {
+    (void)update_only_v_at_end;
+    for (int t = 0; t < k; ++t) {
+        gibbs_sweep(h, h->M, LayerIn{h->v.p, h->v.ld}, h->H, &h->v_new, h->H_new, true, sample, t, h->prow0);
+        Mat tv = h->v; h->v = h->v_new; h->v_new = tv;                    // swap particles (:493)
+        for (int i = 0; i < h->L; ++i) { Mat th = h->H[i]; h->H[i] = h->H_new[i]; h->H_new[i] = th; }
+    }
+}
+
+static size_t sums_off(const bm_dbm *h, int which /* 0: X, 1: v, 2+2i: mu_i, 3+2i: H_i */) {
+    size_t o = 0;
+    if (which == 0) return 0;
+    o += h->V;
+    if (which == 1) return o;
+    o += h->V;
+    for (int i = 0; i < h->L; ++i) {
+        if (which == 2 + 2 * i) return o;
+        o += h->n[i + 1];
+        if (which == 3 + 2 * i) return o;
+        o += h->n[i + 1];
+    }
+    return o;
+}
+
+// gradients + sparsity + momentum + max-norm (dbm.py:550-621) from the current mu / particles
+static int apply_update(bm_dbm *h, const float *X_dev, float lr, float mom) {
+    const int L = h->L;
+    const float N = (float)h->N, M = (float)h->M;
+    // column sums: X, v, mu_i, H_i
+    ColSumArgs c;
+    memset(&c, 0, sizeof(c));
+    int nj = 0;
+    c.job[nj++] = ColSumJob{X_dev, nullptr, h->V, 0, h->V, h->N, h->sums.p + sums_off(h, 0)};
+    c.job[nj++] = ColSumJob{h->v.p, nullptr, h->v.ld, 0, h->V, h->M, h->sums.p + sums_off(h, 1)};
+    for (int i = 0; i < L; ++i) {
+        c.job[nj++] = ColSumJob{h->mu[i].p, nullptr, h->mu[i].ld, 0, h->n[i + 1], h->N, h->sums.p + sums_off(h, 2 + 2 * i)};
+        c.job[nj++] = ColSumJob{h->H[i].p, nullptr, h->H[i].ld, 0, h->n[i + 1], h->M, h->sums.p + sums_off(h, 3 + 2 * i)};
+    }
+    c.njobs = nj;
+    c.first_wave[0] = 0;
+    for (int j = 0; j < nj; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 15) / 16;
+    hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[nj]), dim3(NT), 0, h->stream, c);
+    // biases (+ sparsity penalties)
+    {
+        DbmBiasArgs b;
+        memset(&b, 0, sizeof(b));
+        b.s_pos = h->sums.p + sums_off(h, 0); b.s_neg = h->sums.p + sums_off(h, 1);
+        b.b = h->vb.p; b.db = h->dvb.p; b.n = h->V; b.N = N; b.M = M; b.lr = lr; b.mom = mom;
+        hipLaunchKernelGGL(dbm_bias_kernel, dim3((h->V + 255) / 256), dim3(256), 0, h->stream, b);
+    }
+    for (int i = 0; i < L; ++i) {
+        DbmBiasArgs b;
+        memset(&b, 0, sizeof(b));
+        b.s_pos = h->sums.p + sums_off(h, 2 + 2 * i); b.s_neg = h->sums.p + sums_off(h, 3 + 2 * i);
+        b.b = h->hb[i].p; b.db = h->dhb[i].p; b.q = h->q[i].p; b.mm = h->mm[i].p; b.pen = h->pen[i].p;
+        b.n = h->n[i + 1]; b.layer = i;
+        b.N = N; b.M = M; b.lr = lr; b.mom = mom;
+        b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost[i]; b.target = h->cfg.sparsity_target[i];
+        hipLaunchKernelGGL(dbm_bias_kernel, dim3((b.n + 255) / 256), dim3(256), 0, h->stream, b);
+    }
+    // weights
+    for (int i = 0; i < L; ++i) {
+        GradArgs g;
+        memset(&g, 0, sizeof(g));
+        const float *below_pos = (i == 0) ? X_dev : h->mu[i - 1].p;
+        const int ld_bp = (i == 0) ? h->V : h->mu[i - 1].ld;
+        const Mat &below_neg = (i == 0) ? h->v : h->H[i - 1];
+        g.Ppos = make_operand(h->mu[i].p, h->mu[i].ld, h->n[i + 1]);      // mu_i       [k = b][i]
+        g.Qpos = make_operand(below_pos, ld_bp, h->n[i]);                  // X / mu_{i-1} [k = b][j]
+        g.Kpos = h->N;
+        g.Pneg = make_operand(h->H[i].p, h->H[i].ld, h->n[i + 1]);
+        g.Qneg = make_operand(below_neg.p, below_neg.ld, h->n[i]);
+        g.Kneg = h->M;
+        g.I = h->n[i + 1]; g.J = h->n[i];
+        g.form = 1; g.fused = 1;
+        g.W = h->W[i].p; g.dW = h->dW[i].p; g.Wt = nullptr;                // Wt is rewritten by the max-norm pass
+        g.ldw = h->W[i].ld; g.ldwt = h->Wt[i].ld;
+        g.pen = h->pen[i].p;
+        g.N = N; g.M = M; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
+        launch_grad(g, h->stream);
+        MaxNormArgs m;
+        m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = g.I; m.J = g.J; m.ldw = g.ldw; m.ldwt = g.ldwt;
+        m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
+        hipLaunchKernelGGL(maxnorm_kernel, dim3((g.I + 15) / 16), dim3(NT), 0, h->stream, m);
+    }
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// reconstruction sigma(mu0 W0^T + vb) (dbm.py:625-628) into R (pitch ldr)
+static void reconstruct_from_mu(bm_dbm *h, float *R, int ldr) {
+    layer_update(h, -1, h->N, LayerIn{nullptr, 0}, LayerIn{h->mu[0].p, h->mu[0].ld}, 1.f, 1.f, 0, R, nullptr, ldr,
+                 dkey(h, 0, 0, h->seed, h->call), 0);
+}
+
+extern "C" {
+
+int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
+    BM_CHECK(cfg && out, "null argument");
+    BM_CHECK(cfg->n_layers >= 1 && cfg->n_layers <= MAXL, "n_layers %d outside [1, %d]", cfg->n_layers, MAXL);
+    BM_CHECK(cfg->n_visible >= 1 && cfg->n_particles >= 1 && cfg->batch_size >= 1, "bad sizes");
+    BM_CHECK(bm_device_count() > 0, "no HIP device visible: libbm355 has no CPU fallback");
+    bm_dbm *h = new bm_dbm();
+    h->cfg = *cfg;
+    h->L = cfg->n_layers; h->V = cfg->n_visible; h->N = cfg->batch_size; h->M = cfg->n_particles;
+    h->n[0] = h->V;
+    for (int i = 0; i < h->L; ++i) {
+        BM_CHECK(cfg->n_hiddens[i] >= 1, "bad hidden size");
+        BM_CHECK(cfg->n_hiddens[i] > i, "layer %d needs more than %d units (sparsity index, dbm.py:583)", i, i);
+        h->n[i + 1] = cfg->n_hiddens[i];
+    }
+    BM_HIP(hipStreamCreate(&h->stream));
+    BM_HIP(hipEventCreate(&h->ev0));
+    BM_HIP(hipEventCreate(&h->ev1));
+    size_t nsums = 2 * (size_t)h->V;
+    for (int i = 0; i < h->L; ++i) {
+        const int a = h->n[i], b = h->n[i + 1];
+        BM_TRY(h->W[i].alloc(a, b)); BM_TRY(h->Wt[i].alloc(b, a)); BM_TRY(h->dW[i].alloc(a, b));
+        BM_TRY(h->hb[i].alloc(b)); BM_TRY(h->dhb[i].alloc(b)); BM_TRY(h->q[i].alloc(b)); BM_TRY(h->mm[i].alloc(b));
+        BM_TRY(h->pen[i].alloc(b)); BM_TRY(h->wnorm[i].alloc(b));
+        BM_TRY(h->mu[i].alloc(h->N, b)); BM_TRY(h->mu_alt[i].alloc(h->N, b)); BM_TRY(h->mu_new[i].alloc(h->N, b));
+        BM_TRY(h->H[i].alloc(h->M, b)); BM_TRY(h->H_new[i].alloc(h->M, b));
+        nsums += 2 * (size_t)b;
+    }
+    BM_TRY(h->vb.alloc(h->V)); BM_TRY(h->dvb.alloc(h->V)); BM_TRY(h->sigma.alloc(h->V));
+    BM_TRY(h->v.alloc(h->M, h->V)); BM_TRY(h->v_new.alloc(h->M, h->V));
+    BM_TRY(h->recon.alloc(h->N, h->V));
+    BM_TRY(h->sums.alloc(nsums));
+    BM_HIP(hipMalloc((void **)&h->flag, sizeof(unsigned)));
+    BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
+    {
+        std::vector<float> ones(h->V, 1.0f);
+        BM_HIP(hipMemcpy(h->sigma.p, ones.data(), h->V * sizeof(float), hipMemcpyHostToDevice));
+    }
+    *out = h;
+    return 0;
+}
+
+int bm_dbm_destroy(bm_dbm *h) {
+    if (!h) return 0;
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < h->L; ++i) {
+        Mat *ms[] = {&h->W[i], &h->Wt[i], &h->dW[i], &h->mu[i], &h->mu_alt[i], &h->mu_new[i], &h->H[i], &h->H_new[i]};
+        for (Mat *m : ms) m->release();
+        DevBuf *bs[] = {&h->hb[i], &h->dhb[i], &h->q[i], &h->mm[i], &h->pen[i], &h->wnorm[i]};
+        for (DevBuf *b : bs) b->release();
+    }
+    Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
+    for (Mat *m : ms) m->release();
+    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->sums, &h->alogw, &h->adot, &h->rowtmp};
+    for (DevBuf *b : bs) b->release();
+    if (h->flag) (void)hipFree(h->flag);
+    if (h->scal) (void)hipFree(h->scal);
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int bm_dbm_sync(bm_dbm *h) { BM_HIP(hipStreamSynchronize(h->stream)); return 0; }
+int bm_dbm_seed(bm_dbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 0; }
+int bm_dbm_set_row_offset(bm_dbm *h, int64_t row0, int64_t particle0) { h->row0 = row0; h->prow0 = particle0; return 0; }
+
+// "W", "W_1", "hb_2" ... -> (base, layer)
+static bool split_name(const std::string &nm, std::string &base, int &idx) {
+    const size_t u = nm.rfind('_');
+    base = nm; idx = 0;
+    if (u != std::string::npos && u + 1 < nm.size() && isdigit((unsigned char)nm[u + 1])) {
+        bool digits = true;
+        for (size_t i = u + 1; i < nm.size(); ++i) digits = digits && isdigit((unsigned char)nm[i]);
+        if (digits) { base = nm.substr(0, u); idx = atoi(nm.c_str() + u + 1); }
+    }
+    return true;
+}
+
+static int resolve(bm_dbm *h, const char *name, Mat **mat, DevBuf **vec, bool *is_W) {
+    std::string base; int idx;
+    split_name(std::string(name ? name : ""), base, idx);
+    *mat = nullptr; *vec = nullptr; *is_W = false;
+    BM_CHECK(idx >= 0 && idx < h->L, "layer index %d out of range in '%s'", idx, name ? name : "(null)");
+    if (base == "W") { *mat = &h->W[idx]; *is_W = true; }
+    else if (base == "dW") *mat = &h->dW[idx];
+    else if (base == "mu") *mat = &h->mu[idx];
+    else if (base == "mu_new") *mat = &h->mu_new[idx];
+    else if (base == "h") *mat = &h->H[idx];
+    else if (base == "h_new") *mat = &h->H_new[idx];
+    else if (base == "v" && idx == 0) *mat = &h->v;
+    else if (base == "v_new" && idx == 0) *mat = &h->v_new;
+    else if (base == "hb") *vec = &h->hb[idx];
+    else if (base == "dhb") *vec = &h->dhb[idx];
+    else if (base == "q_means") *vec = &h->q[idx];
+    else if (base == "mu_means") *vec = &h->mm[idx];
+    else if (base == "W_norm") *vec = &h->wnorm[idx];
+    else if (base == "vb" && idx == 0) *vec = &h->vb;
+    else if (base == "dvb" && idx == 0) *vec = &h->dvb;
+    else if (base == "sigma" && idx == 0) *vec = &h->sigma;
+    BM_CHECK(*mat || *vec, "unknown DBM variable '%s'", name ? name : "(null)");
+    return 0;
+}
+
+int bm_dbm_set_param(bm_dbm *h, const char *name, const float *host, size_t n) {
+    Mat *m; DevBuf *v; bool isW;
+    BM_TRY(resolve(h, name, &m, &v, &isW));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    if (m) {
+        BM_CHECK(n == (size_t)m->rows * m->cols, "variable '%s' has %zu elements, got %zu", name, (size_t)m->rows * m->cols, n);
+        BM_TRY(m->upload(host));
+        if (isW) {
+            std::vector<float> t(n);
+            for (int r = 0; r < m->rows; ++r)
+                for (int c = 0; c < m->cols; ++c) t[(size_t)c * m->rows + r] = host[(size_t)r * m->cols + c];
+            Mat *wt = &h->Wt[m - h->W];
+            BM_TRY(wt->upload(t.data()));
+        }
+        return 0;
+    }
+    BM_CHECK(n == v->n, "variable '%s' has %zu elements, got %zu", name, v->n, n);
+    BM_HIP(hipMemcpy(v->p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int bm_dbm_get_param(bm_dbm *h, const char *name, float *host, size_t n) {
+    Mat *m; DevBuf *v; bool isW;
+    BM_TRY(resolve(h, name, &m, &v, &isW));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    if (m) {
+        BM_CHECK(n == (size_t)m->rows * m->cols, "variable '%s' has %zu elements, got %zu", name, (size_t)m->rows * m->cols, n);
+        return m->download(host);
+    }
+    BM_CHECK(n == v->n, "variable '%s' has %zu elements, got %zu", name, v->n, n);
+    BM_HIP(hipMemcpy(host, v->p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bm_dbm_dev_ptr(bm_dbm *h, const char *name, void **out_dev, size_t *out_n) {
+    Mat *m; DevBuf *v; bool isW;
+    BM_TRY(resolve(h, name, &m, &v, &isW));
+    BM_CHECK(v, "no device view for '%s' (matrices are pitched; use get/set_param)", name);
+    *out_dev = v->p;
+    if (out_n) *out_n = v->n;
+    return 0;
+}
+
+int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float lr, float mom, int32_t k,
+                      int32_t *out_n_mf, float *out_msre) {
+    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    int nmf = 0;
+    BM_TRY(mean_field(h, X_dev, &nmf));                       // :517
+    particles_update(h, k, true);                             // :521
+    if (out_msre) {                                           // :625-630 (W before the update)
+        reconstruct_from_mu(h, h->recon.p, h->recon.ld);
+        BM_HIP(hipMemsetAsync(h->scal, 0, sizeof(double), h->stream));
+        hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, X_dev, h->V, (const float *)h->recon.p,
+                           h->recon.ld, h->N, h->V, h->scal);
+        double s = 0.0;
+        BM_HIP(hipMemcpyAsync(&s, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        BM_HIP(hipStreamSynchronize(h->stream));
+        *out_msre = (float)(s / ((double)h->N * h->V));
+    }
+    BM_TRY(apply_update(h, X_dev, lr, mom));
+    if (out_n_mf) *out_n_mf = nmf;
+    h->call++;
+    return 0;
+}
+
+int bm_dbm_grad_step(bm_dbm *, const float *, int32_t, int32_t *) {
+    bm::set_error("bm_dbm_grad_step: data-parallel DBM split is not implemented yet (use bm_dbm_train_step)");
+    return 99;
+}
+int bm_dbm_apply_step(bm_dbm *, int32_t, int32_t, float, float) {
+    bm::set_error("bm_dbm_apply_step: data-parallel DBM split is not implemented yet (use bm_dbm_train_step)");
+    return 99;
+}
+
+int bm_dbm_mean_field(bm_dbm *h, const float *X_dev, float *MU_top_dev, int32_t *out_n_mf) {
+    int nmf = 0;
+    BM_TRY(mean_field(h, X_dev, &nmf));
+    if (MU_top_dev) {
+        const Mat &t = h->mu[h->L - 1];
+        hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)t.p, t.ld, MU_top_dev, t.cols,
+                           t.rows, t.cols);
+    }
+    if (out_n_mf) *out_n_mf = nmf;
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_dbm_reconstruct(bm_dbm *h, const float *X_dev, float *R_dev) {
+    BM_CHECK(R_dev, "null output");
+    BM_TRY(mean_field(h, X_dev, nullptr));
+    reconstruct_from_mu(h, R_dev, h->V);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_dbm_sample_v(bm_dbm *h, int32_t k, float *V_dev) {
+    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1");
+    particles_update(h, k, true);                             // :643-644
+    // `_make_particles_update(sample=False)` whose v assign is the only one fetched (:646-647):
+    // k mean sweeps from the sampled state; only v takes the result, H / *_new keep theirs.
+    std::vector<Mat> Hs(h->L), Hn(h->L);
+    Mat vs = h->v, vn = h->v_new;
+    for (int i = 0; i < h->L; ++i) { Hs[i] = h->H[i]; Hn[i] = h->H_new[i]; }
+    // scratch: reuse mu_alt-sized buffers is not possible (M != N): allocate temporaries
+    Mat tv, tv2; std::vector<Mat> tH(h->L), tH2(h->L);
+    BM_TRY(tv.alloc(h->M, h->V)); BM_TRY(tv2.alloc(h->M, h->V));
+    for (int i = 0; i < h->L; ++i) { BM_TRY(tH[i].alloc(h->M, h->n[i + 1])); BM_TRY(tH2[i].alloc(h->M, h->n[i + 1])); }
+    const Mat *Hin = h->H; LayerIn vin{h->v.p, h->v.ld};
+    Mat *Hout = tH.data(), *Hout2 = tH2.data(); Mat *vout = &tv, *vout2 = &tv2;
+    for (int t = 0; t < k; ++t) {
+        gibbs_sweep(h, h->M, vin, Hin, vout, Hout, true, false, k + t, h->prow0);
+        vin = LayerIn{vout->p, vout->ld}; Hin = Hout;
+        Mat *x = Hout; Hout = Hout2; Hout2 = x;
+        Mat *y = vout; vout = vout2; vout2 = y;
+    }
+    // v <- v_means (the last vout is now vout2 after the swap)
+    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)vout2->p, vout2->ld, h->v.p, h->v.ld,
+                       h->M, h->V);
+    if (V_dev)
+        hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)h->v.p, h->v.ld, V_dev, h->V,
+                           h->M, h->V);
+    BM_HIP(hipStreamSynchronize(h->stream));
+    tv.release(); tv2.release();
+    for (int i = 0; i < h->L; ++i) { tH[i].release(); tH2[i].release(); }
+    h->call++;
+    return 0;
+}
+
+static int ensure_ais(bm_dbm *h, int rows) {
+    if (rows <= h->ais_rows) return 0;
+    Mat *ms[] = {&h->ax, &h->ax2, &h->av, &h->ah2};
+    for (Mat *m : ms) m->release();
+    h->alogw.release(); h->adot.release(); h->rowtmp.release();
+    BM_TRY(h->ax.alloc(rows, h->n[1])); BM_TRY(h->ax2.alloc(rows, h->n[1]));
+    BM_TRY(h->av.alloc(rows, h->V)); BM_TRY(h->ah2.alloc(rows, h->L >= 2 ? h->n[2] : 1));
+    BM_TRY(h->alogw.alloc(rows)); BM_TRY(h->adot.alloc(2 * (size_t)rows)); BM_TRY(h->rowtmp.alloc(rows));
+    h->ais_rows = rows;
+    return 0;
+}
+
+// x0 ~ Bernoulli(1/2): Bernoulli(logits=0).sample(seed) (dbm.py:699-702)
+__global__ void ais_init_kernel(float *X, int ld, int rows, int cols, PhiloxKey key, unsigned long long row0) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
+        X[r * ld + c] = (philox_uniform_at(key, (row0 + r) * (unsigned long long)cols + c) < 0.5f) ? 1.f : 0.f;
+    }
+}
+
+// rowdot[j] = sum_i X[j][i] * vec[i]  (one wave per row)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float *X, int ld, int rows, int cols, const float *vec, float *out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += X[(size_t)row * ld + c] * vec[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[row] = s;
+}
+
+int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0,
+               float *values_host) {
+    BM_CHECK(h->L == 2, "AIS is implemented for 2-layer DBMs only (dbm.py:925)");
+    BM_CHECK(h->cfg.v_unit == BM_UNIT_BERNOULLI, "AIS needs Bernoulli visible units (dbm.py:926-927)");
+    BM_CHECK(n_betas >= 2 && n_runs >= 1 && k >= 1 && values_host, "bad AIS arguments");
+    BM_TRY(ensure_ais(h, n_runs));
+    const int R = n_runs, V = h->V, H1 = h->n[1], H2 = h->n[2];
+    const float db = 1.0f / (float)n_betas;                               // delta_beta (dbm.py:929)
+    float *rdot_cur = h->adot.p, *rdot_next = h->adot.p + R;
+    BM_HIP(hipMemsetAsync(h->alogw.p, 0, (size_t)R * sizeof(float), h->stream));
+    Mat *x = &h->ax, *xn = &h->ax2;
+    hipLaunchKernelGGL(ais_init_kernel, dim3(512), dim3(256), 0, h->stream, x->p, x->ld, R, H1,
+                       dkey(h, SITE_AIS_X0, 0, seed, 0), (unsigned long long)chain0);
+    hipLaunchKernelGGL(rowdot_kernel, dim3((R + 3) / 4), dim3(256), 0, h->stream, (const float *)x->p, x->ld, R, H1,
+                       (const float *)h->hb[0].p, rdot_cur);
+
+    // visit(x; beta_a, beta_b, beta_c): logw += log p*_{beta_b}(x) - log p*_{beta_a}(x) (score != 0),
+    // then k transitions T_{beta_c} (dbm.py:662-694).  `step` feeds the RNG call counter.
+    auto visit = [&](bool score, float ba, float bb, bool transit, float bc, uint32_t step) -> int {
+        for (int t = 0; t < (transit ? k : 1); ++t) {
+            const bool sc = score && t == 0;
+            ActArgs e;
+            // v~ <- P(v | h = x): sigma(beta*x W0^T + beta*vb)  — and the visible softplus term of log p*
+            memset(&e, 0, sizeof(e));
+            if (sc) { e.rowacc = h->alogw.p; e.beta_a = ba; e.beta_b = bb; e.rowdot_in = rdot_cur; }
+            const int smp_v = transit && h->cfg.sample_v_states;
+            layer_update(h, -1, R, LayerIn{nullptr, 0}, LayerIn{x->p, x->ld}, bc, bc, smp_v,
+                         (transit && !smp_v) ? h->av.p : nullptr, (transit && smp_v) ? h->av.p : nullptr, h->av.ld,
+                         dkey(h, SITE_DBM_V, t, seed, step), chain0, nullptr, nullptr, &e);
+            // h2~ <- P(h2 | h = x): sigma(beta*x W1 + beta*hb1)  — and the top softplus term
+            memset(&e, 0, sizeof(e));
+            if (sc) { e.rowacc = h->alogw.p; e.beta_a = ba; e.beta_b = bb; }
+            const int smp_2 = transit && h->cfg.sample_h_states[1];
+            layer_update(h, 1, R, LayerIn{x->p, x->ld}, LayerIn{nullptr, 0}, bc, bc, smp_2,
+                         (transit && !smp_2) ? h->ah2.p : nullptr, (transit && smp_2) ? h->ah2.p : nullptr, h->ah2.ld,
+                         dkey(h, SITE_DBM_H + 1, t, seed, step), chain0, nullptr, nullptr, &e);
+            if (!transit) break;
+            // x^ <- P(h | v~, h2~): sigma(beta*(v W0 + h2 W1^T) + beta*hb0); also x^.hb0 for the next score
+            BM_HIP(hipMemsetAsync(rdot_next, 0, (size_t)R * sizeof(float), h->stream));
+            memset(&e, 0, sizeof(e));
+            e.rowdot_out = rdot_next; e.dot_vec = h->hb[0].p;
+            const int smp_x = h->cfg.sample_h_states[0];
+            layer_update(h, 0, R, LayerIn{h->av.p, h->av.ld}, LayerIn{h->ah2.p, h->ah2.ld}, bc, bc, smp_x,
+                         nullptr, xn->p, xn->ld, dkey(h, SITE_DBM_H + 0, t, seed, step), chain0, nullptr, nullptr, &e);
+            Mat *tm = x; x = xn; xn = tm;
+            float *tr = rdot_cur; rdot_cur = rdot_next; rdot_next = tr;
+        }
+        return 0;
+    };
+    // x_1 ~ T_{db}(x_0)                                                     (:704-705)
+    BM_TRY(visit(false, 0.f, 0.f, true, db, 0));
+    // -log p_0(x_1), then the loop over beta = db, 2db, ... (fp32 accumulation, :710-726)
+    float beta = db, prev = 0.f;
+    uint32_t step = 1;
+    while (beta < 1.0f - db + 1e-5f) {
+        BM_TRY(visit(true, prev, beta, true, beta + db, step++));            // +log p_beta(x) -log p_prev(x); x' ~ T_{beta+db}
+        prev = beta;
+        beta = beta + db;
+    }
+    BM_TRY(visit(true, prev, 1.0f, false, 0.f, step++));                     // +log p_1(x_M) - log p_prev(x_M)  (:728)
+    std::vector<float> w(R);
+    BM_HIP(hipMemcpyAsync(w.data(), h->alogw.p, (size_t)R * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    const float logZ0 = (float)(V + H1 + H2) * logf(2.0f);                   // (:731-734)
+    for (int r = 0; r < R; ++r) values_host[r] = w[r] + logZ0;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// per-row bias terms and entropies of the ELBO (dbm.py:746-756), one wave per row
+__global__ __launch_bounds__(256) void elbo_row_kernel(const float *X, int ldx, int V, const float *vb,
+                                                       const float *mu0, int ld0, int H1, const float *hb0,
+                                                       const float *mu1, int ld1, int H2, const float *hb1,
+                                                       int rows, float *acc) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < V; c += 64) s += X[(size_t)row * ldx + c] * vb[c];
+    for (int c = lane; c < H1; c += 64) {
+        const float m = mu0[(size_t)row * ld0 + c];
+        s += m * hb0[c];
+        const float q = fminf(fmaxf(m, 1e-7f), 1.f - 1e-7f);
+        s += -q * logf(q) - (1.f - q) * logf(1.f - q);
+    }
+    for (int c = lane; c < H2; c += 64) {
+        const float m = mu1[(size_t)row * ld1 + c];
+        s += m * hb1[c];
+        const float q = fminf(fmaxf(m, 1e-7f), 1.f - 1e-7f);
+        s += -q * logf(q) - (1.f - q) * logf(1.f - q);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) atomicAdd(acc + row, s);
+}
+
+int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host) {
+    BM_CHECK(h->L == 2, "log_proba is implemented for 2-layer DBMs only (dbm.py:741-756)");
+    BM_CHECK(out_host, "null output");
+    BM_TRY(mean_field(h, X_dev, nullptr));
+    BM_TRY(ensure_ais(h, h->N));
+    BM_HIP(hipMemsetAsync(h->rowtmp.p, 0, (size_t)h->N * sizeof(float), h->stream));
+    // sum((X W0) * mu0) and sum((mu0 W1) * mu1) as dot-epilogues of the two propagations
+    ActArgs e;
+    memset(&e, 0, sizeof(e));
+    e.rowacc = h->rowtmp.p; e.dot_mat = h->mu[0].p; e.ld_dot = h->mu[0].ld;
+    layer_update(h, 0, h->N, LayerIn{X_dev, h->V}, LayerIn{nullptr, 0}, 1.f, 1.f, 0, nullptr, nullptr, h->mu[0].ld,
+                 dkey(h, 0, 0, h->seed, h->call), 0, nullptr, nullptr, &e);
+    memset(&e, 0, sizeof(e));
+    e.rowacc = h->rowtmp.p; e.dot_mat = h->mu[1].p; e.ld_dot = h->mu[1].ld;
+    layer_update(h, 1, h->N, LayerIn{h->mu[0].p, h->mu[0].ld}, LayerIn{nullptr, 0}, 1.f, 1.f, 0, nullptr, nullptr,
+                 h->mu[1].ld, dkey(h, 0, 0, h->seed, h->call), 0, nullptr, nullptr, &e);
+    hipLaunchKernelGGL(elbo_row_kernel, dim3((h->N + 3) / 4), dim3(256), 0, h->stream, X_dev, h->V, h->V,
+                       (const float *)h->vb.p, (const float *)h->mu[0].p, h->mu[0].ld, h->n[1], (const float *)h->hb[0].p,
+                       (const float *)h->mu[1].p, h->mu[1].ld, h->n[2], (const float *)h->hb[1].p, h->N, h->rowtmp.p);
+    BM_HIP(hipMemcpyAsync(out_host, h->rowtmp.p, (size_t)h->N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    h->call++;
+    return 0;
+}
+
+int bm_dbm_timer_start(bm_dbm *h) { BM_HIP(hipEventRecord(h->ev0, h->stream)); return 0; }
+int bm_dbm_timer_stop(bm_dbm *h, float *out_ms) {
+    BM_HIP(hipEventRecord(h->ev1, h->stream));
+    BM_HIP(hipEventSynchronize(h->ev1));
+    BM_HIP(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+    return 0;
+}
+
+}  // extern "C"

@@ -22,7 +22,8 @@ struct ActArgs {
     int I, J;                    // output is [J rows][I cols], ld = ldo
     const float *bias;           // [I]
     const float *sigma;          // [I], Gaussian units only
-    float mult;                  // propup/propdown multiplier or AIS beta (applied to z and to bias)
+    float mult;                  // propup/propdown multiplier or AIS beta applied to z
+    float bmult;                 // multiplier applied to the bias (== mult except mean-field init, dbm.py:434-446)
     int kind;                    // BM_UNIT_BERNOULLI: sigmoid(mult*z + mult*b); GAUSSIAN: (mult*z)*sigma + mult*b
     int sample;                  // 1: states = draw(means); 0: states = means
     float *means;                // may be null
@@ -32,6 +33,15 @@ struct ActArgs {
     long long row0;              // global row of local row 0 (rank-invariant bitmaps)
     const float *prev;           // mean-field: previous mu (same layout as means) or null
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
+    // optional per-row reductions of the epilogue (AIS log-weights dbm.py:650-660,713-720; ELBO :741-745)
+    float *rowacc;               // [J] += sum_i softplus(beta_b*(z+b)) - softplus(beta_a*(z+b))   (AIS)
+                                 //     or sum_i z * dot_mat[j][i]                                  (ELBO, dot_mat set)
+    float beta_a, beta_b;
+    const float *rowdot_in;      // [J]: rowacc[j] += (beta_b - beta_a) * rowdot_in[j], added once per row (AIS x.hb0 term)
+    float *rowdot_out;           // [J] += sum_i states[j][i] * dot_vec[i]
+    const float *dot_vec;        // [I]
+    const float *dot_mat;        // [J][I] pitch ld_dot
+    int ld_dot;
 #ifdef BM_PROBE
     long long *dbg;              // [grid][4] s_memtime stamps (tools/probe_act.hip only)
 #endif
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = a.mult * z[4 * hlf + r];
-                const float b = a.mult * bs[4 * hlf + r];
+                const float b = a.bmult * bs[4 * hlf + r];
                 m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * sg[4 * hlf + r] + b);
                 s[r] = m[r];
             }
@@ -181,6 +191,35 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
         if (lane == 0 && dmax > 0.f) atomicMax(a.maxdiff, __float_as_uint(dmax));
+    }
+    if (a.rowacc || a.rowdot_out) {           // wave-uniform
+        float racc = 0.f, rdot = 0.f;
+        if (j < a.J) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = ib0 + e;
+                if (i >= a.I) break;
+                if (a.rowacc) {
+                    if (a.dot_mat) {
+                        racc += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
+                    } else {
+                        const float t = z[e] + bs[e];
+                        racc += softplus(a.beta_b * t) - softplus(a.beta_a * t);
+                    }
+                }
+                if (a.rowdot_out) {
+                    // recompute the state of this element from what was stored (states were just written)
+                    rdot += a.states[(size_t)j * a.ldo + i] * a.dot_vec[i];
+                }
+            }
+            if (a.rowacc && a.rowdot_in && ib0 == 0) racc += (a.beta_b - a.beta_a) * a.rowdot_in[j];
+        }
+        racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
+        rdot += __shfl_xor(rdot, 16); rdot += __shfl_xor(rdot, 32);
+        if (g == 0 && j < a.J) {
+            if (a.rowacc) atomicAdd(a.rowacc + j, racc);
+            if (a.rowdot_out) atomicAdd(a.rowdot_out + j, rdot);
+        }
     }
     (void)full8;
     BM_STAMP(2);
@@ -665,6 +704,103 @@ __global__ void pll_index_kernel(int *out, int B, int V, PhiloxKey key, unsigned
     uint32_t w[4];
     philox_block(key, idx >> 2, w);
     out[b] = (int)(w[idx & 3] % (uint32_t)V);
+}
+
+// ------------------------------------------------------------------ DBM update
+// Bias / running-mean / sparsity update of one DBM layer from raw column sums
+// (dbm.py:550-590, 597-600, 611-615), including the reference's scalar-index quirk:
+// the EMA input is the column sum of UNIT `layer` of that layer, broadcast to all units.
+struct DbmBiasArgs {
+    const float *s_pos, *s_neg;      // [n] column sums of mu_i (or X) and of H_i (or v)
+    float *b, *db;                   // bias and its momentum buffer
+    float *q, *mm, *pen;             // q_means, mu_means, penalty out (null for the visible layer)
+    int n, layer;
+    float N, M, lr, mom, damping, cost, target;
+};
+__global__ void dbm_bias_kernel(DbmBiasArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.n) return;
+    float g = a.s_pos[c] / a.N - a.s_neg[c] / a.M;           // reduce_mean(mu) - reduce_mean(H)   :553,573-576
+    if (a.q) {
+        const float qn = a.damping * a.q[c] + (1.0f - a.damping) * a.s_neg[a.layer];    // :582-584 (q_means[i] scalar)
+        const float mn = a.damping * a.mm[c] + (1.0f - a.damping) * a.s_pos[a.layer];   // :585-587
+        a.q[c] = qn;
+        a.mm[c] = mn;
+        const float p1 = a.cost * (qn - a.target);
+        const float p2 = a.cost * (mn - a.target);
+        const float pen = p1 + p2;                                                      // :588-589
+        a.pen[c] = pen;
+        g = g - pen;                                                                    // :591
+    }
+    const float d = a.lr * (a.mom * a.db[c] + g);
+    a.db[c] = d;
+    a.b[c] = a.b[c] + d;
+}
+
+// Max-norm column rescale (dbm.py:511-513, :603-607):  W[:,c] *= min(||W[:,c]||, c_max) / max(||W[:,c]||, 1e-8)
+// One workgroup per 16 columns.  ||.||^2 is the canonical chain sum_j fma(w_j, w_j, acc): the
+// diagonal of the 16x16 Gram block the MFMA produces when both operands are the column block.
+struct MaxNormArgs {
+    float *W, *Wt;          // [J][I] pitch ldw, transpose [I][J] pitch ldwt
+    int I, J, ldw, ldwt;
+    float max_norm;
+    float *norm_out;        // [I] column norms (W_norm metric) or null
+};
+__global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
+    __shared__ __attribute__((aligned(16))) float sA[CS_ROWS * 16];
+    __shared__ float s_num[16], s_den[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int c0 = blockIdx.x * 16;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < a.J; r0 += CS_ROWS) {
+        const int nr = (a.J - r0 < CS_ROWS) ? a.J - r0 : CS_ROWS;
+        for (int e = tid; e < CS_ROWS * 16; e += NT) {
+            const int row = e >> 4, c = c0 + (e & 15);
+            sA[e] = (row < nr && c < a.I) ? a.W[(size_t)(r0 + row) * a.ldw + c] : 0.f;
+        }
+        __syncthreads();
+        if (w == 0) {
+            const int nsteps = (((nr + 3) / 4) + 7) & ~7;
+            for (int s = 0; s < nsteps; s += 8) {
+                float d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d[u] = sA[(4 * (s + u) + g) * 16 + l15];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], d[u], acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (w == 0 && (l15 >> 2) == g) {                         // diagonal element i == j == l15
+        const float nrm = sqrtf(acc[l15 & 3]);
+        s_num[l15] = fminf(nrm, a.max_norm);                 // tf.minimum(T_norm, max_norm)
+        s_den[l15] = fmaxf(nrm, 1e-8f);                      // tf.maximum(T_norm, 1e-8)
+        if (a.norm_out && c0 + l15 < a.I) a.norm_out[c0 + l15] = nrm;
+    }
+    __syncthreads();
+    for (int e = tid; e < a.J * 16; e += NT) {
+        const int row = e >> 4, cc = e & 15, c = c0 + cc;
+        if (c < a.I) {
+            const size_t o = (size_t)row * a.ldw + c;
+            const float wn = (a.W[o] * s_num[cc]) / s_den[cc];     // T * min / max, left to right
+            a.W[o] = wn;
+            if (a.Wt) a.Wt[(size_t)c * a.ldwt + row] = wn;
+        }
+    }
+}
+
+// ||A - B||_inf over a [rows][cols] window -> atomicMax on float bits (mean-field cond, dbm.py:449-452)
+__global__ void maxabsdiff_kernel(const float *A, int lda, const float *B, int ldb, int rows, int cols, unsigned *out) {
+    const size_t n = (size_t)rows * cols;
+    float m = 0.f;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
+        m = fmaxf(m, fabsf(A[r * lda + c] - B[r * ldb + c]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
 }
 
 // ------------------------------------------------------------- host launchers

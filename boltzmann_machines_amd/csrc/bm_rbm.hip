@@ -91,6 +91,7 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.I = h->H; a.J = B;
     a.bias = h->hb.p; a.sigma = nullptr;
     a.mult = 1.0f + (h->cfg.dbm_first ? 1.0f : 0.0f);
+    a.bmult = a.mult;
     a.kind = BM_UNIT_BERNOULLI;
     a.sample = sample;
     a.means = means; a.states = states; a.ldo = ldo;
@@ -111,6 +112,7 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
     a.I = h->V; a.J = B;
     a.bias = h->vb.p; a.sigma = h->sigma.p;
     a.mult = 1.0f + (h->cfg.dbm_last ? 1.0f : 0.0f);
+    a.bmult = a.mult;
     a.kind = h->cfg.v_unit;
     a.sample = sample;
     a.means = means; a.states = states; a.ldo = ldo;

@@ -135,3 +135,120 @@ class RbmEngine(object):
         ms = C.c_float()
         check(self.lib.bm_rbm_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class DbmEngine(object):
+    """One bm_dbm handle: the variables, variational parameters and fantasy particles
+    of a DBM in HBM + the fetch sites of boltzmann_machines/dbm.py (`session.run` at
+    :798,:805,:813,:869,:882,:893,:930,:954)."""
+
+    def __init__(self, n_visible, n_hiddens, v_unit=_ffi.UNIT_BERNOULLI, sample_v_states=True,
+                 sample_h_states=None, n_particles=100, batch_size=100, max_mf_updates=10, mf_tol=1e-7,
+                 l2=0., max_norm=np.inf, sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9):
+        self.lib = _ffi.load()
+        self.V = int(n_visible)
+        self.n_hiddens = [int(x) for x in n_hiddens]
+        self.L = len(self.n_hiddens)
+        self.N, self.M = int(batch_size), int(n_particles)
+        cfg = _ffi.DbmConfig()
+        cfg.n_layers, cfg.n_visible, cfg.v_unit = self.L, self.V, int(v_unit)
+        cfg.sample_v_states = int(bool(sample_v_states))
+        sh = sample_h_states or [True] * self.L
+        st = sparsity_target if hasattr(sparsity_target, '__iter__') else [sparsity_target] * self.L
+        sc = sparsity_cost if hasattr(sparsity_cost, '__iter__') else [sparsity_cost] * self.L
+        for i in range(self.L):
+            cfg.n_hiddens[i] = self.n_hiddens[i]
+            cfg.sample_h_states[i] = int(bool(sh[i]))
+            cfg.sparsity_target[i] = float(st[i])
+            cfg.sparsity_cost[i] = float(sc[i])
+        cfg.n_particles, cfg.batch_size, cfg.max_mf_updates = self.M, self.N, int(max_mf_updates)
+        cfg.mf_tol, cfg.l2, cfg.max_norm = float(mf_tol), float(l2), float(max_norm)
+        cfg.sparsity_damping = float(sparsity_damping)
+        self._h = C.c_void_p()
+        check(self.lib.bm_dbm_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.bm_dbm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- variables ("W", "W_1", "hb", "hb_1", "mu_1", "h", "h_1", "v", ...)
+    def shape(self, name):
+        base, idx = name, 0
+        if '_' in name and name.rsplit('_', 1)[1].isdigit():
+            base, idx = name.rsplit('_', 1)[0], int(name.rsplit('_', 1)[1])
+        n = [self.V] + self.n_hiddens
+        if base in ('W', 'dW'):
+            return (n[idx], n[idx + 1])
+        if base in ('mu', 'mu_new'):
+            return (self.N, n[idx + 1])
+        if base in ('h', 'h_new'):
+            return (self.M, n[idx + 1])
+        if base in ('v', 'v_new'):
+            return (self.M, self.V)
+        if base in ('hb', 'dhb', 'q_means', 'mu_means', 'W_norm'):
+            return (n[idx + 1],)
+        if base in ('vb', 'dvb', 'sigma'):
+            return (self.V,)
+        raise KeyError(name)
+
+    def set(self, name, value):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float32), self.shape(name)))
+        check(self.lib.bm_dbm_set_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get(self, name):
+        a = np.empty(self.shape(name), dtype=np.float32)
+        check(self.lib.bm_dbm_get_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def seed(self, seed):
+        check(self.lib.bm_dbm_seed(self._h, int(seed)))
+
+    def set_row_offset(self, row0, particle0):
+        check(self.lib.bm_dbm_set_row_offset(self._h, int(row0), int(particle0)))
+
+    def sync(self):
+        check(self.lib.bm_dbm_sync(self._h))
+
+    # -- fetch sites
+    def train_step(self, Xd, lr, momentum, k, row=0, want_msre=False):
+        nmf, msre = C.c_int32(), C.c_float()
+        check(self.lib.bm_dbm_train_step(self._h, Xd.offset_ptr(row * self.V), lr, momentum, k, C.byref(nmf),
+                                         C.byref(msre) if want_msre else None))
+        return int(nmf.value), (float(msre.value) if want_msre else None)
+
+    def mean_field(self, Xd, row=0, out=None, out_row=0):
+        nmf = C.c_int32()
+        p = out.offset_ptr(out_row * self.n_hiddens[-1]) if out is not None else None
+        check(self.lib.bm_dbm_mean_field(self._h, Xd.offset_ptr(row * self.V), p, C.byref(nmf)))
+        return int(nmf.value)
+
+    def reconstruct(self, Xd, Rd, row=0, out_row=0):
+        check(self.lib.bm_dbm_reconstruct(self._h, Xd.offset_ptr(row * self.V), Rd.offset_ptr(out_row * self.V)))
+
+    def sample_v(self, k, Vd=None):
+        check(self.lib.bm_dbm_sample_v(self._h, k, Vd.ptr if Vd is not None else None))
+
+    def ais(self, n_betas, n_runs, k, seed, chain0=0):
+        out = np.empty(n_runs, dtype=np.float32)
+        check(self.lib.bm_dbm_ais(self._h, n_betas, n_runs, k, int(seed), int(chain0), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def log_proba(self, Xd, row=0):
+        out = np.empty(self.N, dtype=np.float32)
+        check(self.lib.bm_dbm_log_proba(self._h, Xd.offset_ptr(row * self.V), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def timer_start(self):
+        check(self.lib.bm_dbm_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(self.lib.bm_dbm_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)

@@ -156,11 +156,26 @@ enum { UNIT_BERNOULLI = 0, UNIT_GAUSSIAN = 1 };
  *   Gaussian : m = x*sigma[i] + b            (layers.py:84-86)
  *   states   = sample ? draw(m) : m          (layers.py:34-36,50-51,88-89)
  * P1k [K1][I] and P2k [K2][I] are k-major. */
+void orc_act2(const float *Q1, int K1, const float *P1k,
+              const float *Q2, int K2, const float *P2k,
+              int I, int J, const float *bias, const float *sigma, float mult, float bmult, int kind, int sample,
+              float *means, float *states,
+              uint64_t seed, uint32_t site, uint32_t call, int64_t row0);
+
 void orc_act(const float *Q1, int K1, const float *P1k,
              const float *Q2, int K2, const float *P2k,
              int I, int J, const float *bias, const float *sigma, float mult, int kind, int sample,
              float *means, float *states,
              uint64_t seed, uint32_t site, uint32_t call, int64_t row0) {
+    orc_act2(Q1, K1, P1k, Q2, K2, P2k, I, J, bias, sigma, mult, mult, kind, sample, means, states, seed, site, call, row0);
+}
+
+/* bmult: multiplier of the bias (== mult except in the mean-field init, dbm.py:434-446) */
+void orc_act2(const float *Q1, int K1, const float *P1k,
+              const float *Q2, int K2, const float *P2k,
+              int I, int J, const float *bias, const float *sigma, float mult, float bmult, int kind, int sample,
+              float *means, float *states,
+              uint64_t seed, uint32_t site, uint32_t call, int64_t row0) {
     const orc_key key = make_key(seed, site, call);
 #pragma omp parallel
     {
@@ -172,7 +187,7 @@ void orc_act(const float *Q1, int K1, const float *P1k,
             if (K2 > 0) chain_kmajor(acc, Q2 + (size_t)j * K2, P2k, K2, I);
             for (int i = 0; i < I; ++i) {
                 const float x = mult * acc[i];
-                const float b = mult * bias[i];
+                const float b = bmult * bias[i];
                 const float m = (kind == UNIT_BERNOULLI) ? orc_sigmoid(x + b) : (x * sigma[i] + b);
                 float s = m;
                 if (sample) {
@@ -382,4 +397,314 @@ void orc_rbm_metrics(const orc_rbm_cfg *c, const orc_rbm_state *s, const orc_rbm
     out4[1] = (float)((double)V * -softplus_d(-d));       /* V * log_sigmoid(F(x~) - F(x))  :511-512 */
     out4[3] = (float)fe;
     free(flip);
+}
+
+/* ================================================================= DBM path */
+#define ORC_MAXL 4
+typedef struct {
+    int32_t L, V, n[ORC_MAXL];            /* hidden layer sizes */
+    int32_t v_unit, sample_v, sample_h[ORC_MAXL];
+    int32_t N, M, max_mf;
+    float mf_tol, l2, max_norm, sp_target[ORC_MAXL], sp_cost[ORC_MAXL], sp_damping;
+} orc_dbm_cfg;
+
+typedef struct {
+    float *W[ORC_MAXL], *dW[ORC_MAXL], *hb[ORC_MAXL], *dhb[ORC_MAXL], *q[ORC_MAXL], *mm[ORC_MAXL];
+    float *mu[ORC_MAXL], *mu_new[ORC_MAXL], *H[ORC_MAXL], *H_new[ORC_MAXL];
+    float *vb, *dvb, *sigma, *v, *v_new;
+    float *wnorm[ORC_MAXL];
+} orc_dbm_state;
+
+enum { SITE_DBM_H = 8, SITE_DBM_V = 12, SITE_AIS_X0 = 13 };
+
+static int dn(const orc_dbm_cfg *c, int i) { return i == 0 ? c->V : c->n[i - 1]; }   /* n[0]=V, n[i+1]=hidden i */
+
+/* `_make_gibbs_step` (dbm.py:385-427): bottom-up sweep with NEW below / OLD above */
+static void dbm_sweep(const orc_dbm_cfg *c, const orc_dbm_state *s, int J, const float *vin, float *const *Hin,
+                      float *vout, float *const *Hout, int update_v, int sample, int t,
+                      uint64_t seed, uint32_t call, int64_t row0) {
+    const int L = c->L;
+    for (int i = 0; i < L; ++i) {
+        const float *below = (i == 0) ? vin : Hout[i - 1];
+        const int Kb = dn(c, i), I = dn(c, i + 1);
+        float *Wt = NULL; const float *above = NULL; int Ka = 0;
+        if (i + 1 < L) { Ka = dn(c, i + 2); Wt = transpose(s->W[i + 1], I, Ka); above = Hin[i + 1]; }
+        const int smp = sample && c->sample_h[i];
+        orc_act2(below, Kb, s->W[i], above, Ka, Wt, I, J, s->hb[i], NULL, 1.0f, 1.0f, UNIT_BERNOULLI, smp,
+                 NULL, Hout[i], seed, SITE_DBM_H + (uint32_t)i + 16u * (uint32_t)t, call, row0);
+        free(Wt);
+    }
+    if (update_v) {
+        float *Wt0 = transpose(s->W[0], c->V, dn(c, 1));
+        const int smp = sample && c->sample_v;
+        orc_act2(Hout[0], dn(c, 1), Wt0, NULL, 0, NULL, c->V, J, s->vb, s->sigma, 1.0f, 1.0f, c->v_unit, smp,
+                 NULL, vout, seed, SITE_DBM_V + 16u * (uint32_t)t, call, row0);
+        free(Wt0);
+    }
+}
+
+static float max_abs_diff(const float *a, const float *b, size_t n) {
+    float m = 0.0f;
+    for (size_t e = 0; e < n; ++e) { const float d = fabsf(a[e] - b[e]); if (d > m) m = d; }
+    return m;
+}
+
+/* `_make_mf` (dbm.py:429-478); result in s->mu, init values in s->mu_new; returns the sweeps run */
+int orc_dbm_mean_field(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X) {
+    const int L = c->L, N = c->N;
+    for (int i = 0; i < L; ++i) {                              /* approx-inference init :434-446 */
+        const float *below = (i == 0) ? X : s->mu_new[i - 1];
+        const float mult = (i == 0 || i < L - 1) ? 2.0f : 1.0f;
+        orc_act2(below, dn(c, i), s->W[i], NULL, 0, NULL, dn(c, i + 1), N, s->hb[i], NULL, mult, 1.0f,
+                 UNIT_BERNOULLI, 0, s->mu_new[i], NULL, 0, 0, 0, 0);
+    }
+    float diff = 0.0f;
+    for (int i = 0; i < L; ++i) {
+        const float d = max_abs_diff(s->mu[i], s->mu_new[i], (size_t)N * dn(c, i + 1));
+        if (d > diff) diff = d;
+    }
+    float *cur[ORC_MAXL], *alt[ORC_MAXL];
+    for (int i = 0; i < L; ++i) {
+        cur[i] = s->mu[i];
+        alt[i] = (float *)malloc((size_t)N * dn(c, i + 1) * sizeof(float));
+    }
+    int step = 0;
+    while (step < c->max_mf && diff > c->mf_tol) {             /* cond :449-452, body :454-457 */
+        dbm_sweep(c, s, N, X, cur, NULL, alt, 0, 0, 0, 0, 0, 0);
+        diff = 0.0f;
+        for (int i = 0; i < L; ++i) {
+            const float d = max_abs_diff(cur[i], alt[i], (size_t)N * dn(c, i + 1));
+            if (d > diff) diff = d;
+        }
+        for (int i = 0; i < L; ++i) { float *t = cur[i]; cur[i] = alt[i]; alt[i] = t; }
+        ++step;
+    }
+    for (int i = 0; i < L; ++i) {                              /* mu.assign(result) :477 */
+        if (cur[i] != s->mu[i]) { memcpy(s->mu[i], cur[i], (size_t)N * dn(c, i + 1) * sizeof(float)); free(cur[i]); }
+        else free(alt[i]);
+    }
+    return step;
+}
+
+/* `_make_particles_update` (dbm.py:480-509): k sweeps with swap; latest state ends in v/H */
+void orc_dbm_particles(const orc_dbm_cfg *c, orc_dbm_state *s, int k, int sample,
+                       uint64_t seed, uint32_t call, int64_t prow0) {
+    for (int t = 0; t < k; ++t) {
+        dbm_sweep(c, s, c->M, s->v, s->H, s->v_new, s->H_new, 1, sample, t, seed, call, prow0);
+        float *tv = s->v; s->v = s->v_new; s->v_new = tv;
+        for (int i = 0; i < c->L; ++i) { float *th = s->H[i]; s->H[i] = s->H_new[i]; s->H_new[i] = th; }
+    }
+}
+
+/* reconstruction sigma(mu0 W0^T + vb) (dbm.py:625-628) */
+void orc_dbm_reconstruct_from_mu(const orc_dbm_cfg *c, const orc_dbm_state *s, float *R) {
+    float *Wt0 = transpose(s->W[0], c->V, dn(c, 1));
+    orc_act2(s->mu[0], dn(c, 1), Wt0, NULL, 0, NULL, c->V, c->N, s->vb, s->sigma, 1.0f, 1.0f, c->v_unit, 0,
+             R, NULL, 0, 0, 0, 0);
+    free(Wt0);
+}
+
+/* gradients + sparsity + momentum + max-norm (dbm.py:550-621) */
+static void dbm_apply_update(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X, float lr, float mom) {
+    const int L = c->L;
+    const float N = (float)c->N, M = (float)c->M;
+    float *sx = (float *)malloc(c->V * sizeof(float)), *sv = (float *)malloc(c->V * sizeof(float));
+    colsum_diff(sx, X, NULL, c->N, c->V);
+    colsum_diff(sv, s->v, NULL, c->M, c->V);
+    float *pen[ORC_MAXL];
+    /* the W update reads the gradients of the PRE-update state: compute all raw sums first */
+    float *pos[ORC_MAXL], *neg[ORC_MAXL];
+    for (int i = 0; i < L; ++i) {
+        const int J = dn(c, i), I = dn(c, i + 1);
+        pos[i] = (float *)malloc((size_t)J * I * sizeof(float));
+        neg[i] = (float *)malloc((size_t)J * I * sizeof(float));
+        outer_chain(pos[i], (i == 0) ? X : s->mu[i - 1], J, s->mu[i], I, c->N, 1.0f, 0);      /* :556,565 */
+        outer_chain(neg[i], (i == 0) ? s->v : s->H[i - 1], J, s->H[i], I, c->M, 1.0f, 0);    /* :557,566 */
+    }
+    for (int v = 0; v < c->V; ++v) {                                                          /* :553, :597-600 */
+        const float g = sx[v] / N - sv[v] / M;
+        const float d = lr * (mom * s->dvb[v] + g);
+        s->dvb[v] = d;
+        s->vb[v] = s->vb[v] + d;
+    }
+    for (int i = 0; i < L; ++i) {
+        const int n = dn(c, i + 1);
+        float *smu = (float *)malloc(n * sizeof(float)), *sH = (float *)malloc(n * sizeof(float));
+        colsum_diff(smu, s->mu[i], NULL, c->N, n);
+        colsum_diff(sH, s->H[i], NULL, c->M, n);
+        pen[i] = (float *)malloc(n * sizeof(float));
+        for (int h = 0; h < n; ++h) {
+            float g = smu[h] / N - sH[h] / M;                                                 /* :573-576 */
+            const float qn = c->sp_damping * s->q[i][h] + (1.0f - c->sp_damping) * sH[i];     /* :582-584 scalar index quirk */
+            const float mn = c->sp_damping * s->mm[i][h] + (1.0f - c->sp_damping) * smu[i];   /* :585-587 */
+            s->q[i][h] = qn;
+            s->mm[i][h] = mn;
+            const float p1 = c->sp_cost[i] * (qn - c->sp_target[i]);
+            const float p2 = c->sp_cost[i] * (mn - c->sp_target[i]);
+            pen[i][h] = p1 + p2;
+            g = g - pen[i][h];
+            const float d = lr * (mom * s->dhb[i][h] + g);
+            s->dhb[i][h] = d;
+            s->hb[i][h] = s->hb[i][h] + d;
+        }
+        free(smu); free(sH);
+    }
+    for (int i = 0; i < L; ++i) {
+        const int J = dn(c, i), I = dn(c, i + 1);
+        for (int j = 0; j < J; ++j)
+            for (int h = 0; h < I; ++h) {
+                const size_t e = (size_t)j * I + h;
+                float g = pos[i][e] / N - neg[i][e] / M;                                      /* :556-558 */
+                g = g - c->l2 * s->W[i][e];
+                g = g - pen[i][h];                                                            /* :590 */
+                const float d = lr * (mom * s->dW[i][e] + g);                                 /* :604 */
+                s->dW[i][e] = d;
+                s->W[i][e] = s->W[i][e] + d;                                                  /* :605 */
+            }
+        for (int h = 0; h < I; ++h) {                                                         /* max-norm :511-513,606-607 */
+            float acc = 0.0f;
+            for (int j = 0; j < J; ++j) { const float w = s->W[i][(size_t)j * I + h]; acc = fmaf(w, w, acc); }
+            const float nrm = sqrtf(acc);
+            const float num = fminf(nrm, c->max_norm), den = fmaxf(nrm, 1e-8f);
+            for (int j = 0; j < J; ++j) {
+                const size_t e = (size_t)j * I + h;
+                s->W[i][e] = (s->W[i][e] * num) / den;
+            }
+            if (s->wnorm[i]) s->wnorm[i][h] = nrm;
+        }
+        free(pos[i]); free(neg[i]); free(pen[i]);
+    }
+    free(sx); free(sv);
+}
+
+/* session.run(train_op) — dbm.py:805.  Returns executed mean-field sweeps; *msre as dbm.py:625-630 */
+int orc_dbm_train_step(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X, float lr, float mom, int k,
+                       uint64_t seed, uint32_t call, int64_t prow0, float *msre) {
+    const int nmf = orc_dbm_mean_field(c, s, X);
+    orc_dbm_particles(c, s, k, 1, seed, call, prow0);
+    if (msre) {
+        float *R = (float *)malloc((size_t)c->N * c->V * sizeof(float));
+        orc_dbm_reconstruct_from_mu(c, s, R);
+        double se = 0.0;
+        for (size_t e = 0; e < (size_t)c->N * c->V; ++e) { const double d = (double)X[e] - (double)R[e]; se += d * d; }
+        *msre = (float)(se / ((double)c->N * c->V));
+        free(R);
+    }
+    dbm_apply_update(c, s, X, lr, mom);
+    return nmf;
+}
+
+/* sample_v op (dbm.py:641-648): k sampled sweeps (assigned), then k mean sweeps whose v is assigned */
+void orc_dbm_sample_v(const orc_dbm_cfg *c, orc_dbm_state *s, int k, uint64_t seed, uint32_t call, int64_t prow0) {
+    orc_dbm_particles(c, s, k, 1, seed, call, prow0);
+    const int L = c->L, M = c->M;
+    float *Hin[ORC_MAXL], *Hout[ORC_MAXL], *vin, *vout;
+    vin = (float *)malloc((size_t)M * c->V * sizeof(float)); vout = (float *)malloc((size_t)M * c->V * sizeof(float));
+    memcpy(vin, s->v, (size_t)M * c->V * sizeof(float));
+    for (int i = 0; i < L; ++i) {
+        const size_t n = (size_t)M * dn(c, i + 1);
+        Hin[i] = (float *)malloc(n * sizeof(float)); Hout[i] = (float *)malloc(n * sizeof(float));
+        memcpy(Hin[i], s->H[i], n * sizeof(float));
+    }
+    for (int t = 0; t < k; ++t) {
+        dbm_sweep(c, s, M, vin, Hin, vout, Hout, 1, 0, k + t, seed, call, prow0);
+        float *tv = vin; vin = vout; vout = tv;
+        for (int i = 0; i < L; ++i) { float *th = Hin[i]; Hin[i] = Hout[i]; Hout[i] = th; }
+    }
+    memcpy(s->v, vin, (size_t)M * c->V * sizeof(float));
+    free(vin); free(vout);
+    for (int i = 0; i < L; ++i) { free(Hin[i]); free(Hout[i]); }
+}
+
+/* log p*_beta(x) per chain (dbm.py:650-660), double accumulation */
+static void ais_log_p(const orc_dbm_cfg *c, const orc_dbm_state *s, const float *x, int R, float beta, double *out) {
+    const int V = c->V, H1 = c->n[0], H2 = c->n[1];
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < R; ++r) {
+        const float *xr = x + (size_t)r * H1;
+        double t1 = 0.0;
+        for (int h = 0; h < H1; ++h) t1 += (double)xr[h] * (double)s->hb[0][h];
+        double lp = t1 * (double)beta;
+        for (int v = 0; v < V; ++v) {
+            double z = s->vb[v];
+            for (int h = 0; h < H1; ++h) z += (double)xr[h] * (double)s->W[0][(size_t)v * H1 + h];
+            lp += softplus_d(z * (double)beta);
+        }
+        for (int k2 = 0; k2 < H2; ++k2) {
+            double z = s->hb[1][k2];
+            for (int h = 0; h < H1; ++h) z += (double)xr[h] * (double)s->W[1][(size_t)h * H2 + k2];
+            lp += softplus_d(z * (double)beta);
+        }
+        out[r] = lp;
+    }
+}
+
+/* AIS (dbm.py:696-736) for the 2-layer Bernoulli DBM; values[r] = log Z estimate of chain r */
+void orc_dbm_ais(const orc_dbm_cfg *c, const orc_dbm_state *s, int n_betas, int R, int k,
+                 uint64_t seed, int64_t chain0, float *values) {
+    const int V = c->V, H1 = c->n[0], H2 = c->n[1];
+    float *x = (float *)malloc((size_t)R * H1 * sizeof(float)), *xn = (float *)malloc((size_t)R * H1 * sizeof(float));
+    float *v = (float *)malloc((size_t)R * V * sizeof(float)), *h2 = (float *)malloc((size_t)R * H2 * sizeof(float));
+    double *lz = (double *)calloc(R, sizeof(double)), *lp = (double *)malloc(R * sizeof(double));
+    float *Wt0 = transpose(s->W[0], V, H1), *Wt1 = transpose(s->W[1], H1, H2);
+    const orc_key k0 = make_key(seed, SITE_AIS_X0, 0);
+    for (int r = 0; r < R; ++r)
+        for (int h = 0; h < H1; ++h)
+            x[(size_t)r * H1 + h] = (uniform_at(k0, (uint64_t)(chain0 + r) * (uint64_t)H1 + h) < 0.5f) ? 1.0f : 0.0f;
+    const float db = 1.0f / (float)n_betas;
+#define AIS_TRANSIT(BETA, STEP)                                                                             \
+    for (int t = 0; t < k; ++t) {                                                                           \
+        orc_act2(x, H1, Wt0, NULL, 0, NULL, V, R, s->vb, s->sigma, (BETA), (BETA), UNIT_BERNOULLI,         \
+                 c->sample_v, NULL, v, seed, SITE_DBM_V + 16u * (uint32_t)t, (STEP), chain0);               \
+        orc_act2(x, H1, s->W[1], NULL, 0, NULL, H2, R, s->hb[1], NULL, (BETA), (BETA), UNIT_BERNOULLI,     \
+                 c->sample_h[1], NULL, h2, seed, SITE_DBM_H + 1 + 16u * (uint32_t)t, (STEP), chain0);       \
+        orc_act2(v, V, s->W[0], h2, H2, Wt1, H1, R, s->hb[0], NULL, (BETA), (BETA), UNIT_BERNOULLI,        \
+                 c->sample_h[0], NULL, xn, seed, SITE_DBM_H + 0 + 16u * (uint32_t)t, (STEP), chain0);       \
+        float *tx = x; x = xn; xn = tx;                                                                     \
+    }
+    AIS_TRANSIT(db, 0u)                                                     /* x_1 ~ T_1(x_1|x_0)      :704-705 */
+    ais_log_p(c, s, x, R, 0.0f, lp);                                        /* -log p_0(x_1)           :708 */
+    for (int r = 0; r < R; ++r) lz[r] -= lp[r];
+    float beta = db; uint32_t step = 1;
+    while (beta < 1.0f - db + 1e-5f) {                                      /* :710-726 */
+        ais_log_p(c, s, x, R, beta, lp);
+        for (int r = 0; r < R; ++r) lz[r] += lp[r];
+        AIS_TRANSIT(beta + db, step)
+        ++step;
+        ais_log_p(c, s, x, R, beta, lp);
+        for (int r = 0; r < R; ++r) lz[r] -= lp[r];
+        beta = beta + db;
+    }
+    ais_log_p(c, s, x, R, 1.0f, lp);                                        /* + log p_M(x_M)          :728 */
+    const double logZ0 = (double)(V + H1 + H2) * (double)logf(2.0f);        /* :731-734 */
+    for (int r = 0; r < R; ++r) values[r] = (float)(lz[r] + lp[r] + logZ0);
+    free(x); free(xn); free(v); free(h2); free(lz); free(lp); free(Wt0); free(Wt1);
+#undef AIS_TRANSIT
+}
+
+/* variational lower bound terms per row (dbm.py:738-759) given mu from mean-field, double accumulation */
+void orc_dbm_log_proba(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X, float *out) {
+    orc_dbm_mean_field(c, s, X);
+    const int V = c->V, H1 = c->n[0], H2 = c->n[1], N = c->N;
+    for (int r = 0; r < N; ++r) {
+        const float *x = X + (size_t)r * V, *m0 = s->mu[0] + (size_t)r * H1, *m1 = s->mu[1] + (size_t)r * H2;
+        double e = 0.0;
+        for (int h = 0; h < H1; ++h) {
+            double z = 0.0;
+            for (int v = 0; v < V; ++v) z += (double)x[v] * (double)s->W[0][(size_t)v * H1 + h];
+            e += z * (double)m0[h];
+        }
+        for (int k2 = 0; k2 < H2; ++k2) {
+            double z = 0.0;
+            for (int h = 0; h < H1; ++h) z += (double)m0[h] * (double)s->W[1][(size_t)h * H2 + k2];
+            e += z * (double)m1[k2];
+        }
+        for (int v = 0; v < V; ++v) e += (double)x[v] * (double)s->vb[v];
+        for (int h = 0; h < H1; ++h) e += (double)m0[h] * (double)s->hb[0][h];
+        for (int k2 = 0; k2 < H2; ++k2) e += (double)m1[k2] * (double)s->hb[1][k2];
+        double ent = 0.0;
+        for (int h = 0; h < H1; ++h) { double q = fmin(fmax((double)m0[h], 1e-7), 1.0 - 1e-7); ent += -q * log(q) - (1 - q) * log(1 - q); }
+        for (int k2 = 0; k2 < H2; ++k2) { double q = fmin(fmax((double)m1[k2], 1e-7), 1.0 - 1e-7); ent += -q * log(q) - (1 - q) * log(1 - q); }
+        out[r] = (float)(e + ent);
+    }
 }

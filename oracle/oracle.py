@@ -193,3 +193,141 @@ def normal(seed, site, call, n, idx0=0):
     out = np.zeros(n, dtype=np.float32)
     lib().orc_normal(seed, site, call, idx0, n, out)
     return out
+
+
+# ------------------------------------------------------------------------------ DBM
+MAXL = 4
+
+
+class DbmCfg(C.Structure):
+    _fields_ = [('L', C.c_int32), ('V', C.c_int32), ('n', C.c_int32 * MAXL),
+                ('v_unit', C.c_int32), ('sample_v', C.c_int32), ('sample_h', C.c_int32 * MAXL),
+                ('N', C.c_int32), ('M', C.c_int32), ('max_mf', C.c_int32),
+                ('mf_tol', C.c_float), ('l2', C.c_float), ('max_norm', C.c_float),
+                ('sp_target', C.c_float * MAXL), ('sp_cost', C.c_float * MAXL), ('sp_damping', C.c_float)]
+
+
+class DbmState(C.Structure):
+    _fields_ = [(n, C.c_void_p * MAXL) for n in ('W', 'dW', 'hb', 'dhb', 'q', 'mm', 'mu', 'mu_new', 'H', 'H_new')] + \
+               [(n, C.c_void_p) for n in ('vb', 'dvb', 'sigma', 'v', 'v_new')] + [('wnorm', C.c_void_p * MAXL)]
+
+
+def _dbm_lib():
+    L = lib()
+    if not getattr(L, '_dbm_ready', False):
+        cp, sp = C.POINTER(DbmCfg), C.POINTER(DbmState)
+        L.orc_dbm_mean_field.restype = C.c_int
+        L.orc_dbm_mean_field.argtypes = [cp, sp, f32p]
+        L.orc_dbm_particles.argtypes = [cp, sp, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int64]
+        L.orc_dbm_reconstruct_from_mu.argtypes = [cp, sp, f32p]
+        L.orc_dbm_train_step.restype = C.c_int
+        L.orc_dbm_train_step.argtypes = [cp, sp, f32p, C.c_float, C.c_float, C.c_int, C.c_uint64, C.c_uint32,
+                                         C.c_int64, C.POINTER(C.c_float)]
+        L.orc_dbm_sample_v.argtypes = [cp, sp, C.c_int, C.c_uint64, C.c_uint32, C.c_int64]
+        L.orc_dbm_ais.argtypes = [cp, sp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, f32p]
+        L.orc_dbm_log_proba.argtypes = [cp, sp, f32p, f32p]
+        L._dbm_ready = True
+    return L
+
+
+class OracleDBM(object):
+    """CPU twin of one bm_dbm handle (same variable names as DbmEngine.get/set)."""
+
+    def __init__(self, n_visible, n_hiddens, v_unit=0, sample_v_states=True, sample_h_states=None,
+                 n_particles=100, batch_size=100, max_mf_updates=10, mf_tol=1e-7, l2=0., max_norm=np.inf,
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9):
+        self.V, self.nh = int(n_visible), [int(x) for x in n_hiddens]
+        self.L, self.N, self.M = len(self.nh), int(batch_size), int(n_particles)
+        c = DbmCfg()
+        c.L, c.V, c.v_unit, c.sample_v = self.L, self.V, int(v_unit), int(bool(sample_v_states))
+        sh = sample_h_states or [True] * self.L
+        st = sparsity_target if hasattr(sparsity_target, '__iter__') else [sparsity_target] * self.L
+        sc = sparsity_cost if hasattr(sparsity_cost, '__iter__') else [sparsity_cost] * self.L
+        for i in range(self.L):
+            c.n[i], c.sample_h[i], c.sp_target[i], c.sp_cost[i] = self.nh[i], int(bool(sh[i])), st[i], sc[i]
+        c.N, c.M, c.max_mf = self.N, self.M, int(max_mf_updates)
+        c.mf_tol, c.l2, c.sp_damping = mf_tol, l2, sparsity_damping
+        c.max_norm = float(max_norm)
+        self.cfg = c
+        n = [self.V] + self.nh
+        z = lambda *s: np.zeros(s, dtype=np.float32)
+        self.p = dict(vb=z(self.V), dvb=z(self.V), sigma=np.ones(self.V, dtype=np.float32),
+                      v=z(self.M, self.V), v_new=z(self.M, self.V))
+        for i in range(self.L):
+            sfx = '' if i == 0 else '_%d' % i
+            self.p['W' + sfx] = z(n[i], n[i + 1]); self.p['dW' + sfx] = z(n[i], n[i + 1])
+            for nm in ('hb', 'dhb', 'q_means', 'mu_means', 'W_norm'):
+                self.p[nm + sfx] = z(n[i + 1])
+            for nm in ('mu', 'mu_new'):
+                self.p[nm + sfx] = z(self.N, n[i + 1])
+            for nm in ('h', 'h_new'):
+                self.p[nm + sfx] = z(self.M, n[i + 1])
+        self.seed, self.call, self.prow0 = 0, 0, 0
+
+    def set_seed(self, seed):
+        self.seed, self.call = int(seed), 0
+
+    def _state(self):
+        s = DbmState()
+        names = dict(W='W', dW='dW', hb='hb', dhb='dhb', q='q_means', mm='mu_means', mu='mu', mu_new='mu_new',
+                     H='h', H_new='h_new', wnorm='W_norm')
+        for fld, nm in names.items():
+            arr = getattr(s, fld)
+            for i in range(self.L):
+                arr[i] = _ptr(self.p[nm + ('' if i == 0 else '_%d' % i)])
+        for nm in ('vb', 'dvb', 'sigma', 'v', 'v_new'):
+            setattr(s, nm, _ptr(self.p[nm]))
+        return s
+
+    def _sync_back(self, s):
+        """the C side swaps particle pointers: re-bind names to the buffers that now hold them"""
+        byaddr = {a.ctypes.data: a for a in self.p.values()}
+        self.p['v'], self.p['v_new'] = byaddr[s.v], byaddr[s.v_new]
+        for i in range(self.L):
+            sfx = '' if i == 0 else '_%d' % i
+            self.p['h' + sfx], self.p['h_new' + sfx] = byaddr[s.H[i]], byaddr[s.H_new[i]]
+
+    def mean_field(self, X):
+        s = self._state()
+        n = _dbm_lib().orc_dbm_mean_field(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32))
+        self.call += 1
+        return n
+
+    def train_step(self, X, lr, momentum, k, want_msre=False):
+        s = self._state()
+        msre = C.c_float()
+        n = _dbm_lib().orc_dbm_train_step(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32),
+                                          lr, momentum, k, self.seed, self.call, self.prow0,
+                                          C.byref(msre) if want_msre else None)
+        self._sync_back(s)
+        self.call += 1
+        return n, (msre.value if want_msre else None)
+
+    def reconstruct(self, X):
+        s = self._state()
+        L_ = _dbm_lib()
+        L_.orc_dbm_mean_field(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32))
+        R = np.zeros((self.N, self.V), dtype=np.float32)
+        L_.orc_dbm_reconstruct_from_mu(C.byref(self.cfg), C.byref(s), R)
+        self.call += 1
+        return R
+
+    def sample_v(self, k):
+        s = self._state()
+        _dbm_lib().orc_dbm_sample_v(C.byref(self.cfg), C.byref(s), k, self.seed, self.call, self.prow0)
+        self._sync_back(s)
+        self.call += 1
+        return self.p['v'].copy()
+
+    def ais(self, n_betas, n_runs, k, seed, chain0=0):
+        s = self._state()
+        out = np.zeros(n_runs, dtype=np.float32)
+        _dbm_lib().orc_dbm_ais(C.byref(self.cfg), C.byref(s), n_betas, n_runs, k, int(seed), int(chain0), out)
+        return out
+
+    def log_proba(self, X):
+        s = self._state()
+        out = np.zeros(self.N, dtype=np.float32)
+        _dbm_lib().orc_dbm_log_proba(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32), out)
+        self.call += 1
+        return out

@@ -1,0 +1,104 @@
+"""-m gpu parity of the DBM path (mean-field, PCD particles, train op with sparsity and
+max-norm, sample_v, reconstruction, AIS, ELBO) against the CPU oracle.
+Bit-exact for everything that feeds back into state; AIS / ELBO values (fp32 sums of
+softplus / entropies, reference accumulates them in arbitrary TF order) to 1e-5 relative."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(V, nh, N, M, seed=3, **kw):
+    from boltzmann_machines_amd.engine import DbmEngine
+    eng = DbmEngine(V, nh, n_particles=M, batch_size=N, **kw)
+    twin = orc.OracleDBM(V, nh, n_particles=M, batch_size=N, **kw)
+    n = [V] + list(nh)
+    for i in range(len(nh)):
+        sfx = '' if i == 0 else '_%d' % i
+        W = (orc.normal(87654321, seed + i, 0, n[i] * n[i + 1]) * np.float32(0.1)).reshape(n[i], n[i + 1])
+        hb = (orc.uniform(87654321, seed + 10 + i, 0, n[i + 1]) - np.float32(0.5)) * np.float32(0.4)
+        for nm, val in (('W' + sfx, W), ('hb' + sfx, hb)):
+            eng.set(nm, val); twin.p[nm][...] = val
+        Hp = (orc.uniform(87654321, seed + 20 + i, 0, M * n[i + 1]) < 0.5).astype(np.float32).reshape(M, n[i + 1])
+        eng.set('h' + sfx, Hp); twin.p['h' + sfx][...] = Hp
+    vb = (orc.uniform(87654321, seed + 30, 0, V) - np.float32(0.5)) * np.float32(0.4)
+    eng.set('vb', vb); twin.p['vb'][...] = vb
+    vp = (orc.uniform(87654321, seed + 31, 0, M * V) < 0.3).astype(np.float32).reshape(M, V)
+    eng.set('v', vp); twin.p['v'][...] = vp
+    return eng, twin
+
+
+def data(N, V, s):
+    return (orc.uniform(87654321, 99 + s, 0, N * V) < 0.2).astype(np.float32).reshape(N, V)
+
+
+def assert_equal(eng, twin, names):
+    for nm in names:
+        g, c = eng.get(nm), twin.p[nm]
+        bad = int(np.sum(g.view(np.uint32) != c.view(np.uint32)))
+        assert bad == 0, '%s: %d / %d differ (max abs %.3e)' % (nm, bad, g.size, float(np.max(np.abs(g - c))))
+
+
+CASES = [
+    (20, [12, 16], 10, 10, dict(max_mf_updates=5, mf_tol=1e-5, l2=1e-3, max_norm=1.5,
+                                sparsity_target=[0.2, 0.1], sparsity_cost=[1e-2, 5e-3])),
+    (36, [24], 8, 12, dict(max_mf_updates=3, l2=1e-4)),                                   # 1 layer (RBM with PCD)
+    (28, [20, 12, 8], 12, 8, dict(max_mf_updates=6, mf_tol=1e-6, max_norm=2.0)),          # 3 layers
+    (784, [512, 1024], 64, 64, dict(max_mf_updates=4, mf_tol=1e-7, l2=1e-7, max_norm=6.)),  # BASELINE config[3] layer sizes
+]
+
+
+@pytest.mark.parametrize('V,nh,N,M,kw', CASES)
+def test_train_steps_bit_exact(gpu_lib, V, nh, N, M, kw):
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, nh, N, M, **kw)
+    eng.seed(42); twin.set_seed(42)
+    names = ['vb', 'dvb', 'v']
+    for i in range(len(nh)):
+        sfx = '' if i == 0 else '_%d' % i
+        names += [b + sfx for b in ('W', 'dW', 'hb', 'dhb', 'q_means', 'mu_means', 'mu', 'h')]
+    for s in range(2):
+        X = data(N, V, s)
+        n1, m1 = eng.train_step(as_device(X), 0.05, 0.5, 2, want_msre=True)
+        n2, m2 = twin.train_step(X, 0.05, 0.5, 2, want_msre=True)
+        assert n1 == n2
+        np.testing.assert_allclose(m1, m2, rtol=1e-5)
+        assert_equal(eng, twin, names)
+    eng.close()
+
+
+def test_mean_field_reconstruct_sample_v(gpu_lib):
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 20, [12, 16], 10, 10
+    eng, twin = make_pair(V, nh, N, M, max_mf_updates=8, mf_tol=1e-6)
+    eng.seed(7); twin.set_seed(7)
+    X = data(N, V, 5)
+    top = DeviceArray((N, nh[-1]))
+    assert eng.mean_field(as_device(X), out=top) == twin.mean_field(X)
+    assert np.array_equal(top.numpy(), twin.p['mu_1'])
+    Rd = DeviceArray((N, V))
+    eng.reconstruct(as_device(X), Rd)
+    eng.sync()
+    assert np.array_equal(Rd.numpy(), twin.reconstruct(X))
+    Vd = DeviceArray((M, V))
+    eng.sample_v(3, Vd)
+    assert np.array_equal(Vd.numpy(), twin.sample_v(3))
+    assert_equal(eng, twin, ['v', 'h', 'h_1'])
+    eng.close()
+
+
+@pytest.mark.parametrize('k', [1, 2])
+def test_ais_and_log_proba(gpu_lib, k):
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 20, [12, 16], 10, 10
+    eng, twin = make_pair(V, nh, N, M, max_mf_updates=8, mf_tol=1e-6)
+    g = eng.ais(n_betas=25, n_runs=37, k=k, seed=2222, chain0=5)
+    c = twin.ais(n_betas=25, n_runs=37, k=k, seed=2222, chain0=5)
+    np.testing.assert_allclose(g, c, rtol=1e-5)
+    eng.seed(1); twin.set_seed(1)
+    X = data(N, V, 2)
+    np.testing.assert_allclose(eng.log_proba(as_device(X)), twin.log_proba(X), rtol=1e-5)
+    eng.close()
