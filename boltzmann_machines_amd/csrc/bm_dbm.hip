@@ -454,7 +454,7 @@ int bm_dbm_reconstruct(bm_dbm *h, const float *X_dev, float *R_dev) {
 }
 
 int bm_dbm_sample_v(bm_dbm *h, int32_t k, float *V_dev) {
-    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1");
+    BM_CHECK(k >= 0, "n_gibbs_steps must be >= 0");
     particles_update(h, k, true);                             // :643-644
     // `_make_particles_update(sample=False)` whose v assign is the only one fetched (:646-647):
     // k mean sweeps from the sampled state; only v takes the result, H / *_new keep theirs.

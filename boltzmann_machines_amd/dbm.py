@@ -1,0 +1,357 @@
+"""Deep Boltzmann Machine with the reference's API on the MI355X engine.
+
+Drop-in for boltzmann_machines/dbm.py of the reference: constructor keywords
+(:89-99), `load_rbms` weight composition (:207-231, :266-291), `fit`, `transform`
+(:859-872), `reconstruct` (:874-885), `sample_v` (:887-897), `log_Z` (:899-939),
+`log_proba` (:941-957), `get_tf_params`, `load_model`, attributes `epoch_`, `iter_`,
+`n_layers_`, `n_visible_`, `n_hiddens_`, `n_samples_generated_`.  The TF graph
+(mean-field, PCD, train op, AIS, ELBO) is executed by libbm355 (csrc/bm_dbm.hip).
+
+Unit types: Bernoulli hidden layers, Bernoulli or Gaussian visible layer
+(Multinomial layers are out of the hot-path scope).
+"""
+import numpy as np
+
+from . import _ffi
+from .base import EngineModel, run_on_engine
+from .engine import DbmEngine, as_device
+from .rbm import GaussianRBM
+from .utils import (epoch_iter, make_list_from, write_during_training,
+                    log_sum_exp, log_mean_exp, log_diff_exp, log_std_exp)
+from .utils import philox
+
+# Philox sites of the host-evaluated initialisers (`layer.init`, dbm.py:362-383)
+_SITE_V_INIT, _SITE_V_NEW_INIT, _SITE_H_INIT = 20, 21, 22
+
+
+class DBM(EngineModel):
+    def __init__(self, rbms=None,
+                 n_particles=100, v_particle_init=None, h_particles_init=None,
+                 n_gibbs_steps=5, max_mf_updates=10, mf_tol=1e-7,
+                 learning_rate=0.0005, momentum=0.9, max_epoch=10, batch_size=100,
+                 l2=0., max_norm=np.inf,
+                 sample_v_states=True, sample_h_states=None,
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9,
+                 train_metrics_every_iter=10, val_metrics_every_epoch=1,
+                 verbose=False, save_after_each_epoch=True,
+                 display_filters=0, display_particles=0, v_shape=(28, 28),
+                 model_path='dbm_model/', *args, **kwargs):
+        super(DBM, self).__init__(model_path=model_path, *args, **kwargs)
+        self.n_layers_ = len(rbms) if rbms is not None else None
+        self.n_visible_ = None
+        self.n_hiddens_ = []
+        self._rbms = None
+        self._W_init = self._vb_init = self._hb_init = None
+        self.v_unit_ = _ffi.UNIT_BERNOULLI     # visible unit type (attribute: restored by load_model)
+        self._sigma_init = None
+        self.load_rbms(rbms)
+
+        self.n_particles = n_particles
+        self._v_particle_init = v_particle_init
+        self._h_particles_init = h_particles_init
+
+        self.n_gibbs_steps = make_list_from(n_gibbs_steps)
+        self.max_mf_updates = max_mf_updates
+        self.mf_tol = mf_tol
+
+        self.learning_rate = make_list_from(learning_rate)
+        self.momentum = make_list_from(momentum)
+        self.max_epoch = max_epoch
+        self.batch_size = batch_size
+        self.l2 = l2
+        self.max_norm = max_norm
+
+        self.sample_v_states = sample_v_states
+        self.sample_h_states = sample_h_states or [True] * (self.n_layers_ or 0)
+
+        self.sparsity_target = make_list_from(sparsity_target)
+        self.sparsity_cost = make_list_from(sparsity_cost)
+        if self.n_layers_ is not None and self.n_layers_ > 1:
+            for x in (self.sparsity_target, self.sparsity_cost):
+                if len(x) == 1:
+                    x *= self.n_layers_
+        self.sparsity_damping = sparsity_damping
+
+        self.train_metrics_every_iter = train_metrics_every_iter
+        self.val_metrics_every_epoch = val_metrics_every_epoch
+        self.verbose = verbose
+        self.save_after_each_epoch = save_after_each_epoch
+
+        for nh in self.n_hiddens_:
+            assert nh >= display_filters
+        self.display_filters = display_filters
+        assert display_particles <= self.n_particles
+        self.display_particles = display_particles
+        self.v_shape = v_shape
+        if len(self.v_shape) == 2:
+            self.v_shape = (self.v_shape[0], self.v_shape[1], 1)
+
+        self.epoch_ = 0
+        self.iter_ = 0
+        self.n_samples_generated_ = 0
+
+    # ---- composition from pre-trained RBMs (reference dbm.py:207-231) ------------------
+    def load_rbms(self, rbms):
+        if rbms is not None:
+            self._rbms = rbms
+            self.n_layers_ = len(self._rbms)
+            self.n_visible_ = self._rbms[0].n_visible
+            self.n_hiddens_ = [rbm.n_hidden for rbm in self._rbms]
+            self._W_init, self._vb_init, self._hb_init = [], [], []
+            for i in range(self.n_layers_):
+                weights = self._rbms[i].get_tf_params(scope='weights')
+                self._W_init.append(weights['W'])
+                self._vb_init.append(weights['vb'])
+                self._hb_init.append(weights['hb'])
+            if isinstance(self._rbms[0], GaussianRBM):
+                self.v_unit_ = _ffi.UNIT_GAUSSIAN
+                self._sigma_init = self._rbms[0]._sigma_vector()
+
+    def _composed_weights(self):
+        """`_make_vars` (reference dbm.py:266-291): halve the intermediate RBMs' weights and
+        average the biases that two RBMs give to the same layer."""
+        L = self.n_layers_
+        W_init, hb_init = [], []
+        vb_init = np.array(self._vb_init[0], dtype=np.float32)
+        for i in range(L):
+            W = np.array(self._W_init[i], dtype=np.float32)
+            vb = np.array(self._vb_init[i], dtype=np.float32)
+            hb = np.array(self._hb_init[i], dtype=np.float32)
+            if 0 < i < L - 1:
+                W *= 0.5
+                vb *= 0.5
+                hb *= 0.5
+            W_init.append(W)
+            if i == 0:
+                hb_init.append(0.5 * hb)
+            else:
+                hb_init[i - 1] += 0.5 * vb
+                hb_init.append(0.5 * hb if i < L - 1 else hb)
+        return W_init, vb_init, hb_init
+
+    @staticmethod
+    def _sfx(i):
+        return '' if i == 0 else '_%d' % i
+
+    def _var_names(self):
+        L = self.n_layers_
+        names = [('vb', 'weights'), ('dvb', 'grads_accumulators'), ('sigma', 'input_data'),
+                 ('v', 'negative_particles'), ('v_new', 'negative_particles')]
+        for i in range(L):
+            s = self._sfx(i)
+            names += [('W' + s, 'weights'), ('hb' + s, 'weights'),
+                      ('dW' + s, 'grads_accumulators'), ('dhb' + s, 'grads_accumulators'),
+                      ('mu' + s, 'variational_params'), ('mu_new' + s, 'variational_params'),
+                      ('q_means' + s, 'hidden_means_accumulators'), ('mu_means' + s, 'hidden_means_accumulators'),
+                      ('h' + s, 'negative_particles'), ('h_new' + s, 'negative_particles')]
+        return names
+
+    def _initial_variables(self):
+        W_init, vb_init, hb_init = self._composed_weights()
+        L, M, V = self.n_layers_, self.n_particles, self.n_visible_
+        seed = self._graph_seed if self._graph_seed is not None else philox.DEFAULT_GRAPH_SEED
+        d = dict(vb=vb_init)
+        if self._sigma_init is not None:
+            d['sigma'] = np.asarray(self._sigma_init, dtype=np.float32)
+
+        def v_init(site):       # `layer.init`: U[0,1) reals for Bernoulli (layers.py:43-45), N(0,1)*sigma for Gaussian
+            if self.v_unit_ == _ffi.UNIT_GAUSSIAN:
+                return philox.normal(seed, site, 0, M * V).reshape(M, V) * d.get('sigma', np.float32(1.))
+            return philox.uniform(seed, site, 0, M * V).reshape(M, V)
+        d['v'] = np.asarray(self._v_particle_init, dtype=np.float32) if self._v_particle_init is not None \
+            else v_init(_SITE_V_INIT)
+        d['v_new'] = v_init(_SITE_V_NEW_INIT)
+        for i in range(L):
+            s, n = self._sfx(i), self.n_hiddens_[i]
+            d['W' + s], d['hb' + s] = W_init[i], hb_init[i]
+            if self._h_particles_init is not None:
+                d['h' + s] = np.asarray(self._h_particles_init[i], dtype=np.float32).reshape(M, n)
+            else:
+                d['h' + s] = philox.uniform(seed, _SITE_H_INIT + 2 * i, 0, M * n).reshape(M, n)
+            d['h_new' + s] = philox.uniform(seed, _SITE_H_INIT + 2 * i + 1, 0, M * n).reshape(M, n)
+        return d
+
+    # ---- engine hooks ---------------------------------------------------------------------
+    def _make_engine(self):
+        if self.n_layers_ is None:
+            raise RuntimeError('DBM has no layers: pass `rbms` or use `load_model`')
+        if np.dtype(self.dtype) != np.float32:
+            raise NotImplementedError("the MI355X engine computes in float32 (dtype='%s' requested)" % self.dtype)
+        self._engine = DbmEngine(self.n_visible_, self.n_hiddens_, v_unit=self.v_unit_,
+                                 sample_v_states=self.sample_v_states, sample_h_states=self.sample_h_states,
+                                 n_particles=self.n_particles, batch_size=self.batch_size,
+                                 max_mf_updates=self.max_mf_updates, mf_tol=self.mf_tol, l2=self.l2,
+                                 max_norm=self.max_norm, sparsity_target=self.sparsity_target,
+                                 sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping)
+        if self._pending_vars is None:          # fresh model (load_model uploads its checkpoint instead)
+            self._upload_variables(self._initial_variables())
+
+    def _upload_variables(self, d):
+        for name, _ in self._var_names():
+            if name in d:
+                self._engine.set(name, d[name])
+
+    def _seed_engine(self, seed):
+        self._engine.seed(seed)
+
+    def _variables(self):
+        return {name: self._engine.get(name) for name, _ in self._var_names()}
+
+    def _scoped_variables(self):
+        return {name: (scope, self._engine.get(name)) for name, scope in self._var_names()}
+
+    @classmethod
+    def load_model(cls, model_path):
+        model = super(DBM, cls).load_model(model_path)
+        model.n_layers_ = len(model.n_hiddens_)
+        return model
+
+    # ---- schedules (reference dbm.py:771-791) -------------------------------------------
+    def _feed(self, n_gibbs_steps=None):
+        pick = lambda v: v[min(self.epoch_, len(v) - 1)]
+        k = n_gibbs_steps if n_gibbs_steps is not None else pick(self.n_gibbs_steps)
+        return float(pick(self.learning_rate)), float(pick(self.momentum)), int(k)
+
+    def _check_batches(self, X):
+        if len(X) % self.batch_size != 0:
+            raise ValueError('DBM variational parameters have a fixed [batch_size, n] shape (dbm.py:345-348): '
+                             '{0} rows are not a multiple of batch_size={1}'.format(len(X), self.batch_size))
+
+    # ---- training loop (reference dbm.py:793-857) -------------------------------------------
+    def _train_epoch(self, Xd, N):
+        lr, mom, k = self._feed()
+        msres, nmfs = [], []
+        for start in range(0, N, self.batch_size):
+            self.iter_ += 1
+            if self.iter_ % self.train_metrics_every_iter == 0:
+                nmf, msre = self._engine.train_step(Xd, lr, mom, k, row=start, want_msre=True)
+                msres.append(msre)
+                nmfs.append(nmf)
+            else:
+                self._engine.train_step(Xd, lr, mom, k, row=start)
+        return (np.mean(msres) if msres else None, np.mean(nmfs) if nmfs else None)
+
+    def _run_val_metrics(self, X_val, Xvd):
+        msres, nmfs = [], []
+        Rd = _ffi.DeviceArray((self.batch_size, self.n_visible_))
+        for start in range(0, len(X_val), self.batch_size):
+            nmfs.append(self._engine.mean_field(Xvd, row=start))
+            self._engine.reconstruct(Xvd, Rd, row=start)
+            self._engine.sync()
+            msres.append(np.mean((X_val[start:start + self.batch_size] - Rd.numpy()) ** 2))
+        return np.mean(msres), np.mean(nmfs)
+
+    def _fit(self, X, X_val=None, *args, **kwargs):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        self._check_batches(X)
+        Xd, N = as_device(X), len(X)
+        Xvd = None
+        if X_val is not None:
+            X_val = np.ascontiguousarray(X_val, dtype=np.float32)
+            self._check_batches(X_val)
+            Xvd = as_device(X_val)
+        val_msre, val_n_mf_updates = None, None
+        for self.epoch_ in epoch_iter(start_epoch=self.epoch_, max_epoch=self.max_epoch, verbose=self.verbose):
+            train_msre, train_n_mf_updates = self._train_epoch(Xd, N)
+            if X_val is not None and self.epoch_ % self.val_metrics_every_epoch == 0:
+                val_msre, val_n_mf_updates = self._run_val_metrics(X_val, Xvd)
+            if self.verbose:
+                s = "epoch: {0:{1}}/{2}".format(self.epoch_, len(str(self.max_epoch)), self.max_epoch)
+                if train_msre:
+                    s += "; msre: {0:.5f}".format(train_msre)
+                if train_n_mf_updates:
+                    s += "; n_mf_upds: {0:.1f}".format(train_n_mf_updates)
+                if val_msre:
+                    s += "; val.msre: {0:.5f}".format(val_msre)
+                if val_n_mf_updates:
+                    s += "; val.n_mf_upds: {0:.1f}".format(val_n_mf_updates)
+                write_during_training(s)
+            if self.save_after_each_epoch:
+                self._save_model(global_step=self.epoch_)
+        self._engine.sync()
+
+    # ---- public inference API ---------------------------------------------------------------
+    # The reference re-loads the variables from disk at the start of every public call
+    # (tf_model.py:22-28), so a call that does not save leaves the persistent state (the
+    # mean-field parameters that seed the next minibatch, the fantasy particles) untouched.
+    # Here the state is resident, so those calls snapshot and restore what they overwrite.
+    def _snapshot(self, bases):
+        names = [b + self._sfx(i) for b in bases for i in range(self.n_layers_) if b not in ('v', 'v_new')]
+        names += [b for b in bases if b in ('v', 'v_new')]
+        return {n: self._engine.get(n) for n in names}
+
+    def _restore(self, snap):
+        for n, a in snap.items():
+            self._engine.set(n, a)
+
+    @run_on_engine()
+    def transform(self, X, np_dtype=None):
+        """Mean-field activations of the last hidden layer (reference dbm.py:859-872)."""
+        np_dtype = np_dtype or self._np_dtype
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        self._check_batches(X)
+        Xd = as_device(X)
+        Gd = _ffi.DeviceArray((len(X), self.n_hiddens_[-1]))
+        snap = self._snapshot(('mu', 'mu_new'))
+        for start in range(0, len(X), self.batch_size):
+            self._engine.mean_field(Xd, row=start, out=Gd, out_row=start)
+        self._engine.sync()
+        self._restore(snap)
+        return Gd.numpy().astype(np_dtype)
+
+    @run_on_engine(update_seed=True)
+    def reconstruct(self, X):
+        """p(v | h_0 = q), q = mean-field p(h_0 | v = x) (reference dbm.py:874-885)."""
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        self._check_batches(X)
+        Xd = as_device(X)
+        Rd = _ffi.DeviceArray(X.shape)
+        snap = self._snapshot(('mu', 'mu_new'))
+        for start in range(0, len(X), self.batch_size):
+            self._engine.reconstruct(Xd, Rd, row=start, out_row=start)
+        self._engine.sync()
+        self._restore(snap)
+        return Rd.numpy()
+
+    @run_on_engine(update_seed=True)
+    def sample_v(self, n_gibbs_steps=0, save_model=False):
+        """Visible particle activation probabilities after `n_gibbs_steps` sweeps
+        (reference dbm.py:887-897, op :641-648)."""
+        Vd = _ffi.DeviceArray((self.n_particles, self.n_visible_))
+        snap = None if save_model else self._snapshot(('v', 'v_new', 'h', 'h_new'))
+        self._engine.sample_v(int(n_gibbs_steps), Vd)
+        v = Vd.numpy()
+        if save_model:
+            self.n_samples_generated_ += n_gibbs_steps
+            self._save_model()
+        else:
+            self._restore(snap)
+        return v
+
+    @run_on_engine(update_seed=True)
+    def log_Z(self, n_betas=100, n_runs=100, n_gibbs_steps=5):
+        """AIS estimate of the log partition function of the 2-layer binary DBM
+        (reference dbm.py:899-939).  Returns log_mean, (log_low, log_high), values."""
+        assert self.n_layers_ == 2
+        assert self.v_unit_ == _ffi.UNIT_BERNOULLI
+        values = self._engine.ais(n_betas, n_runs, n_gibbs_steps, seed=self._graph_seed)
+        log_mean = log_mean_exp(values)
+        log_std = log_std_exp(values, log_mean_exp_x=log_mean)
+        log_high = log_sum_exp([log_std, log_mean])
+        log_low = log_diff_exp([log_std, log_mean])[0]
+        return log_mean, (log_low, log_high), values
+
+    @run_on_engine()
+    def log_proba(self, X_test, log_Z):
+        """Variational lower bound on log p(x) for the 2-layer binary DBM (reference dbm.py:941-957)."""
+        assert self.n_layers_ == 2
+        assert self.v_unit_ == _ffi.UNIT_BERNOULLI
+        X_test = np.ascontiguousarray(X_test, dtype=np.float32)
+        self._check_batches(X_test)
+        Xd = as_device(X_test)
+        P = np.zeros(len(X_test))
+        snap = self._snapshot(('mu', 'mu_new'))
+        for start in range(0, len(X_test), self.batch_size):
+            P[start:start + self.batch_size] = self._engine.log_proba(Xd, row=start)
+        self._restore(snap)
+        return P - log_Z

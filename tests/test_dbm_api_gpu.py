@@ -1,0 +1,93 @@
+"""DBM class API on the GPU: composition from pre-trained RBMs (dbm.py:266-291), fit,
+transform, reconstruct, sample_v, log_Z, log_proba, checkpoint/resume determinism."""
+import shutil
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose
+
+from boltzmann_machines_amd import DBM, BernoulliRBM
+from boltzmann_machines_amd.utils import RNG
+
+pytestmark = pytest.mark.gpu
+
+V, H1, H2, N, BS = 16, 12, 8, 20, 10
+X = (RNG(seed=1).rand(N, V) < 0.3).astype(np.float32)
+
+
+def pretrain(tmp, tag):
+    r1 = BernoulliRBM(n_visible=V, n_hidden=H1, dbm_first=True, max_epoch=2, batch_size=BS, random_seed=11,
+                      verbose=False, model_path=str(tmp / (tag + 'r1')) + '/').fit(X)
+    Q = r1.transform(X)
+    r2 = BernoulliRBM(n_visible=H1, n_hidden=H2, dbm_last=True, max_epoch=2, batch_size=BS, random_seed=12,
+                      verbose=False, model_path=str(tmp / (tag + 'r2')) + '/').fit(Q)
+    return r1, r2
+
+
+def make_dbm(tmp, tag, **kw):
+    r1, r2 = pretrain(tmp, tag)
+    cfg = dict(rbms=[r1, r2], n_particles=BS, n_gibbs_steps=2, max_mf_updates=5, mf_tol=1e-5, learning_rate=0.01,
+               max_epoch=2, batch_size=BS, l2=1e-4, max_norm=3., sparsity_target=[0.2, 0.1], sparsity_cost=[1e-3, 1e-4],
+               random_seed=1337, verbose=False, train_metrics_every_iter=1, model_path=str(tmp / (tag + 'dbm')) + '/')
+    cfg.update(kw)
+    return DBM(**cfg), (r1, r2)
+
+
+def test_composition_from_rbms(gpu_lib, tmp_path):
+    dbm, (r1, r2) = make_dbm(tmp_path, 'a')
+    dbm.init()
+    w = dbm.get_tf_params(scope='weights')
+    w1, w2 = r1.get_tf_params(scope='weights'), r2.get_tf_params(scope='weights')
+    assert set(w) == {'W', 'W_1', 'vb', 'hb', 'hb_1'}                   # examples/dbm_mnist.py:367-371
+    assert_allclose(w['W'], w1['W']); assert_allclose(w['W_1'], w2['W'])
+    assert_allclose(w['vb'], w1['vb'])
+    assert_allclose(w['hb'], 0.5 * w1['hb'] + 0.5 * w2['vb'])            # dbm.py:287-290
+    assert_allclose(w['hb_1'], w2['hb'])                                 # last layer keeps full hb
+    assert dbm.n_layers_ == 2 and dbm.n_visible_ == V and dbm.n_hiddens_ == [H1, H2]
+
+
+def test_fit_resume_and_inference(gpu_lib, tmp_path):
+    d1, _ = make_dbm(tmp_path, 'b')
+    d2, _ = make_dbm(tmp_path, 'c')
+    d1.fit(X); d2.fit(X)
+    for k in ('W', 'W_1', 'hb', 'hb_1', 'vb'):
+        assert_allclose(d1.get_tf_params('weights')[k], d2.get_tf_params('weights')[k])
+    assert d1.epoch_ == 2 and d1.iter_ == 4
+    # resume from disk right after fit: identical continuation (the reference's consistency protocol)
+    d3 = DBM.load_model(d1._model_dirpath)
+    assert d3.n_layers_ == 2 and d3.epoch_ == 2 and d3.n_hiddens_ == [H1, H2]
+    assert_allclose(d3.get_tf_params('weights')['W'], d1.get_tf_params('weights')['W'])
+    d1.set_params(max_epoch=3).fit(X)
+    d2.set_params(max_epoch=3).fit(X)
+    d3.set_params(max_epoch=3).fit(X)
+    for d in (d2, d3):
+        assert_allclose(d1.get_tf_params('weights')['W_1'], d.get_tf_params('weights')['W_1'])
+        assert_allclose(d1.get_tf_params('negative_particles')['v'], d.get_tf_params('negative_particles')['v'])
+    # inference calls
+    G = d1.transform(X)
+    assert G.shape == (N, H2) and np.all((G >= 0) & (G <= 1))
+    assert_allclose(G, d2.transform(X))
+    R = d1.reconstruct(X)
+    assert R.shape == X.shape and np.all((R >= 0) & (R <= 1))
+    p_before = d1.get_tf_params('negative_particles')['v'].copy()
+    vs = d1.sample_v(n_gibbs_steps=3)
+    assert vs.shape == (BS, V)
+    assert_allclose(d1.get_tf_params('negative_particles')['v'], p_before)    # not saved => state untouched
+    d2.reconstruct(X)
+    assert_allclose(vs, d2.sample_v(n_gibbs_steps=3))
+    lz, (lo, hi), vals = d1.log_Z(n_betas=50, n_runs=16, n_gibbs_steps=1)
+    assert vals.shape == (16,) and lo <= lz <= hi
+    assert abs(lz - (V + H1 + H2) * np.log(2)) < 10.0                    # small weights: near the uniform value
+    lp = d1.log_proba(X, lz)
+    assert lp.shape == (N,) and np.all(lp < 0)
+    mu_before = d1.get_tf_params('variational_params')['mu'].copy()
+    d1.transform(X)
+    assert_allclose(d1.get_tf_params('variational_params')['mu'], mu_before)
+
+
+def test_errors(gpu_lib, tmp_path):
+    dbm, _ = make_dbm(tmp_path, 'd')
+    with pytest.raises(RuntimeError):
+        dbm.transform(X)
+    with pytest.raises(ValueError):
+        dbm.fit(X[:15])                                                  # not a multiple of batch_size
