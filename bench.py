@@ -102,14 +102,12 @@ def main():
     Xd = as_device(X)
 
     if world > 1:
-        ext = torch.cuda.ExternalStream(eng.stream(), device=torch.device('cuda', local_rank))
-        gbuf = torch.as_tensor(eng.device_view('grad'), device=torch.device('cuda', local_rank))
+        from boltzmann_machines_amd import parallel
+        dev = torch.device('cuda', local_rank)
+        dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.torch_allreduce_on_engine_stream(eng, dev))
 
         def step(i):
-            eng.grad_step(Xd, B, k, row=(i % N_BATCHES) * B)
-            with torch.cuda.stream(ext):
-                dist.all_reduce(gbuf)                      # RCCL sum over xGMI, same HIP stream
-            eng.apply_step(B * world, LR, MOM)
+            dp.train_step(Xd, LR, MOM, k, row=(i % N_BATCHES) * B)     # grad_step -> RCCL all-reduce -> apply_step
     else:
         def step(i):
             eng.train_step(Xd, B, LR, MOM, k, row=(i % N_BATCHES) * B)
