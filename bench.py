@@ -63,6 +63,21 @@ def cpu_baseline(k, budget_s=15.0):
                       '(oracle/bm_oracle.c, restatement of base_rbm.py:415-479; TF1.3 cannot run here)' % (n, k, dt)}
 
 
+def pmc_traffic():
+    """HBM-side bytes per CD-1 update from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this same command, tools/profile_r1.sh + tools/summarize_profile.py); None
+    when no profile has been collected for this tree.  Counters cannot be read live from inside the
+    process, so this is the one roofline field that comes from profiles/."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))['traffic_bytes_per_update'])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -171,10 +186,11 @@ def main():
                        'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
                        'parallelism': 'dp%d' % world},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4), 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4),
+                         'traffic': pmc_traffic() if k == 1 else None,
                          'scope': 'whole CD-%d update = (2k+3)*2*B*V*H = %.3f GFLOP per launch sequence, '
                                   'HIP events on the engine stream over the timed region' % (k, flops_update / 1e9),
-                         'dominant_kernel': 'act_kernel<KM,XM> (prop-up GEMM + sigmoid + Philox)',
+                         'dominant_kernel': 'act_kernel (propagation GEMM + sigmoid + Philox Bernoulli, 3 of the 4 launches)',
                          'dominant_kernel_tflops': round(F / (up_us * 1e-6) / 1e12, 3) if up_us else None,
                          'kernels': kern},
         }
