@@ -1,0 +1,130 @@
+"""CPU tests (-m "not gpu") of the checker itself: the oracle against (i) the golden values the
+reference's own tests hold, (ii) an independent float64 NumPy restatement of the reference graph,
+(iii) the committed regression fixtures of tests/golden/."""
+import os
+
+import numpy as np
+import pytest
+from numpy.testing import assert_allclose, assert_almost_equal
+
+from boltzmann_machines_amd.utils import RNG, philox
+from oracle import oracle as orc
+from tests import np_reference as ref
+from tests.golden import make_golden
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_reference_known_answers():
+    """rbm/tests/test_rbm.py:64-67 (W-init KAT, f32 and f64) and utils/rng.py:18-22."""
+    n32 = orc.normal(87654321, 1337, 0, 4) * np.float32(0.01)
+    assert_almost_equal(n32[0], -0.0094548017)
+    assert_almost_equal(philox.tf_random_normal((12, 8), 0.01, 1337)[0][0], -0.0094548017)
+    assert_almost_equal(philox.tf_random_normal((12, 8), 0.01, 1337, np.float64)[0][0], -0.0077341544416)
+    assert RNG(1337).rand() == 0.2620246750155817
+
+
+def test_philox_stream_layout():
+    """element i = word i % 4 of block i // 4; streams differ by (site, call)"""
+    w = orc.philox_words(123, 7, 9, 0, 3)
+    u = orc.uniform(123, 7, 9, 12)
+    expect = ((w.reshape(-1) & 0x7fffff) | 0x3f800000).view(np.float32) - np.float32(1)
+    assert np.array_equal(u, expect)
+    assert np.array_equal(orc.uniform(123, 7, 9, 5, idx0=6), u[6:11])
+    assert not np.array_equal(orc.uniform(123, 8, 9, 12), u) and not np.array_equal(orc.uniform(123, 7, 10, 12), u)
+    assert np.all((u >= 0) & (u < 1))
+
+
+def test_sigmoid_spec_accuracy():
+    x = np.concatenate([np.linspace(-100, 100, 20001), np.float32([0, -0.0, 1e-8, -1e-8, 88, -88])]).astype(np.float32)
+    s = np.array([orc.lib().orc_sigmoid(float(v)) for v in x], dtype=np.float32)
+    exact = 1. / (1. + np.exp(-x.astype(np.float64)))
+    core = np.abs(x) <= 80                                       # the spec clamps |x| at 80 (sigma = 1.8e-35 there)
+    assert np.max(np.abs(s[core] - exact[core]) / exact[core]) < 3e-7
+    assert np.max(np.abs(s[~core] - exact[~core])) < 1e-34
+    assert np.all(np.diff(s[:20001]) >= 0)                       # monotone on the grid
+    assert s[20001] == 0.5 and s[20002] == 0.5
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(sample_v_states=True, dropout=0.8, sparsity_cost=0.05),
+                                dict(sample_h_states=False, dbm_first=True), dict(dbm_last=True, sample_v_states=True)])
+def test_oracle_vs_numpy_restatement(kw):
+    """C oracle (fp32 canonical chains) vs float64 matrix-form restatement of base_rbm.py:415-479:
+    probabilities to 1e-6, bitmaps identical away from ties, parameters to 1e-6."""
+    V, H, B, k = 30, 20, 14, 2
+    X = (philox.uniform(3, 1, 0, B * V) < 0.3).astype(np.float32).reshape(B, V)
+    W0 = (philox.normal(3, 2, 0, V * H) * np.float32(0.1)).reshape(V, H)
+    okw = dict(kw)
+    t = orc.OracleRBM(V, H, l2=1e-3, **okw)
+    t.p['W'][...] = W0
+    t.set_seed(99)
+    P = {n: t.p[n].astype(np.float64).copy() for n in ('W', 'vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means')}
+    nkw = dict(l2=1e-3, sample_v=kw.get('sample_v_states', False), sample_h=kw.get('sample_h_states', True),
+               dropout=kw.get('dropout'), sp_cost=kw.get('sparsity_cost', 0.), dbm_first=kw.get('dbm_first', False),
+               dbm_last=kw.get('dbm_last', False))
+    for step in range(2):
+        t.train_step(X, 0.05, 0.7, k)
+        r = ref.cd_step(P, X, 0.05, 0.7, k, 99, step, **nkw)
+        assert_allclose(t.work['h0m'], r['h0_means'], rtol=2e-6, atol=1e-7)
+        assert_allclose(t.work['vm'], r['v_means'], rtol=2e-6, atol=1e-7)
+        # bitmaps: identical wherever the uniform is not within 1e-6 of the probability
+        tie = np.abs(r['u_h0'] - r['h0_means']) < 1e-6
+        assert np.array_equal(t.work['h0s'][~tie], (r['u_h0'] < r['h0_means'].astype(np.float32))[~tie].astype(np.float32))
+        for n in ('W', 'vb', 'hb', 'q_means'):
+            assert_allclose(t.p[n], P[n], rtol=2e-5, atol=2e-7)
+    assert_allclose(t.free_energy(X), ref.free_energy(P, X.astype(np.float64)), rtol=1e-5)
+
+
+def test_metrics_definition():
+    """msre / l2 / pll as base_rbm.py:482-513 (PLL = V * log_sigmoid(F(x~) - F(x)) of batch-MEAN free energies)."""
+    V, H, B = 18, 10, 9
+    t = orc.OracleRBM(V, H, l2=0.01)
+    t.p['W'][...] = (philox.normal(5, 1, 0, V * H) * np.float32(0.3)).reshape(V, H)
+    t.p['vb'][...] = philox.uniform(5, 2, 0, V) - np.float32(0.5)
+    t.set_seed(11)
+    X = (philox.uniform(5, 3, 0, B * V) < 0.4).astype(np.float32).reshape(B, V)
+    m, flip = t.metrics(X, 1, advance=False)
+    P = {n: t.p[n].astype(np.float64) for n in ('W', 'vb', 'hb')}
+    Xc = X.astype(np.float64).copy()
+    Xc[np.arange(B), flip] = 1 - Xc[np.arange(B), flip]
+    d = ref.free_energy(P, Xc) - ref.free_energy(P, X.astype(np.float64))
+    assert_allclose(m[1], V * -ref.softplus(-d), rtol=1e-5)
+    assert_allclose(m[2], 0.01 * 0.5 * np.sum(P['W'] ** 2), rtol=1e-6)
+    assert_allclose(m[0], np.mean((t.work['Xin'] - t.work['vm']) ** 2), rtol=1e-6)
+    assert np.all((flip >= 0) & (flip < V))
+
+
+def test_golden_fixtures_rbm():
+    g = np.load(os.path.join(GOLD, 'rbm_12x8.npz'))
+    now = make_golden.rbm_case()
+    for k in g.files:
+        assert np.array_equal(g[k], now[k]), k
+
+
+def test_golden_fixtures_dbm():
+    g = np.load(os.path.join(GOLD, 'dbm_20_12_16.npz'))
+    now = make_golden.dbm_case()
+    for k in ('W', 'W_1', 'hb', 'hb_1', 'vb', 'v', 'mu_1', 'n_mf'):
+        assert np.array_equal(g[k], now[k]), k
+    for k in ('msre', 'ais', 'log_proba'):
+        assert_allclose(g[k], now[k], rtol=1e-6)
+
+
+def test_dbm_oracle_invariants():
+    """DBM restatement checks that need no fixture: max-norm bound, mean-field fixed point,
+    AIS of a zero-weight DBM is exact ((V+H1+H2) ln 2)."""
+    V, nh, N, M = 12, [8, 6], 6, 6
+    t = orc.OracleDBM(V, nh, n_particles=M, batch_size=N, max_mf_updates=50, mf_tol=1e-6, max_norm=0.5)
+    vals = t.ais(10, 5, 1, 1)
+    assert_allclose(vals, (V + 8 + 6) * np.log(2), rtol=1e-6)
+    t.p['W'][...] = (philox.normal(9, 1, 0, 96) * np.float32(0.5)).reshape(12, 8)
+    t.p['W_1'][...] = (philox.normal(9, 2, 0, 48) * np.float32(0.5)).reshape(8, 6)
+    X = (philox.uniform(9, 3, 0, N * V) < 0.3).astype(np.float32).reshape(N, V)
+    t.set_seed(5)
+    n1 = t.mean_field(X)
+    mu_a = t.p['mu'].copy()
+    n2 = t.mean_field(X)                                           # restart from the fixed point: converged at once
+    assert n1 > 1 and n2 <= 1 and np.max(np.abs(t.p['mu'] - mu_a)) < 1e-5
+    t.train_step(X, 0.5, 0.0, 1)
+    for nm in ('W', 'W_1'):
+        assert np.all(np.linalg.norm(t.p[nm], axis=0) <= 0.5 * (1 + 1e-5))

@@ -139,3 +139,31 @@ def test_errors(gpu_lib):
     with pytest.raises(Bm355Error):
         eng.train_step(as_device(np.zeros((2, 8), np.float32)), 2, 0.1, 0.5, 0)   # k < 1
     eng.close()
+
+
+def test_against_committed_golden_fixture(gpu_lib):
+    """HIP path vs tests/golden/rbm_12x8.npz (no oracle in the loop): the reference's test shape,
+    data (RNG(1337).rand(16, 12)), dropout 0.9, both samplers on."""
+    import os
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import RbmEngine, as_device
+    from boltzmann_machines_amd.utils import RNG, philox
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'rbm_12x8.npz'))
+    V, H = 12, 8
+    X = RNG(seed=1337).rand(16, V).astype(np.float32)
+    eng = RbmEngine(V, H, max_batch=10, sample_v_states=True, sample_h_states=True, dropout=0.9)
+    eng.set('W', philox.tf_random_normal((V, H), 0.01, 1337))
+    eng.seed(4242)
+    Xd = as_device(X)
+    for _ in range(3):
+        eng.train_step(Xd, 10, 0.01, 0.9, 1, row=0)
+        eng.train_step(Xd, 6, 0.01, 0.9, 1, row=10)
+    m = eng.metrics(Xd, 10, 1)
+    Hd = DeviceArray((8, H))
+    eng.transform(Xd, 8, 1, Hd)
+    eng.sync()
+    for k in ('W', 'vb', 'hb', 'dW', 'q_means'):
+        assert np.array_equal(eng.get(k).view(np.uint32), g[k].view(np.uint32)), k
+    np.testing.assert_allclose(m, g['metrics'], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(Hd.numpy(), g['transform'])
+    eng.close()
