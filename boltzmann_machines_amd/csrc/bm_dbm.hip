@@ -195,7 +195,7 @@ static int apply_update(bm_dbm *h, const float *X_dev, float lr, float mom) {
     }
     c.njobs = nj;
     c.first_wave[0] = 0;
-    for (int j = 0; j < nj; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 15) / 16;
+    for (int j = 0; j < nj; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 63) / 64;
     hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[nj]), dim3(NT), 0, h->stream, c);
     // biases (+ sparsity penalties)
     {

@@ -242,72 +242,87 @@ struct ColSumArgs {
     int njobs;
 };
 
-// Canonical column sums of 16 columns [c0, c0+16) by one 256-thread workgroup.
-//   sum1[c] = sum_k (A - Bm)[k][c]   (wave 0)      sum2[c] = sum_k Bm[k][c]   (wave 1, optional)
-// The MFMA chain D[i][*] += A[k][i] * 1 is sequential in k (that IS the canonical
-// order), so the only parallelism is in the loads: all 4 waves stage CS_ROWS rows of
-// both operands into LDS with 16-byte loads (one memory round trip), then one wave per
-// sum runs the 128-MFMA chain out of LDS (stride 16 floats: lanes 0-15 / 16-31 hit
-// disjoint bank halves).  Returns the sums in lanes with (lane & 15) == 0: acc[r] is
-// column c0 + 4*(lane>>4) + r.
-constexpr int CS_ROWS = 512;
-constexpr int CS_SMEM_FLOATS = 2 * CS_ROWS * 16;    // 64 KiB
+// Canonical column sums of 64 columns [c0, c0+64) by one 256-thread workgroup; wave w owns the
+// 16 columns c0 + 16w ...:
+//   sum1[c] = sum_k (A - Bm)[k][c]          sum2[c] = sum_k Bm[k][c]   (optional)
+// The MFMA chain D[i][*] += A[k][i] * 1 is sequential in k (that IS the canonical order), so the
+// parallelism is across columns and in the loads: all 4 waves stage CS_ROWS rows x 64 columns of
+// both operands into LDS with 16-byte loads (the next chunk is already in flight in registers
+// while the current one is consumed), then every wave runs its chain(s) out of LDS (row stride
+// 80 floats: lanes 0-15 / 16-31 hit disjoint bank halves).  Results land in the lanes with
+// (lane & 15) == 0: acc[r] is column c0 + 16w + 4*(lane>>4) + r.
+constexpr int CS_ROWS = 128;
+constexpr int CS_LD = 80;
+constexpr int CS_SMEM_FLOATS = 2 * CS_ROWS * CS_LD;    // 80 KiB
 
 __device__ __forceinline__ void block_colsum(const float *A, int lda, const float *Bm, int ldb,
                                              int c0, int ncols, int nrows, bool want2,
                                              float *smem, f32x4 &sum1, f32x4 &sum2) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    float *sA = smem, *sB = smem + CS_ROWS * 16;
+    float *sA = smem, *sB = smem + CS_ROWS * CS_LD;
     sum1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     sum2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool vecA = (((uintptr_t)A & 15u) == 0) && ((lda & 3) == 0) && (c0 + 16 <= ncols);
-    const bool vecB = !Bm || ((((uintptr_t)Bm & 15u) == 0) && ((ldb & 3) == 0) && (c0 + 16 <= ncols));
+    // 16-byte path: aligned operands and whole float4s (a ragged last column group is handled by
+    // clamping the column and zeroing at the LDS store, not by the scalar path)
+    const bool vec = (((uintptr_t)A & 15u) == 0) && ((lda & 3) == 0) && ((ncols & 3) == 0) &&
+                     (!Bm || ((((uintptr_t)Bm & 15u) == 0) && ((ldb & 3) == 0)));
+    constexpr int NV = CS_ROWS * 16 / NT;     // float4 per thread per operand (8)
+    float4 ra[NV], rb[NV];
+    auto fetch = [&](int r0) {                // rows [r0, r0 + CS_ROWS) -> registers (clamped, branch-free)
+        const int c4 = tid & 15;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int row = (tid >> 4) + 16 * n;
+            const int rc = min(r0 + row, nrows - 1);
+            const int cc = min(c0 + 4 * c4, ncols - 4);
+            ra[n] = *reinterpret_cast<const float4 *>(A + (size_t)rc * lda + cc);
+            rb[n] = Bm ? *reinterpret_cast<const float4 *>(Bm + (size_t)rc * ldb + cc)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int r0) {                // registers -> LDS, rows past nrows zeroed
+        const int c4 = tid & 15;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int row = (tid >> 4) + 16 * n;
+            const bool ok = (r0 + row < nrows) && (c0 + 4 * c4 < ncols);
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(sA + row * CS_LD + 4 * c4) = ok ? ra[n] : z;
+            *reinterpret_cast<float4 *>(sB + row * CS_LD + 4 * c4) = ok ? rb[n] : z;
+        }
+    };
+    if (vec) fetch(0);
     for (int r0 = 0; r0 < nrows; r0 += CS_ROWS) {
         const int nr = (nrows - r0 < CS_ROWS) ? nrows - r0 : CS_ROWS;
-        if (vecA && vecB) {
-            const int c4 = tid & 3;
-#pragma unroll
-            for (int n = 0; n < CS_ROWS / 64; ++n) {
-                const int row = (tid >> 2) + 64 * n;
-                const int rc = (row < nr) ? row : nr - 1;            // clamp: always a legal load
-                float4 va = *reinterpret_cast<const float4 *>(A + (size_t)(r0 + rc) * lda + c0 + 4 * c4);
-                float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (Bm) vb = *reinterpret_cast<const float4 *>(Bm + (size_t)(r0 + rc) * ldb + c0 + 4 * c4);
-                if (row >= nr) { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
-                *reinterpret_cast<float4 *>(sA + row * 16 + 4 * c4) = va;
-                *reinterpret_cast<float4 *>(sB + row * 16 + 4 * c4) = vb;
-            }
+        if (vec) {
+            stash(r0);
         } else {
-            for (int e = tid; e < CS_ROWS * 16; e += NT) {
-                const int row = e >> 4, c = c0 + (e & 15);
+            for (int e = tid; e < CS_ROWS * 64; e += NT) {
+                const int row = e >> 6, cc = e & 63, c = c0 + cc;
                 const bool ok = row < nr && c < ncols;
-                sA[e] = ok ? A[(size_t)(r0 + row) * lda + c] : 0.f;
-                sB[e] = (ok && Bm) ? Bm[(size_t)(r0 + row) * ldb + c] : 0.f;
+                sA[row * CS_LD + cc] = ok ? A[(size_t)(r0 + row) * lda + c] : 0.f;
+                sB[row * CS_LD + cc] = (ok && Bm) ? Bm[(size_t)(r0 + row) * ldb + c] : 0.f;
             }
         }
         __syncthreads();
+        if (vec && r0 + CS_ROWS < nrows) fetch(r0 + CS_ROWS);     // next chunk in flight under the chain
         // rows >= nr are zero in LDS, so the chain may run to a multiple of 8 steps:
         // 8 fragment reads are issued ahead of the 8 dependent MFMAs that consume them
         const int nsteps = (((nr + 3) / 4) + 7) & ~7;
-        if (w == 0) {
-            for (int s = 0; s < nsteps; s += 8) {
-                float d[8];
+        const int co = w * 16 + l15;
+        for (int s = 0; s < nsteps; s += 8) {
+            float d[8], e[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int o = (4 * (s + u) + g) * 16 + l15;
-                    d[u] = sA[o] - sB[o];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sum1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], 1.0f, sum1, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                const int o = (4 * (s + u) + g) * CS_LD + co;
+                e[u] = sB[o];
+                d[u] = sA[o] - e[u];
             }
-        } else if (w == 1 && want2) {
-            for (int s = 0; s < nsteps; s += 8) {
-                float d[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) d[u] = sB[(4 * (s + u) + g) * 16 + l15];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) sum2 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], 1.0f, sum2, 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                sum1 = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], 1.0f, sum1, 0, 0, 0);
+                if (want2) sum2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e[u], 1.0f, sum2, 0, 0, 0);
             }
         }
         __syncthreads();
@@ -320,14 +335,14 @@ __global__ __launch_bounds__(NT) void colsum_kernel(ColSumArgs a) {
     int jb = 0;
     while (jb + 1 < a.njobs && wv >= a.first_wave[jb + 1]) ++jb;
     const ColSumJob J = a.job[jb];
-    const int c0 = (wv - a.first_wave[jb]) * 16;
+    const int c0 = (wv - a.first_wave[jb]) * 64;
     f32x4 s1, s2;
     block_colsum(J.A, J.lda, J.Bm, J.ldb, c0, J.ncols, J.nrows, false, smem, s1, s2);
-    if (w == 0 && (lane & 15) == 0) {
+    if ((lane & 15) == 0) {
         const int g = lane >> 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int cc = c0 + g * 4 + r;
+            const int cc = c0 + w * 16 + g * 4 + r;
             if (cc < J.ncols) J.out[cc] = s1[r];
         }
     }
@@ -370,19 +385,18 @@ struct RbmBiasFusedArgs {
     float *raw_tail;                    // [V | H | H] raw sums are still published (metrics / tests)
     RbmBiasArgs u;
 };
-// body of one 16-column group (block index wv); smem >= CS_SMEM_FLOATS + 16 floats
+// body of one 64-column group (block index wv); smem >= CS_SMEM_FLOATS floats
 __device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, int wv, float *smem) {
-    float *s_sq = smem + CS_SMEM_FLOATS;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4;
-    const int nv = (a.u.V + 15) / 16;
+    const int nv = (a.u.V + 63) / 64;
     f32x4 s1, s2;
     if (wv < nv) {
-        const int c0 = wv * 16;
+        const int c0 = wv * 64;
         block_colsum(a.X, a.ldx, a.vs, a.ldv, c0, a.u.V, a.B, false, smem, s1, s2);   // sum(X - v_k)
-        if (w == 0 && (lane & 15) == 0) {
+        if ((lane & 15) == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int c = c0 + g * 4 + r;
+                const int c = c0 + w * 16 + g * 4 + r;
                 if (c < a.u.V) {
                     a.raw_tail[c] = s1[r];
                     const float gr = s1[r] / a.u.N;
@@ -393,19 +407,14 @@ __device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, 
             }
         }
     } else {
-        const int c0 = (wv - nv) * 16;
+        const int c0 = (wv - nv) * 64;
         block_colsum(a.h0m, a.ldh0, a.hm, a.ldh, c0, a.u.H, a.B, true, smem, s1, s2);  // sum(h0 - h_k), sum(h_k)
-        if (w == 1 && (lane & 15) == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_sq[g * 4 + r] = s2[r];
-        }
-        __syncthreads();
-        if (w == 0 && (lane & 15) == 0) {
+        if ((lane & 15) == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int h = c0 + g * 4 + r;
+                const int h = c0 + w * 16 + g * 4 + r;
                 if (h < a.u.H) {
-                    const float sq = s_sq[g * 4 + r];
+                    const float sq = s2[r];
                     a.raw_tail[a.u.V + h] = s1[r];
                     a.raw_tail[a.u.V + a.u.H + h] = sq;
                     const float qn = a.u.damping * a.u.q[h] + (1.0f - a.u.damping) * sq;
@@ -424,7 +433,7 @@ __device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, 
 }
 
 __global__ __launch_bounds__(NT) void rbm_bias_fused_kernel(RbmBiasFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[CS_SMEM_FLOATS + 16];
+    __shared__ __attribute__((aligned(16))) float smem[CS_SMEM_FLOATS];
     rbm_bias_fused_block(a, blockIdx.x, smem);
 }
 
@@ -463,7 +472,7 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
 template <bool FAST>
 __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS2];
-    static_assert(SMEM_FLOATS2 >= CS_SMEM_FLOATS + 16, "bias path reuses the tile LDS");
+    static_assert(SMEM_FLOATS2 >= CS_SMEM_FLOATS, "bias path reuses the tile LDS");
     // the bias/colsum workgroups sit BEHIND the tile workgroups in dispatch order: 208 tiles
     // (784x1024) take 208 CUs for the whole launch, the short bias groups cycle through
     // the CUs that are left and finish inside the tiles' shadow.
@@ -747,15 +756,16 @@ struct MaxNormArgs {
     float *norm_out;        // [I] column norms (W_norm metric) or null
 };
 __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
-    __shared__ __attribute__((aligned(16))) float sA[CS_ROWS * 16];
+    constexpr int MN_ROWS = 512;
+    __shared__ __attribute__((aligned(16))) float sA[MN_ROWS * 16];
     __shared__ float s_num[16], s_den[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int c0 = blockIdx.x * 16;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < a.J; r0 += CS_ROWS) {
-        const int nr = (a.J - r0 < CS_ROWS) ? a.J - r0 : CS_ROWS;
-        for (int e = tid; e < CS_ROWS * 16; e += NT) {
+    for (int r0 = 0; r0 < a.J; r0 += MN_ROWS) {
+        const int nr = (a.J - r0 < MN_ROWS) ? a.J - r0 : MN_ROWS;
+        for (int e = tid; e < MN_ROWS * 16; e += NT) {
             const int row = e >> 4, c = c0 + (e & 15);
             sA[e] = (row < nr && c < a.I) ? a.W[(size_t)(r0 + row) * a.ldw + c] : 0.f;
         }

@@ -164,7 +164,7 @@ static void launch_colsums(bm_rbm *h, int B) {
     c.job[1] = ColSumJob{h->h0m.p, h->hm.p, h->h0m.ld, h->hm.ld, h->H, B, tail + h->V};        // sum(h0 - h_k)
     c.job[2] = ColSumJob{h->hm.p, nullptr, h->hm.ld, 0, h->H, B, tail + h->V + h->H};          // sum(h_k)
     c.first_wave[0] = 0;
-    for (int j = 0; j < c.njobs; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 15) / 16;
+    for (int j = 0; j < c.njobs; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 63) / 64;
     hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[c.njobs]), dim3(NT), 0, h->stream, c);
 }
 
@@ -192,7 +192,7 @@ static int fill_bias_fused(bm_rbm *h, int B, float lr, float mom, RbmBiasFusedAr
     b.V = h->V; b.H = h->H;
     b.N = (float)B; b.lr = lr; b.mom = mom;
     b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost; b.target = h->cfg.sparsity_target;
-    return (h->V + 15) / 16 + (h->H + 15) / 16;
+    return (h->V + 63) / 64 + (h->H + 63) / 64;
 }
 
 static void launch_bias_fused(bm_rbm *h, int B, float lr, float mom) {
