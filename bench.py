@@ -45,7 +45,9 @@ def synth(seed, rows):
     return X, W
 
 
-def cpu_baseline(k, budget_s=15.0):
+def _cpu_worker(k, threads, budget_s, q):
+    os.environ['OMP_NUM_THREADS'] = str(threads)
+    os.environ['OMP_WAIT_POLICY'] = 'passive'
     from oracle import oracle as orc
     X, W = synth(0, B)
     twin = orc.OracleRBM(V, H, l2=L2, sample_v_states=True)
@@ -56,11 +58,31 @@ def cpu_baseline(k, budget_s=15.0):
     while time.time() - t0 < budget_s:
         twin.train_step(X, LR, MOM, k)
         n += 1
-    dt = time.time() - t0
-    cores = int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1))
-    return {'value': round(n * k / dt, 3), 'unit': 'Gibbs-steps/s (512-row)', 'cores': cores, 'kind': 'port',
-            'sample': '%d CD-%d updates of the same 784x1024 batch-512 workload, %.1f s, OpenMP C oracle '
-                      '(oracle/bm_oracle.c, restatement of base_rbm.py:415-479; TF1.3 cannot run here)' % (n, k, dt)}
+    q.put((n, time.time() - t0))
+
+
+def cpu_baseline(k, budget_s=6.0):
+    """The CPU oracle (restatement of the reference maths) timed on this box's host cores, in
+    fresh processes so that the OpenMP team size can be chosen; the best of three team sizes is
+    reported with its thread count."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    best = None
+    for threads in sorted({min(16, ncpu), min(64, ncpu), ncpu}):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        p = ctx.Process(target=_cpu_worker, args=(k, threads, budget_s, q))
+        p.start()
+        n, dt = q.get()
+        p.join()
+        rate = n * k / dt
+        if best is None or rate > best[0]:
+            best = (rate, threads, n, dt)
+    rate, threads, n, dt = best
+    return {'value': round(rate, 3), 'unit': 'Gibbs-steps/s (512-row)', 'cores': threads, 'kind': 'port',
+            'sample': '%d CD-%d updates of the same 784x1024 batch-512 workload in %.1f s, OpenMP C oracle '
+                      '(oracle/bm_oracle.c, restatement of base_rbm.py:415-479; TF1.3 cannot run here), best of '
+                      'OMP team sizes 16/64/%d' % (n, k, dt, ncpu)}
 
 
 def pmc_traffic():

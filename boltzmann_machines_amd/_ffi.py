@@ -83,6 +83,8 @@ SIGNATURES = {
     'bm_dbm_train_step': [_vp, _vp, _f32, _f32, _i32, _ip, _fp],
     'bm_dbm_grad_step': [_vp, _vp, _i32, _ip],
     'bm_dbm_apply_step': [_vp, _i32, _i32, _f32, _f32],
+    'bm_dbm_set_mf_allreduce': [_vp, _vp, _vp],
+    'bm_dbm_stream': [_vp, C.POINTER(_vp)],
     'bm_dbm_mean_field': [_vp, _vp, _vp, _ip],
     'bm_dbm_reconstruct': [_vp, _vp, _vp],
     'bm_dbm_sample_v': [_vp, _i32, _vp],
@@ -92,6 +94,7 @@ SIGNATURES = {
     'bm_dbm_timer_stop': [_vp, _fp],
 }
 _RESTYPE = {'bm_last_error': C.c_char_p, 'bm_version': C.c_char_p}
+MF_REDUCE_FN = C.CFUNCTYPE(C.c_float, C.c_float, C.c_void_p)
 
 _lib = None
 

@@ -32,7 +32,11 @@ struct bm_dbm {
     Mat mu[MAXL], mu_alt[MAXL], mu_new[MAXL];      // [N][n[i+1]]: result, ping-pong partner, approx-inference init
     Mat v, v_new, H[MAXL], H_new[MAXL];            // particles [M][*]
     Mat recon;                                     // [N][V]
-    DevBuf sums;                                   // column sums: [V | V | (n_i | n_i) per layer]
+    DevBuf grad;                                   // data-parallel payload: [pos_i | neg_i per layer | sums]
+    float *sums_p = nullptr;                       // column sums inside `grad`: [V | V | (n_i | n_i) per layer]
+    size_t raw_off[MAXL][2];                       // offsets of the raw pos / neg outer products of layer i
+    float (*mf_reduce)(float, void *) = nullptr;   // max over ranks of the mean-field residual (data-parallel)
+    void *mf_ctx = nullptr;
     DevBuf wnorm[MAXL];
     unsigned *flag = nullptr;                      // mean-field max-norm cell
     double *scal = nullptr;
@@ -118,6 +122,8 @@ static int read_flag(bm_dbm *h, float *out) {
     BM_HIP(hipMemcpyAsync(&bits, h->flag, sizeof(bits), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     memcpy(out, &bits, sizeof(float));
+    // data-parallel: the loop condition (dbm.py:449-452) is over ALL rows, i.e. the max over ranks
+    if (h->mf_reduce) *out = h->mf_reduce(*out, h->mf_ctx);
     return 0;
 }
 
@@ -179,66 +185,83 @@ static size_t sums_off(const bm_dbm *h, int which /* 0: X, 1: v, 2+2i: mu_i, 3+2
     return o;
 }
 
-// gradients + sparsity + momentum + max-norm (dbm.py:550-621) from the current mu / particles
-static int apply_update(bm_dbm *h, const float *X_dev, float lr, float mom) {
+// raw column sums of X, v, mu_i, H_i (dbm.py:553, :573-576, :581-586)
+static void launch_dbm_colsums(bm_dbm *h, const float *X_dev) {
     const int L = h->L;
-    const float N = (float)h->N, M = (float)h->M;
-    // column sums: X, v, mu_i, H_i
     ColSumArgs c;
     memset(&c, 0, sizeof(c));
     int nj = 0;
-    c.job[nj++] = ColSumJob{X_dev, nullptr, h->V, 0, h->V, h->N, h->sums.p + sums_off(h, 0)};
-    c.job[nj++] = ColSumJob{h->v.p, nullptr, h->v.ld, 0, h->V, h->M, h->sums.p + sums_off(h, 1)};
+    c.job[nj++] = ColSumJob{X_dev, nullptr, h->V, 0, h->V, h->N, h->sums_p + sums_off(h, 0)};
+    c.job[nj++] = ColSumJob{h->v.p, nullptr, h->v.ld, 0, h->V, h->M, h->sums_p + sums_off(h, 1)};
     for (int i = 0; i < L; ++i) {
-        c.job[nj++] = ColSumJob{h->mu[i].p, nullptr, h->mu[i].ld, 0, h->n[i + 1], h->N, h->sums.p + sums_off(h, 2 + 2 * i)};
-        c.job[nj++] = ColSumJob{h->H[i].p, nullptr, h->H[i].ld, 0, h->n[i + 1], h->M, h->sums.p + sums_off(h, 3 + 2 * i)};
+        c.job[nj++] = ColSumJob{h->mu[i].p, nullptr, h->mu[i].ld, 0, h->n[i + 1], h->N, h->sums_p + sums_off(h, 2 + 2 * i)};
+        c.job[nj++] = ColSumJob{h->H[i].p, nullptr, h->H[i].ld, 0, h->n[i + 1], h->M, h->sums_p + sums_off(h, 3 + 2 * i)};
     }
     c.njobs = nj;
     c.first_wave[0] = 0;
     for (int j = 0; j < nj; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 63) / 64;
     hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[nj]), dim3(NT), 0, h->stream, c);
-    // biases (+ sparsity penalties)
+}
+
+// bias / running-mean / sparsity updates from the (possibly all-reduced) column sums
+static void launch_dbm_biases(bm_dbm *h, float N, float M, float lr, float mom) {
     {
         DbmBiasArgs b;
         memset(&b, 0, sizeof(b));
-        b.s_pos = h->sums.p + sums_off(h, 0); b.s_neg = h->sums.p + sums_off(h, 1);
+        b.s_pos = h->sums_p + sums_off(h, 0); b.s_neg = h->sums_p + sums_off(h, 1);
         b.b = h->vb.p; b.db = h->dvb.p; b.n = h->V; b.N = N; b.M = M; b.lr = lr; b.mom = mom;
         hipLaunchKernelGGL(dbm_bias_kernel, dim3((h->V + 255) / 256), dim3(256), 0, h->stream, b);
     }
-    for (int i = 0; i < L; ++i) {
+    for (int i = 0; i < h->L; ++i) {
         DbmBiasArgs b;
         memset(&b, 0, sizeof(b));
-        b.s_pos = h->sums.p + sums_off(h, 2 + 2 * i); b.s_neg = h->sums.p + sums_off(h, 3 + 2 * i);
+        b.s_pos = h->sums_p + sums_off(h, 2 + 2 * i); b.s_neg = h->sums_p + sums_off(h, 3 + 2 * i);
         b.b = h->hb[i].p; b.db = h->dhb[i].p; b.q = h->q[i].p; b.mm = h->mm[i].p; b.pen = h->pen[i].p;
         b.n = h->n[i + 1]; b.layer = i;
         b.N = N; b.M = M; b.lr = lr; b.mom = mom;
         b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost[i]; b.target = h->cfg.sparsity_target[i];
         hipLaunchKernelGGL(dbm_bias_kernel, dim3((b.n + 255) / 256), dim3(256), 0, h->stream, b);
     }
-    // weights
-    for (int i = 0; i < L; ++i) {
-        GradArgs g;
-        memset(&g, 0, sizeof(g));
-        const float *below_pos = (i == 0) ? X_dev : h->mu[i - 1].p;
-        const int ld_bp = (i == 0) ? h->V : h->mu[i - 1].ld;
-        const Mat &below_neg = (i == 0) ? h->v : h->H[i - 1];
-        g.Ppos = make_operand(h->mu[i].p, h->mu[i].ld, h->n[i + 1]);      // mu_i       [k = b][i]
-        g.Qpos = make_operand(below_pos, ld_bp, h->n[i]);                  // X / mu_{i-1} [k = b][j]
-        g.Kpos = h->N;
-        g.Pneg = make_operand(h->H[i].p, h->H[i].ld, h->n[i + 1]);
-        g.Qneg = make_operand(below_neg.p, below_neg.ld, h->n[i]);
-        g.Kneg = h->M;
-        g.I = h->n[i + 1]; g.J = h->n[i];
-        g.form = 1; g.fused = 1;
-        g.W = h->W[i].p; g.dW = h->dW[i].p; g.Wt = nullptr;                // Wt is rewritten by the max-norm pass
-        g.ldw = h->W[i].ld; g.ldwt = h->Wt[i].ld;
-        g.pen = h->pen[i].p;
-        g.N = N; g.M = M; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
-        launch_grad(g, h->stream);
-        MaxNormArgs m;
-        m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = g.I; m.J = g.J; m.ldw = g.ldw; m.ldwt = g.ldwt;
-        m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
-        hipLaunchKernelGGL(maxnorm_kernel, dim3((g.I + 15) / 16), dim3(NT), 0, h->stream, m);
+}
+
+// outer products of layer i: fused (update in the epilogue) or raw pos / neg into `grad`
+static void launch_dbm_grad(bm_dbm *h, const float *X_dev, int i, int fused, float N, float M, float lr, float mom) {
+    GradArgs g;
+    memset(&g, 0, sizeof(g));
+    const float *below_pos = (i == 0) ? X_dev : h->mu[i - 1].p;
+    const int ld_bp = (i == 0) ? h->V : h->mu[i - 1].ld;
+    const Mat &below_neg = (i == 0) ? h->v : h->H[i - 1];
+    g.Ppos = make_operand(h->mu[i].p, h->mu[i].ld, h->n[i + 1]);      // mu_i         [k = b][i]
+    g.Qpos = make_operand(below_pos, ld_bp, h->n[i]);                  // X / mu_{i-1} [k = b][j]
+    g.Kpos = h->N;
+    g.Pneg = make_operand(h->H[i].p, h->H[i].ld, h->n[i + 1]);
+    g.Qneg = make_operand(below_neg.p, below_neg.ld, h->n[i]);
+    g.Kneg = h->M;
+    g.I = h->n[i + 1]; g.J = h->n[i];
+    g.form = 1; g.fused = fused;
+    g.raw = h->grad.p + h->raw_off[i][0]; g.raw2 = h->grad.p + h->raw_off[i][1];
+    g.W = h->W[i].p; g.dW = h->dW[i].p; g.Wt = nullptr;                // Wt is rewritten by the max-norm pass
+    g.ldw = h->W[i].ld; g.ldwt = h->Wt[i].ld;
+    g.pen = h->pen[i].p;
+    g.N = N; g.M = M; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
+    launch_grad(g, h->stream);
+}
+
+static void launch_dbm_maxnorm(bm_dbm *h, int i) {
+    MaxNormArgs m;
+    m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = h->n[i + 1]; m.J = h->n[i]; m.ldw = h->W[i].ld; m.ldwt = h->Wt[i].ld;
+    m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
+    hipLaunchKernelGGL(maxnorm_kernel, dim3((m.I + 15) / 16), dim3(NT), 0, h->stream, m);
+}
+
+// gradients + sparsity + momentum + max-norm (dbm.py:550-621) from the current mu / particles
+static int apply_update(bm_dbm *h, const float *X_dev, float lr, float mom) {
+    const float N = (float)h->N, M = (float)h->M;
+    launch_dbm_colsums(h, X_dev);
+    launch_dbm_biases(h, N, M, lr, mom);
+    for (int i = 0; i < h->L; ++i) {
+        launch_dbm_grad(h, X_dev, i, 1, N, M, lr, mom);
+        launch_dbm_maxnorm(h, i);
     }
     BM_HIP(hipGetLastError());
     return 0;
@@ -282,7 +305,13 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
     BM_TRY(h->vb.alloc(h->V)); BM_TRY(h->dvb.alloc(h->V)); BM_TRY(h->sigma.alloc(h->V));
     BM_TRY(h->v.alloc(h->M, h->V)); BM_TRY(h->v_new.alloc(h->M, h->V));
     BM_TRY(h->recon.alloc(h->N, h->V));
-    BM_TRY(h->sums.alloc(nsums));
+    {   // one contiguous buffer so that data-parallel training needs ONE all-reduce
+        size_t off = 0;
+        for (int i = 0; i < h->L; ++i)
+            for (int s = 0; s < 2; ++s) { h->raw_off[i][s] = off; off += h->W[i].count(); }
+        BM_TRY(h->grad.alloc(off + nsums));
+        h->sums_p = h->grad.p + off;
+    }
     BM_HIP(hipMalloc((void **)&h->flag, sizeof(unsigned)));
     BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
     {
@@ -304,7 +333,7 @@ int bm_dbm_destroy(bm_dbm *h) {
     }
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
-    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->sums, &h->alogw, &h->adot, &h->rowtmp};
+    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->alogw, &h->adot, &h->rowtmp};
     for (DevBuf *b : bs) b->release();
     if (h->flag) (void)hipFree(h->flag);
     if (h->scal) (void)hipFree(h->scal);
@@ -391,6 +420,11 @@ int bm_dbm_get_param(bm_dbm *h, const char *name, float *host, size_t n) {
 }
 
 int bm_dbm_dev_ptr(bm_dbm *h, const char *name, void **out_dev, size_t *out_n) {
+    if (name && std::string(name) == "grad") {
+        *out_dev = h->grad.p;
+        if (out_n) *out_n = h->grad.n;
+        return 0;
+    }
     Mat *m; DevBuf *v; bool isW;
     BM_TRY(resolve(h, name, &m, &v, &isW));
     BM_CHECK(v, "no device view for '%s' (matrices are pitched; use get/set_param)", name);
@@ -421,14 +455,44 @@ int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float lr, float mom, int32_
     return 0;
 }
 
-int bm_dbm_grad_step(bm_dbm *, const float *, int32_t, int32_t *) {
-    bm::set_error("bm_dbm_grad_step: data-parallel DBM split is not implemented yet (use bm_dbm_train_step)");
-    return 99;
+int bm_dbm_set_mf_allreduce(bm_dbm *h, float (*fn)(float, void *), void *ctx) {
+    h->mf_reduce = fn; h->mf_ctx = ctx;
+    return 0;
 }
-int bm_dbm_apply_step(bm_dbm *, int32_t, int32_t, float, float) {
-    bm::set_error("bm_dbm_apply_step: data-parallel DBM split is not implemented yet (use bm_dbm_train_step)");
-    return 99;
+
+// data-parallel halves: phase 1 leaves the raw local sums in "grad", the caller
+// all-reduces that buffer, phase 2 normalises with the GLOBAL N and M and applies the update.
+int bm_dbm_grad_step(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf) {
+    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    int nmf = 0;
+    BM_TRY(mean_field(h, X_dev, &nmf));
+    particles_update(h, k, true);
+    launch_dbm_colsums(h, X_dev);
+    for (int i = 0; i < h->L; ++i) launch_dbm_grad(h, X_dev, i, 0, 1.f, 1.f, 0.f, 0.f);
+    if (out_n_mf) *out_n_mf = nmf;
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
 }
+
+int bm_dbm_apply_step(bm_dbm *h, int32_t N_global, int32_t M_global, float lr, float mom) {
+    const float N = (float)N_global, M = (float)M_global;
+    launch_dbm_biases(h, N, M, lr, mom);
+    for (int i = 0; i < h->L; ++i) {
+        ApplyWArgs a;
+        memset(&a, 0, sizeof(a));
+        a.raw = h->grad.p + h->raw_off[i][0]; a.raw2 = h->grad.p + h->raw_off[i][1];
+        a.W = h->W[i].p; a.dW = h->dW[i].p; a.Wt = nullptr; a.pen = h->pen[i].p;
+        a.I = h->n[i + 1]; a.J = h->n[i]; a.ldw = h->W[i].ld; a.ldwt = h->Wt[i].ld; a.form = 1;
+        a.N = N; a.M = M; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
+        hipLaunchKernelGGL(apply_w_kernel, dim3(1024), dim3(256), 0, h->stream, a);
+        launch_dbm_maxnorm(h, i);
+    }
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+int bm_dbm_stream(bm_dbm *h, void **out_stream) { *out_stream = (void *)h->stream; return 0; }
 
 int bm_dbm_mean_field(bm_dbm *h, const float *X_dev, float *MU_top_dev, int32_t *out_n_mf) {
     int nmf = 0;

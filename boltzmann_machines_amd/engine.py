@@ -223,6 +223,29 @@ class DbmEngine(object):
                                          C.byref(msre) if want_msre else None))
         return int(nmf.value), (float(msre.value) if want_msre else None)
 
+    def grad_step(self, Xd, k, row=0):
+        nmf = C.c_int32()
+        check(self.lib.bm_dbm_grad_step(self._h, Xd.offset_ptr(row * self.V), k, C.byref(nmf)))
+        return int(nmf.value)
+
+    def apply_step(self, N_global, M_global, lr, momentum):
+        check(self.lib.bm_dbm_apply_step(self._h, N_global, M_global, lr, momentum))
+
+    def set_mf_allreduce(self, fn):
+        """fn(local_max: float) -> global max over ranks (mean-field loop condition)"""
+        self._mf_cb = _ffi.MF_REDUCE_FN(lambda x, ctx: float(fn(x))) if fn is not None else None
+        check(self.lib.bm_dbm_set_mf_allreduce(self._h, C.cast(self._mf_cb, C.c_void_p) if self._mf_cb else None, None))
+
+    def device_view(self, name):
+        p, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.bm_dbm_dev_ptr(self._h, name.encode(), C.byref(p), C.byref(n)))
+        return DeviceArray((n.value,), np.float32, ptr=p.value, owner=self)
+
+    def stream(self):
+        p = C.c_void_p()
+        check(self.lib.bm_dbm_stream(self._h, C.byref(p)))
+        return p.value
+
     def mean_field(self, Xd, row=0, out=None, out_row=0):
         nmf = C.c_int32()
         p = out.offset_ptr(out_row * self.n_hiddens[-1]) if out is not None else None

@@ -82,3 +82,36 @@ def torch_allgather(device=None):
         dist.all_gather(outs, t)
         return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(outs, counts)])
     return allgather
+
+
+class DataParallelDBM(object):
+    """Data-parallel DBM update (BASELINE configs[3]): rank r owns rows [r*N_local, ...) of every
+    minibatch (its own mean-field parameters) and particles [r*M_local, ...).  Per update:
+    `grad_step` (mean-field with an all-reduce(max) of the residual per sweep, PCD, raw sums) ->
+    ONE all-reduce(sum) of the fused buffer -> `apply_step` with the global N and M."""
+
+    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None):
+        self.engine, self.rank, self.world = engine, rank, world
+        self.allreduce_ = allreduce_
+        engine.set_row_offset(rank * engine.N, rank * engine.M)
+        if allreduce_max is not None and world > 1:
+            engine.set_mf_allreduce(allreduce_max)
+
+    def train_step(self, X_local, lr, momentum, k, **kw):
+        n_mf = self.engine.grad_step(X_local, k, **kw)
+        self.allreduce_()
+        self.engine.apply_step(self.engine.N * self.world, self.engine.M * self.world, lr, momentum)
+        return n_mf
+
+
+def torch_allreduce_max():
+    import torch
+    import torch.distributed as dist
+
+    def allreduce_max(x):
+        t = torch.tensor([x], dtype=torch.float32)
+        if dist.get_backend() == 'nccl':
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return allreduce_max

@@ -192,10 +192,18 @@ int bm_dbm_dev_ptr(bm_dbm *h, const char *name, void **out_dev, size_t *out_n);
  * out_msre (host, may be NULL) the reconstruction msre (dbm.py:625-630). */
 int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float learning_rate, float momentum,
                       int32_t n_gibbs_steps, int32_t *out_n_mf, float *out_msre);
-/* data-parallel halves, as for the RBM */
+/* data-parallel halves, as for the RBM: phase 1 (mean-field, PCD, raw sums) leaves
+ * [sum_b below^T mu_i | sum_m below^T H_i per layer | column sums of X, v, mu_i, H_i] in the
+ * "grad" buffer (bm_dbm_dev_ptr); the caller all-reduces it; phase 2 applies the update of
+ * dbm.py:550-621 with the GLOBAL batch size and particle count. */
 int bm_dbm_grad_step(bm_dbm *h, const float *X_dev, int32_t n_gibbs_steps, int32_t *out_n_mf);
 int bm_dbm_apply_step(bm_dbm *h, int32_t N_global, int32_t M_global,
                       float learning_rate, float momentum);
+/* The mean-field loop condition (dbm.py:449-452) is a max over ALL rows of the minibatch:
+ * under data parallelism the library calls `fn(local_max, ctx)` once per sweep and uses the
+ * returned value (the caller implements it as an all-reduce(max) over ranks).  NULL = local. */
+int bm_dbm_set_mf_allreduce(bm_dbm *h, float (*fn)(float local_max, void *ctx), void *ctx);
+int bm_dbm_stream(bm_dbm *h, void **out_stream);
 
 /* _make_mf (dbm.py:429-478) on X_dev [batch_size, V]; leaves mu in the
  * handle; copies the top layer's mu to MU_top_dev if non-NULL

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# the CPU oracle is OpenMP: on the 256-thread GPU-box host the default team oversubscribes the
+# tiny test problems (minutes of spin-waiting); a small passive team is faster there
+os.environ.setdefault('OMP_NUM_THREADS', '16')
+os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

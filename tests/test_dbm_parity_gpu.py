@@ -102,3 +102,29 @@ def test_ais_and_log_proba(gpu_lib, k):
     X = data(N, V, 2)
     np.testing.assert_allclose(eng.log_proba(as_device(X)), twin.log_proba(X), rtol=1e-5)
     eng.close()
+
+
+def test_split_step_matches_fused(gpu_lib):
+    """grad_step + apply_step (the data-parallel halves, world = 1) == fused train_step, bitwise;
+    the mean-field residual goes through the injected all-reduce(max) callback."""
+    from boltzmann_machines_amd import parallel
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 20, [12, 16], 10, 10
+    kw = dict(max_mf_updates=5, mf_tol=1e-5, l2=1e-3, max_norm=1.5, sparsity_target=[0.2, 0.1], sparsity_cost=[1e-2, 5e-3])
+    e1, _ = make_pair(V, nh, N, M, **kw)
+    e2, _ = make_pair(V, nh, N, M, **kw)
+    e1.seed(42); e2.seed(42)
+    calls = []
+    dp = parallel.DataParallelDBM(e2, 0, 1, lambda: None)
+    e2.set_mf_allreduce(lambda x: (calls.append(x), x)[1])
+    for s in range(2):
+        Xd = as_device(data(N, V, s))
+        n1, _ = e1.train_step(Xd, 0.05, 0.5, 2)
+        n2 = dp.train_step(Xd, 0.05, 0.5, 2)
+        assert n1 == n2
+    assert len(calls) >= 2 and all(c >= 0 for c in calls)
+    for nm in ('W', 'W_1', 'dW', 'hb', 'hb_1', 'vb', 'q_means', 'mu_means_1', 'v', 'h_1', 'mu'):
+        assert np.array_equal(e1.get(nm).view(np.uint32), e2.get(nm).view(np.uint32)), nm
+    g = e2.device_view('grad')
+    assert g.shape[0] > 2 * (20 * 12 + 12 * 16)
+    e1.close(); e2.close()
