@@ -38,7 +38,9 @@ struct bm_dbm {
     float (*mf_reduce)(float, void *) = nullptr;   // max over ranks of the mean-field residual (data-parallel)
     void *mf_ctx = nullptr;
     DevBuf wnorm[MAXL];
-    unsigned *flag = nullptr;                      // mean-field max-norm cell
+    unsigned *flag = nullptr;                      // mean-field residual cell (= &ctl->maxdiff)
+    MfCtl *ctl = nullptr;                          // device-side loop control
+    Mat xw0;                                       // [N][n1] hoisted X.W0 of the current minibatch
     double *scal = nullptr;
     // AIS / ELBO workspaces (allocated on demand)
     int ais_rows = 0;
@@ -84,6 +86,7 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
         a.K1 = h->n[1];
         a.bias = h->vb.p; a.sigma = h->sigma.p; a.kind = h->cfg.v_unit;
     }
+    if (extra && extra->kind == 2) a.kind = 2;     // raw pre-activation requested (mean-field hoist)
     a.J = J;
     a.mult = mult; a.bmult = bmult;
     a.sample = sample;
@@ -98,16 +101,34 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
 //   out_means  : Hout receives means (sample == 0) or samples (per-layer flags)
 static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout, Mat *Hout,
                         bool update_v, bool sample, int t, int64_t row0,
-                        unsigned *maxdiff = nullptr) {
+                        unsigned *maxdiff = nullptr, const Mat *xw0 = nullptr, const int *skip = nullptr) {
     const int L = h->L;
     for (int i = 0; i < L; ++i) {
         LayerIn below = (i == 0) ? vin : LayerIn{Hout[i - 1].p, Hout[i - 1].ld};       // NEW below   :400-402
         LayerIn above = (i + 1 < L) ? LayerIn{Hin[i + 1].p, Hin[i + 1].ld} : LayerIn{nullptr, 0};   // OLD above
         const int smp = sample && h->cfg.sample_h_states[i];
+        ActArgs e;
+        memset(&e, 0, sizeof(e));
+        e.skip = skip;
+        if (i == 0 && xw0 && above.p) {
+            // mean-field: X.W0 is loop invariant — start the chain from the hoisted partial sum and
+            // stream only the top-down segment (bit-identical to recomputing X.W0 every sweep)
+            e.acc_init = xw0->p; e.ld_init = xw0->ld;
+            e.I = h->n[1]; e.J = J;
+            e.P1 = make_operand(h->Wt[1].p, h->Wt[1].ld, e.I);
+            e.Q1 = make_operand(above.p, above.ld, J);
+            e.K1 = h->n[2];
+            e.bias = h->hb[0].p; e.kind = BM_UNIT_BERNOULLI;
+            e.mult = 1.f; e.bmult = 1.f; e.sample = 0;
+            e.means = Hout[0].p; e.ldo = Hout[0].ld;
+            e.prev = maxdiff ? Hin[0].p : nullptr; e.maxdiff = maxdiff;
+            launch_act(e, h->stream);
+            continue;
+        }
         // without sampling the layer's value is its mean: write it as `means` only
         layer_update(h, i, J, below, above, 1.f, 1.f, smp, smp ? nullptr : Hout[i].p, smp ? Hout[i].p : nullptr,
                      Hout[i].ld, dkey(h, SITE_DBM_H + i, t, h->seed, h->call), row0,
-                     maxdiff ? Hin[i].p : nullptr, maxdiff);
+                     maxdiff ? Hin[i].p : nullptr, maxdiff, &e);
     }
     if (update_v) {                                                                       // :419-425
         const int smp = sample && h->cfg.sample_v_states;
@@ -128,8 +149,13 @@ static int read_flag(bm_dbm *h, float *out) {
 }
 
 // `_make_mf` (dbm.py:429-478).  Leaves the result in h->mu; returns executed sweeps.
+// The loop trip count is data dependent (residual > tol).  Single GPU: the sweeps are enqueued in
+// groups of MF_GROUP without host round trips — a device-side control word (MfCtl) latches `done`
+// and every later launch of the group returns at once — and the host reads the control word once
+// per group.  Data parallel (all-reduce(max) hook installed): one host round trip per sweep.
 static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
     const int L = h->L, N = h->N;
+    constexpr int MF_GROUP = 8;
     // approximate-inference init into the mu_new VARIABLES (:434-446): doubled bottom-up pass
     for (int i = 0; i < L; ++i) {
         LayerIn below = (i == 0) ? LayerIn{X_dev, h->V} : LayerIn{h->mu_new[i - 1].p, h->mu_new[i - 1].ld};
@@ -137,22 +163,59 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         layer_update(h, i, N, below, LayerIn{nullptr, 0}, mult, 1.f, 0, h->mu_new[i].p, nullptr, h->mu_new[i].ld,
                      dkey(h, 0, 0, h->seed, h->call), 0);
     }
+    // hoisted loop invariant of the sweeps: z0 = X.W0 (raw chain, no activation)
+    const bool hoist = L >= 2;
+    if (hoist) {
+        ActArgs e;
+        memset(&e, 0, sizeof(e));
+        e.kind = 2;
+        layer_update(h, 0, N, LayerIn{X_dev, h->V}, LayerIn{nullptr, 0}, 1.f, 1.f, 0, h->xw0.p, nullptr, h->xw0.ld,
+                     dkey(h, 0, 0, h->seed, h->call), 0, nullptr, nullptr, &e);
+    }
     // cond at step 0 compares the persistent mu with the init values (:449-452)
     BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
     for (int i = 0; i < L; ++i)
         hipLaunchKernelGGL(maxabsdiff_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
                            (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
-    float diff = 0.f;
-    BM_TRY(read_flag(h, &diff));
     int step = 0;
-    // body (:454-457): mu_new = sweep(X, mu) (values, not the mu_new variables), then swap
     Mat *cur = h->mu, *alt = h->mu_alt;
-    while (step < h->cfg.max_mf_updates && diff > h->cfg.mf_tol) {
-        BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
-        gibbs_sweep(h, N, LayerIn{X_dev, h->V}, cur, nullptr, alt, false, false, 0, 0, h->flag);
+    if (h->mf_reduce) {
+        float diff = 0.f;
         BM_TRY(read_flag(h, &diff));
-        Mat *t = cur; cur = alt; alt = t;
-        ++step;
+        // body (:454-457): mu_new = sweep(X, mu) (values, not the mu_new variables), then swap
+        while (step < h->cfg.max_mf_updates && diff > h->cfg.mf_tol) {
+            BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
+            gibbs_sweep(h, N, LayerIn{X_dev, h->V}, cur, nullptr, alt, false, false, 0, 0, h->flag,
+                        hoist ? &h->xw0 : nullptr);
+            BM_TRY(read_flag(h, &diff));
+            Mat *t = cur; cur = alt; alt = t;
+            ++step;
+        }
+    } else {
+        hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(1), 0, h->stream, h->ctl, h->cfg.mf_tol, 1);
+        int enq = 0;
+        MfCtl host;
+        host.done = 0; host.steps = 0;
+        while (enq < h->cfg.max_mf_updates) {
+            const int g = (h->cfg.max_mf_updates - enq < MF_GROUP) ? h->cfg.max_mf_updates - enq : MF_GROUP;
+            for (int s = 0; s < g; ++s) {
+                // sweep number enq+s runs only if all before it ran, so its ping-pong parity is static
+                Mat *src = ((enq + s) & 1) ? h->mu_alt : h->mu, *dst = ((enq + s) & 1) ? h->mu : h->mu_alt;
+                gibbs_sweep(h, N, LayerIn{X_dev, h->V}, src, nullptr, dst, false, false, 0, 0, h->flag,
+                            hoist ? &h->xw0 : nullptr, &h->ctl->done);
+                hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(1), 0, h->stream, h->ctl, h->cfg.mf_tol, 0);
+            }
+            enq += g;
+            BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
+            BM_HIP(hipStreamSynchronize(h->stream));
+            if (host.done) break;
+        }
+        if (!host.done) {      // max_mf_updates reached (or zero): fetch the final counter
+            BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
+            BM_HIP(hipStreamSynchronize(h->stream));
+        }
+        step = host.steps;
+        if (step & 1) { cur = h->mu_alt; alt = h->mu; }
     }
     if (cur != h->mu)                  // `self._mu[i].assign(mu[i])` (:477): keep the handle's mu as the result
         for (int i = 0; i < L; ++i) { Mat t = h->mu[i]; h->mu[i] = h->mu_alt[i]; h->mu_alt[i] = t; }
@@ -312,7 +375,10 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
         BM_TRY(h->grad.alloc(off + nsums));
         h->sums_p = h->grad.p + off;
     }
-    BM_HIP(hipMalloc((void **)&h->flag, sizeof(unsigned)));
+    BM_HIP(hipMalloc((void **)&h->ctl, sizeof(MfCtl)));
+    BM_HIP(hipMemset(h->ctl, 0, sizeof(MfCtl)));
+    h->flag = &h->ctl->maxdiff;
+    BM_TRY(h->xw0.alloc(h->N, h->n[1]));
     BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
     {
         std::vector<float> ones(h->V, 1.0f);
@@ -335,7 +401,8 @@ int bm_dbm_destroy(bm_dbm *h) {
     for (Mat *m : ms) m->release();
     DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->alogw, &h->adot, &h->rowtmp};
     for (DevBuf *b : bs) b->release();
-    if (h->flag) (void)hipFree(h->flag);
+    if (h->ctl) (void)hipFree(h->ctl);
+    h->xw0.release();
     if (h->scal) (void)hipFree(h->scal);
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);

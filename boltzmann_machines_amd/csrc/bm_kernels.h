@@ -42,6 +42,12 @@ struct ActArgs {
     const float *dot_vec;        // [I]
     const float *dot_mat;        // [J][I] pitch ld_dot
     int ld_dot;
+    // mean-field plumbing: a loop-invariant partial pre-activation to start the chain from
+    // (X.W0, hoisted out of the sweeps: continuing the chain from it is bit-identical to
+    // recomputing segment 1), and a device-side "loop finished" flag that turns the launch into a no-op
+    const float *acc_init;       // [J][I] pitch ld_init or null
+    int ld_init;
+    const int *skip;             // device int: != 0 -> return immediately
 #ifdef BM_PROBE
     long long *dbg;              // [grid][4] s_memtime stamps (tools/probe_act.hip only)
 #endif
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
     const int tiles_j = (a.J + TJ - 1) / TJ;
     int ti, tj;
     BM_STAMP(0);
+    if (a.skip && *a.skip) return;                 // wave-uniform: converged mean-field loop
     block_to_tile(tiles_j, ti, tj);
     const int i0 = ti * TI, j0 = tj * TJ;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -127,6 +134,15 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
     f32x4 acc[2][1];
     acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.acc_init && j < a.J) {                   // start the chain from a stored partial sum
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int i = ib0 + 2 * r + t;
+                if (i < a.I) acc[t][0][r] = a.acc_init[(size_t)j * a.ld_init + i];
+            }
+    }
     KRange kr;
     kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
     kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2; kr.sgn2 = 1.0f;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const float x = a.mult * z[4 * hlf + r];
                 const float b = a.bmult * bs[4 * hlf + r];
-                m[r] = (a.kind == 0) ? sigmoid(x + b) : (x * sg[4 * hlf + r] + b);
+                m[r] = (a.kind == 0) ? sigmoid(x + b) : (a.kind == 1 ? (x * sg[4 * hlf + r] + b) : x);   // kind 2: raw z
                 s[r] = m[r];
             }
             if (a.sample) {
@@ -798,6 +814,21 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
             if (a.Wt) a.Wt[(size_t)c * a.ldwt + row] = wn;
         }
     }
+}
+
+// device-side mean-field loop control (dbm.py:449-452): after each sweep, advance the counter
+// and latch `done` when the residual no longer exceeds the tolerance; `init` evaluates the
+// step-0 condition from the residual between the persistent mu and the init values.
+struct MfCtl { unsigned maxdiff; int done; int steps; };
+__global__ void mf_ctl_kernel(MfCtl *c, float tol, int init) {
+    if (init) {
+        c->steps = 0;
+        c->done = !(__uint_as_float(c->maxdiff) > tol);
+    } else if (!c->done) {
+        c->steps += 1;
+        c->done = !(__uint_as_float(c->maxdiff) > tol);
+    }
+    c->maxdiff = 0u;
 }
 
 // ||A - B||_inf over a [rows][cols] window -> atomicMax on float bits (mean-field cond, dbm.py:449-452)
