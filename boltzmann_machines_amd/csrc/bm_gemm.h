@@ -293,12 +293,16 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, 
     ChunkRegs<NJ> g0, g1;      // named sets (never arrays: must stay in VGPRs)
     Frags<NJ> fa, fb;
     BM_MSTAMP(0);
-    load_chunk<QL, NJ, FAST, SEG2>(g0, kr, nch1, i0, j0, 0, tid);
-    load_chunk<QL, NJ, FAST, SEG2>(g1, kr, nch1, i0, j0, 1, tid);
-    store_chunk<QL, NJ, FAST, SEG2>(g0, kr, nch1, 0, sP, sQ, tid);
-    load_chunk<QL, NJ, FAST, SEG2>(g0, kr, nch1, i0, j0, 2, tid);
-    store_chunk<QL, NJ, FAST, SEG2>(g1, kr, nch1, 1, sP + P_BUF, sQ + G::Q_BUF, tid);
-    load_chunk<QL, NJ, FAST, SEG2>(g1, kr, nch1, i0, j0, 3, tid);
+    {   // pipeline fill: the four chunk loads go out back to back (ONE memory round trip);
+        // chunks 0/1 pass through two prologue-only sets, chunks 2/3 land in the loop's sets
+        ChunkRegs<NJ> ga, gb;
+        load_chunk<QL, NJ, FAST, SEG2>(ga, kr, nch1, i0, j0, 0, tid);
+        load_chunk<QL, NJ, FAST, SEG2>(gb, kr, nch1, i0, j0, 1, tid);
+        load_chunk<QL, NJ, FAST, SEG2>(g0, kr, nch1, i0, j0, 2, tid);
+        load_chunk<QL, NJ, FAST, SEG2>(g1, kr, nch1, i0, j0, 3, tid);
+        store_chunk<QL, NJ, FAST, SEG2>(ga, kr, nch1, 0, sP, sQ, tid);
+        store_chunk<QL, NJ, FAST, SEG2>(gb, kr, nch1, 1, sP + P_BUF, sQ + G::Q_BUF, tid);
+    }
     BM_MSTAMP(1);
     __syncthreads();
     read_frags<QL, NJ, ABL>(fa, sP, sQ, wi, wj, lane);
@@ -315,7 +319,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, 
     {                                                                                             \
         if (!BM_ABL(3)) read_frags<QL, NJ, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * G::Q_BUF, wi, wj, lane); \
         if (!BM_ABL(2)) store_chunk<QL, NJ, FAST, SEG2>(G_, kr, nch1, cc + 2, sP + b2 * P_BUF, sQ + b2 * G::Q_BUF, tid); \
-        if (!BM_ABL(0)) load_chunk<QL, NJ, FAST, SEG2>(G_, kr, nch1, i0, j0, cc + 4, tid);              \
+        if (!BM_ABL(0)) load_chunk<QL, NJ, FAST, SEG2>(G_, kr, nch1, i0, j0, cc + 4, tid);        \
         side.step();                                                                              \
         mfma_frags<NJ, ABL>(acc, FC);                                                             \
         BM_SCHED_STEP                                                                             \
@@ -324,12 +328,29 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, 
         b2 = (b2 == NBUF - 1) ? 0 : b2 + 1;                                                       \
         ++cc;                                                                                     \
     }
-    for (int pi = 0; pi < nch / 2; ++pi) {
+    // steady state: steps 0 .. nch-3 carry the full LDS / global traffic; the last two steps
+    // (pipeline drain) only have fragments to read and MFMAs to issue
+    const int full = (nch > 2) ? nch - 2 : 0;
+    for (int pi = 0; pi < full / 2; ++pi) {
         BM_STEP(fa, fb, g0)
         BM_STEP(fb, fa, g1)
     }
+    if (full & 1) {
+        BM_STEP(fa, fb, g0)
+        fa = fb;               // keep the current fragments in `fa` for the drain (once per kernel)
+    }
     BM_MSTAMP(3);
-    if (nch & 1) BM_STEP(fa, fb, g0)
+    if (nch >= 2) {
+        if (!BM_ABL(3)) read_frags<QL, NJ, ABL>(fb, sP + b1 * P_BUF, sQ + b1 * G::Q_BUF, wi, wj, lane);
+        side.step();
+        mfma_frags<NJ, ABL>(acc, fa);
+        side.step();
+        mfma_frags<NJ, ABL>(acc, fb);
+    } else {
+        side.step();
+        mfma_frags<NJ, ABL>(acc, fa);
+    }
+    __syncthreads();           // the LDS ring may be refilled by a following pipeline
     BM_MSTAMP(4);
 #undef BM_STEP
 #undef BM_SCHED_STEP

@@ -146,12 +146,17 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
     KRange kr;
     kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
     kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2; kr.sgn2 = 1.0f;
+    if (a.sample) {          // wave-uniform: the Philox rounds ride along only when a draw follows
 #ifdef BM_PROBE
-    mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+        mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
 #else
-    mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng);
+        mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng);
 #endif
-    rng.finish();
+    } else {
+        NoSide none;
+        mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, none);
+    }
+    if (a.sample) rng.finish();
     BM_STAMP(1);
 
     float z[8];
@@ -271,6 +276,39 @@ constexpr int CS_ROWS = 128;
 constexpr int CS_LD = 80;
 constexpr int CS_SMEM_FLOATS = 2 * CS_ROWS * CS_LD;    // 80 KiB
 
+constexpr int CS_NV = CS_ROWS * 16 / NT;     // float4 per thread per operand (8)
+struct ColRegs { float4 a[CS_NV], b[CS_NV]; };    // (a struct of fixed arrays + unrolled loops stays in VGPRs;
+                                                  //  lambdas capturing the arrays by reference went to scratch)
+
+// rows [r0, r0 + CS_ROWS) x 64 columns of both operands -> registers (clamped, branch-free)
+__device__ __forceinline__ void cs_fetch(ColRegs &r, const float *A, int lda, const float *Bm, int ldb,
+                                         int c0, int ncols, int nrows, int r0, int tid) {
+    const int c4 = tid & 15;
+    const int cc = min(c0 + 4 * c4, ncols - 4);
+#pragma unroll
+    for (int n = 0; n < CS_NV; ++n) {
+        const int rc = min(r0 + (tid >> 4) + 16 * n, nrows - 1);
+        r.a[n] = *reinterpret_cast<const float4 *>(A + (size_t)rc * lda + cc);
+        r.b[n] = Bm ? *reinterpret_cast<const float4 *>(Bm + (size_t)rc * ldb + cc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// registers -> LDS, rows past nrows / columns past ncols zeroed
+__device__ __forceinline__ void cs_stash(const ColRegs &r, float *sA, float *sB, int c0, int ncols, int nrows,
+                                         int r0, int tid) {
+    const int c4 = tid & 15;
+#pragma unroll
+    for (int n = 0; n < CS_NV; ++n) {
+        const int row = (tid >> 4) + 16 * n;
+        const bool ok = (r0 + row < nrows) && (c0 + 4 * c4 < ncols);
+        // (select VALUES: `ok ? r.a[n] : z` on lvalues selects a pointer and forces the set into scratch)
+        float4 va = r.a[n], vb = r.b[n];
+        if (!ok) { va = make_float4(0.f, 0.f, 0.f, 0.f); vb = va; }
+        *reinterpret_cast<float4 *>(sA + row * CS_LD + 4 * c4) = va;
+        *reinterpret_cast<float4 *>(sB + row * CS_LD + 4 * c4) = vb;
+    }
+}
+
 __device__ __forceinline__ void block_colsum(const float *A, int lda, const float *Bm, int ldb,
                                              int c0, int ncols, int nrows, bool want2,
                                              float *smem, f32x4 &sum1, f32x4 &sum2) {
@@ -283,36 +321,12 @@ __device__ __forceinline__ void block_colsum(const float *A, int lda, const floa
     // clamping the column and zeroing at the LDS store, not by the scalar path)
     const bool vec = (((uintptr_t)A & 15u) == 0) && ((lda & 3) == 0) && ((ncols & 3) == 0) &&
                      (!Bm || ((((uintptr_t)Bm & 15u) == 0) && ((ldb & 3) == 0)));
-    constexpr int NV = CS_ROWS * 16 / NT;     // float4 per thread per operand (8)
-    float4 ra[NV], rb[NV];
-    auto fetch = [&](int r0) {                // rows [r0, r0 + CS_ROWS) -> registers (clamped, branch-free)
-        const int c4 = tid & 15;
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int row = (tid >> 4) + 16 * n;
-            const int rc = min(r0 + row, nrows - 1);
-            const int cc = min(c0 + 4 * c4, ncols - 4);
-            ra[n] = *reinterpret_cast<const float4 *>(A + (size_t)rc * lda + cc);
-            rb[n] = Bm ? *reinterpret_cast<const float4 *>(Bm + (size_t)rc * ldb + cc)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stash = [&](int r0) {                // registers -> LDS, rows past nrows zeroed
-        const int c4 = tid & 15;
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-            const int row = (tid >> 4) + 16 * n;
-            const bool ok = (r0 + row < nrows) && (c0 + 4 * c4 < ncols);
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(sA + row * CS_LD + 4 * c4) = ok ? ra[n] : z;
-            *reinterpret_cast<float4 *>(sB + row * CS_LD + 4 * c4) = ok ? rb[n] : z;
-        }
-    };
-    if (vec) fetch(0);
+    ColRegs regs;
+    if (vec) cs_fetch(regs, A, lda, Bm, ldb, c0, ncols, nrows, 0, tid);
     for (int r0 = 0; r0 < nrows; r0 += CS_ROWS) {
         const int nr = (nrows - r0 < CS_ROWS) ? nrows - r0 : CS_ROWS;
         if (vec) {
-            stash(r0);
+            cs_stash(regs, sA, sB, c0, ncols, nrows, r0, tid);
         } else {
             for (int e = tid; e < CS_ROWS * 64; e += NT) {
                 const int row = e >> 6, cc = e & 63, c = c0 + cc;
@@ -322,7 +336,8 @@ __device__ __forceinline__ void block_colsum(const float *A, int lda, const floa
             }
         }
         __syncthreads();
-        if (vec && r0 + CS_ROWS < nrows) fetch(r0 + CS_ROWS);     // next chunk in flight under the chain
+        // next chunk in flight under the chain (clamped loads are legal for any r0)
+        if (vec) cs_fetch(regs, A, lda, Bm, ldb, c0, ncols, nrows, r0 + CS_ROWS, tid);
         // rows >= nr are zero in LDS, so the chain may run to a multiple of 8 steps:
         // 8 fragment reads are issued ahead of the 8 dependent MFMAs that consume them
         const int nsteps = (((nr + 3) / 4) + 7) & ~7;
@@ -473,6 +488,9 @@ struct GradArgs {
     // only when the W update does not need the penalty they produce (sparsity_cost == 0).
     int nbias;
     RbmBiasFusedArgs bias;
+#ifdef BM_PROBE
+    long long *dbg;
+#endif
 };
 
 // the scalar update rule shared by the fused epilogue and the split (data-parallel) apply kernel
@@ -503,6 +521,12 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     block_to_tile(tiles_j, ti, tj, 0, a.nbias);
     const int i0 = ti * TI, j0 = tj * TJ2;
 
+#ifdef BM_PROBE
+#define BM_GSTAMP(n) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + (n)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define BM_GSTAMP(n) do {} while (0)
+#endif
+    BM_GSTAMP(0);
     f32x4 pos[2][2], neg[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -524,6 +548,7 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         mainloop<KM, 2, FAST, false>(neg, kr, i0, j0, smem, none);
     }
 
+    BM_GSTAMP(1);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
@@ -537,22 +562,54 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         lane_outputs<2>(pos, n, pv);
         lane_outputs<2>(neg, n, nv);
         const size_t o = (size_t)j * a.ldw + ib0;
+        const bool vec8 = (ib0 + 7 < a.I) && ((a.ldw & 3) == 0);      // 16-byte aligned run of 8 (ib0 % 8 == 0)
+        if (!a.fused) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (ib0 + e >= a.I) break;
-            if (!a.fused) {
+            for (int e = 0; e < 8; ++e) {
+                if (ib0 + e >= a.I) break;
                 a.raw[o + e] = pv[e];
                 if (a.form != 0) a.raw2[o + e] = nv[e];
-            } else {
-                const float gr = (a.form == 0) ? pv[e] / a.N : (pv[e] / a.N - nv[e] / a.M);
-                float wv = a.W[o + e], dv = a.dW[o + e];
-                apply_w_update(gr, a.pen ? a.pen[ib0 + e] : 0.f, a.l2, a.lr, a.mom, wv, dv);
-                a.W[o + e] = wv;
-                a.dW[o + e] = dv;
-                if (a.Wt) a.Wt[(size_t)(ib0 + e) * a.ldwt + j] = wv;     // maintained transpose (prop-down P operand)
+            }
+            continue;
+        }
+        float wv[8], dv[8], pe[8];
+        if (vec8) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(a.W + o), w1 = *reinterpret_cast<const float4 *>(a.W + o + 4);
+            const float4 d0 = *reinterpret_cast<const float4 *>(a.dW + o), d1 = *reinterpret_cast<const float4 *>(a.dW + o + 4);
+            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+            dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w; dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = ib0 + e < a.I;
+                wv[e] = ok ? a.W[o + e] : 0.f;
+                dv[e] = ok ? a.dW[o + e] : 0.f;
             }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pe[e] = (a.pen && ib0 + e < a.I) ? a.pen[ib0 + e] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gr = (a.form == 0) ? pv[e] / a.N : (pv[e] / a.N - nv[e] / a.M);
+            apply_w_update(gr, pe[e], a.l2, a.lr, a.mom, wv[e], dv[e]);
+        }
+        if (vec8) {
+            *reinterpret_cast<float4 *>(a.W + o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            *reinterpret_cast<float4 *>(a.W + o + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
+            *reinterpret_cast<float4 *>(a.dW + o) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+            *reinterpret_cast<float4 *>(a.dW + o + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ib0 + e < a.I) { a.W[o + e] = wv[e]; a.dW[o + e] = dv[e]; }
+        }
+        if (a.Wt) {                                   // maintained transpose (prop-down P operand)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ib0 + e < a.I) a.Wt[(size_t)(ib0 + e) * a.ldwt + j] = wv[e];
+        }
     }
+    BM_GSTAMP(2);
 }
 
 // split path: W update from (all-reduced) raw sums

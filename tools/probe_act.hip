@@ -62,5 +62,37 @@ int main(int argc, char **argv) {
     RUN(37, "no gload+write+barrier")
     RUN(45, "only mfma (+epilogue)")
     RUN(63, "nothing")
+    {   // ---- grad kernel (RBM form 0, fused update) with and without the bias groups
+        Mat dW, Wt, Vs, Hk;
+        dW.alloc(V, H); Wt.alloc(H, V); Vs.alloc(B, V); Hk.alloc(B, H);
+        Vs.upload(hx.data());
+        float *pen; CK(hipMalloc((void **)&pen, H * 4)); CK(hipMemset(pen, 0, H * 4));
+        GradArgs g; memset(&g, 0, sizeof(g));
+        g.Ppos = make_operand(Hm.p, Hm.ld, H); g.Qpos = make_operand(X.p, X.ld, V); g.Kpos = B;
+        g.Pneg = make_operand(Hk.p, Hk.ld, H); g.Qneg = make_operand(Vs.p, Vs.ld, V); g.Kneg = B;
+        g.I = H; g.J = V; g.form = 0; g.fused = 1; g.W = W.p; g.dW = dW.p; g.Wt = Wt.p; g.ldw = W.ld; g.ldwt = Wt.ld;
+        g.pen = pen; g.N = B; g.M = B; g.l2 = 1e-5f; g.lr = 0.f; g.mom = 0.9f; g.dbg = dbg;
+        {   // standalone bias/colsum groups
+            RbmBiasFusedArgs bfa; memset(&bfa, 0, sizeof(bfa));
+            float *vec6; CK(hipMalloc((void **)&vec6, 8 * (V + H) * 4)); CK(hipMemset(vec6, 0, 8 * (V + H) * 4));
+            bfa.X = X.p; bfa.ldx = X.ld; bfa.vs = Vs.p; bfa.ldv = Vs.ld; bfa.h0m = Hm.p; bfa.ldh0 = Hm.ld; bfa.hm = Hk.p; bfa.ldh = Hk.ld; bfa.B = B;
+            bfa.raw_tail = vec6;
+            bfa.u.vb = vec6 + 2 * (V + H); bfa.u.dvb = bfa.u.vb + V; bfa.u.hb = bfa.u.dvb + V; bfa.u.dhb = bfa.u.hb + H; bfa.u.q = bfa.u.dhb + H; bfa.u.pen = bfa.u.q + H;
+            bfa.u.V = V; bfa.u.H = H; bfa.u.N = B; bfa.u.lr = 0.f; bfa.u.mom = 0.f; bfa.u.damping = 0.9f;
+            const int nw = (V + 63) / 64 + (H + 63) / 64;
+            printf("rbm_bias_fused_kernel %d groups alone: %.2f us\n", nw, time_it(st, e0, e1, [&] { hipLaunchKernelGGL(rbm_bias_fused_kernel, dim3(nw), dim3(NT), 0, st, bfa); }));
+            g.nbias = nw; g.bias = bfa;
+            printf("grad + bias groups in one launch: %.2f us\n", time_it(st, e0, e1, [&] { launch_grad(g, st); }));
+            g.nbias = 0;
+        }
+        for (int variant = 0; variant < 3; ++variant) {
+            g.Wt = (variant == 2) ? nullptr : Wt.p;
+            float us = time_it(st, e0, e1, [&] { launch_grad(g, st); });
+            std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost));
+            double s1 = 0, s2 = 0; int nb = 208;
+            for (int b = 0; b < nb; ++b) { s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; }
+            printf("grad %-22s %6.2f us | mainloop %6.0f epilogue %5.0f cycles\n", variant == 0 ? "tiles only" : variant == 1 ? "(repeat)" : "no Wt write", us, s1/nb, s2/nb);
+        }
+    }
     return 0;
 }
