@@ -107,6 +107,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--k', type=int, default=1, help='n_gibbs_steps of CD-k')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='take the data-parallel code path (grad_step -> all-reduce -> apply_step) even at N=1')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -125,10 +127,12 @@ def main():
     torch.cuda.set_device(local_rank)
     _ffi.check(lib.bm_set_device(local_rank))
     dist = None
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     k = args.k
     X, W = synth(rank, B * N_BATCHES)
@@ -138,7 +142,7 @@ def main():
     eng.set_row_offset(rank * B)
     Xd = as_device(X)
 
-    if world > 1:
+    if use_dp:
         from boltzmann_machines_amd import parallel
         dev = torch.device('cuda', local_rank)
         dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.torch_allreduce_on_engine_stream(eng, dev))
@@ -176,7 +180,7 @@ def main():
     if rank == 0:
         n_prof = min(args.steps, 200)
         eng.profile(True)
-        if world == 1:
+        if not use_dp:
             for i in range(n_prof):
                 step(i)
         else:   # kernels only (no collective) so that other ranks need not participate
@@ -206,7 +210,7 @@ def main():
             'config': {'workload': 'BernoulliRBM 784x1024 CD-%d batch=512 fp32 (BASELINE configs[1])' % k,
                        'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
                        'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
-                       'parallelism': 'dp%d' % world},
+                       'parallelism': 'dp%d' % world, 'dp_path': bool(use_dp)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
                          'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4),
                          'traffic': pmc_traffic() if k == 1 else None,

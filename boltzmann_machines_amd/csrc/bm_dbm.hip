@@ -589,9 +589,6 @@ int bm_dbm_sample_v(bm_dbm *h, int32_t k, float *V_dev) {
     particles_update(h, k, true);                             // :643-644
     // `_make_particles_update(sample=False)` whose v assign is the only one fetched (:646-647):
     // k mean sweeps from the sampled state; only v takes the result, H / *_new keep theirs.
-    std::vector<Mat> Hs(h->L), Hn(h->L);
-    Mat vs = h->v, vn = h->v_new;
-    for (int i = 0; i < h->L; ++i) { Hs[i] = h->H[i]; Hn[i] = h->H_new[i]; }
     // scratch: reuse mu_alt-sized buffers is not possible (M != N): allocate temporaries
     Mat tv, tv2; std::vector<Mat> tH(h->L), tH2(h->L);
     BM_TRY(tv.alloc(h->M, h->V)); BM_TRY(tv2.alloc(h->M, h->V));

@@ -414,6 +414,7 @@ struct RbmBiasFusedArgs {
     const float *X, *vs, *h0m, *hm;     // [B][V] pitch ldx / ldv, [B][H] pitch ldh0 / ldh
     int ldx, ldv, ldh0, ldh, B;
     float *raw_tail;                    // [V | H | H] raw sums are still published (metrics / tests)
+    int raw_only;                       // 1: publish the raw sums only (data-parallel phase 1), no update
     RbmBiasArgs u;
 };
 // body of one 64-column group (block index wv); smem >= CS_SMEM_FLOATS floats
@@ -430,6 +431,7 @@ __device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, 
                 const int c = c0 + w * 16 + g * 4 + r;
                 if (c < a.u.V) {
                     a.raw_tail[c] = s1[r];
+                    if (a.raw_only) continue;
                     const float gr = s1[r] / a.u.N;
                     const float d = a.u.lr * (a.u.mom * a.u.dvb[c] + gr);
                     a.u.dvb[c] = d;
@@ -448,6 +450,7 @@ __device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, 
                     const float sq = s2[r];
                     a.raw_tail[a.u.V + h] = s1[r];
                     a.raw_tail[a.u.V + a.u.H + h] = sq;
+                    if (a.raw_only) continue;
                     const float qn = a.u.damping * a.u.q[h] + (1.0f - a.u.damping) * sq;
                     a.u.q[h] = qn;
                     const float pen = a.u.cost * (qn - a.u.target);
@@ -503,7 +506,7 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
     w = w + d;                     // W.assign_add               (base_rbm.py:468)
 }
 
-template <bool FAST>
+template <bool FAST, int ABL = 0>
 __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS2];
     static_assert(SMEM_FLOATS2 >= CS_SMEM_FLOATS, "bias path reuses the tile LDS");
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         // RBM: ONE chain, positive rows then negative rows with the product negated
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
         kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = a.Kneg; kr.sgn2 = -1.0f;
-        mainloop<KM, 2, FAST, true>(pos, kr, i0, j0, smem, none);
+        mainloop<KM, 2, FAST, true, ABL>(pos, kr, i0, j0, smem, none);
     } else {
         // DBM: pos/N - neg/M with N != M needs the two sums separately
         kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0; kr.sgn2 = 1.0f;

@@ -153,21 +153,6 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out)
     return 0;
 }
 
-// raw column sums -> grad tail (base_rbm.py:450-453,457)
-static void launch_colsums(bm_rbm *h, int B) {
-    ProfScope _ps(h, KC_COLSUM);
-    ColSumArgs c;
-    memset(&c, 0, sizeof(c));
-    float *tail = h->grad.p + h->grad_tail();
-    c.njobs = 3;
-    c.job[0] = ColSumJob{h->Xin, h->vs.p, h->Xin_ld, h->vs.ld, h->V, B, tail};                 // sum(X - v_k)
-    c.job[1] = ColSumJob{h->h0m.p, h->hm.p, h->h0m.ld, h->hm.ld, h->H, B, tail + h->V};        // sum(h0 - h_k)
-    c.job[2] = ColSumJob{h->hm.p, nullptr, h->hm.ld, 0, h->H, B, tail + h->V + h->H};          // sum(h_k)
-    c.first_wave[0] = 0;
-    for (int j = 0; j < c.njobs; ++j) c.first_wave[j + 1] = c.first_wave[j] + (c.job[j].ncols + 63) / 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3(c.first_wave[c.njobs]), dim3(NT), 0, h->stream, c);
-}
-
 static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
     ProfScope _ps(h, KC_BIAS);
     RbmBiasArgs b;
@@ -231,7 +216,10 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
     g.ldw = h->W.ld; g.ldwt = h->Wt.ld;
     g.pen = with_bias ? nullptr : h->pen.p;
     g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
-    if (with_bias) g.nbias = fill_bias_fused(h, B, lr, mom, g.bias);
+    if (with_bias) {
+        g.nbias = fill_bias_fused(h, B, lr, mom, g.bias);
+        g.bias.raw_only = fused ? 0 : 1;      // split (data-parallel) step: raw column sums only
+    }
     bm::launch_grad(g, h->stream);
 }
 
@@ -431,8 +419,7 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, 
 
 int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
-    launch_colsums(h, B);
-    rbm_grad(h, B, 0, (float)B, 0.f, 0.f, false);
+    rbm_grad(h, B, 0, (float)B, 0.f, 0.f, true);     // raw outer products + raw column sums, one launch
     h->call++;
     BM_HIP(hipGetLastError());
     return 0;

@@ -85,7 +85,20 @@ int main(int argc, char **argv) {
             printf("grad + bias groups in one launch: %.2f us\n", time_it(st, e0, e1, [&] { launch_grad(g, st); }));
             g.nbias = 0;
         }
-        for (int variant = 0; variant < 3; ++variant) {
+#define GRUN(MASK, NAME) { \
+            const dim3 gg(((g.I + TI - 1) / TI) * ((g.J + 63) / 64)); \
+            float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<true, MASK>), gg, dim3(NT), 0, st, g); }); \
+            std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
+            double s1 = 0, s2 = 0; for (int b = 0; b < 208; ++b) { s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
+            printf("grad %-26s %6.2f us | mainloop %6.0f epilogue %5.0f\n", NAME, us, s1/208, s2/208); }
+        GRUN(0, "full")
+        GRUN(1, "no-gload")
+        GRUN(2, "no-mfma")
+        GRUN(4, "no-ldswrite")
+        GRUN(8, "no-ldsread")
+        GRUN(32, "no-barrier")
+        GRUN(45, "only mfma")
+        for (int variant = 0; variant < 1; ++variant) {
             g.Wt = (variant == 2) ? nullptr : Wt.p;
             float us = time_it(st, e0, e1, [&] { launch_grad(g, st); });
             std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost));
