@@ -128,3 +128,29 @@ def test_split_step_matches_fused(gpu_lib):
     g = e2.device_view('grad')
     assert g.shape[0] > 2 * (20 * 12 + 12 * 16)
     e1.close(); e2.close()
+
+
+def test_gaussian_visible_pcd(gpu_lib):
+    """BASELINE configs[2] in miniature: Gaussian-Bernoulli RBM trained with PCD = 1-layer DBM with a
+    Gaussian visible layer (README.md:96 of the reference).  Without visible sampling everything is
+    bit-exact; with Normal sampling (device logf/sincosf) parameters agree to 1e-5."""
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 44, [28], 12, 12
+    sig = np.linspace(0.7, 1.3, V).astype(np.float32)
+    for sample_v, exact in ((False, True), (True, False)):
+        eng, twin = make_pair(V, nh, N, M, v_unit=1, sample_v_states=sample_v, max_mf_updates=3, l2=1e-3)
+        eng.set('sigma', sig); twin.p['sigma'][...] = sig
+        vp = orc.normal(87654321, 77, 0, M * V).reshape(M, V)
+        eng.set('v', vp); twin.p['v'][...] = vp
+        eng.seed(9); twin.set_seed(9)
+        for s in range(2):
+            X = orc.normal(87654321, 500 + s, 0, N * V).reshape(N, V)
+            n1, _ = eng.train_step(as_device(X), 5e-3, 0.5, 3)
+            n2, _ = twin.train_step(X, 5e-3, 0.5, 3)
+            assert n1 == n2
+        if exact:
+            assert_equal(eng, twin, ['W', 'hb', 'vb', 'v', 'h', 'mu'])
+        else:
+            for nm in ('W', 'hb', 'vb'):
+                np.testing.assert_allclose(eng.get(nm), twin.p[nm], rtol=2e-5, atol=1e-6)
+        eng.close()
