@@ -232,6 +232,19 @@ class EngineModel(BaseModel, DtypeMixin):
             model._pending_vars = {k: z[k] for k in z.files}
         return model
 
+    # ---- scalar logs: the TensorBoard-free stand-in for tf.summary (base_rbm.py:520-525,
+    # :584-589, dbm.py:636-639): one JSON line per record under logs/train or logs/val ----------
+    def _log_scalars(self, kind, step, values):
+        values = {k: float(v) for k, v in values.items() if v is not None}
+        if not values:
+            return
+        d = self._train_summary_dirpath if kind == 'train' else self._val_summary_dirpath
+        if not os.path.exists(d):
+            os.makedirs(d)
+        values['step'] = int(step)
+        with open(os.path.join(d, 'scalars.jsonl'), 'a') as f:
+            f.write(json.dumps(values, sort_keys=True) + '\n')
+
     # ---- public API (reference tf_model.py:164-202) ------------------------------
     def _fit(self, X, X_val=None, *args, **kwargs):
         raise NotImplementedError('`fit` is not implemented')

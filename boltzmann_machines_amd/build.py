@@ -40,14 +40,25 @@ def build(force=False, verbose=False):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: cannot build libbm355.so')
-    cmd = [hipcc] + FLAGS + _sources() + ['-o', LIB]
-    if verbose:
-        print(' '.join(cmd))
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + r.stdout)
-    if verbose and r.stdout:
-        print(r.stdout)
+    # one process per GPU may reach this point at the same time (torch.distributed.run): build
+    # under an exclusive lock into a temporary file and rename, re-checking once the lock is held
+    import fcntl
+    with open(os.path.join(HERE, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB
+        tmp = LIB + '.tmp.%d' % os.getpid()
+        cmd = [hipcc] + FLAGS + _sources() + ['-o', tmp]
+        if verbose:
+            print(' '.join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError('hipcc failed:\n' + r.stdout)
+        os.replace(tmp, LIB)
+        if verbose and r.stdout:
+            print(r.stdout)
     return LIB
 
 

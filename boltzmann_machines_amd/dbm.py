@@ -255,6 +255,9 @@ class DBM(EngineModel):
             train_msre, train_n_mf_updates = self._train_epoch(Xd, N)
             if X_val is not None and self.epoch_ % self.val_metrics_every_epoch == 0:
                 val_msre, val_n_mf_updates = self._run_val_metrics(X_val, Xvd)
+            self._log_scalars('train', self.iter_, dict(msre=train_msre, n_mf_updates=train_n_mf_updates, epoch=self.epoch_))
+            if X_val is not None and self.epoch_ % self.val_metrics_every_epoch == 0:
+                self._log_scalars('val', self.iter_, dict(msre=val_msre, n_mf_updates=val_n_mf_updates))
             if self.verbose:
                 s = "epoch: {0:{1}}/{2}".format(self.epoch_, len(str(self.max_epoch)), self.max_epoch)
                 if train_msre:

@@ -282,6 +282,8 @@ class BaseRBM(EngineModel):
             if X_val is not None and self.metrics_config['feg'] and \
                     self.epoch_ % self.metrics_config['feg_every_epoch'] == 0:
                 feg = self._run_feg(Xd, N, Xvd, Nv)
+            self._log_scalars('train', self.iter_, dict(train_results, epoch=self.epoch_))
+            self._log_scalars('val', self.iter_, dict(val_results, feg=feg))
             if self.verbose:
                 s = "epoch: {0:{1}}/{2}".format(self.epoch_, len(str(self.max_epoch)), self.max_epoch)
                 for m, v in sorted(train_results.items()):

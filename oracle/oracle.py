@@ -33,10 +33,18 @@ class RbmWork(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('Xin', 'h0m', 'h0s', 'vm', 'vs', 'hm', 'hs')]
 
 
-def build(force=False):
+def _stale():
     src = os.path.join(HERE, 'bm_oracle.c')
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
-        subprocess.check_call(['make', '-C', HERE, '-s', 'clean', 'all'])
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src)
+
+
+def build(force=False):
+    if force or _stale():
+        import fcntl
+        with open(os.path.join(HERE, '.build.lock'), 'w') as lock:      # several ranks may import at once
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or _stale():
+                subprocess.check_call(['make', '-C', HERE, '-s', 'clean', 'all'])
     return LIB
 
 

@@ -121,3 +121,22 @@ def test_errors(gpu_lib, dirs):
     r64 = BernoulliRBM(n_visible=4, n_hidden=3, dtype='float64', model_path=dirs[1], verbose=False).init()
     with pytest.raises(NotImplementedError):
         r64.fit(np.zeros((4, 4)))
+
+
+def test_scalar_logs_and_checkpoint_files(gpu_lib, dirs):
+    """what lands on disk after fit(): params.json (+ class name), random_state.json, the variable
+    checkpoint, and the scalar logs that stand in for the TF summaries."""
+    import json
+    mc = dict(msre=True, pll=True, l2_loss=True, train_metrics_every_iter=1)
+    rbm = BernoulliRBM(max_epoch=2, model_path=dirs[0], metrics_config=mc, **CONFIG)
+    rbm.fit(X, X_VAL)
+    d = dirs[0]
+    p = json.load(open(os.path.join(d, 'params.json')))
+    assert p['__class_name__'] == 'BernoulliRBM' and p['epoch_'] == 2 and p['n_hidden'] == N_HIDDEN
+    assert os.path.isfile(os.path.join(d, 'random_state.json')) and os.path.isfile(os.path.join(d, 'model.npz'))
+    z = np.load(os.path.join(d, 'model.npz'))
+    assert set(z.files) >= {'W', 'vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means'}
+    tr = [json.loads(l) for l in open(os.path.join(d, 'logs/train/scalars.jsonl'))]
+    va = [json.loads(l) for l in open(os.path.join(d, 'logs/val/scalars.jsonl'))]
+    assert len(tr) == 2 and len(va) == 2 and {'msre', 'pll', 'l2_loss', 'epoch', 'step'} <= set(tr[0])
+    assert tr[-1]['step'] == rbm.iter_ and np.isfinite(tr[-1]['pll']) and tr[-1]['msre'] > 0
