@@ -310,11 +310,39 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, 
     int cc = 0, b1 = 1, b2 = 2;   // LDS slots of chunk cc+1 / cc+2
     // masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
 #define BM_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
+#ifndef BM_SCHED_VARIANT
+#define BM_SCHED_VARIANT 0
+#endif
+#if BM_SCHED_VARIANT == 0
 #define BM_SCHED_STEP                                                                             \
     _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, NJ) BM_SG(0x100, 1 + NJ) }    \
     _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) } \
     _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
     BM_SG(0x008, 18 * NJ - 12)
+#elif BM_SCHED_VARIANT == 1   /* stores first */
+#define BM_SCHED_STEP                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, 2 * NJ) BM_SG(0x100, 1 + NJ) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
+    BM_SG(0x008, 12 * NJ - 8)
+#elif BM_SCHED_VARIANT == 2   /* global loads first */
+#define BM_SCHED_STEP                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, NJ) BM_SG(0x100, 1 + NJ) }    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) } \
+    BM_SG(0x008, 18 * NJ - 12)
+#elif BM_SCHED_VARIANT == 3   /* reads spread 1:1 over the MFMAs */
+#define BM_SCHED_STEP                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8 * (1 + NJ); ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
+    BM_SG(0x008, 32 * NJ)
+#elif BM_SCHED_VARIANT == 4   /* stores and loads paired, after the reads */
+#define BM_SCHED_STEP                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, NJ) BM_SG(0x100, 1 + NJ) }    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) BM_SG(0x020, 1) } \
+    BM_SG(0x008, 32 * NJ)
+#endif
 #define BM_STEP(FC, FN, G_)                                                                       \
     {                                                                                             \
         if (!BM_ABL(3)) read_frags<QL, NJ, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * G::Q_BUF, wi, wj, lane); \

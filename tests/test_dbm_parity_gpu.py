@@ -154,3 +154,33 @@ def test_gaussian_visible_pcd(gpu_lib):
             for nm in ('W', 'hb', 'vb'):
                 np.testing.assert_allclose(eng.get(nm), twin.p[nm], rtol=2e-5, atol=1e-6)
         eng.close()
+
+
+def test_randomised_dbm_bit_exact(gpu_lib):
+    """random layer counts / sizes / flags: one DBM update + AIS sample path against the oracle"""
+    from boltzmann_machines_amd.engine import as_device
+    rng = np.random.RandomState(7)
+    for case in range(12):
+        L = int(rng.randint(1, 4))
+        V = int(rng.randint(4, 90))
+        nh = [int(rng.randint(L + 1, 70)) for _ in range(L)]
+        if rng.rand() < 0.5:
+            V, nh = 4 * max(1, V // 4), [4 * max(1, n // 4) for n in nh]
+        N, M = int(rng.randint(1, 40)), int(rng.randint(1, 40))
+        kw = dict(max_mf_updates=int(rng.randint(0, 7)), mf_tol=float(10 ** rng.uniform(-7, -3)),
+                  l2=float(10 ** rng.uniform(-6, -2)), max_norm=float(rng.choice([np.inf, 1.0, 3.0])),
+                  sample_v_states=bool(rng.rand() < 0.7), sample_h_states=[bool(rng.rand() < 0.8) for _ in range(L)],
+                  sparsity_cost=[float(rng.choice([0., 1e-2]))] * L, sparsity_target=[0.15] * L)
+        eng, twin = make_pair(V, nh, N, M, seed=50 + case, **kw)
+        eng.seed(300 + case); twin.set_seed(300 + case)
+        X = data(N, V, case)
+        k = int(rng.randint(1, 4))
+        n1, _ = eng.train_step(as_device(X), 0.03, 0.6, k)
+        n2, _ = twin.train_step(X, 0.03, 0.6, k)
+        names = ['vb', 'v'] + [b + ('' if i == 0 else '_%d' % i) for i in range(L) for b in ('W', 'hb', 'mu', 'h', 'q_means')]
+        try:
+            assert n1 == n2
+            assert_equal(eng, twin, names)
+        except AssertionError as e:
+            raise AssertionError('case %d V=%d nh=%r N=%d M=%d k=%d %r: %s' % (case, V, nh, N, M, k, kw, e))
+        eng.close()

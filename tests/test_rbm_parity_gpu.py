@@ -167,3 +167,56 @@ def test_against_committed_golden_fixture(gpu_lib):
     np.testing.assert_allclose(m, g['metrics'], rtol=1e-5, atol=1e-6)
     assert np.array_equal(Hd.numpy(), g['transform'])
     eng.close()
+
+
+def _random_cases(n, seed):
+    rng = np.random.RandomState(seed)
+    for _ in range(n):
+        V, H = int(rng.randint(1, 200)), int(rng.randint(1, 200))
+        if rng.rand() < 0.5:                       # half of the cases on the 16-byte fast path
+            V, H = 4 * max(1, V // 4), 4 * max(1, H // 4)
+        B = int(rng.randint(1, 70))
+        k = int(rng.randint(1, 4))
+        kw = dict(sample_v_states=bool(rng.rand() < 0.5), sample_h_states=bool(rng.rand() < 0.7),
+                  dbm_first=bool(rng.rand() < 0.2), dbm_last=bool(rng.rand() < 0.2),
+                  l2=float(10 ** rng.uniform(-5, -2)), sparsity_cost=float(rng.choice([0., 1e-3])),
+                  dropout=(None if rng.rand() < 0.6 else float(rng.uniform(0.5, 0.95))))
+        yield V, H, B, k, kw
+
+
+def test_randomised_shapes_and_flags_bit_exact(gpu_lib):
+    """40 random (V, H, B, k, flags) draws incl. 1-wide layers, B = 1, ragged tiles, both load paths:
+    parameters after two updates and the transform output are bit-identical to the oracle."""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    for case, (V, H, B, k, kw) in enumerate(_random_cases(40, 2024)):
+        eng, twin = make_pair(V, H, max_batch=B, **kw)
+        eng.seed(1000 + case); twin.set_seed(1000 + case)
+        for s in range(2):
+            X = synth_data(B, V, s + case)
+            eng.train_step(as_device(X), B, 0.05, 0.8, k)
+            twin.train_step(X, 0.05, 0.8, k)
+        try:
+            assert_state_equal(eng, twin)
+            Hd = DeviceArray((B, H))
+            Xt = synth_data(B, V, 77 + case)
+            eng.transform(as_device(Xt), B, k, Hd)
+            eng.sync()
+            assert np.array_equal(Hd.numpy().view(np.uint32), twin.transform(Xt, k).view(np.uint32))
+        except AssertionError as e:
+            raise AssertionError('case %d V=%d H=%d B=%d k=%d %r: %s' % (case, V, H, B, k, kw, e))
+        eng.close()
+
+
+def test_short_last_batch_and_epoch_driver(gpu_lib):
+    """bm_rbm_train_epoch == the per-batch loop of base_rbm.py:549-571 incl. the short last batch (utils.py:37)."""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, N, bs = 40, 24, 53, 16
+    eng, twin = make_pair(V, H, max_batch=bs, sample_v_states=True)
+    eng.seed(5); twin.set_seed(5)
+    X = synth_data(N, V, 3)
+    eng.train_epoch(as_device(X), N, bs, 0.05, 0.9, 2)
+    for s in range(0, N, bs):
+        twin.train_step(X[s:s + bs], 0.05, 0.9, 2)
+    assert_state_equal(eng, twin)
+    eng.close()
