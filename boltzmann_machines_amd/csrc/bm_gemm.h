@@ -8,18 +8,19 @@
 //     acc = 0; for k in 0..K-1: acc = fmaf(p[k], q[k], acc)
 // which is the order the CPU oracle uses ("canonical order").
 //
-// Geometry (wave64, gfx950):
-//   output tile per workgroup : TI=64 (i, the contiguous output dim) x TJ=32 (j)
-//   4 waves = 2 (i) x 2 (j); a wave owns 32 i x 16 j = two 16x16 MFMA tiles.
-//   MFMA roles: A-operand <- P[i][k], B-operand <- Q[j][k].  The two MFMA tiles of
-//   a wave interleave along i (tile t holds i = base + 2m + t, m = MFMA row), so
+// Geometry (wave64, gfx950), a compile-time parameter pack Geo<WI, WJ, MI, NJ, BK>:
+//   workgroup = WI x WJ waves; a wave owns MI x NJ MFMA tiles of 16 x 16 outputs, i.e.
+//   16*MI outputs along i (the contiguous output dim) x 16*NJ along j.
+//   MFMA roles: A-operand <- P[i][k], B-operand <- Q[j][k].  With MI = 2 the two MFMA
+//   tiles of a wave interleave along i (tile t holds i = base + 2m + t, m = MFMA row), so
 //     * ONE ds_read_b64 feeds the A operand of both MFMAs of a k-step, and
 //     * accumulator lane (l&15)=j, group g=l>>4 holds the 8 CONSECUTIVE outputs
 //       i = base + 8g + 2r + t  (r = register, t = tile) of output row j:
 //       two 16-byte stores and exactly two Philox blocks per lane.
-//   K is streamed in BK=32 chunks through double-buffered LDS; global->VGPR
-//   prefetch runs PF chunks ahead (the whole problem is L2/MALL resident, the
-//   loop is latency- not bandwidth-limited, one workgroup per CU).
+//   With MI = 1 a lane holds the 4 consecutive outputs i = base + 4g + r (one Philox block).
+//   K is streamed in BK chunks through a 3-slot LDS ring; global->VGPR loads run four
+//   chunks ahead (the whole problem is L2/MALL resident, the loop is latency- not
+//   bandwidth-limited).
 //
 // Operand storage:
 //   P is always k-major  [k][i] (i contiguous): W for prop-up, the maintained
@@ -27,10 +28,10 @@
 //   Q is k-major [k][j] (outer products: X, v) or x-major [j][k] (propagations:
 //     rows of X / h, k contiguous).
 // LDS strides make every fragment read conflict free:
-//   P  (ds_read_b64, 64 banks): stride 96 == 32 (mod 64): lanes 0-15 cover 32
+//   P  MI=2 (ds_read_b64, 64 banks): stride == 32 (mod 64): lanes 0-15 cover 32
 //      consecutive dwords of row k, lanes 16-31 the other 32 banks with row k+1.
-//   Q KM (ds_read_b32, 32 banks): stride 48 == 16 (mod 32).
-//   Q XM (ds_read_b32): stride 34 == 2 (mod 4): bank = (2j + k) mod 32 is a
+//   P  MI=1 / Q KM (ds_read_b32, 32 banks): stride == 16 (mod 32).
+//   Q XM (ds_read_b32): stride BK+2 == 2 (mod 4): bank = (2j + k) mod 32 is a
 //      bijection on 16 j x 2 k.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -38,8 +39,8 @@
 
 namespace bm {
 
-// VALU side work threaded through the main loop, one call per K step (default: none)
-struct NoSide { __device__ __forceinline__ void step() {} };
+// VALU side work run in the shadow of the pipeline fill (the first global round trip): default none
+struct NoSide { __device__ __forceinline__ void fill() {} };
 
 // compile-time ablation mask (template parameter ABL, 0 in the product; tools/probe_act.hip
 // instantiates other values to price each pipeline stage)
@@ -47,28 +48,36 @@ struct NoSide { __device__ __forceinline__ void step() {} };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TI = 64;    // tile extent along i
-constexpr int BK = 64;    // K chunk
-// tile extent along j = 32 * NJ (NJ = 16-wide j sub-tiles per wave): NJ = 1 for the
-// propagations (batch 512 -> 16 x 16 = 256 tiles = one per CU), NJ = 2 for the outer
-// products (64 x 64 tiles: 4 MFMAs per fragment pair, one wave of 208 tiles at 784x1024)
-constexpr int TJ = 32;    // NJ = 1 extent (kept for the host-side grid helpers)
-constexpr int NT = 256;   // threads per workgroup
+constexpr int NT = 256;   // threads per workgroup of the non-tile kernels (column sums, max-norm)
+constexpr int NBUF = 3;   // LDS ring depth
 
 enum : int { KM = 0, XM = 1 };
 
-constexpr int P_STRIDE    = TI + 32;   // 96
-constexpr int Q_STRIDE_XM = BK + 2;    // 66
-constexpr int P_BUF = BK * P_STRIDE;
-constexpr int NBUF = 3;   // LDS ring depth
-template <int NJ> struct TileGeom {
-    static constexpr int TJn = 32 * NJ;
-    static constexpr int Q_STRIDE_KM = TJn + 16;   // == 16 (mod 32)
-    static constexpr int Q_BUF = (BK * Q_STRIDE_KM > TJn * Q_STRIDE_XM) ? BK * Q_STRIDE_KM : TJn * Q_STRIDE_XM;
+// Tile geometry (see the header comment).  GeoAct: propagations at the north-star shape
+// (batch 512 x 1024 hidden -> 16 x 16 = 256 tiles, one per CU); GeoGrad: 64 x 64 outer-product
+// tiles (4 MFMAs per fragment pair, 208 tiles at 784 x 1024).
+template <int WI_, int WJ_, int MI_, int NJ_, int BK_>
+struct Geo {
+    static constexpr int WI = WI_, WJ = WJ_, MI = MI_, NJ = NJ_, BK = BK_;
+    static constexpr int NT = 64 * WI * WJ;              // threads per workgroup
+    static constexpr int TI = 16 * MI * WI;              // tile extent along i
+    static constexpr int TJ = 16 * NJ * WJ;              // tile extent along j
+    static constexpr int E = 4 * MI;                     // consecutive outputs per lane and j sub-tile
+    static constexpr int P_STRIDE = (MI == 2) ? ((TI % 64 == 0) ? TI + 32 : TI) : ((TI % 32 == 0) ? TI + 16 : TI);
+    static constexpr int Q_STRIDE_XM = BK + 2;
+    static constexpr int Q_STRIDE_KM = (TJ % 32 == 0) ? TJ + 16 : TJ;
+    static constexpr int P_BUF = BK * P_STRIDE;
+    static constexpr int Q_BUF = (BK * Q_STRIDE_KM > TJ * Q_STRIDE_XM) ? BK * Q_STRIDE_KM : TJ * Q_STRIDE_XM;
     static constexpr int SMEM_FLOATS = NBUF * (P_BUF + Q_BUF);
+    static constexpr int NVP = TI * BK / (4 * NT);       // float4 per thread per chunk, P tile
+    static constexpr int NVQ = TJ * BK / (4 * NT);       // ... Q tile
+    static_assert(MI == 1 || MI == 2, "MI");
+    static_assert(NVP >= 1 && NVP * 4 * NT == TI * BK, "P chunk must split evenly over the threads");
+    static_assert(NVQ >= 1 && NVQ * 4 * NT == TJ * BK, "Q chunk must split evenly over the threads");
+    static_assert(BK % 8 == 0, "BK");
 };
-constexpr int SMEM_FLOATS = TileGeom<1>::SMEM_FLOATS;      // 108 KiB
-constexpr int SMEM_FLOATS2 = TileGeom<2>::SMEM_FLOATS;     // 132 KiB
+using GeoAct = Geo<2, 2, 2, 1, 64>;      // 64 x 32 tile, 108 KiB LDS
+using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 132 KiB LDS
 
 struct Operand {
     const float *ptr;
@@ -83,9 +92,6 @@ static inline Operand make_operand(const float *p, int ld, int nx) {
     o.vec = (((uintptr_t)p & 15u) == 0 && (ld & 3) == 0) ? 1 : 0;
     return o;
 }
-
-// 16 zero bytes for branch-free guarded scalar loads (colsum_kernel)
-static __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // host: can this operand take the branch-free load path?
 static inline bool operand_fast(const Operand &o, int layout, int K) {
@@ -109,19 +115,20 @@ __device__ __forceinline__ float4 load4_guard(const float *p, bool row_ok, int c
     return v;
 }
 
-// global -> registers for one BK chunk of one operand tile (TX = tile extent along x).
+// global -> registers for one BK chunk of one operand tile (TX = tile extent along x,
+// NTH = threads of the workgroup).
 // FAST: every float4 is either fully inside or fully outside the operand (host
 // guarantees 16B alignment, ld % 4 == 0 and a contiguous extent % 4 == 0), so the
 // load is unconditional and branch free: indices are clamped into range; the K tail is
 // zeroed when the set is stored to LDS, and x-tail garbage only reaches outputs
 // i >= I / j >= J, which are never stored.
-template <int L, int TX, bool FAST>
-__device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NT)], const float *ptr, int ld, int nx, int vec,
+template <int L, int TX, int BK, int NTH, bool FAST>
+__device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NTH)], const float *ptr, int ld, int nx, int vec,
                                     int x0, int k0, int K, int tid) {
-    constexpr int NV = TX * BK / (4 * NT);   // float4 per thread
+    constexpr int NV = TX * BK / (4 * NTH);   // float4 per thread
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-        const int f = tid + n * NT;
+        const int f = tid + n * NTH;
         int k, x;
         if (L == KM) {
             const int row = f / (TX / 4), c4 = f % (TX / 4);
@@ -144,88 +151,88 @@ __device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NT)], const flo
 }
 
 // registers -> LDS.  kz = K - k0 (rows/cols of this chunk at k >= K are zeroed; only the
-// FAST path needs it, the guarded loads already returned zeros).
-template <int L, int TX, int STRIDE_K, bool FAST, bool SIGN = false>
-__device__ __forceinline__ void r2s(const float4 (&reg)[TX * BK / (4 * NT)], float *s, int tid, int kz,
-                                    uint32_t signmask = 0u) {
-    constexpr int NV = TX * BK / (4 * NT);
+// FAST path needs it, the guarded loads already returned zeros).  STRIDE = LDS row stride
+// of this layout (k rows for KM, x rows for XM).
+template <int L, int TX, int BK, int NTH, int STRIDE, bool FAST>
+__device__ __forceinline__ void r2s(const float4 (&reg)[TX * BK / (4 * NTH)], float *s, int tid, int kz) {
+    constexpr int NV = TX * BK / (4 * NTH);
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
-        const int f = tid + n * NT;
+        const int f = tid + n * NTH;
         float4 v = reg[n];
-        if (SIGN) {              // branch-free (a branch would split the step's scheduling region)
-            v.x = __uint_as_float(__float_as_uint(v.x) ^ signmask);
-            v.y = __uint_as_float(__float_as_uint(v.y) ^ signmask);
-            v.z = __uint_as_float(__float_as_uint(v.z) ^ signmask);
-            v.w = __uint_as_float(__float_as_uint(v.w) ^ signmask);
-        }
         if (L == KM) {
             const int row = f / (TX / 4), c4 = f % (TX / 4);
             if (FAST && row >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(s + row * STRIDE_K + c4 * 4) = v;
+            *reinterpret_cast<float4 *>(s + row * STRIDE + c4 * 4) = v;
         } else {
             const int row = f / (BK / 4), c4 = f % (BK / 4);
             if (FAST && c4 * 4 >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 *d = reinterpret_cast<float2 *>(s + row * Q_STRIDE_XM + c4 * 4);
+            float2 *d = reinterpret_cast<float2 *>(s + row * STRIDE + c4 * 4);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
         }
     }
 }
 
-// MFMA operand fragments of one BK chunk for this wave (48 VGPRs at BK = 64, NJ = 1)
-template <int NJ> struct Frags {
-    float2 p[BK / 4];       // p[kk] = P[k = 4kk+g][i = base + 2*l15 + {0,1}]
-    float q[BK / 4][NJ];    // q[kk][n] = Q[j = 16n + l15][k = 4kk+g]
+// MFMA operand fragments of one BK chunk for this wave (48 VGPRs for GeoAct)
+template <class G> struct Frags {
+    float p[G::BK / 4][G::MI];     // p[kk][t] = P[k = 4kk+g][i = base + MI*l15 + t]
+    float q[G::BK / 4][G::NJ];     // q[kk][n] = Q[j = 16n + l15][k = 4kk+g]
 };
 
-template <int QL, int NJ, int ABL = 0>
-__device__ __forceinline__ void read_frags(Frags<NJ> &f, const float *sP, const float *sQ, int wi, int wj, int lane) {
-    using G = TileGeom<NJ>;
+template <int QL, class G, int ABL = 0>
+__device__ __forceinline__ void read_frags(Frags<G> &f, const float *sP, const float *sQ, int wi, int wj, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
-    const float *pP = sP + g * P_STRIDE + wi * 32 + 2 * l15;
-    const float *pQ = (QL == KM) ? sQ + g * G::Q_STRIDE_KM + wj * 16 * NJ + l15
-                                 : sQ + (wj * 16 * NJ + l15) * Q_STRIDE_XM + g;
+    const float *pP = sP + g * G::P_STRIDE + wi * (16 * G::MI) + G::MI * l15;
+    const float *pQ = (QL == KM) ? sQ + g * G::Q_STRIDE_KM + wj * 16 * G::NJ + l15
+                                 : sQ + (wj * 16 * G::NJ + l15) * G::Q_STRIDE_XM + g;
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-        if (BM_ABL(3)) { f.p[kk] = make_float2(1.f, 2.f); f.q[kk][0] = 1.f; continue; }
+    for (int kk = 0; kk < G::BK / 4; ++kk) {
+        if (BM_ABL(3)) { f.p[kk][0] = 1.f; if (G::MI == 2) f.p[kk][G::MI - 1] = 2.f; f.q[kk][0] = 1.f; continue; }
         // (hipcc fuses pairs of these into ds_read2st64_b64; keeping them as separate ds_read_b64
         // was measured 34 % SLOWER in the loop, so the fused form stays)
-        f.p[kk] = *reinterpret_cast<const float2 *>(pP + kk * 4 * P_STRIDE);
+        if (G::MI == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(pP + kk * 4 * G::P_STRIDE);
+            f.p[kk][0] = t.x; f.p[kk][G::MI - 1] = t.y;
+        } else {
+            f.p[kk][0] = pP[kk * 4 * G::P_STRIDE];
+        }
 #pragma unroll
-        for (int n = 0; n < NJ; ++n)
-            f.q[kk][n] = (QL == KM) ? pQ[kk * 4 * G::Q_STRIDE_KM + 16 * n] : pQ[16 * n * Q_STRIDE_XM + kk * 4];
+        for (int n = 0; n < G::NJ; ++n)
+            f.q[kk][n] = (QL == KM) ? pQ[kk * 4 * G::Q_STRIDE_KM + 16 * n] : pQ[16 * n * G::Q_STRIDE_XM + kk * 4];
     }
 }
 
 // acc[t][n] += P-frag(t) x Q-frag(n)
-template <int NJ, int ABL = 0>
-__device__ __forceinline__ void mfma_frags(f32x4 (&acc)[2][NJ], const Frags<NJ> &f) {
+template <class G, int ABL = 0>
+__device__ __forceinline__ void mfma_frags(f32x4 (&acc)[G::MI][G::NJ], const Frags<G> &f) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
+    for (int kk = 0; kk < G::BK / 4; ++kk) {
 #pragma unroll
-        for (int n = 0; n < NJ; ++n) {
+        for (int n = 0; n < G::NJ; ++n) {
             const float q = f.q[kk][n];
-            if (BM_ABL(1)) { acc[0][n][0] += f.p[kk].x * q; acc[1][n][0] += f.p[kk].y; continue; }
-            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk].x, q, acc[0][n], 0, 0, 0);
-            acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk].y, q, acc[1][n], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < G::MI; ++t) {
+                if (BM_ABL(1)) { acc[t][n][0] += f.p[kk][t] * q; continue; }
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk][t], q, acc[t][n], 0, 0, 0);
+            }
         }
     }
 }
 
 // one register set = one BK chunk of both operand tiles, global -> VGPR staging
-template <int NJ> struct ChunkRegs {
-    float4 p[TI * BK / (4 * NT)];
-    float4 q[32 * NJ * BK / (4 * NT)];
+template <class G> struct ChunkRegs {
+    float4 p[G::NVP];
+    float4 q[G::NVQ];
 };
 
 // The K range of a contraction: segment 1 followed by an optional segment 2 with its own
 // operands (DBM two-sided layer input; positive then negative phase of the outer
-// products), streamed as ONE continuous pipeline (one fill, one drain).
+// products, the latter with a NEGATED P operand: fma(-p, q, acc) == acc - p*q exactly),
+// streamed as ONE continuous pipeline (one fill, one drain).
 struct KRange {
     Operand P1, Q1; int K1;
     Operand P2, Q2; int K2;     // K2 == 0: absent
-    float sgn2;                 // +1 or -1: sign applied to segment-2 products
 };
 
 // branch-free wave-uniform selects (a branch inside a step would split its scheduling region)
@@ -235,123 +242,241 @@ __device__ __forceinline__ const float *sel_p(const float *a, const float *b, in
     return (const float *)(ua ^ ((ua ^ ub) & (uintptr_t)(intptr_t)m));
 }
 
-template <int QL, int NJ, bool FAST, bool SEG2>
-__device__ __forceinline__ void load_chunk(ChunkRegs<NJ> &r, const KRange &kr, int nch1, int i0, int j0, int c, int tid) {
+template <int QL, class G, bool FAST, bool SEG2>
+__device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, int nch1, int i0, int j0, int c, int tid) {
+    constexpr int BK = G::BK;
     if (!SEG2) {
-        g2r<KM, TI, FAST>(r.p, kr.P1.ptr, kr.P1.ld, kr.P1.nx, kr.P1.vec, i0, c * BK, kr.K1, tid);
-        g2r<QL, 32 * NJ, FAST>(r.q, kr.Q1.ptr, kr.Q1.ld, kr.Q1.nx, kr.Q1.vec, j0, c * BK, kr.K1, tid);
+        g2r<KM, G::TI, BK, G::NT, FAST>(r.p, kr.P1.ptr, kr.P1.ld, kr.P1.nx, kr.P1.vec, i0, c * BK, kr.K1, tid);
+        g2r<QL, G::TJ, BK, G::NT, FAST>(r.q, kr.Q1.ptr, kr.Q1.ld, kr.Q1.nx, kr.Q1.vec, j0, c * BK, kr.K1, tid);
     } else {
         const int m = -(int)((c >= nch1) & (kr.K2 > 0));   // all-ones in segment 2 (wave-uniform)
         const int kc = c - (nch1 & m);
         const int K = sel_i(kr.K1, kr.K2, m);
-        g2r<KM, TI, FAST>(r.p, sel_p(kr.P1.ptr, kr.P2.ptr, m), sel_i(kr.P1.ld, kr.P2.ld, m),
-                          sel_i(kr.P1.nx, kr.P2.nx, m), sel_i(kr.P1.vec, kr.P2.vec, m), i0, kc * BK, K, tid);
-        g2r<QL, 32 * NJ, FAST>(r.q, sel_p(kr.Q1.ptr, kr.Q2.ptr, m), sel_i(kr.Q1.ld, kr.Q2.ld, m),
-                               sel_i(kr.Q1.nx, kr.Q2.nx, m), sel_i(kr.Q1.vec, kr.Q2.vec, m), j0, kc * BK, K, tid);
+        g2r<KM, G::TI, BK, G::NT, FAST>(r.p, sel_p(kr.P1.ptr, kr.P2.ptr, m), sel_i(kr.P1.ld, kr.P2.ld, m),
+                                        sel_i(kr.P1.nx, kr.P2.nx, m), sel_i(kr.P1.vec, kr.P2.vec, m), i0, kc * BK, K, tid);
+        g2r<QL, G::TJ, BK, G::NT, FAST>(r.q, sel_p(kr.Q1.ptr, kr.Q2.ptr, m), sel_i(kr.Q1.ld, kr.Q2.ld, m),
+                                        sel_i(kr.Q1.nx, kr.Q2.nx, m), sel_i(kr.Q1.vec, kr.Q2.vec, m), j0, kc * BK, K, tid);
     }
 }
 
-template <int QL, int NJ, bool FAST, bool SEG2>
-__device__ __forceinline__ void store_chunk(const ChunkRegs<NJ> &r, const KRange &kr, int nch1, int c,
+template <int QL, class G, bool FAST, bool SEG2>
+__device__ __forceinline__ void store_chunk(const ChunkRegs<G> &r, const KRange &kr, int nch1, int c,
                                             float *sP, float *sQ, int tid) {
+    constexpr int BK = G::BK;
     const int m = SEG2 ? -(int)((c >= nch1) & (kr.K2 > 0)) : 0;
     const int kz = sel_i(kr.K1, kr.K2, m) - (c - (nch1 & m)) * BK;
-    r2s<KM, TI, P_STRIDE, FAST>(r.p, sP, tid, kz);
-    // the sign of segment 2 (-1 for the negative CD phase) is applied once per element here,
-    // off the MFMA dependency chain: fma(p, -q, acc) == acc - p*q exactly
-    const uint32_t sm = (SEG2 && kr.sgn2 < 0.f) ? (0x80000000u & (uint32_t)m) : 0u;
-    r2s<QL, 32 * NJ, TileGeom<NJ>::Q_STRIDE_KM, FAST, SEG2>(r.q, sQ, tid, kz, sm);
+    r2s<KM, G::TI, BK, G::NT, G::P_STRIDE, FAST>(r.p, sP, tid, kz);
+    r2s<QL, G::TJ, BK, G::NT, (QL == KM) ? G::Q_STRIDE_KM : G::Q_STRIDE_XM, FAST>(r.q, sQ, tid, kz);
+}
+
+// ---- steady-state ("slim") chunk path -------------------------------------------------------
+// One wave issues its instructions strictly in order and an MFMA holds the wave for its 32
+// cycles (tools/ubench.hip: MFMA + n VALU = 41 + 4.4 n cycles in one wave), so every VALU
+// instruction inside the K loop is paid in full.  For chunks that lie completely inside K the
+// loads therefore use per-thread byte offsets computed ONCE per kernel (x clamps folded in)
+// on top of a wave-uniform chunk base (SGPR arithmetic), and the LDS stores skip the K-tail
+// zero fill.  Chunks that touch the end of a segment go through load_chunk/store_chunk above.
+template <class G> struct LoadPlan {
+    uint32_t p[G::NVP], q[G::NVQ];     // byte offsets relative to the chunk base of the operand
+};
+
+template <int L, int TX, int BK, int NTH>
+__device__ __forceinline__ void plan_offsets(uint32_t (&off)[TX * BK / (4 * NTH)], int ld, int nx, int x0, int tid) {
+    constexpr int NV = TX * BK / (4 * NTH);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int f = tid + n * NTH;
+        if (L == KM) {
+            const int row = f / (TX / 4), c4 = f % (TX / 4);
+            off[n] = (uint32_t)(row * ld + min(x0 + c4 * 4, nx - 4)) * 4u;
+        } else {
+            const int row = f / (BK / 4), c4 = f % (BK / 4);
+            off[n] = (uint32_t)(min(x0 + row, nx - 1) * ld + c4 * 4) * 4u;
+        }
+    }
+}
+
+template <int QL, class G>
+__device__ __forceinline__ void make_plan(LoadPlan<G> &pl, const Operand &P, const Operand &Q, int i0, int j0, int tid) {
+    plan_offsets<KM, G::TI, G::BK, G::NT>(pl.p, P.ld, P.nx, i0, tid);
+    plan_offsets<QL, G::TJ, G::BK, G::NT>(pl.q, Q.ld, Q.nx, j0, tid);
+}
+
+// chunk c (must be a FULL chunk of its segment; c >= nch: prefetch overrun, any full chunk does)
+template <int QL, class G, bool SEG2>
+__device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &kr, const LoadPlan<G> &pl1,
+                                                const LoadPlan<G> &pl2, int nch1, int nch, int c) {
+    constexpr int BK = G::BK;
+    const int cl = (c < nch) ? c : 0;
+    const int m = SEG2 ? -(int)(cl >= nch1) : 0;          // all-ones in segment 2 (wave-uniform)
+    const int kc = cl - (nch1 & m);
+    const int ldp = SEG2 ? sel_i(kr.P1.ld, kr.P2.ld, m) : kr.P1.ld;
+    const int ldq = SEG2 ? sel_i(kr.Q1.ld, kr.Q2.ld, m) : kr.Q1.ld;
+    const char *pb = (const char *)((SEG2 ? sel_p(kr.P1.ptr, kr.P2.ptr, m) : kr.P1.ptr) + (size_t)kc * BK * ldp);
+    const char *qb = (const char *)((SEG2 ? sel_p(kr.Q1.ptr, kr.Q2.ptr, m) : kr.Q1.ptr) +
+                                    ((QL == KM) ? (size_t)kc * BK * ldq : (size_t)kc * BK));
+#pragma unroll
+    for (int n = 0; n < G::NVP; ++n) {
+        const uint32_t o1 = pl1.p[n], o2 = SEG2 ? pl2.p[n] : 0u;
+        const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
+        r.p[n] = *reinterpret_cast<const float4 *>(pb + o);
+    }
+#pragma unroll
+    for (int n = 0; n < G::NVQ; ++n) {
+        const uint32_t o1 = pl1.q[n], o2 = SEG2 ? pl2.q[n] : 0u;
+        const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
+        r.q[n] = *reinterpret_cast<const float4 *>(qb + o);
+    }
+}
+
+template <int QL, class G>
+__device__ __forceinline__ void store_chunk_slim(const ChunkRegs<G> &r, float *sP, float *sQ, int tid) {
+    r2s<KM, G::TI, G::BK, G::NT, G::P_STRIDE, false>(r.p, sP, tid, 0);
+    r2s<QL, G::TJ, G::BK, G::NT, (QL == KM) ? G::Q_STRIDE_KM : G::Q_STRIDE_XM, false>(r.q, sQ, tid, 0);
 }
 
 // acc += sum_k P[k][i] * Q[j][k] over the K range, k ascending (canonical order).
 //
-// One wave per SIMD has nobody to hide behind, so the loop is software-pipelined by
-// hand over a 3-deep LDS ring.  In step c (between barriers B(c-1) and B(c)) a wave
+// The loop is software-pipelined by hand over a 3-deep LDS ring.  In step c (between
+// barriers B(c-1) and B(c)) a wave
 //   * runs the MFMAs of chunk c on fragments F(c) that are ALREADY in registers,
 //   * reads the fragments F(c+1) from LDS slot (c+1)%3 (published by B(c-1)),
 //   * stores chunk c+2 (global data that arrived in registers) to LDS slot (c+2)%3
 //     (last read for F(c-1), complete before B(c-2)),
-//   * re-issues the global loads of chunk c+4 into the register set just stored,
-//   * runs one call of the VALU side work (Philox round).
+//   * re-issues the global loads of chunk c+4 into the register set just stored.
 // sched_group_barrier pins that issue order: hipcc otherwise issues the LDS traffic
-// AFTER the MFMAs and the two phases run back to back.  No load sits under a branch
-// (chunks past K are clamped / zero-filled), so all waits are counted.
-template <int QL, int NJ, bool FAST, bool SEG2, int ABL = 0, class Side = NoSide>
-__device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, int i0, int j0, float *smem,
+// AFTER the MFMAs and the two phases run back to back.  Steps come in two flavours, chosen
+// per PAIR of steps by a wave-uniform branch around the whole pair (so each flavour is one
+// scheduling region): the slim one for full chunks (see LoadPlan) and the careful one
+// (clamped loads, K-tail zero fill) for chunks that touch the end of a segment.
+// `side.fill()` (the lane's Philox blocks in act_kernel) runs while the first loads are in
+// flight, when the wave would otherwise idle for one memory round trip.
+template <int QL, class G, bool FAST, bool SEG2, int ABL = 0, class Side = NoSide>
+__device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRange &kr, int i0, int j0, float *smem,
                                          Side &side, long long *stamps = nullptr) {
 #ifdef BM_PROBE
 #define BM_MSTAMP(n) do { if (stamps && threadIdx.x == 0) stamps[n] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define BM_MSTAMP(n) do {} while (0)
 #endif
-    using G = TileGeom<NJ>;
+    constexpr int BK = G::BK, P_BUF = G::P_BUF, Q_BUF = G::Q_BUF;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w & 1, wj = w >> 1;
+    const int wi = w % G::WI, wj = w / G::WI;
     float *sP = smem, *sQ = smem + NBUF * P_BUF;
     const int nch1 = (kr.K1 + BK - 1) / BK;
     const int nch = nch1 + (SEG2 ? (kr.K2 + BK - 1) / BK : 0);
-    ChunkRegs<NJ> g0, g1;      // named sets (never arrays: must stay in VGPRs)
-    Frags<NJ> fa, fb;
+    const int nfull1 = kr.K1 / BK, nfull2 = SEG2 ? kr.K2 / BK : 0;
+    ChunkRegs<G> g0, g1;      // named sets (never arrays: must stay in VGPRs)
+    Frags<G> fa, fb;
+    LoadPlan<G> pl1, pl2;
+    if (FAST) {
+        make_plan<QL, G>(pl1, kr.P1, kr.Q1, i0, j0, tid);
+        if (SEG2) make_plan<QL, G>(pl2, kr.P2, kr.Q2, i0, j0, tid);
+    }
     BM_MSTAMP(0);
     {   // pipeline fill: the four chunk loads go out back to back (ONE memory round trip);
         // chunks 0/1 pass through two prologue-only sets, chunks 2/3 land in the loop's sets
-        ChunkRegs<NJ> ga, gb;
-        load_chunk<QL, NJ, FAST, SEG2>(ga, kr, nch1, i0, j0, 0, tid);
-        load_chunk<QL, NJ, FAST, SEG2>(gb, kr, nch1, i0, j0, 1, tid);
-        load_chunk<QL, NJ, FAST, SEG2>(g0, kr, nch1, i0, j0, 2, tid);
-        load_chunk<QL, NJ, FAST, SEG2>(g1, kr, nch1, i0, j0, 3, tid);
-        store_chunk<QL, NJ, FAST, SEG2>(ga, kr, nch1, 0, sP, sQ, tid);
-        store_chunk<QL, NJ, FAST, SEG2>(gb, kr, nch1, 1, sP + P_BUF, sQ + G::Q_BUF, tid);
+        ChunkRegs<G> ga, gb;
+        load_chunk<QL, G, FAST, SEG2>(ga, kr, nch1, i0, j0, 0, tid);
+        load_chunk<QL, G, FAST, SEG2>(gb, kr, nch1, i0, j0, 1, tid);
+        load_chunk<QL, G, FAST, SEG2>(g0, kr, nch1, i0, j0, 2, tid);
+        load_chunk<QL, G, FAST, SEG2>(g1, kr, nch1, i0, j0, 3, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        side.fill();
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk<QL, G, FAST, SEG2>(ga, kr, nch1, 0, sP, sQ, tid);
+        store_chunk<QL, G, FAST, SEG2>(gb, kr, nch1, 1, sP + P_BUF, sQ + Q_BUF, tid);
     }
     BM_MSTAMP(1);
     __syncthreads();
-    read_frags<QL, NJ, ABL>(fa, sP, sQ, wi, wj, lane);
+    read_frags<QL, G, ABL>(fa, sP, sQ, wi, wj, lane);
     BM_MSTAMP(2);
     int cc = 0, b1 = 1, b2 = 2;   // LDS slots of chunk cc+1 / cc+2
+    // Issue order of one step.  Instruction counts per wave and step:
+    //   NM MFMAs; NRG fused fragment-read groups of (1 + NJ) DS reads (hipcc pairs the reads of
+    //   two k-steps into ds_read2st64); NW DS writes; NL global loads.
     // masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
+    constexpr int NM = (BK / 4) * G::MI * G::NJ;
+    constexpr int NRG = BK / 8, RPG = 1 + G::NJ;
+    constexpr int NW = G::NVP + ((QL == XM) ? 2 * G::NVQ : G::NVQ);
+    constexpr int NL = G::NVP + G::NVQ;
+    constexpr int MR = (NM >= 64) ? 2 : 1;            // MFMAs per read group
+    constexpr int MW = (NM >= 32) ? 2 : 1;            // MFMAs per DS write
+    constexpr int REST = NM - (NRG * MR + NW * MW + NL);
 #define BM_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 #ifndef BM_SCHED_VARIANT
 #define BM_SCHED_VARIANT 0
 #endif
 #if BM_SCHED_VARIANT == 0
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, NJ) BM_SG(0x100, 1 + NJ) }    \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
-    BM_SG(0x008, 18 * NJ - 12)
-#elif BM_SCHED_VARIANT == 1   /* stores first */
+    _Pragma("unroll") for (int s_ = 0; s_ < NRG; ++s_) { BM_SG(0x008, MR) BM_SG(0x100, RPG) }    \
+    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, MW) BM_SG(0x200, 1) }        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }         \
+    if (REST > 0) { BM_SG(0x008, (REST > 0 ? REST : 1)) }
+#elif BM_SCHED_VARIANT == 1    /* every memory op behind its own MFMA: reads, writes, loads */
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, 2 * NJ) BM_SG(0x100, 1 + NJ) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
-    BM_SG(0x008, 12 * NJ - 8)
-#elif BM_SCHED_VARIANT == 2   /* global loads first */
+    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) }         \
+    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }         \
+    BM_SG(0x008, NM)
+#elif BM_SCHED_VARIANT == 2    /* loads, writes, then reads, 1:1 */
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, NJ) BM_SG(0x100, 1 + NJ) }    \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) } \
-    BM_SG(0x008, 18 * NJ - 12)
-#elif BM_SCHED_VARIANT == 3   /* reads spread 1:1 over the MFMAs */
+    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }         \
+    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) }         \
+    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
+    BM_SG(0x008, NM)
+#elif BM_SCHED_VARIANT == 3    /* writes and loads paired 1:1 first, then reads 1:1 */
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8 * (1 + NJ); ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } \
-    BM_SG(0x008, 32 * NJ)
-#elif BM_SCHED_VARIANT == 4   /* stores and loads paired, after the reads */
+    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) BM_SG(0x020, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
+    BM_SG(0x008, NM)
+#elif BM_SCHED_VARIANT == 4    /* reads 1 per 2 MFMAs with a write or load in the other slot */
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) { BM_SG(0x008, NJ) BM_SG(0x100, 1 + NJ) }    \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4 + 2 * NJ; ++s_) { BM_SG(0x008, 2) BM_SG(0x200, 1) BM_SG(0x020, 1) } \
-    BM_SG(0x008, 32 * NJ)
+    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) BM_SG(0x008, 1) BM_SG(0x200, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) BM_SG(0x008, 1) BM_SG(0x020, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
+    BM_SG(0x008, NM)
+#elif BM_SCHED_VARIANT == 5    /* no pinning: leave the order to hipcc */
+#define BM_SCHED_STEP
 #endif
-#define BM_STEP(FC, FN, G_)                                                                       \
-    {                                                                                             \
-        if (!BM_ABL(3)) read_frags<QL, NJ, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * G::Q_BUF, wi, wj, lane); \
-        if (!BM_ABL(2)) store_chunk<QL, NJ, FAST, SEG2>(G_, kr, nch1, cc + 2, sP + b2 * P_BUF, sQ + b2 * G::Q_BUF, tid); \
-        if (!BM_ABL(0)) load_chunk<QL, NJ, FAST, SEG2>(G_, kr, nch1, i0, j0, cc + 4, tid);        \
-        side.step();                                                                              \
-        mfma_frags<NJ, ABL>(acc, FC);                                                             \
+#define BM_STEP_TAIL                                                                              \
         BM_SCHED_STEP                                                                             \
         if (!BM_ABL(5)) __syncthreads();                                                          \
+        b1 = b2;                                                                                  \
+        b2 = (b2 == NBUF - 1) ? 0 : b2 + 1;                                                       \
+        ++cc;
+    // careful step: clamped loads, K-tail zero fill
+#define BM_STEP(FC, FN, G_)                                                                       \
+    {                                                                                             \
+        if (!BM_ABL(3)) read_frags<QL, G, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
+        if (!BM_ABL(2)) store_chunk<QL, G, FAST, SEG2>(G_, kr, nch1, cc + 2, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid); \
+        if (!BM_ABL(0)) load_chunk<QL, G, FAST, SEG2>(G_, kr, nch1, i0, j0, cc + 4, tid);         \
+        mfma_frags<G, ABL>(acc, FC);                                                              \
+        BM_STEP_TAIL                                                                              \
+    }
+    // slim step: chunks cc+2 (stored) and cc+4 (loaded) are full chunks
+#ifdef BM_PROBE
+    // ABL bit 7: phase-ordered step (reads | stores | loads | MFMAs | barrier) with a cycle stamp
+    // between the phases of step 4 -> where does one wave's issue time go?
+    long long pst[6] = {0, 0, 0, 0, 0, 0};
+#define BM_PSTAMP(k) if (BM_ABL(7)) { __builtin_amdgcn_sched_barrier(0); if (cc == 4) pst[k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define BM_PSTAMP(k)
+#endif
+#define BM_STEP_SLIM(FC, FN, G_)                                                                  \
+    {                                                                                             \
+        BM_PSTAMP(0)                                                                              \
+        if (!BM_ABL(3)) read_frags<QL, G, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
+        BM_PSTAMP(1)                                                                              \
+        if (!BM_ABL(2)) store_chunk_slim<QL, G>(G_, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid);       \
+        BM_PSTAMP(2)                                                                              \
+        if (!BM_ABL(0)) load_chunk_slim<QL, G, SEG2>(G_, kr, pl1, pl2, nch1, nch, cc + 4);        \
+        BM_PSTAMP(3)                                                                              \
+        mfma_frags<G, ABL>(acc, FC);                                                              \
+        BM_PSTAMP(4)                                                                              \
+        if (!BM_ABL(7)) { BM_SCHED_STEP }                                                         \
+        if (!BM_ABL(5)) __syncthreads();                                                          \
+        BM_PSTAMP(5)                                                                              \
         b1 = b2;                                                                                  \
         b2 = (b2 == NBUF - 1) ? 0 : b2 + 1;                                                       \
         ++cc;                                                                                     \
@@ -359,9 +484,44 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, 
     // steady state: steps 0 .. nch-3 carry the full LDS / global traffic; the last two steps
     // (pipeline drain) only have fragments to read and MFMAs to issue
     const int full = (nch > 2) ? nch - 2 : 0;
-    for (int pi = 0; pi < full / 2; ++pi) {
-        BM_STEP(fa, fb, g0)
-        BM_STEP(fb, fa, g1)
+    const int npairs = full / 2;
+    // can the pair of steps starting at step c0 take the slim path?  chunks c0+2, c0+3 (stored)
+    // and c0+4, c0+5 (loaded; past nch: prefetch overrun) must all be full chunks
+    auto pair_is_slim = [&](int c0) -> bool {
+        if (!FAST || BM_ABL(6) || nfull1 == 0) return false;      // (overrun loads fall back on chunk 0)
+        bool ok = true;
+#pragma unroll
+        for (int d = 2; d < 6; ++d) {
+            const int c = c0 + d;
+            ok = ok && ((c < nfull1) | (SEG2 && c >= nch1 && c - nch1 < nfull2) | (d >= 4 && c >= nch));
+        }
+        return ok;
+    };
+    // Runs of slim / careful pairs as separate COUNTED loops (an if/else inside one loop, or a
+    // loop whose exit test depends on the chunk state, makes hipcc copy ~100 loop-carried
+    // registers - and wait for the loads in flight - on every back edge).
+    auto run_length = [&](int c0, int remaining, bool want_slim) -> int {
+        int n = 0;
+        while (n < remaining && pair_is_slim(c0 + 2 * n) == want_slim) ++n;
+        return n;
+    };
+    int left = npairs;
+#pragma unroll 1
+    for (int round = 0; round < 2 && left > 0; ++round) {       // segment 1, then segment 2
+        const int ns = run_length(cc, left, true);
+#pragma unroll 1
+        for (int q = 0; q < ns; ++q) {
+            BM_STEP_SLIM(fa, fb, g0)
+            BM_STEP_SLIM(fb, fa, g1)
+        }
+        left -= ns;
+        const int nc = (round == 1) ? left : run_length(cc, left, false);
+#pragma unroll 1
+        for (int q = 0; q < nc; ++q) {
+            BM_STEP(fa, fb, g0)
+            BM_STEP(fb, fa, g1)
+        }
+        left -= nc;
     }
     if (full & 1) {
         BM_STEP(fa, fb, g0)
@@ -369,30 +529,35 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[2][NJ], const KRange &kr, 
     }
     BM_MSTAMP(3);
     if (nch >= 2) {
-        if (!BM_ABL(3)) read_frags<QL, NJ, ABL>(fb, sP + b1 * P_BUF, sQ + b1 * G::Q_BUF, wi, wj, lane);
-        side.step();
-        mfma_frags<NJ, ABL>(acc, fa);
-        side.step();
-        mfma_frags<NJ, ABL>(acc, fb);
+        if (!BM_ABL(3)) read_frags<QL, G, ABL>(fb, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane);
+        mfma_frags<G, ABL>(acc, fa);
+        mfma_frags<G, ABL>(acc, fb);
     } else {
-        side.step();
-        mfma_frags<NJ, ABL>(acc, fa);
+        mfma_frags<G, ABL>(acc, fa);
     }
     __syncthreads();           // the LDS ring may be refilled by a following pipeline
     BM_MSTAMP(4);
+#ifdef BM_PROBE
+    if (BM_ABL(7) && stamps && lane == 0 && (w == 0 || w == 3)) {
+        long long *o = stamps + 2048 + (long long)blockIdx.x * 8 + (w ? 8 : 0);    // (stamps = dbg + 2048 + 8*block)
+        for (int k = 0; k < 6; ++k) o[k] = pst[k];
+    }
+#undef BM_PSTAMP
+#endif
 #undef BM_STEP
+#undef BM_STEP_SLIM
+#undef BM_STEP_TAIL
 #undef BM_SCHED_STEP
 #undef BM_SG
 }
 
-// the 8 consecutive outputs of a lane for j sub-tile n: v[e], e = 2r + t  <->  i = ib + e
-template <int NJ>
-__device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[2][NJ], int n, float (&v)[8]) {
+// the E = 4*MI consecutive outputs of a lane for j sub-tile n: v[e], e = MI*r + t  <->  i = ib + e
+template <class G>
+__device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[G::MI][G::NJ], int n, float (&v)[G::E]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        v[2 * r] = acc[0][n][r];
-        v[2 * r + 1] = acc[1][n][r];
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < G::MI; ++t) v[G::MI * r + t] = acc[t][n][r];
 }
 
 // XCD-aware block -> tile map: blocks are dispatched round-robin over the 8 XCDs

@@ -28,6 +28,7 @@ struct ActArgs {
     int sample;                  // 1: states = draw(means); 0: states = means
     float *means;                // may be null
     float *states;               // may be null
+    float *negmeans;             // may be null: -means (P operand of the negative phase in grad_kernel form 0)
     int ldo;
     PhiloxKey key;
     long long row0;              // global row of local row 0 (rank-invariant bitmaps)
@@ -102,72 +103,78 @@ __device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int
     }
 }
 
-template <bool SEG2, bool FAST, int ABL = 0>
-__global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    const int tiles_j = (a.J + TJ - 1) / TJ;
+template <int MI> struct PhiloxFor { typedef PhiloxPair type; };
+template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
+
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0>
+__global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
+    constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
+    const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
     int ti, tj;
     BM_STAMP(0);
     if (a.skip && *a.skip) return;                 // wave-uniform: converged mean-field loop
     block_to_tile(tiles_j, ti, tj);
-    const int i0 = ti * TI, j0 = tj * TJ;
+    const int i0 = ti * G::TI, j0 = tj * G::TJ;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w & 1, wj = w >> 1;
+    const int wi = w % G::WI, wj = w / G::WI;
     const int g = lane >> 4, l15 = lane & 15;
-    const int j = j0 + wj * 16 + l15;
-    const int ib0 = i0 + wi * 32 + g * 8;          // 8 consecutive outputs i = ib0 + e
+    const int ib0 = i0 + wi * (16 * G::MI) + g * E;     // E consecutive outputs i = ib0 + e
 
     // epilogue inputs fetched before the main loop so their latency is off the tail
-    const bool full8 = (ib0 + 7 < a.I);
-    float bs[8], sg[8];
+    float bs[E], sg[E];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < E; ++e) {
         const int i = (ib0 + e < a.I) ? ib0 + e : a.I - 1;
         bs[e] = a.bias[i];
         sg[e] = a.sigma ? a.sigma[i] : 1.0f;
     }
-    // the lane's two Philox blocks advance one round per K step inside the main loop
     const bool rng_fast = ((a.I & 3) == 0);
-    PhiloxPair rng;
+    KRange kr;
+    kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
+    kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2;
+    static_assert(G::NJ == 1, "act_kernel: one j sub-tile per wave");
+    const int j = j0 + wj * 16 + l15;
+    // the lane's Philox block(s) are computed inside the main loop's pipeline fill
+    typename PhiloxFor<G::MI>::type rng;
     rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
-    f32x4 acc[2][1];
-    acc[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[G::MI][1];
+#pragma unroll
+    for (int t = 0; t < G::MI; ++t) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.acc_init && j < a.J) {                   // start the chain from a stored partial sum
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int i = ib0 + 2 * r + t;
+            for (int t = 0; t < G::MI; ++t) {
+                const int i = ib0 + G::MI * r + t;
                 if (i < a.I) acc[t][0][r] = a.acc_init[(size_t)j * a.ld_init + i];
             }
     }
-    KRange kr;
-    kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
-    kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2; kr.sgn2 = 1.0f;
     if (a.sample) {          // wave-uniform: the Philox rounds ride along only when a draw follows
 #ifdef BM_PROBE
-        mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+        mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
 #else
-        mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng);
+        mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng);
 #endif
     } else {
         NoSide none;
-        mainloop<XM, 1, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, none);
+        mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, none);
     }
-    if (a.sample) rng.finish();
     BM_STAMP(1);
 
-    float z[8];
-    lane_outputs<1>(acc, 0, z);
+    float z[E];
+    lane_outputs<G>(acc, 0, z);
     float dmax = 0.f;
     if (BM_ABL(4)) {
-        if (j < a.J && ib0 < a.I && a.states) a.states[(size_t)j * a.ldo + ib0] = z[0] + z[1] + z[2] + z[3] + z[4] + z[5] + z[6] + z[7];
+        float zs = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) zs += z[e];
+        if (j < a.J && ib0 < a.I && a.states) a.states[(size_t)j * a.ldo + ib0] = zs;
     } else if (j < a.J && ib0 < a.I) {
         const bool al_out = ((a.ldo & 3) == 0);
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
+        for (int hlf = 0; hlf < NH; ++hlf) {
             const int ib = ib0 + 4 * hlf;
             if (ib >= a.I) break;
             const int nvalid = (a.I - ib < 4) ? a.I - ib : 4;
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
             }
             if (a.sample) {
                 if (rng_fast) {          // the 4 outputs are exactly one (precomputed) Philox block
-                    const uint32_t *wds = hlf ? rng.b : rng.a;
+                    const uint32_t *wds = rng.words(hlf);
                     if (a.kind == 0) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s[r] = (u32_to_uniform(wds[r]) < m[r]) ? 1.f : 0.f;
@@ -205,6 +212,12 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
             }
             const bool v4 = al_out && nvalid == 4;
             if (a.means) store4(a.means, o, m, nvalid, v4 && (((uintptr_t)a.means & 15u) == 0));
+            if (a.negmeans) {
+                float nm[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) nm[r] = -m[r];
+                store4(a.negmeans, o, nm, nvalid, v4 && (((uintptr_t)a.negmeans & 15u) == 0));
+            }
             if (a.states) store4(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
         }
     }
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
         float racc = 0.f, rdot = 0.f;
         if (j < a.J) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < E; ++e) {
                 const int i = ib0 + e;
                 if (i >= a.I) break;
                 if (a.rowacc) {
@@ -242,7 +255,6 @@ __global__ __launch_bounds__(NT, 1) void act_kernel(ActArgs a) {
             if (a.rowdot_out) atomicAdd(a.rowdot_out + j, rdot);
         }
     }
-    (void)full8;
     BM_STAMP(2);
 }
 
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(NT) void rbm_bias_fused_kernel(RbmBiasFusedArgs a) 
 // out[j][i] over i = above-units (contiguous in W), j = below-units; K = rows.
 struct GradArgs {
     Operand Ppos, Qpos; int Kpos;     // positive phase:  sum_b Qpos[b][j] * Ppos[b][i]
-    Operand Pneg, Qneg; int Kneg;     // negative phase
+    Operand Pneg, Qneg; int Kneg;     // negative phase (form 0: Pneg holds the NEGATED means, see below)
     int I, J;
     int form;                         // 0: (pos-neg)/N  (RBM, base_rbm.py:447-449); 1: pos/N - neg/M (DBM, dbm.py:553-570)
     int fused;                        // 1: apply the update in the epilogue; 0: write raw sums to `raw`
@@ -508,8 +520,10 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
 
 template <bool FAST, int ABL = 0>
 __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS2];
-    static_assert(SMEM_FLOATS2 >= CS_SMEM_FLOATS, "bias path reuses the tile LDS");
+    using G = GeoGrad;
+    constexpr int TI = G::TI;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
+    static_assert(G::SMEM_FLOATS >= CS_SMEM_FLOATS && G::NT == NT, "bias path reuses the tile LDS");
     // the bias/colsum workgroups sit BEHIND the tile workgroups in dispatch order: 208 tiles
     // (784x1024) take 208 CUs for the whole launch, the short bias groups cycle through
     // the CUs that are left and finish inside the tiles' shadow.
@@ -539,16 +553,17 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     KRange kr;
     kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
     if (a.form == 0) {
-        // RBM: ONE chain, positive rows then negative rows with the product negated
+        // RBM: ONE chain, positive rows then negative rows with the product negated: the caller
+        // passes Pneg = -h_k (act_kernel's `negmeans` output), fma(-p, q, acc) == acc - p*q exactly
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
-        kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = a.Kneg; kr.sgn2 = -1.0f;
-        mainloop<KM, 2, FAST, true, ABL>(pos, kr, i0, j0, smem, none);
+        kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = a.Kneg;
+        mainloop<KM, G, FAST, true, ABL>(pos, kr, i0, j0, smem, none);
     } else {
         // DBM: pos/N - neg/M with N != M needs the two sums separately
-        kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0; kr.sgn2 = 1.0f;
-        mainloop<KM, 2, FAST, false>(pos, kr, i0, j0, smem, none);
+        kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0;
+        mainloop<KM, G, FAST, false>(pos, kr, i0, j0, smem, none);
         kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
-        mainloop<KM, 2, FAST, false>(neg, kr, i0, j0, smem, none);
+        mainloop<KM, G, FAST, false>(neg, kr, i0, j0, smem, none);
     }
 
     BM_GSTAMP(1);
@@ -562,8 +577,8 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         const int j = j0 + wj * 32 + n * 16 + l15;
         if (j >= a.J) continue;
         float pv[8], nv[8];
-        lane_outputs<2>(pos, n, pv);
-        lane_outputs<2>(neg, n, nv);
+        lane_outputs<G>(pos, n, pv);
+        lane_outputs<G>(neg, n, nv);
         const size_t o = (size_t)j * a.ldw + ib0;
         const bool vec8 = (ib0 + 7 < a.I) && ((a.ldw & 3) == 0);      // 16-byte aligned run of 8 (ib0 % 8 == 0)
         if (!a.fused) {
@@ -703,7 +718,9 @@ struct FeArgs {
 };
 template <bool FAST>
 __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    using G = GeoAct;
+    constexpr int TI = G::TI, TJ = G::TJ;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
     const int tiles_j = (a.J + TJ - 1) / TJ;
     int ti, tj;
     block_to_tile(tiles_j, ti, tj);
@@ -713,8 +730,8 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
     NoSide none;
     KRange kr;
     kr.P1 = a.P; kr.Q1 = a.Q; kr.K1 = a.K;
-    kr.P2 = a.P; kr.Q2 = a.Q; kr.K2 = 0; kr.sgn2 = 1.0f;
-    mainloop<XM, 1, FAST, false>(acc, kr, i0, j0, smem, none);
+    kr.P2 = a.P; kr.Q2 = a.Q; kr.K2 = 0;
+    mainloop<XM, G, FAST, false>(acc, kr, i0, j0, smem, none);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
@@ -727,7 +744,7 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
             delta = 1.0f - 2.0f * a.Q.ptr[(size_t)j * a.Q.ld + fc];
         }
         float zz[8];
-        lane_outputs<1>(acc, 0, zz);
+        lane_outputs<G>(acc, 0, zz);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int i = i0 + wi * 32 + g * 8 + e;
@@ -905,33 +922,35 @@ __global__ void maxabsdiff_kernel(const float *A, int lda, const float *B, int l
 }
 
 // ------------------------------------------------------------- host launchers
-static inline int tile_grid(int I, int J) { return ((I + TI - 1) / TI) * ((J + TJ - 1) / TJ); }
+template <class G> static inline int tile_grid(int I, int J) { return ((I + G::TI - 1) / G::TI) * ((J + G::TJ - 1) / G::TJ); }
 
-static inline void launch_act(const ActArgs &a, hipStream_t st) {
+template <class G, int MINB>
+static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
     const bool seg2 = a.K2 > 0;
     const bool fast = operand_fast(a.P1, KM, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
                       (!seg2 || (operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2)));
-    const dim3 grid(tile_grid(a.I, a.J)), blk(NT);
+    const dim3 grid(tile_grid<G>(a.I, a.J)), blk(G::NT);
     if (seg2) {
-        if (fast) hipLaunchKernelGGL((act_kernel<true, true>), grid, blk, 0, st, a);
-        else      hipLaunchKernelGGL((act_kernel<true, false>), grid, blk, 0, st, a);
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true>), grid, blk, 0, st, a);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false>), grid, blk, 0, st, a);
     } else {
-        if (fast) hipLaunchKernelGGL((act_kernel<false, true>), grid, blk, 0, st, a);
-        else      hipLaunchKernelGGL((act_kernel<false, false>), grid, blk, 0, st, a);
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true>), grid, blk, 0, st, a);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false>), grid, blk, 0, st, a);
     }
 }
+static inline void launch_act(const ActArgs &a, hipStream_t st) { launch_act_geo<GeoAct, 1>(a, st); }
 
 static inline void launch_grad(const GradArgs &g, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
-    const dim3 grid(((g.I + TI - 1) / TI) * ((g.J + 63) / 64) + g.nbias), blk(NT);
+    const dim3 grid(tile_grid<GeoGrad>(g.I, g.J) + g.nbias), blk(NT);
     if (fast) hipLaunchKernelGGL((grad_kernel<true>), grid, blk, 0, st, g);
     else      hipLaunchKernelGGL((grad_kernel<false>), grid, blk, 0, st, g);
 }
 
 static inline void launch_fe_hidden(const FeArgs &f, hipStream_t st) {
     const bool fast = operand_fast(f.P, KM, f.K) && operand_fast(f.Q, XM, f.K);
-    const dim3 grid(tile_grid(f.I, f.J)), blk(NT);
+    const dim3 grid(tile_grid<GeoAct>(f.I, f.J)), blk(NT);
     if (fast) hipLaunchKernelGGL((fe_hidden_kernel<true>), grid, blk, 0, st, f);
     else      hipLaunchKernelGGL((fe_hidden_kernel<false>), grid, blk, 0, st, f);
 }

@@ -36,7 +36,7 @@ struct bm_rbm {
     Mat W, Wt, dW;                     // [V][H], [H][V], [V][H]
     DevBuf vb, hb, dvb, dhb, q, sigma;
     // chain workspaces
-    Mat h0m, h0s, hm, hs;              // [maxB][H]
+    Mat h0m, h0s, hm, hs, hneg;        // [maxB][H]; hneg = -hm (negative-phase operand of the outer products)
     Mat vm, vs, Xs, Xd;                // [maxB][V]
     DevBuf grad;      // [V*ldH | V | H | H] raw sums (the data-parallel all-reduce buffer)
     DevBuf pen;       // [H]
@@ -81,7 +81,7 @@ static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
 
 // E[h|v] (+ sample): base_rbm.py:339-351.  v [B][V] pitch ldv
 static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, float *states, int ldo,
-                      int sample, uint32_t site, int t) {
+                      int sample, uint32_t site, int t, float *negmeans = nullptr) {
     ProfScope _ps(h, KC_UP);
     ActArgs a;
     memset(&a, 0, sizeof(a));
@@ -94,7 +94,7 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.bmult = a.mult;
     a.kind = BM_UNIT_BERNOULLI;
     a.sample = sample;
-    a.means = means; a.states = states; a.ldo = ldo;
+    a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
     launch_act(a, h->stream);
@@ -147,7 +147,7 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out)
         launch_down(h, hstate, h->hs.ld, B, h->vm.p, h->vs.p, h->vm.ld, h->cfg.sample_v_states, SITE_V, t);
         const bool last_out = hm_out && t == k - 1;
         launch_up(h, h->vs.p, h->vs.ld, B, last_out ? hm_out : h->hm.p, h->hs.p, last_out ? h->H : h->hm.ld,
-                  h->cfg.sample_h_states, SITE_H, t);
+                  h->cfg.sample_h_states, SITE_H, t, (!hm_out && t == k - 1) ? h->hneg.p : nullptr);
         hstate = h->hs.p;
     }
     return 0;
@@ -206,7 +206,7 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
     g.Ppos = make_operand(h->h0m.p, h->h0m.ld, h->H);   // h0 means [k=b][i=h]           :447
     g.Qpos = make_operand(h->Xin, h->Xin_ld, h->V);     // X        [k=b][j=v]
     g.Kpos = B;
-    g.Pneg = make_operand(h->hm.p, h->hm.ld, h->H);     // h_k means                     :448
+    g.Pneg = make_operand(h->hneg.p, h->hneg.ld, h->H); // -(h_k means): the chain subtracts  :448
     g.Qneg = make_operand(h->vs.p, h->vs.ld, h->V);     // v_k states
     g.Kneg = B;
     g.I = h->H; g.J = h->V;
@@ -298,7 +298,7 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     BM_TRY(h->W.alloc(V, H)); BM_TRY(h->Wt.alloc(H, V)); BM_TRY(h->dW.alloc(V, H));
     BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
     BM_TRY(h->q.alloc(H)); BM_TRY(h->sigma.alloc(V));
-    BM_TRY(h->h0m.alloc(B, H)); BM_TRY(h->h0s.alloc(B, H)); BM_TRY(h->hm.alloc(B, H)); BM_TRY(h->hs.alloc(B, H));
+    BM_TRY(h->h0m.alloc(B, H)); BM_TRY(h->h0s.alloc(B, H)); BM_TRY(h->hm.alloc(B, H)); BM_TRY(h->hs.alloc(B, H)); BM_TRY(h->hneg.alloc(B, H));
     BM_TRY(h->vm.alloc(B, V)); BM_TRY(h->vs.alloc(B, V)); BM_TRY(h->Xs.alloc(B, V)); BM_TRY(h->Xd.alloc(B, V));
     BM_TRY(h->grad.alloc(h->grad_tail() + V + 2 * (size_t)H));
     BM_TRY(h->pen.alloc(H));
@@ -316,7 +316,7 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
 int bm_rbm_destroy(bm_rbm *h) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->stream);
-    Mat *mats[] = {&h->W, &h->Wt, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->vm, &h->vs, &h->Xs, &h->Xd};
+    Mat *mats[] = {&h->W, &h->Wt, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
     DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->pen, &h->rowacc};
     for (DevBuf *b : all) b->release();

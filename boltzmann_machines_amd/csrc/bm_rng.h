@@ -42,39 +42,53 @@ __device__ __forceinline__ void philox_block(const PhiloxKey &key, uint64_t bloc
     philox4x32_10((uint32_t)block, (uint32_t)(block >> 32), key.site, key.call, key.k0, key.k1, out);
 }
 
-// Two consecutive Philox blocks (= a lane's 8 consecutive outputs) advanced ONE ROUND
-// AT A TIME, so that the GEMM main loop can thread the ~50 VALU ops of a round
-// between the MFMAs of each K step (the matrix pipe and the VALU run concurrently)
-// instead of paying ~1.8k cycles per wave in the epilogue.  Branch free: rounds past
-// the 10th are computed and discarded, so the step body stays one scheduling region.
+// Two consecutive Philox blocks (= a lane's 8 consecutive outputs).  act_kernel computes them
+// in `fill()`, which the GEMM main loop calls while the first global loads are in flight
+// (the wave idles for one memory round trip there), so the ~250 VALU ops cost nothing and
+// stay out of the K loop, where every VALU instruction is paid in full (bm_gemm.h).
 struct PhiloxPair {
     uint32_t a[4], b[4];
     uint32_t k0, k1;
-    int done;
     __device__ __forceinline__ void init(const PhiloxKey &key, uint64_t block) {
         a[0] = (uint32_t)block; a[1] = (uint32_t)(block >> 32); a[2] = key.site; a[3] = key.call;
         const uint64_t nb = block + 1;
         b[0] = (uint32_t)nb; b[1] = (uint32_t)(nb >> 32); b[2] = key.site; b[3] = key.call;
-        k0 = key.k0; k1 = key.k1; done = 0;
+        k0 = key.k0; k1 = key.k1;
     }
-    static __device__ __forceinline__ void round1(uint32_t (&c)[4], uint32_t k0, uint32_t k1, bool live) {
+    static __device__ __forceinline__ void round1(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
         constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
         const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
         const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
         const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
-        c[0] = live ? n0 : c[0]; c[1] = live ? lo1 : c[1]; c[2] = live ? n2 : c[2]; c[3] = live ? lo0 : c[3];
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     }
-    __device__ __forceinline__ void step() {   // one round for both blocks (no-op after 10)
-        const bool live = done < 10;
-        round1(a, k0, k1, live);
-        round1(b, k0, k1, live);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        done += live ? 1 : 0;
+    __device__ __forceinline__ void fill() {
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            round1(a, k0, k1);
+            round1(b, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
     }
-    __device__ __forceinline__ void finish() {
-#pragma unroll 1
-        while (done < 10) step();
+    __device__ __forceinline__ const uint32_t *words(int h) const { return h ? b : a; }
+};
+
+// the same for ONE block (a lane's 4 consecutive outputs: geometries with MI = 1)
+struct PhiloxOne {
+    uint32_t a[4];
+    uint32_t k0, k1;
+    __device__ __forceinline__ void init(const PhiloxKey &key, uint64_t block) {
+        a[0] = (uint32_t)block; a[1] = (uint32_t)(block >> 32); a[2] = key.site; a[3] = key.call;
+        k0 = key.k0; k1 = key.k1;
     }
+    __device__ __forceinline__ void fill() {
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            PhiloxPair::round1(a, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+    }
+    __device__ __forceinline__ const uint32_t *words(int) const { return a; }
 };
 
 // TF Uint32ToFloat: 23 mantissa bits, [1,2) - 1

@@ -9,7 +9,7 @@ using namespace bm;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 __global__ __launch_bounds__(256) void k_empty(float *o) { if (threadIdx.x == 999) o[0] = 1.f; }
 __global__ __launch_bounds__(256, 2) void k_lds(float *o) {
-    __shared__ float sm[SMEM_FLOATS];
+    __shared__ float sm[GeoAct::SMEM_FLOATS];
     sm[threadIdx.x] = threadIdx.x;
     __syncthreads();
     if (sm[(threadIdx.x + 1) & 255] == 999.f) o[0] = 1.f;
@@ -45,23 +45,76 @@ int main(int argc, char **argv) {
     printf("k_args 256x256       %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_args, dim3(256), dim3(256), 0, st, a); }));
     long long *dbg; CK(hipMalloc((void **)&dbg, 8192 * 8)); CK(hipMemset(dbg, 0, 8192 * 8));
     a.dbg = dbg;
-    const dim3 grid(tile_grid(a.I, a.J)), blk(NT);
-#define RUN(MASK, NAME) { \
-        float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<false, true, MASK>), grid, blk, 0, st, a); }); \
+#define RUNG(GEO, MINB, MASK, NAME) { \
+        const int nblk = tile_grid<GEO>(a.I, a.J); \
+        const dim3 grid(nblk), blk(GEO::NT); \
+        float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, MASK>), grid, blk, 0, st, a); }); \
         std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
         double d[4] = {0, 0, 0, 0}, s1 = 0, s2 = 0; \
-        for (int b = 0; b < 256; ++b) { for (int q = 0; q < 4; ++q) d[q] += hd[2048 + b * 8 + q + 1] - hd[2048 + b * 8 + q]; s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
-        printf("%-26s %6.2f us | prologue-issue %5.0f  wait+store+sync %5.0f  loop %6.0f  tail %5.0f | mainloop %6.0f epilogue %5.0f\n", NAME, us, d[0]/256, d[1]/256, d[2]/256, d[3]/256, s1/256, s2/256); }
+        for (int b = 0; b < nblk; ++b) { for (int q = 0; q < 4; ++q) d[q] += hd[2048 + b * 8 + q + 1] - hd[2048 + b * 8 + q]; s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
+        printf("%-34s %6.2f us | fill %5.0f  sync %5.0f  loop %6.0f  tail %5.0f | mainloop %6.0f epilogue %5.0f  (%d wgs x %d thr, lds %d KB)\n", NAME, us, d[0]/nblk, d[1]/nblk, d[2]/nblk, d[3]/nblk, s1/nblk, s2/nblk, nblk, GEO::NT, GEO::SMEM_FLOATS * 4 / 1024); }
+#define RUN(MASK, NAME) RUNG(GeoAct, 1, MASK, NAME)
     RUN(0, "full")
+    RUN(64, "full, careful steps only")
     RUN(16, "no-epilogue")
     RUN(1, "no-gload")
     RUN(2, "no-mfma")
     RUN(4, "no-ldswrite")
     RUN(8, "no-ldsread")
     RUN(32, "no-barrier")
-    RUN(37, "no gload+write+barrier")
     RUN(45, "only mfma (+epilogue)")
     RUN(63, "nothing")
+    RUN(37, "mfma + reads")
+    RUN(5, "mfma + reads + barrier")
+    RUN(33, "mfma + reads + writes")
+    RUN(9, "mfma + writes + barrier")
+    RUN(4, "mfma + reads + gloads + barrier")
+    {   // phase-ordered step with stamps (wave 0 and wave 3 of every workgroup, step 4)
+        RUN(128, "phase-ordered steps")
+        std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost));
+        for (int wv = 0; wv < 2; ++wv) {
+            double d[5] = {0, 0, 0, 0, 0};
+            for (int b = 0; b < 256; ++b) for (int q = 0; q < 5; ++q) d[q] += hd[4096 + b * 16 + wv * 8 + q + 1] - hd[4096 + b * 16 + wv * 8 + q];
+            printf("   wave %d step 4: reads %5.0f  stores %5.0f  gloads %5.0f  mfmas %5.0f  barrier %5.0f cycles\n", wv * 3, d[0]/256, d[1]/256, d[2]/256, d[3]/256, d[4]/256);
+        }
+    }
+    {   // ---- alternative geometries (same problem)
+        typedef Geo<4, 2, 1, 1, 64> GA;      // 8 waves, 64 x 32 tile, wave 16 x 16
+        typedef Geo<2, 4, 1, 1, 64> GA2;     // 8 waves, 32 x 64 tile
+        typedef Geo<2, 2, 1, 1, 64> GS;      // 4 waves, 32 x 32 tile, 2 workgroups per CU
+        typedef Geo<2, 2, 1, 1, 32> GS32;    // ... BK = 32
+        typedef Geo<2, 2, 2, 1, 32> GB32;    // baseline tile, BK = 32
+        RUNG(GA, 1, 0, "8w 64x32 bk64 full")
+        RUNG(GA, 1, 45, "8w 64x32 bk64 only-mfma")
+        RUNG(GA2, 1, 0, "8w 32x64 bk64 full")
+        RUNG(GS, 2, 0, "4w 32x32 bk64 x2/CU full")
+        RUNG(GS, 2, 45, "4w 32x32 bk64 x2/CU only-mfma")
+        RUNG(GS32, 2, 0, "4w 32x32 bk32 x2/CU full")
+        RUNG(GS32, 4, 0, "4w 32x32 bk32 (minb 4) full")
+        RUNG(GB32, 1, 0, "4w 64x32 bk32 full")
+        // two half-batch launches on two streams (independent Gibbs chains of rows 0-255 / 256-511)
+        hipStream_t st2; CK(hipStreamCreate(&st2));
+        hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+        ActArgs h1 = a, h2 = a;
+        h1.J = B / 2; h1.Q1 = make_operand(X.p, X.ld, B / 2); h1.dbg = nullptr;
+        h2.J = B / 2; h2.Q1 = make_operand(X.p + (size_t)(B / 2) * X.ld, X.ld, B / 2); h2.row0 = B / 2;
+        h2.means = Hm.p + (size_t)(B / 2) * Hm.ld; h2.states = Hs.p + (size_t)(B / 2) * Hs.ld; h2.dbg = nullptr;
+#define RUN2(GEO, MINB, NAME, CHAIN) { \
+            const dim3 grid(tile_grid<GEO>(h1.I, h1.J)), blk(GEO::NT); \
+            auto once = [&] { \
+                (void)hipEventRecord(f0, st); (void)hipStreamWaitEvent(st2, f0, 0); \
+                for (int c = 0; c < CHAIN; ++c) { \
+                    hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, 0>), grid, blk, 0, st, h1); \
+                    hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, 0>), grid, blk, 0, st2, h2); } \
+                (void)hipEventRecord(f1, st2); (void)hipStreamWaitEvent(st, f1, 0); }; \
+            float us = time_it(st, e0, e1, once); \
+            printf("%-34s %6.2f us per fork-join of %d kernels per stream = %6.2f us per full-batch kernel\n", NAME, us, CHAIN, us / CHAIN); }
+        RUN2(GS, 2, "2 streams 4w 32x32 bk64", 1)
+        RUN2(GS, 2, "2 streams 4w 32x32 bk64", 3)
+        RUN2(GS32, 2, "2 streams 4w 32x32 bk32", 3)
+        RUN2(GB32, 2, "2 streams 4w 64x32 bk32 (128 wgs each)", 3)
+        RUN2(GeoAct, 1, "2 streams baseline geo (128 wgs each)", 3)
+    }
     {   // ---- grad kernel (RBM form 0, fused update) with and without the bias groups
         Mat dW, Wt, Vs, Hk;
         dW.alloc(V, H); Wt.alloc(H, V); Vs.alloc(B, V); Hk.alloc(B, H);
@@ -86,12 +139,13 @@ int main(int argc, char **argv) {
             g.nbias = 0;
         }
 #define GRUN(MASK, NAME) { \
-            const dim3 gg(((g.I + TI - 1) / TI) * ((g.J + 63) / 64)); \
+            const dim3 gg(tile_grid<GeoGrad>(g.I, g.J)); \
             float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<true, MASK>), gg, dim3(NT), 0, st, g); }); \
             std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
             double s1 = 0, s2 = 0; for (int b = 0; b < 208; ++b) { s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
             printf("grad %-26s %6.2f us | mainloop %6.0f epilogue %5.0f\n", NAME, us, s1/208, s2/208); }
         GRUN(0, "full")
+        GRUN(64, "full, careful steps only")
         GRUN(1, "no-gload")
         GRUN(2, "no-mfma")
         GRUN(4, "no-ldswrite")
