@@ -65,18 +65,26 @@ struct Geo {
     static constexpr int E = 4 * MI;                     // consecutive outputs per lane and j sub-tile
     static constexpr int P_STRIDE = (MI == 2) ? ((TI % 64 == 0) ? TI + 32 : TI) : ((TI % 32 == 0) ? TI + 16 : TI);
     static constexpr int Q_STRIDE_XM = BK + 2;
-    static constexpr int Q_STRIDE_KM = (TJ % 32 == 0) ? TJ + 16 : TJ;
+    // k-major Q: NJ == 2 interleaves the two j sub-tiles like the i side (sub-tile n holds
+    // j = base + 2*l15 + n: ONE ds_read_b64 per k-step, stride == 32 mod 64); NJ == 1 reads b32
+    static constexpr int Q_STRIDE_KM = (NJ == 2) ? ((TJ % 64 == 0) ? TJ + 32 : TJ) : ((TJ % 32 == 0) ? TJ + 16 : TJ);
     static constexpr int P_BUF = BK * P_STRIDE;
     static constexpr int Q_BUF = (BK * Q_STRIDE_KM > TJ * Q_STRIDE_XM) ? BK * Q_STRIDE_KM : TJ * Q_STRIDE_XM;
     static constexpr int SMEM_FLOATS = NBUF * (P_BUF + Q_BUF);
     static constexpr int NVP = TI * BK / (4 * NT);       // float4 per thread per chunk, P tile
     static constexpr int NVQ = TJ * BK / (4 * NT);       // ... Q tile
     static_assert(MI == 1 || MI == 2, "MI");
+    static_assert(NJ == 1 || NJ == 2, "NJ");
     static_assert(NVP >= 1 && NVP * 4 * NT == TI * BK, "P chunk must split evenly over the threads");
     static_assert(NVQ >= 1 && NVQ * 4 * NT == TJ * BK, "Q chunk must split evenly over the threads");
     static_assert(BK % 8 == 0, "BK");
 };
-using GeoAct = Geo<2, 2, 2, 1, 64>;      // 64 x 32 tile, 108 KiB LDS
+using GeoAct = Geo<2, 2, 2, 1, 64>;      // 64 x 32 tile, 4 waves of 32 x 16, 108 KiB LDS
+using GeoAct8 = Geo<2, 4, 1, 1, 64>;     // 32 x 64 tile, 8 waves of 16 x 16 (two per SIMD), 96 KiB LDS:
+                                         // more LDS traffic per MFMA but half the per-wave fill and
+                                         // epilogue; wins while the launch is about one tile per CU
+using GeoActS = Geo<2, 2, 1, 1, 64>;     // 32 x 32 tile, 4 waves of 16 x 16, 72 KiB LDS (two per CU): for
+                                         // outputs too small to give every CU a larger tile
 using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 132 KiB LDS
 
 struct Operand {
@@ -184,7 +192,7 @@ template <int QL, class G, int ABL = 0>
 __device__ __forceinline__ void read_frags(Frags<G> &f, const float *sP, const float *sQ, int wi, int wj, int lane) {
     const int g = lane >> 4, l15 = lane & 15;
     const float *pP = sP + g * G::P_STRIDE + wi * (16 * G::MI) + G::MI * l15;
-    const float *pQ = (QL == KM) ? sQ + g * G::Q_STRIDE_KM + wj * 16 * G::NJ + l15
+    const float *pQ = (QL == KM) ? sQ + g * G::Q_STRIDE_KM + wj * 16 * G::NJ + ((G::NJ == 2) ? 2 * l15 : l15)
                                  : sQ + (wj * 16 * G::NJ + l15) * G::Q_STRIDE_XM + g;
 #pragma unroll
     for (int kk = 0; kk < G::BK / 4; ++kk) {
@@ -197,9 +205,14 @@ __device__ __forceinline__ void read_frags(Frags<G> &f, const float *sP, const f
         } else {
             f.p[kk][0] = pP[kk * 4 * G::P_STRIDE];
         }
+        if (QL == KM && G::NJ == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(pQ + kk * 4 * G::Q_STRIDE_KM);
+            f.q[kk][0] = t.x; f.q[kk][G::NJ - 1] = t.y;
+        } else {
 #pragma unroll
-        for (int n = 0; n < G::NJ; ++n)
-            f.q[kk][n] = (QL == KM) ? pQ[kk * 4 * G::Q_STRIDE_KM + 16 * n] : pQ[16 * n * G::Q_STRIDE_XM + kk * 4];
+            for (int n = 0; n < G::NJ; ++n)
+                f.q[kk][n] = (QL == KM) ? pQ[kk * 4 * G::Q_STRIDE_KM + 16 * n] : pQ[16 * n * G::Q_STRIDE_XM + kk * 4];
+        }
     }
 }
 
@@ -215,6 +228,29 @@ __device__ __forceinline__ void mfma_frags(f32x4 (&acc)[G::MI][G::NJ], const Fra
             for (int t = 0; t < G::MI; ++t) {
                 if (BM_ABL(1)) { acc[t][n][0] += f.p[kk][t] * q; continue; }
                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk][t], q, acc[t][n], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// the same for the first `nq` groups of 4 k-steps only (last chunk of a contraction whose
+// K tail is shorter than BK: the zero-filled remainder would only add fma(0, 0, acc))
+template <class G, int ABL = 0>
+__device__ __forceinline__ void mfma_frags_head(f32x4 (&acc)[G::MI][G::NJ], const Frags<G> &f, int nq) {
+#pragma unroll
+    for (int q = 0; q < G::BK / 16; ++q) {
+        if (q < nq) {                    // wave-uniform
+#pragma unroll
+            for (int kk = 4 * q; kk < 4 * q + 4; ++kk) {
+#pragma unroll
+                for (int n = 0; n < G::NJ; ++n) {
+                    const float qv = f.q[kk][n];
+#pragma unroll
+                    for (int t = 0; t < G::MI; ++t) {
+                        if (BM_ABL(1)) { acc[t][n][0] += f.p[kk][t] * qv; continue; }
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.p[kk][t], qv, acc[t][n], 0, 0, 0);
+                    }
+                }
             }
         }
     }
@@ -397,7 +433,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     //   two k-steps into ds_read2st64); NW DS writes; NL global loads.
     // masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
     constexpr int NM = (BK / 4) * G::MI * G::NJ;
-    constexpr int NRG = BK / 8, RPG = 1 + G::NJ;
+    constexpr int NRG = BK / 8, RPG = (QL == KM && G::NJ == 2) ? 2 : 1 + G::NJ;
     constexpr int NW = G::NVP + ((QL == XM) ? 2 * G::NVQ : G::NVQ);
     constexpr int NL = G::NVP + G::NVQ;
     constexpr int MR = (NM >= 64) ? 2 : 1;            // MFMAs per read group
@@ -528,12 +564,15 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         fa = fb;               // keep the current fragments in `fa` for the drain (once per kernel)
     }
     BM_MSTAMP(3);
+    // groups of 16 k that the last chunk really holds
+    const int klast = (SEG2 && kr.K2 > 0) ? kr.K2 - (nch - nch1 - 1) * BK : kr.K1 - (nch1 - 1) * BK;
+    const int nq_last = (klast + 15) / 16;
     if (nch >= 2) {
         if (!BM_ABL(3)) read_frags<QL, G, ABL>(fb, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane);
         mfma_frags<G, ABL>(acc, fa);
-        mfma_frags<G, ABL>(acc, fb);
+        mfma_frags_head<G, ABL>(acc, fb, nq_last);
     } else {
-        mfma_frags<G, ABL>(acc, fa);
+        mfma_frags_head<G, ABL>(acc, fa, nq_last);
     }
     __syncthreads();           // the LDS ring may be refilled by a following pipeline
     BM_MSTAMP(4);
@@ -549,6 +588,13 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #undef BM_STEP_TAIL
 #undef BM_SCHED_STEP
 #undef BM_SG
+}
+
+// j coordinate (within the wave's 16*NJ columns) of a lane's outputs in j sub-tile n.
+// Must match read_frags: k-major Q with NJ == 2 interleaves the sub-tiles.
+template <int QL, class G>
+__device__ __forceinline__ int lane_j(int l15, int n) {
+    return (QL == KM && G::NJ == 2) ? 2 * l15 + n : 16 * n + l15;
 }
 
 // the E = 4*MI consecutive outputs of a lane for j sub-tile n: v[e], e = MI*r + t  <->  i = ib + e

@@ -9,6 +9,10 @@
 //                   canonical sequential order) + bias / q_means updates.
 //   elementwise / reduction helpers for dropout, msre, l2, free energy, PLL.
 #pragma once
+#include <stdlib.h>
+#include <array>
+#include <map>
+#include <mutex>
 #include "bm_gemm.h"
 #include "bm_numerics.h"
 #include "bm_rng.h"
@@ -106,13 +110,38 @@ __device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int
 template <int MI> struct PhiloxFor { typedef PhiloxPair type; };
 template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
 
+// act_kernel's side work for the main loop's pipeline fill
+template <int E, class Rng> struct ActSide {
+    const float *bias, *sigma;
+    int ib0, I, with_rng;
+    float bs[E], sg[E];
+    Rng rng;
+    __device__ __forceinline__ void fill() {
+        const float *sp = sigma ? sigma : bias;     // unconditional loads + select: no branch, no early wait
+        const bool has_sigma = sigma != nullptr;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = (ib0 + e < I) ? ib0 + e : I - 1;
+            bs[e] = bias[i];
+            const float sv = sp[i];
+            sg[e] = has_sigma ? sv : 1.0f;
+        }
+        if (with_rng) rng.fill();       // wave-uniform
+    }
+};
+
 template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
+    BM_STAMP(0);
+    // All hot kernel arguments in SGPRs after ONE scalar-memory round trip (hipcc otherwise
+    // loads them lazily: five serialized kernarg waits before the first operand load goes out).
+    asm volatile("" :: "s"(a.P1.ptr), "s"(a.Q1.ptr), "s"(a.P1.ld), "s"(a.Q1.ld), "s"(a.P1.nx), "s"(a.Q1.nx),
+                       "s"(a.K1), "s"(a.K2), "s"(a.bias), "s"(a.sigma), "s"(a.means), "s"(a.states), "s"(a.ldo),
+                       "s"(a.sample), "s"(a.kind), "s"(a.row0), "s"(a.I), "s"(a.J), "s"(a.skip));
     const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
     int ti, tj;
-    BM_STAMP(0);
     if (a.skip && *a.skip) return;                 // wave-uniform: converged mean-field loop
     block_to_tile(tiles_j, ti, tj);
     const int i0 = ti * G::TI, j0 = tj * G::TJ;
@@ -121,23 +150,17 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     const int g = lane >> 4, l15 = lane & 15;
     const int ib0 = i0 + wi * (16 * G::MI) + g * E;     // E consecutive outputs i = ib0 + e
 
-    // epilogue inputs fetched before the main loop so their latency is off the tail
-    float bs[E], sg[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = (ib0 + e < a.I) ? ib0 + e : a.I - 1;
-        bs[e] = a.bias[i];
-        sg[e] = a.sigma ? a.sigma[i] : 1.0f;
-    }
     const bool rng_fast = ((a.I & 3) == 0);
     KRange kr;
     kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
     kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2;
     static_assert(G::NJ == 1, "act_kernel: one j sub-tile per wave");
     const int j = j0 + wj * 16 + l15;
-    // the lane's Philox block(s) are computed inside the main loop's pipeline fill
-    typename PhiloxFor<G::MI>::type rng;
-    rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
+    // Side work for the pipeline fill (runs while the first operand loads are in flight):
+    // the epilogue inputs (bias, sigma) and, when a draw follows, the lane's Philox block(s).
+    ActSide<E, typename PhiloxFor<G::MI>::type> side;
+    side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
+    side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
     f32x4 acc[G::MI][1];
 #pragma unroll
@@ -151,16 +174,14 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
                 if (i < a.I) acc[t][0][r] = a.acc_init[(size_t)j * a.ld_init + i];
             }
     }
-    if (a.sample) {          // wave-uniform: the Philox rounds ride along only when a draw follows
 #ifdef BM_PROBE
-        mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+    mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
 #else
-        mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, rng);
+    mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, side);
 #endif
-    } else {
-        NoSide none;
-        mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, none);
-    }
+    const float (&bs)[E] = side.bs;
+    const float (&sg)[E] = side.sg;
+    const typename PhiloxFor<G::MI>::type &rng = side.rng;
     BM_STAMP(1);
 
     float z[E];
@@ -574,7 +595,7 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     if (ib0 >= a.I) return;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int j = j0 + wj * 32 + n * 16 + l15;
+        const int j = j0 + wj * 32 + lane_j<KM, G>(l15, n);
         if (j >= a.J) continue;
         float pv[8], nv[8];
         lane_outputs<G>(pos, n, pv);
@@ -938,7 +959,79 @@ static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
         else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false>), grid, blk, 0, st, a);
     }
 }
-static inline void launch_act(const ActArgs &a, hipStream_t st) { launch_act_geo<GeoAct, 1>(a, st); }
+// ---- act_kernel geometry choice ---------------------------------------------------------
+// Three geometries compute bit-identical results (tests run all of them); which one is fastest
+// depends on how the output tiles fill the 256 CUs and on the K length, and did not follow a
+// simple rule in measurements (784x1024x512: 8-wave; AIS 20000 chains and 3072x5000: 32x32
+// tiles; DBM 784-512-1024 mean-field: 64x32).  So the launcher measures: the first 9 launches
+// of every distinct shape rotate through the candidates bracketed by HIP events on the
+// engine stream (they are REAL launches of the caller's work - no extra launches, no side
+// effects, no synchronisation: the events are polled on later launches), then the fastest is
+// used.  BM355_ACT_GEO=4|8|1 forces one geometry (experiments, tests).
+static inline int act_geo_override() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("BM355_ACT_GEO"); v = e ? atoi(e) : 0; }
+    return v;
+}
+static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
+    if (geo == 8)      launch_act_geo<GeoAct8, 1>(a, st);
+    else if (geo == 1) launch_act_geo<GeoActS, 2>(a, st);
+    else               launch_act_geo<GeoAct, 1>(a, st);
+}
+struct ActTune {
+    static constexpr int NC = 3, R = 3;
+    int best = 0, nlaunch = 0, ndone = 0;
+    float tmin[NC] = {1e30f, 1e30f, 1e30f};
+    struct Sample { hipEvent_t e0 = nullptr, e1 = nullptr; int cand = 0; bool pending = false; } s[NC * R];
+};
+static inline void launch_act(const ActArgs &a, hipStream_t st) {
+    static const int cand_geo[ActTune::NC] = {8, 4, 1};
+    const int ov = act_geo_override();
+    if (ov) { launch_act_as(ov, a, st); return; }
+    static std::mutex mu;
+    static std::map<std::array<long long, 6>, ActTune> table;
+    const std::array<long long, 6> key = {a.I, a.J, a.K1, a.K2, (long long)((a.sample ? 1 : 0) | (a.kind << 1) | (a.prev ? 8 : 0) | (a.rowacc ? 16 : 0) | (a.acc_init ? 32 : 0)), 0LL};
+    int geo;
+    ActTune::Sample *smp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        ActTune &T = table[key];
+        if (!T.best) {
+            for (auto &q : T.s) {
+                if (q.pending && hipEventQuery(q.e1) == hipSuccess) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess && ms < T.tmin[q.cand]) T.tmin[q.cand] = ms;
+                    (void)hipEventDestroy(q.e0); (void)hipEventDestroy(q.e1);
+                    q.pending = false; ++T.ndone;
+                }
+            }
+            if (T.ndone == ActTune::NC * ActTune::R) {
+                int b = 0;
+                for (int c = 1; c < ActTune::NC; ++c) if (T.tmin[c] < T.tmin[b]) b = c;
+                T.best = cand_geo[b];
+            }
+        }
+        if (T.best) {
+            geo = T.best;
+        } else if (T.nlaunch < ActTune::NC * ActTune::R) {
+            smp = &T.s[T.nlaunch];
+            smp->cand = T.nlaunch % ActTune::NC;
+            geo = cand_geo[smp->cand];
+            if (hipEventCreate(&smp->e0) != hipSuccess || hipEventCreate(&smp->e1) != hipSuccess) { smp = nullptr; T.best = geo = 4; }
+            ++T.nlaunch;
+        } else {
+            geo = (tile_grid<GeoAct>(a.I, a.J) <= 512) ? 8 : 1;      // samples still in flight
+        }
+        if (smp) {
+            (void)hipEventRecord(smp->e0, st);
+            launch_act_as(geo, a, st);
+            (void)hipEventRecord(smp->e1, st);
+            smp->pending = true;
+            return;
+        }
+    }
+    launch_act_as(geo, a, st);
+}
 
 static inline void launch_grad(const GradArgs &g, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
