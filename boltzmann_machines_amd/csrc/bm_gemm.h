@@ -39,8 +39,10 @@
 
 namespace bm {
 
-// VALU side work run in the shadow of the pipeline fill (the first global round trip): default none
-struct NoSide { __device__ __forceinline__ void fill() {} };
+// Side work hooks of the main loop: fill() runs in the shadow of the pipeline fill (the first
+// global round trip), drain() is issued before the MFMAs of the last two chunks (loads the
+// epilogue needs: their latency hides under ~2k cycles of matrix work).  Default: none.
+struct NoSide { __device__ __forceinline__ void fill() {} __device__ __forceinline__ void drain() {} };
 
 // compile-time ablation mask (template parameter ABL, 0 in the product; tools/probe_act.hip
 // instantiates other values to price each pipeline stage)
@@ -567,6 +569,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     // groups of 16 k that the last chunk really holds
     const int klast = (SEG2 && kr.K2 > 0) ? kr.K2 - (nch - nch1 - 1) * BK : kr.K1 - (nch1 - 1) * BK;
     const int nq_last = (klast + 15) / 16;
+    side.drain();
     if (nch >= 2) {
         if (!BM_ABL(3)) read_frags<QL, G, ABL>(fb, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane);
         mfma_frags<G, ABL>(acc, fa);

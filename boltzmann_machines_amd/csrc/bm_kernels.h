@@ -128,6 +128,7 @@ template <int E, class Rng> struct ActSide {
         }
         if (with_rng) rng.fill();       // wave-uniform
     }
+    __device__ __forceinline__ void drain() {}
 };
 
 template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0>
@@ -539,6 +540,44 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
     w = w + d;                     // W.assign_add               (base_rbm.py:468)
 }
 
+// x / N, bit-identical to the IEEE division: a power-of-two N (the usual batch sizes) turns it
+// into an exact scaling by 1/N; anything else takes the real division.
+struct DivBy {
+    float n, inv; bool pow2;
+    __device__ __forceinline__ explicit DivBy(float N) : n(N), inv(1.0f / N),
+        pow2((__float_as_uint(N) & 0x007fffffu) == 0u && N >= 1.0f && N <= 16777216.0f) {}
+};
+
+// grad_kernel's side work: the W / dW values of the lane's outputs are fetched at the start of
+// the pipeline drain, so the read-modify-write epilogue does not start with a memory round trip
+struct GradSide {
+    const float *W, *dW; int ldw, I, J, ib0, jb[2]; bool on, vec8;
+    float4 w[2][2], d[2][2];
+    __device__ __forceinline__ void fill() {}
+    __device__ __forceinline__ void drain() {
+        if (!on || ib0 >= I) return;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (jb[n] >= J) continue;
+            const size_t o = (size_t)jb[n] * ldw + ib0;
+            if (vec8) {
+                w[n][0] = *reinterpret_cast<const float4 *>(W + o);  w[n][1] = *reinterpret_cast<const float4 *>(W + o + 4);
+                d[n][0] = *reinterpret_cast<const float4 *>(dW + o); d[n][1] = *reinterpret_cast<const float4 *>(dW + o + 4);
+            } else {
+                float tw[8], td[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool ok = ib0 + e < I;
+                    tw[e] = ok ? W[o + e] : 0.f;
+                    td[e] = ok ? dW[o + e] : 0.f;
+                }
+                w[n][0] = make_float4(tw[0], tw[1], tw[2], tw[3]); w[n][1] = make_float4(tw[4], tw[5], tw[6], tw[7]);
+                d[n][0] = make_float4(td[0], td[1], td[2], td[3]); d[n][1] = make_float4(td[4], td[5], td[6], td[7]);
+            }
+        }
+    }
+};
+
 template <bool FAST, int ABL = 0>
 __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     using G = GeoGrad;
@@ -553,11 +592,19 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         rbm_bias_fused_block(a.bias, (int)blockIdx.x - ntile_blocks, smem);
         return;
     }
-    constexpr int TJ2 = 64;                       // NJ = 2: 64 x 64 tiles
+    // hot kernel arguments after ONE scalar-memory round trip (see act_kernel)
+    asm volatile("" :: "s"(a.Ppos.ptr), "s"(a.Qpos.ptr), "s"(a.Ppos.ld), "s"(a.Qpos.ld), "s"(a.Ppos.nx), "s"(a.Qpos.nx),
+                       "s"(a.Pneg.ptr), "s"(a.Qneg.ptr), "s"(a.Pneg.ld), "s"(a.Qneg.ld), "s"(a.Kpos), "s"(a.Kneg),
+                       "s"(a.I), "s"(a.J), "s"(a.W), "s"(a.dW), "s"(a.ldw), "s"(a.form), "s"(a.fused));
+    constexpr int TJ2 = G::TJ;                    // NJ = 2: 64 x 64 tiles
     const int tiles_j = (a.J + TJ2 - 1) / TJ2;
     int ti, tj;
     block_to_tile(tiles_j, ti, tj, 0, a.nbias);
     const int i0 = ti * TI, j0 = tj * TJ2;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int ib0 = i0 + wi * 32 + g * 8;
 
 #ifdef BM_PROBE
 #define BM_GSTAMP(n) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 4 + (n)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -570,7 +617,15 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int n = 0; n < 2; ++n) pos[t][n] = neg[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    NoSide none;
+    GradSide side;
+    side.W = a.W; side.dW = a.dW; side.ldw = a.ldw; side.I = a.I; side.J = a.J; side.ib0 = ib0;
+    side.jb[0] = j0 + wj * 32 + lane_j<KM, G>(l15, 0);
+    side.jb[1] = j0 + wj * 32 + lane_j<KM, G>(l15, 1);
+    side.vec8 = (ib0 + 7 < a.I) && ((a.ldw & 3) == 0);            // 16-byte aligned run of 8 (ib0 % 8 == 0)
+#ifndef BM_GRAD_PREFETCH
+#define BM_GRAD_PREFETCH 0
+#endif
+    side.on = BM_GRAD_PREFETCH && a.fused != 0;
     KRange kr;
     kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
     if (a.form == 0) {
@@ -578,30 +633,32 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         // passes Pneg = -h_k (act_kernel's `negmeans` output), fma(-p, q, acc) == acc - p*q exactly
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
         kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = a.Kneg;
-        mainloop<KM, G, FAST, true, ABL>(pos, kr, i0, j0, smem, none);
+        mainloop<KM, G, FAST, true, ABL>(pos, kr, i0, j0, smem, side);
     } else {
         // DBM: pos/N - neg/M with N != M needs the two sums separately
         kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0;
-        mainloop<KM, G, FAST, false>(pos, kr, i0, j0, smem, none);
+        side.on = false;
+        mainloop<KM, G, FAST, false>(pos, kr, i0, j0, smem, side);
         kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
-        mainloop<KM, G, FAST, false>(neg, kr, i0, j0, smem, none);
+        side.on = BM_GRAD_PREFETCH && a.fused != 0;
+        mainloop<KM, G, FAST, false>(neg, kr, i0, j0, smem, side);
     }
 
     BM_GSTAMP(1);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w & 1, wj = w >> 1;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int ib0 = i0 + wi * 32 + g * 8;
     if (ib0 >= a.I) return;
+    if (!BM_GRAD_PREFETCH) { side.on = a.fused != 0; side.drain(); }
+    const DivBy divN(a.N), divM(a.M);
+    float wt[2][8];                 // updated W values of both j (adjacent columns of Wt)
+    bool jok[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-        const int j = j0 + wj * 32 + lane_j<KM, G>(l15, n);
-        if (j >= a.J) continue;
+        const int j = side.jb[n];
+        jok[n] = j < a.J;
+        if (!jok[n]) continue;
         float pv[8], nv[8];
         lane_outputs<G>(pos, n, pv);
         lane_outputs<G>(neg, n, nv);
         const size_t o = (size_t)j * a.ldw + ib0;
-        const bool vec8 = (ib0 + 7 < a.I) && ((a.ldw & 3) == 0);      // 16-byte aligned run of 8 (ib0 % 8 == 0)
         if (!a.fused) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -611,28 +668,25 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
             }
             continue;
         }
-        float wv[8], dv[8], pe[8];
-        if (vec8) {
-            const float4 w0 = *reinterpret_cast<const float4 *>(a.W + o), w1 = *reinterpret_cast<const float4 *>(a.W + o + 4);
-            const float4 d0 = *reinterpret_cast<const float4 *>(a.dW + o), d1 = *reinterpret_cast<const float4 *>(a.dW + o + 4);
-            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
-            dv[0] = d0.x; dv[1] = d0.y; dv[2] = d0.z; dv[3] = d0.w; dv[4] = d1.x; dv[5] = d1.y; dv[6] = d1.z; dv[7] = d1.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool ok = ib0 + e < a.I;
-                wv[e] = ok ? a.W[o + e] : 0.f;
-                dv[e] = ok ? a.dW[o + e] : 0.f;
-            }
-        }
+        float wv[8] = {side.w[n][0].x, side.w[n][0].y, side.w[n][0].z, side.w[n][0].w, side.w[n][1].x, side.w[n][1].y, side.w[n][1].z, side.w[n][1].w};
+        float dv[8] = {side.d[n][0].x, side.d[n][0].y, side.d[n][0].z, side.d[n][0].w, side.d[n][1].x, side.d[n][1].y, side.d[n][1].z, side.d[n][1].w};
+        float pe[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) pe[e] = (a.pen && ib0 + e < a.I) ? a.pen[ib0 + e] : 0.f;
+        float gr[8];
+        if (divN.pow2 && divM.pow2) {          // wave-uniform: exact scaling instead of 8-16 IEEE divisions
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gr[e] = (a.form == 0) ? pv[e] * divN.inv : (pv[e] * divN.inv - nv[e] * divM.inv);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gr[e] = (a.form == 0) ? pv[e] / a.N : (pv[e] / a.N - nv[e] / a.M);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float gr = (a.form == 0) ? pv[e] / a.N : (pv[e] / a.N - nv[e] / a.M);
-            apply_w_update(gr, pe[e], a.l2, a.lr, a.mom, wv[e], dv[e]);
+            apply_w_update(gr[e], pe[e], a.l2, a.lr, a.mom, wv[e], dv[e]);
+            wt[n][e] = wv[e];
         }
-        if (vec8) {
+        if (side.vec8) {
             *reinterpret_cast<float4 *>(a.W + o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
             *reinterpret_cast<float4 *>(a.W + o + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
             *reinterpret_cast<float4 *>(a.dW + o) = make_float4(dv[0], dv[1], dv[2], dv[3]);
@@ -642,10 +696,20 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
             for (int e = 0; e < 8; ++e)
                 if (ib0 + e < a.I) { a.W[o + e] = wv[e]; a.dW[o + e] = dv[e]; }
         }
-        if (a.Wt) {                                   // maintained transpose (prop-down P operand)
+    }
+    if (a.fused && a.Wt) {                            // maintained transpose (prop-down P operand)
+        const int ja = side.jb[0];                    // the lane's two columns are adjacent: ja, ja + 1
+        const bool pair = jok[0] && jok[1] && ((a.ldwt & 1) == 0);     // (ja is even)
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (ib0 + e < a.I) a.Wt[(size_t)(ib0 + e) * a.ldwt + j] = wv[e];
+        for (int e = 0; e < 8; ++e) {
+            if (ib0 + e >= a.I) break;
+            float *dst = a.Wt + (size_t)(ib0 + e) * a.ldwt + ja;
+            if (pair) {
+                *reinterpret_cast<float2 *>(dst) = make_float2(wt[0][e], wt[1][e]);
+            } else {
+                if (jok[0]) dst[0] = wt[0][e];
+                if (jok[1]) dst[1] = wt[1][e];
+            }
         }
     }
     BM_GSTAMP(2);
