@@ -31,8 +31,11 @@
 //   P  MI=2 (ds_read_b64, 64 banks): stride == 32 (mod 64): lanes 0-15 cover 32
 //      consecutive dwords of row k, lanes 16-31 the other 32 banks with row k+1.
 //   P  MI=1 / Q KM (ds_read_b32, 32 banks): stride == 16 (mod 32).
-//   Q XM (ds_read_b32): stride BK+2 == 2 (mod 4): bank = (2j + k) mod 32 is a
-//      bijection on 16 j x 2 k.
+//   Q XM (ds_read_b32, half-wave passes over 32 banks): stride BK+2 == 2 (mod 4): bank =
+//      (2j + k) mod 32 is a bijection on 16 j x 2 k.  The b64 stores of an x-major tile go out
+//      in passes of 16 lanes; xm_slot() gives 16 consecutive lanes the first (or second) 8
+//      float4 of TWO adjacent rows, whose dwords 4c+{0,1} (+2 for the odd row) cover all 32
+//      banks (16 lanes of ONE row collide 2-way: rocprofv3 SQ_LDS_BANK_CONFLICT).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -125,6 +128,17 @@ __device__ __forceinline__ float4 load4_guard(const float *p, bool row_ok, int c
     return v;
 }
 
+// float4 slot f of an x-major tile chunk -> (row, c4); see the bank note in the header
+template <int BK>
+__device__ __forceinline__ void xm_slot(int f, int &row, int &c4) {
+    constexpr int C = BK / 4;                  // float4 per row
+    static_assert(C % 8 == 0, "xm_slot: rows of at least 8 float4");
+    const int blk = f / (2 * C), r = f % (2 * C);          // two rows per block of 2*C slots
+    const int q = r / 8;                                   // run of 8 lanes
+    row = 2 * blk + (q & 1);
+    c4 = (q >> 1) * 8 + (r & 7);
+}
+
 // global -> registers for one BK chunk of one operand tile (TX = tile extent along x,
 // NTH = threads of the workgroup).
 // FAST: every float4 is either fully inside or fully outside the operand (host
@@ -144,7 +158,8 @@ __device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NTH)], const fl
             const int row = f / (TX / 4), c4 = f % (TX / 4);
             k = k0 + row; x = x0 + c4 * 4;
         } else {
-            const int row = f / (BK / 4), c4 = f % (BK / 4);
+            int row, c4;
+            xm_slot<BK>(f, row, c4);
             x = x0 + row; k = k0 + c4 * 4;
         }
         if (FAST) {
@@ -173,9 +188,12 @@ __device__ __forceinline__ void r2s(const float4 (&reg)[TX * BK / (4 * NTH)], fl
         if (L == KM) {
             const int row = f / (TX / 4), c4 = f % (TX / 4);
             if (FAST && row >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4 *>(s + row * STRIDE + c4 * 4) = v;
+            float2 *d = reinterpret_cast<float2 *>(s + row * STRIDE + c4 * 4);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
         } else {
-            const int row = f / (BK / 4), c4 = f % (BK / 4);
+            int row, c4;
+            xm_slot<BK>(f, row, c4);
             if (FAST && c4 * 4 >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
             float2 *d = reinterpret_cast<float2 *>(s + row * STRIDE + c4 * 4);
             d[0] = make_float2(v.x, v.y);
@@ -328,7 +346,8 @@ __device__ __forceinline__ void plan_offsets(uint32_t (&off)[TX * BK / (4 * NTH)
             const int row = f / (TX / 4), c4 = f % (TX / 4);
             off[n] = (uint32_t)(row * ld + min(x0 + c4 * 4, nx - 4)) * 4u;
         } else {
-            const int row = f / (BK / 4), c4 = f % (BK / 4);
+            int row, c4;
+            xm_slot<BK>(f, row, c4);
             off[n] = (uint32_t)(min(x0 + row, nx - 1) * ld + c4 * 4) * 4u;
         }
     }

@@ -15,12 +15,21 @@ tag = sys.argv[2] if len(sys.argv) > 2 else 'r1'
 os.makedirs('profiles', exist_ok=True)
 
 
+totals = collections.defaultdict(float)      # counter -> sum over every dispatch of the engine's kernels
+ndisp = collections.defaultdict(int)         # kernel -> dispatches seen in the FETCH pass
+
+
 def agg(path):
     rows = list(csv.DictReader(open(path)))
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
+        if 'bm::' not in r['Kernel_Name']:
+            continue
         a[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in a.items() if 'bm::' in k}
+        totals[r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Counter_Name'] == 'FETCH_SIZE':
+            ndisp[r['Kernel_Name']] += 1
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in a.items()}
 
 
 shutil.copy(os.path.join(src, 'stats/s_kernel_stats.csv'), 'profiles/%s_kernel_stats.csv' % tag)
@@ -29,8 +38,9 @@ pmc = {}
 for sub, f in (('fetch', 'f'), ('write', 'w'), ('sq', 'q')):
     for k, d in agg(os.path.join(src, sub, f + '_counter_collection.csv')).items():
         pmc.setdefault(k, {}).update(d)
-launches = {'act_kernel': 3, 'grad_kernel': 1}          # per CD-1 update
-traffic = 0.0
+# one grad_kernel dispatch per CD-1 update: per-update traffic = all engine dispatches / updates
+n_updates = max(1, sum(n for k, n in ndisp.items() if 'grad_kernel' in k))
+traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_updates
 lines = ['# rocprofv3 summary %s — `python bench.py` (BernoulliRBM 784x1024, CD-1, batch 512, 1x MI355X)' % tag, '',
          '| kernel | calls | avg us (kernel-trace) | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | LDS bank-conflict cycles |',
          '|---|---|---|---|---|---|---|---|']
@@ -41,11 +51,8 @@ for k, d in sorted(pmc.items()):
     lines.append('| `%s` | %s | %.2f | %.0f | %.1f | %.0f | %.1f | %.0f |' % (
         k.split('(')[0], st.get('Calls', '?'), float(st.get('AverageNs', 0)) / 1e3, d.get('FETCH_SIZE', 0), fetch2,
         d.get('WRITE_SIZE', 0), busy, d.get('SQ_LDS_BANK_CONFLICT', 0)))
-    for name, n in launches.items():
-        if name in k:
-            traffic += n * (2 * d.get('FETCH_SIZE', 0) + d.get('WRITE_SIZE', 0)) * 1024
 lines += ['', 'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs).',
-          'HBM-side traffic per CD-1 update (3 act_kernel + 1 grad_kernel launches, FETCH doubled + WRITE): %.1f MB' % (traffic / 1e6),
+          'HBM-side traffic per CD-1 update (all engine dispatches of the counter pass / %d updates, FETCH doubled + WRITE): %.1f MB' % (n_updates, traffic / 1e6),
           '(the working set is Infinity-Cache resident; these are L2-miss side counters, not DRAM bytes).', '']
 open('profiles/%s_summary.md' % tag, 'w').write('\n'.join(lines))
 json.dump({'traffic_bytes_per_update': traffic, 'pmc': pmc}, open('profiles/%s_pmc.json' % tag, 'w'), indent=1)
