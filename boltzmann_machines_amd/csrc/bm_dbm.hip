@@ -552,7 +552,7 @@ int bm_dbm_apply_step(bm_dbm *h, int32_t N_global, int32_t M_global, float lr, f
         a.W = h->W[i].p; a.dW = h->dW[i].p; a.Wt = nullptr; a.pen = h->pen[i].p;
         a.I = h->n[i + 1]; a.J = h->n[i]; a.ldw = h->W[i].ld; a.ldwt = h->Wt[i].ld; a.form = 1;
         a.N = N; a.M = M; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
-        hipLaunchKernelGGL(apply_w_kernel, dim3(1024), dim3(256), 0, h->stream, a);
+        launch_apply_w(a, nullptr, h->stream);
         launch_dbm_maxnorm(h, i);
     }
     BM_HIP(hipGetLastError());

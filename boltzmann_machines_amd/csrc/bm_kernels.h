@@ -10,6 +10,7 @@
 //   elementwise / reduction helpers for dropout, msre, l2, free energy, PLL.
 #pragma once
 #include <stdlib.h>
+#include <string.h>
 #include <array>
 #include <map>
 #include <mutex>
@@ -735,6 +736,101 @@ __global__ void apply_w_kernel(ApplyWArgs a) {
         a.W[o] = wv;
         a.dW[o] = dv;
         if (a.Wt) a.Wt[(size_t)i * a.ldwt + j] = wv;
+    }
+}
+
+// Tiled form of the split apply (data-parallel step): 64 x 64 tiles of W, every global access a
+// 16-byte one, the transpose for Wt staged through LDS.  The trailing `nbias` workgroups run
+// rbm_bias_kernel's update (legal in the same launch when the W update does not need the
+// penalty they produce, i.e. sparsity_cost == 0: `a.pen` is then null).
+__device__ __forceinline__ void rbm_bias_update(const RbmBiasArgs &a, int c) {
+    if (c < a.V) {
+        const float g = a.sv[c] / a.N;
+        const float d = a.lr * (a.mom * a.dvb[c] + g);
+        a.dvb[c] = d;
+        a.vb[c] = a.vb[c] + d;
+    } else if (c < a.V + a.H) {
+        const int h = c - a.V;
+        const float qn = a.damping * a.q[h] + (1.0f - a.damping) * a.sq[h];
+        a.q[h] = qn;
+        const float pen = a.cost * (qn - a.target);
+        a.pen[h] = pen;
+        float g = a.sh[h] / a.N;
+        g = g - pen;
+        const float d = a.lr * (a.mom * a.dhb[h] + g);
+        a.dhb[h] = d;
+        a.hb[h] = a.hb[h] + d;
+    }
+}
+__global__ __launch_bounds__(256) void apply_w_tiled_kernel(ApplyWArgs a, RbmBiasArgs b, int nbias) {
+    __shared__ float tile[64][65];
+    const int ntile = (int)gridDim.x - nbias;
+    if ((int)blockIdx.x >= ntile) {
+        rbm_bias_update(b, ((int)blockIdx.x - ntile) * 256 + (int)threadIdx.x);
+        return;
+    }
+    const int tiles_i = (a.I + 63) / 64;
+    const int i0 = ((int)blockIdx.x % tiles_i) * 64, j0 = ((int)blockIdx.x / tiles_i) * 64;
+    const int tid = threadIdx.x, c4 = tid & 15, r0 = tid >> 4;       // 16 float4 per row, 16 rows per pass
+    const bool pow2 = ((__float_as_uint(a.N) & 0x007fffffu) == 0u) && ((__float_as_uint(a.M) & 0x007fffffu) == 0u) &&
+                      a.N >= 1.0f && a.M >= 1.0f;
+    const float invN = 1.0f / a.N, invM = 1.0f / a.M;
+    const int i = i0 + 4 * c4;
+    float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.pen && i < a.I) pe = *reinterpret_cast<const float4 *>(a.pen + i);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int jl = r0 + 16 * p, j = j0 + jl;
+        if (j < a.J && i < a.I) {                                   // I % 4 == 0: whole float4 in range
+            const size_t o = (size_t)j * a.ldw + i;
+            const float4 r = *reinterpret_cast<const float4 *>(a.raw + o);
+            float4 wv = *reinterpret_cast<const float4 *>(a.W + o), dv = *reinterpret_cast<const float4 *>(a.dW + o);
+            float4 g;
+            if (a.form == 0) {
+                if (pow2) g = make_float4(r.x * invN, r.y * invN, r.z * invN, r.w * invN);
+                else      g = make_float4(r.x / a.N, r.y / a.N, r.z / a.N, r.w / a.N);
+            } else {
+                const float4 r2 = *reinterpret_cast<const float4 *>(a.raw2 + o);
+                if (pow2) g = make_float4(r.x * invN - r2.x * invM, r.y * invN - r2.y * invM, r.z * invN - r2.z * invM, r.w * invN - r2.w * invM);
+                else      g = make_float4(r.x / a.N - r2.x / a.M, r.y / a.N - r2.y / a.M, r.z / a.N - r2.z / a.M, r.w / a.N - r2.w / a.M);
+            }
+            apply_w_update(g.x, pe.x, a.l2, a.lr, a.mom, wv.x, dv.x);
+            apply_w_update(g.y, pe.y, a.l2, a.lr, a.mom, wv.y, dv.y);
+            apply_w_update(g.z, pe.z, a.l2, a.lr, a.mom, wv.z, dv.z);
+            apply_w_update(g.w, pe.w, a.l2, a.lr, a.mom, wv.w, dv.w);
+            *reinterpret_cast<float4 *>(a.W + o) = wv;
+            *reinterpret_cast<float4 *>(a.dW + o) = dv;
+            tile[jl][4 * c4] = wv.x; tile[jl][4 * c4 + 1] = wv.y; tile[jl][4 * c4 + 2] = wv.z; tile[jl][4 * c4 + 3] = wv.w;
+        }
+    }
+    if (!a.Wt) return;
+    __syncthreads();
+    const int jq = j0 + 4 * c4;                                     // 4 consecutive j of row i
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int il = r0 + 16 * p, ii = i0 + il;
+        if (ii >= a.I || jq >= a.J) continue;
+        float *dst = a.Wt + (size_t)ii * a.ldwt + jq;
+        if (jq + 3 < a.J) {
+            *reinterpret_cast<float4 *>(dst) = make_float4(tile[4 * c4][il], tile[4 * c4 + 1][il], tile[4 * c4 + 2][il], tile[4 * c4 + 3][il]);
+        } else {
+            for (int e = 0; e < 4; ++e) if (jq + e < a.J) dst[e] = tile[4 * c4 + e][il];
+        }
+    }
+}
+// host: tiled path needs whole 16-byte groups (I % 4 == 0, pitches % 4 == 0); else the elementwise kernels
+static inline void launch_apply_w(const ApplyWArgs &a, const RbmBiasArgs *bias, hipStream_t st) {
+    const bool tiled = (a.I % 4 == 0) && (a.ldw % 4 == 0) && (!a.Wt || a.ldwt % 4 == 0);
+    if (tiled) {
+        RbmBiasArgs b;
+        memset(&b, 0, sizeof(b));
+        int nb = 0;
+        if (bias) { b = *bias; nb = (b.V + b.H + 255) / 256; }
+        const int ntile = ((a.I + 63) / 64) * ((a.J + 63) / 64);
+        hipLaunchKernelGGL(apply_w_tiled_kernel, dim3(ntile + nb), dim3(256), 0, st, a, b, nb);
+    } else {
+        if (bias) hipLaunchKernelGGL(rbm_bias_kernel, dim3((bias->V + bias->H + 255) / 256), dim3(256), 0, st, *bias);
+        hipLaunchKernelGGL(apply_w_kernel, dim3(1024), dim3(256), 0, st, a);
     }
 }
 

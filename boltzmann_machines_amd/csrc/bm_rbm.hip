@@ -153,17 +153,13 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out)
     return 0;
 }
 
-static void launch_bias(bm_rbm *h, float N, float lr, float mom) {
-    ProfScope _ps(h, KC_BIAS);
-    RbmBiasArgs b;
+static void fill_bias(bm_rbm *h, float N, float lr, float mom, RbmBiasArgs &b) {
     float *tail = h->grad.p + h->grad_tail();
     b.sv = tail; b.sh = tail + h->V; b.sq = tail + h->V + h->H;
     b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
     b.V = h->V; b.H = h->H;
     b.N = N; b.lr = lr; b.mom = mom;
     b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost; b.target = h->cfg.sparsity_target;
-    const int n = h->V + h->H;
-    hipLaunchKernelGGL(rbm_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, b);
 }
 
 // single-GPU path: column sums + bias/q update in ONE launch (or inside the grad launch)
@@ -426,15 +422,23 @@ int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
 }
 
 int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float lr, float mom) {
-    launch_bias(h, (float)B_global, lr, mom);
     ProfScope _ps(h, KC_BIAS);
+    RbmBiasArgs b;
+    fill_bias(h, (float)B_global, lr, mom, b);
     ApplyWArgs a;
     memset(&a, 0, sizeof(a));
     a.raw = h->grad.p; a.raw2 = nullptr;
-    a.W = h->W.p; a.dW = h->dW.p; a.Wt = h->Wt.p; a.pen = h->pen.p;
+    a.W = h->W.p; a.dW = h->dW.p; a.Wt = h->Wt.p;
     a.I = h->H; a.J = h->V; a.ldw = h->W.ld; a.ldwt = h->Wt.ld; a.form = 0;
     a.N = (float)B_global; a.M = a.N; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
-    hipLaunchKernelGGL(apply_w_kernel, dim3(1024), dim3(256), 0, h->stream, a);
+    if (h->cfg.sparsity_cost != 0.f) {      // the W update needs the penalty: bias update first
+        hipLaunchKernelGGL(rbm_bias_kernel, dim3((h->V + h->H + 255) / 256), dim3(256), 0, h->stream, b);
+        a.pen = h->pen.p;
+        launch_apply_w(a, nullptr, h->stream);
+    } else {                                // penalty == 0 (pen stays 0): one launch for both
+        a.pen = nullptr;
+        launch_apply_w(a, &b, h->stream);
+    }
     BM_HIP(hipGetLastError());
     return 0;
 }
