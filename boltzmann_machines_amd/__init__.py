@@ -2,7 +2,7 @@
 yell/boltzmann-machines.  The compute path is libbm355.so
 (hand-written HIP for gfx950 behind the C-ABI of include/bm355.h); importing this
 package never falls back to a CPU implementation."""
-from .rbm import BernoulliRBM, GaussianRBM, BaseRBM, logit_mean          # noqa: F401
+from .rbm import BernoulliRBM, MultinomialRBM, GaussianRBM, BaseRBM, logit_mean          # noqa: F401
 from .base import EngineModel, BaseModel                                  # noqa: F401
 from .utils import RNG                                                    # noqa: F401
 

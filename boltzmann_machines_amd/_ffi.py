@@ -12,7 +12,7 @@ import numpy as np
 from . import build as _build
 
 MAX_LAYERS = 4
-UNIT_BERNOULLI, UNIT_GAUSSIAN = 0, 1
+UNIT_BERNOULLI, UNIT_GAUSSIAN, UNIT_MULTINOMIAL = 0, 1, 2
 
 
 class Bm355Error(RuntimeError):
@@ -24,7 +24,8 @@ class RbmConfig(C.Structure):
                 ('sample_v_states', C.c_int32), ('sample_h_states', C.c_int32),
                 ('dbm_first', C.c_int32), ('dbm_last', C.c_int32), ('max_batch', C.c_int32),
                 ('l2', C.c_float), ('sparsity_target', C.c_float), ('sparsity_cost', C.c_float),
-                ('sparsity_damping', C.c_float), ('dropout', C.c_float)]
+                ('sparsity_damping', C.c_float), ('dropout', C.c_float),
+                ('h_unit', C.c_int32), ('n_samples', C.c_int32)]
 
 
 class DbmConfig(C.Structure):

@@ -29,7 +29,8 @@ struct ActArgs {
     const float *sigma;          // [I], Gaussian units only
     float mult;                  // propup/propdown multiplier or AIS beta applied to z
     float bmult;                 // multiplier applied to the bias (== mult except mean-field init, dbm.py:434-446)
-    int kind;                    // BM_UNIT_BERNOULLI: sigmoid(mult*z + mult*b); GAUSSIAN: (mult*z)*sigma + mult*b
+    int kind;                    // 0 BERNOULLI: sigmoid(mult*z + mult*b); 1 GAUSSIAN: (mult*z)*sigma + mult*b;
+                                 // 2: raw mult*z; 3: logits mult*z + bmult*b (input of softmax_multinomial_kernel)
     int sample;                  // 1: states = draw(means); 0: states = means
     float *means;                // may be null
     float *states;               // may be null
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const float x = a.mult * z[4 * hlf + r];
                 const float b = a.bmult * bs[4 * hlf + r];
-                m[r] = (a.kind == 0) ? sigmoid(x + b) : (a.kind == 1 ? (x * sg[4 * hlf + r] + b) : x);   // kind 2: raw z
+                m[r] = (a.kind == 0) ? sigmoid(x + b) : (a.kind == 1 ? (x * sg[4 * hlf + r] + b) : (a.kind == 3 ? x + b : x));
                 s[r] = m[r];
             }
             if (a.sample) {
@@ -834,6 +835,86 @@ static inline void launch_apply_w(const ApplyWArgs &a, const RbmBiasArgs *bias, 
     }
 }
 
+// ------------------------------------------------------ MultinomialLayer (layers.py:54-70)
+// One wave per row of logits L[j][0..I) (written by act_kernel kind 3), in place:
+//   means = M * softmax(l);  states = counts of M categorical draws (or = means when !sample).
+// Same operation sequence as oracle/bm_oracle.c softmax_multinomial_row (bit-exact):
+//   mx = max l;  e[i] = exp_neg(min(mx - l[i], 80));  c[i] = c[i-1] + e[i] SEQUENTIALLY (lane 0);
+//   S = c[I-1];  means[i] = M * (e[i] / S);  draw d: t = u(row*M + d) * S, category = first c[i] > t.
+// LDS: c[I] | e[I] (e is reused for the integer counts); I <= 8192.
+struct SmArgs {
+    float *L; int ld, I, J, M, sample;
+    float *states, *negmeans;        // may be null
+    PhiloxKey key; long long row0;
+};
+__global__ __launch_bounds__(64) void softmax_multinomial_kernel(SmArgs a) {
+    extern __shared__ float sm_dyn[];
+    float *c = sm_dyn, *e = sm_dyn + a.I;
+    const int row = blockIdx.x, lane = threadIdx.x;
+    float *l = a.L + (size_t)row * a.ld;
+    float mx = -3.402823466e38f;
+    for (int i = lane; i < a.I; i += 64) mx = fmaxf(mx, l[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    for (int i = lane; i < a.I; i += 64) {
+        float d = mx - l[i];
+        if (d > 80.0f) d = 80.0f;
+        e[i] = exp_neg(d);
+    }
+    __syncthreads();
+    if (lane == 0) {                                 // canonical (sequential) prefix sums
+        float run = 0.0f;
+        int i = 0;
+        for (; i + 8 <= a.I; i += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = e[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { run = run + t[u]; c[i + u] = run; }
+        }
+        for (; i < a.I; ++i) { run = run + e[i]; c[i] = run; }
+    }
+    __syncthreads();
+    const float S = c[a.I - 1], Mf = (float)a.M;
+    for (int i = lane; i < a.I; i += 64) {
+        const float m = Mf * (e[i] / S);
+        l[i] = m;
+        if (a.negmeans) a.negmeans[(size_t)row * a.ld + i] = -m;
+        if (a.states && !a.sample) a.states[(size_t)row * a.ld + i] = m;
+    }
+    if (!a.states || !a.sample) return;
+    __syncthreads();
+    int *cnt = reinterpret_cast<int *>(e);
+    for (int i = lane; i < a.I; i += 64) cnt[i] = 0;
+    __syncthreads();
+    for (int d = lane; d < a.M; d += 64) {
+        const float u = philox_uniform_at(a.key, (unsigned long long)(a.row0 + row) * (unsigned long long)a.M + (unsigned long long)d);
+        const float t = u * S;
+        int lo = 0, hi = a.I - 1;                    // smallest i with c[i] > t (exists: t < S)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        atomicAdd(cnt + lo, 1);
+    }
+    __syncthreads();
+    for (int i = lane; i < a.I; i += 64) a.states[(size_t)row * a.ld + i] = (float)cnt[i];
+}
+
+// h_hat ~ Multinomial(M, uniform over K) (rbm.py:58): counts of floor(u * K); three independent
+// vectors (streams t = 0, 1, 2: free_energy_op, F(x) and F(x~) of the PLL), hhat [3][K] zeroed by the caller
+__global__ void mn_hhat_kernel(float *hhat, int K, int M, PhiloxKey k0, PhiloxKey k1, PhiloxKey k2) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= M) return;
+    const PhiloxKey keys[3] = {k0, k1, k2};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int idx = (int)(philox_uniform_at(keys[t], (unsigned long long)d) * (float)K);
+        if (idx > K - 1) idx = K - 1;
+        atomicAdd(hhat + (size_t)t * K + idx, 1.0f);
+    }
+}
+
 // ----------------------------------------------------------------- elementwise
 // tf.nn.dropout(x, keep): x / keep * floor(keep + u)   (base_rbm.py:417-418)
 // X [rows][cols] pitch ldx -> Y pitch ldy; RNG index = flat0 + row*cols + col
@@ -896,6 +977,10 @@ struct FeArgs {
     float *rowacc;           // [J], zero-initialised
     float *rowacc2;          // [J] or null
     const int *flip_col;     // [J] or null
+    // MultinomialRBM free energy (rbm.py:52-62): the hidden term is (xW).h_hat instead of the softplus
+    // sum; hvec [3][I] = the h_hat of free_energy_op, of F(x) and of F(x~); rowacc3 [J] takes F(x)'s
+    const float *hvec;
+    float *rowacc3;
 };
 template <bool FAST>
 __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
@@ -917,7 +1002,7 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
     const int wi = w & 1, wj = w >> 1;
     const int g = lane >> 4, l15 = lane & 15;
     const int j = j0 + wj * 16 + l15;
-    float s = 0.f, s2 = 0.f;
+    float s = 0.f, s2 = 0.f, s3 = 0.f;
     if (j < a.J) {
         float delta = 0.f; int fc = -1;
         if (a.flip_col) {
@@ -930,17 +1015,25 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
         for (int e = 0; e < 8; ++e) {
             const int i = i0 + wi * 32 + g * 8 + e;
             if (i < a.I) {
-                const float z = zz[e] + a.hb[i];
-                s += softplus(z);
-                if (fc >= 0) s2 += softplus(z + delta * a.P.ptr[(size_t)fc * a.P.ld + i]);
+                if (a.hvec) {
+                    s += zz[e] * a.hvec[i];
+                    s3 += zz[e] * a.hvec[a.I + i];
+                    if (fc >= 0) s2 += (zz[e] + delta * a.P.ptr[(size_t)fc * a.P.ld + i]) * a.hvec[2 * (size_t)a.I + i];
+                } else {
+                    const float z = zz[e] + a.hb[i];
+                    s += softplus(z);
+                    if (fc >= 0) s2 += softplus(z + delta * a.P.ptr[(size_t)fc * a.P.ld + i]);
+                }
             }
         }
     }
     s += __shfl_xor(s, 16);  s += __shfl_xor(s, 32);
     s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+    s3 += __shfl_xor(s3, 16); s3 += __shfl_xor(s3, 32);
     if (g == 0 && j < a.J) {
         atomicAdd(a.rowacc + j, s);
         if (a.rowacc2) atomicAdd(a.rowacc2 + j, s2);
+        if (a.rowacc3) atomicAdd(a.rowacc3 + j, s3);
     }
 }
 
@@ -949,7 +1042,7 @@ __global__ __launch_bounds__(NT, 1) void fe_hidden_kernel(FeArgs a) {
 struct FeRowArgs {
     const float *X; int ld, V, B;
     const float *vb, *sigma;     // sigma null => Bernoulli
-    const float *rowacc, *rowacc2;
+    const float *rowacc, *rowacc2, *rowacc3;    // rowacc3: MultinomialRBM's second F(x) (out[2]) or null
     const int *flip_col;
     double *out;
 };
@@ -976,6 +1069,7 @@ __global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) {
     if (lane == 0) {
         atomicAdd(a.out + 0, t - (double)a.rowacc[row]);
         if (a.rowacc2) atomicAdd(a.out + 1, t2 - (double)a.rowacc2[row]);
+        if (a.rowacc3) atomicAdd(a.out + 2, t - (double)a.rowacc3[row]);
     }
 }
 
@@ -1158,7 +1252,9 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
         ActTune &T = table[key];
         if (!T.best) {
             for (auto &q : T.s) {
-                if (q.pending && hipEventQuery(q.e1) == hipSuccess) {
+                if (!q.pending) continue;
+                if (hipEventQuery(q.e1) != hipSuccess) { (void)hipGetLastError(); continue; }   // not ready: clear the sticky status
+                {
                     float ms = 0.f;
                     if (hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess && ms < T.tmin[q.cand]) T.tmin[q.cand] = ms;
                     (void)hipEventDestroy(q.e0); (void)hipEventDestroy(q.e1);

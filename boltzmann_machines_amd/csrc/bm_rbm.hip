@@ -21,7 +21,7 @@ void set_error(const char *fmt, ...) {
 }
 
 // RNG site ids (counter word 2 = site + 16 * gibbs_step); DESIGN.md "RNG"
-enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5 };
+enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5, SITE_FE = 6 };
 
 }  // namespace bm
 
@@ -40,9 +40,11 @@ struct bm_rbm {
     Mat vm, vs, Xs, Xd;                // [maxB][V]
     DevBuf grad;      // [V*ldH | V | H | H] raw sums (the data-parallel all-reduce buffer)
     DevBuf pen;       // [H]
-    DevBuf rowacc;    // [2*maxB]
+    DevBuf rowacc;    // [3*maxB]
+    DevBuf hhat;      // [3*H] MultinomialRBM free-energy h_hat vectors (rbm.py:58)
     int *flip = nullptr;
-    double *scal = nullptr;   // [4] device accumulators
+    double *scal = nullptr;   // [6] device accumulators: msre, l2, F(x), F(x~), F'(x) (multinomial), spare
+    bool multinomial() const { return cfg.h_unit == BM_UNIT_MULTINOMIAL; }
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0;
@@ -97,6 +99,19 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
+    if (h->multinomial()) {
+        // MultinomialLayer (layers.py:54-70): logits from the GEMM, then one wave per row for the
+        // softmax (activation) and the multinomial counts (sample)
+        if (!means) { means = h->hm.p; ldo = h->hm.ld; }     // pure sampling sweep: hm is the scratch row store
+        a.kind = 3; a.sample = 0; a.means = means; a.ldo = ldo; a.states = nullptr; a.negmeans = nullptr;
+        launch_act(a, h->stream);
+        SmArgs m;
+        memset(&m, 0, sizeof(m));
+        m.L = means; m.ld = ldo; m.I = h->H; m.J = B; m.M = h->cfg.n_samples; m.sample = sample;
+        m.states = states; m.negmeans = negmeans; m.key = a.key; m.row0 = h->row0;
+        hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(B), dim3(64), 2 * (size_t)h->H * sizeof(float), h->stream, m);
+        return;
+    }
     launch_act(a, h->stream);
 }
 
@@ -228,19 +243,34 @@ static void launch_fe(bm_rbm *h, const float *Xin, int ldx, int B, bool with_fli
     f.hb = h->hb.p;
     f.rowacc = h->rowacc.p;
     if (with_flip) { f.rowacc2 = h->rowacc.p + h->maxB; f.flip_col = h->flip; }
+    if (h->multinomial()) {                    // rbm.py:52-62: fresh h_hat draws, streams t = 0, 1, 2
+        (void)hipMemsetAsync(h->hhat.p, 0, 3 * (size_t)h->H * sizeof(float), h->stream);
+        const int M = h->cfg.n_samples;
+        hipLaunchKernelGGL(mn_hhat_kernel, dim3((M + 255) / 256), dim3(256), 0, h->stream, h->hhat.p, h->H, M,
+                           make_key(h, SITE_FE, 0), make_key(h, SITE_FE, 1), make_key(h, SITE_FE, 2));
+        f.hvec = h->hhat.p;
+        f.rowacc3 = h->rowacc.p + 2 * (size_t)h->maxB;
+    }
     launch_fe_hidden(f, h->stream);
     FeRowArgs r;
     memset(&r, 0, sizeof(r));
     r.X = Xin; r.ld = ldx; r.V = h->V; r.B = B;
     r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
-    r.rowacc = f.rowacc; r.rowacc2 = f.rowacc2; r.flip_col = f.flip_col; r.out = h->scal + 2;
+    r.rowacc = f.rowacc; r.rowacc2 = f.rowacc2; r.rowacc3 = f.rowacc3; r.flip_col = f.flip_col; r.out = h->scal + 2;
     hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
+}
+
+// -lgamma(M + K) + lgamma(M + 1) + lgamma(K)  (rbm.py:61); 0 for the other RBMs
+static double mn_fe_const(const bm_rbm *h) {
+    if (!h->multinomial()) return 0.0;
+    const double M = h->cfg.n_samples, K = h->H;
+    return -lgamma(M + K) + lgamma(M + 1.0) + lgamma(K);
 }
 
 // metrics from the chain currently in the handle (base_rbm.py:482-517)
 static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
-    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
-    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 2 * (size_t)h->maxB * sizeof(float), h->stream));
+    BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
+    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 3 * (size_t)h->maxB * sizeof(float), h->stream));
     hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, h->Xin_ld, h->vm.p, h->vm.ld,
                        B, h->V, h->scal + 0);                                                             // msre
     hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->W.p, h->W.ld, (const float *)nullptr, 0,
@@ -248,12 +278,15 @@ static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
     hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
                        make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
     launch_fe(h, h->Xin, h->Xin_ld, B, true);
-    double host[4];
+    double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    const double fe = host[2] / B, fe2 = host[3] / B;
+    // MultinomialRBM: every _free_energy() call draws its own h_hat (host[4] = F(x) of the PLL pair)
+    // and carries the constant of rbm.py:61 (it cancels in the PLL difference)
+    const double fe = host[2] / B + mn_fe_const(h), fe1 = h->multinomial() ? host[4] / B + mn_fe_const(h) : fe;
+    const double fe2 = host[3] / B + mn_fe_const(h);
     out4[0] = (float)(host[0] / ((double)B * h->V));            // msre          :487
-    const float d = (float)(fe2 - fe);                          // pll           :511-512
+    const float d = (float)(fe2 - fe1);                         // pll           :511-512
     const float ls = -(fmaxf(-d, 0.f) + log1pf(expf(-fabsf(d))));
     out4[1] = (float)h->V * ls;
     out4[2] = h->cfg.l2 * (float)(0.5 * host[1]);               // l2_loss       :483
@@ -283,6 +316,11 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     BM_CHECK(cfg->n_visible >= 1 && cfg->n_hidden >= 1, "bad layer sizes %d x %d", cfg->n_visible, cfg->n_hidden);
     BM_CHECK(cfg->max_batch >= 1, "max_batch must be >= 1");
     BM_CHECK(cfg->v_unit == BM_UNIT_BERNOULLI || cfg->v_unit == BM_UNIT_GAUSSIAN, "unknown visible unit %d", cfg->v_unit);
+    BM_CHECK(cfg->h_unit == BM_UNIT_BERNOULLI || cfg->h_unit == BM_UNIT_MULTINOMIAL, "unknown hidden unit %d", cfg->h_unit);
+    if (cfg->h_unit == BM_UNIT_MULTINOMIAL) {
+        BM_CHECK(cfg->n_samples >= 1, "MultinomialRBM: n_samples must be >= 1 (got %d)", cfg->n_samples);
+        BM_CHECK(cfg->n_hidden <= 8192, "MultinomialRBM: n_hidden %d > 8192 (softmax row staged in LDS)", cfg->n_hidden);
+    }
     BM_CHECK(bm_device_count() > 0, "no HIP device visible: libbm355 has no CPU fallback");
     bm_rbm *h = new bm_rbm();
     h->cfg = *cfg;
@@ -298,9 +336,9 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     BM_TRY(h->vm.alloc(B, V)); BM_TRY(h->vs.alloc(B, V)); BM_TRY(h->Xs.alloc(B, V)); BM_TRY(h->Xd.alloc(B, V));
     BM_TRY(h->grad.alloc(h->grad_tail() + V + 2 * (size_t)H));
     BM_TRY(h->pen.alloc(H));
-    BM_TRY(h->rowacc.alloc(2 * (size_t)B));
+    BM_TRY(h->rowacc.alloc(3 * (size_t)B)); BM_TRY(h->hhat.alloc(3 * (size_t)H));
     BM_HIP(hipMalloc((void **)&h->flip, B * sizeof(int)));
-    BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
+    BM_HIP(hipMalloc((void **)&h->scal, 6 * sizeof(double)));
     {   // sigma defaults to 1 (rbm.py:88)
         std::vector<float> ones(V, 1.0f);
         BM_HIP(hipMemcpy(h->sigma.p, ones.data(), V * sizeof(float), hipMemcpyHostToDevice));
@@ -314,7 +352,7 @@ int bm_rbm_destroy(bm_rbm *h) {
     (void)hipStreamSynchronize(h->stream);
     Mat *mats[] = {&h->W, &h->Wt, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
-    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->pen, &h->rowacc};
+    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->pen, &h->rowacc, &h->hhat};
     for (DevBuf *b : all) b->release();
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
@@ -467,13 +505,14 @@ int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1) {
                            h->Xs.ld, B, h->V);
         Xin = h->Xs.p; ldx = h->Xs.ld;
     }
-    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
-    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 2 * (size_t)h->maxB * sizeof(float), h->stream));
+    BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
+    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 3 * (size_t)h->maxB * sizeof(float), h->stream));
     launch_fe(h, Xin, ldx, B, false);
-    double host[4];
+    double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    *out1 = (float)(host[2] / B);
+    *out1 = (float)(host[2] / B + mn_fe_const(h));
+    if (h->multinomial()) h->call++;          // the random h_hat consumed one call of the stream
     return 0;
 }
 

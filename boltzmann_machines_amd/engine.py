@@ -25,13 +25,15 @@ def as_device(X):
 class RbmEngine(object):
     def __init__(self, n_visible, n_hidden, v_unit=_ffi.UNIT_BERNOULLI, sample_v_states=False,
                  sample_h_states=True, dbm_first=False, dbm_last=False, max_batch=10, l2=1e-4,
-                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, dropout=None):
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, dropout=None,
+                 h_unit=_ffi.UNIT_BERNOULLI, n_samples=0):
         self.lib = _ffi.load()
         self.V, self.H, self.max_batch = int(n_visible), int(n_hidden), int(max_batch)
         cfg = _ffi.RbmConfig(self.V, self.H, int(v_unit), int(bool(sample_v_states)),
                              int(bool(sample_h_states)), int(bool(dbm_first)), int(bool(dbm_last)),
                              self.max_batch, float(l2), float(sparsity_target), float(sparsity_cost),
-                             float(sparsity_damping), -1.0 if dropout is None else float(dropout))
+                             float(sparsity_damping), -1.0 if dropout is None else float(dropout),
+                             int(h_unit), int(n_samples))
         self._h = C.c_void_p()
         check(self.lib.bm_rbm_create(C.byref(cfg), C.byref(self._h)))
 

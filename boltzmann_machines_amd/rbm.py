@@ -51,6 +51,7 @@ class BaseRBM(EngineModel):
     """Restricted Boltzmann machine trained with CD-k (reference base_rbm.py:14-94)."""
 
     _V_UNIT = _ffi.UNIT_BERNOULLI
+    _H_UNIT = _ffi.UNIT_BERNOULLI
 
     def __init__(self,
                  n_visible=784, v_layer_cls=None, v_layer_params=None,
@@ -175,7 +176,8 @@ class BaseRBM(EngineModel):
                                      dbm_first=self.dbm_first, dbm_last=self.dbm_last, max_batch=self.batch_size,
                                      l2=self.l2, sparsity_target=self.sparsity_target,
                                      sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping,
-                                     dropout=self.dropout)
+                                     dropout=self.dropout, h_unit=self._H_UNIT,
+                                     n_samples=getattr(self, 'n_samples', 0))
             self._upload_variables(variables)
         else:
             self._engine = _HostVars(variables)
@@ -338,6 +340,33 @@ class BernoulliRBM(BaseRBM):
 
     def __init__(self, model_path='b_rbm_model/', *args, **kwargs):
         super(BernoulliRBM, self).__init__(model_path=model_path, *args, **kwargs)
+
+
+class MultinomialRBM(BaseRBM):
+    """RBM with Bernoulli visible and a single Multinomial hidden unit (= `n_samples` softmax units
+    with tied weights; reference rbm/rbm.py:25-65, layers.py:54-70).
+
+    Parameters
+    ----------
+    n_hidden : int
+        Number of possible states of the multinomial unit.
+    n_samples : int
+        Number of softmax units with shared weights (= draws from one softmax unit).
+
+    Hidden means are `n_samples * softmax(vW + hb)`, hidden states the counts of `n_samples`
+    categorical draws; `transform` returns the means divided by `n_samples` (rbm.py:62-65).
+    """
+
+    _H_UNIT = _ffi.UNIT_MULTINOMIAL
+
+    def __init__(self, n_samples=100, model_path='m_rbm_model/', *args, **kwargs):
+        self.n_samples = n_samples
+        super(MultinomialRBM, self).__init__(model_path=model_path, *args, **kwargs)
+
+    def transform(self, *args, **kwargs):
+        H = super(MultinomialRBM, self).transform(*args, **kwargs)
+        H /= float(self.n_samples)
+        return H
 
 
 class GaussianRBM(BaseRBM):

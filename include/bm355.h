@@ -46,7 +46,7 @@ int bm_dev_memset(void *dst_dev, int value, size_t bytes);
 /* ------------------------------------------------------------------- RBM */
 typedef struct bm_rbm bm_rbm;
 
-enum { BM_UNIT_BERNOULLI = 0, BM_UNIT_GAUSSIAN = 1 };
+enum { BM_UNIT_BERNOULLI = 0, BM_UNIT_GAUSSIAN = 1, BM_UNIT_MULTINOMIAL = 2 };
 
 /* ctor kwargs of BaseRBM.__init__ that influence the device graph
  * (rbm/base_rbm.py:95-105, :244-327). */
@@ -64,6 +64,9 @@ typedef struct bm_rbm_config {
     float   sparsity_cost;
     float   sparsity_damping;
     float   dropout;           /* keep-prob of tf.nn.dropout; <0 => no dropout (base_rbm.py:417-418) */
+    int32_t h_unit;            /* BM_UNIT_BERNOULLI, or BM_UNIT_MULTINOMIAL = MultinomialRBM (rbm/rbm.py:25-65,
+                                  layers.py:54-70): means = n_samples*softmax, states = multinomial counts */
+    int32_t n_samples;         /* MultinomialLayer.n_samples (rbm.py:46); ignored for Bernoulli hidden units */
 } bm_rbm_config;
 
 int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out);

@@ -148,7 +148,7 @@ static float *transpose(const float *A, int R, int C) {   /* A[R][C] -> T[C][R] 
     return T;
 }
 
-enum { UNIT_BERNOULLI = 0, UNIT_GAUSSIAN = 1 };
+enum { UNIT_BERNOULLI = 0, UNIT_GAUSSIAN = 1, UNIT_MULTINOMIAL = 2 };
 
 /* One fused "activation" stage = what act_kernel does on the GPU:
  *   z[j][i] = chain(seg1) then chain(seg2);  x = mult*z; b = mult*bias[i]
@@ -170,6 +170,50 @@ void orc_act(const float *Q1, int K1, const float *P1k,
     orc_act2(Q1, K1, P1k, Q2, K2, P2k, I, J, bias, sigma, mult, mult, kind, sample, means, states, seed, site, call, row0);
 }
 
+/* MultinomialLayer (layers.py:54-70) on one row of logits l[0..I):
+ *   means = M * softmax(l)                                   activation, :64-65
+ *   states = counts of M categorical draws with p = softmax   _sample,   :67-69
+ *            (Multinomial(total_count=M, probs=means/reduce_sum(means)): tf.multinomial
+ *             renormalises, so the whole-batch reduce_sum of :68 cancels)
+ * Specified like the sigmoid, operation by operation, so the GPU reproduces it bit for bit:
+ *   mx = max_i l[i];  e[i] = exp_neg(min(mx - l[i], 80));  c[i] = c[i-1] + e[i]  (sequential fp32)
+ *   S = c[I-1];  means[i] = M * (e[i] / S)
+ *   draw d (0 <= d < M): u = uniform(flat index row*M + d);  t = u * S;
+ *                        category = smallest i with c[i] > t   (exists: t < S)
+ * TF's own multinomial kernel consumes its RNG stream in an undocumented order: parity unpinned,
+ * pinned by this definition. */
+static void softmax_multinomial_row(const float *l, int I, int M, int sample, float *means, float *states,
+                                    orc_key key, uint64_t row, float *e, float *c) {
+    float mx = l[0];
+    for (int i = 1; i < I; ++i) mx = fmaxf(mx, l[i]);
+    float run = 0.0f;
+    for (int i = 0; i < I; ++i) {
+        float a = mx - l[i];
+        if (a > 80.0f) a = 80.0f;
+        e[i] = exp_neg(a);
+        run = run + e[i];
+        c[i] = run;
+    }
+    const float S = c[I - 1];
+    for (int i = 0; i < I; ++i) {
+        const float m = (float)M * (e[i] / S);
+        if (means) means[i] = m;
+        if (states) states[i] = sample ? 0.0f : m;
+    }
+    if (sample && states) {
+        for (int d = 0; d < M; ++d) {
+            const float u = uniform_at(key, row * (uint64_t)M + (uint64_t)d);
+            const float t = u * S;
+            int lo = 0, hi = I - 1;                 /* smallest i with c[i] > t */
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (c[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            states[lo] = states[lo] + 1.0f;
+        }
+    }
+}
+
 /* bmult: multiplier of the bias (== mult except in the mean-field init, dbm.py:434-446) */
 void orc_act2(const float *Q1, int K1, const float *P1k,
               const float *Q2, int K2, const float *P2k,
@@ -185,6 +229,15 @@ void orc_act2(const float *Q1, int K1, const float *P1k,
             for (int i = 0; i < I; ++i) acc[i] = 0.0f;
             chain_kmajor(acc, Q1 + (size_t)j * K1, P1k, K1, I);
             if (K2 > 0) chain_kmajor(acc, Q2 + (size_t)j * K2, P2k, K2, I);
+            if (kind >= 16) {               /* Multinomial: kind = 16 + n_samples, logits x + b */
+                const int M = kind - 16;
+                float *e = (float *)malloc(2 * (size_t)I * sizeof(float));
+                for (int i = 0; i < I; ++i) acc[i] = mult * acc[i] + bmult * bias[i];
+                softmax_multinomial_row(acc, I, M, sample, means ? means + (size_t)j * I : NULL,
+                                        states ? states + (size_t)j * I : NULL, key, (uint64_t)(row0 + j), e, e + I);
+                free(e);
+                continue;
+            }
             for (int i = 0; i < I; ++i) {
                 const float x = mult * acc[i];
                 const float b = bmult * bias[i];
@@ -235,6 +288,7 @@ typedef struct {
     int32_t V, H;
     int32_t v_unit, sample_v, sample_h, dbm_first, dbm_last;
     float l2, sp_target, sp_cost, sp_damping, dropout;   /* dropout < 0: off */
+    int32_t h_unit, n_samples;                           /* UNIT_MULTINOMIAL: MultinomialRBM (rbm.py:25-65) */
 } orc_rbm_cfg;
 
 typedef struct { float *W, *vb, *hb, *dW, *dvb, *dhb, *q, *sigma; } orc_rbm_state;
@@ -242,7 +296,7 @@ typedef struct { float *W, *vb, *hb, *dW, *dvb, *dhb, *q, *sigma; } orc_rbm_stat
 /* chain intermediates, all caller-allocated: Xin [B,V], h0m/h0s/hm/hs [B,H], vm/vs [B,V] */
 typedef struct { float *Xin, *h0m, *h0s, *vm, *vs, *hm, *hs; } orc_rbm_work;
 
-enum { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5 };
+enum { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5, SITE_FE = 6 };
 
 /* base_rbm.py:417-426 (+ rbm.py:107 for the Gaussian input scaling) */
 void orc_rbm_chain(const orc_rbm_cfg *c, const orc_rbm_state *s, const float *X, int B, int k,
@@ -265,13 +319,14 @@ void orc_rbm_chain(const orc_rbm_cfg *c, const orc_rbm_state *s, const float *X,
     const float down = 1.0f + (c->dbm_last ? 1.0f : 0.0f);                         /* :261-262 */
     float *Wt = transpose(s->W, V, H);                                             /* Wt[h][v] */
     /* h0 (always sampled, used iff sample_h_states)  :421-423 */
-    orc_act(w->Xin, V, s->W, NULL, 0, NULL, H, B, s->hb, NULL, up, UNIT_BERNOULLI, 1,
+    const int hkind = (c->h_unit == UNIT_MULTINOMIAL) ? 16 + c->n_samples : UNIT_BERNOULLI;
+    orc_act(w->Xin, V, s->W, NULL, 0, NULL, H, B, s->hb, NULL, up, hkind, 1,
             w->h0m, w->h0s, seed, SITE_H0, call, row0);
     const float *hstate = c->sample_h ? w->h0s : w->h0m;
     for (int t = 0; t < k; ++t) {                                                  /* :367-378 */
         orc_act(hstate, H, Wt, NULL, 0, NULL, V, B, s->vb, s->sigma, down, c->v_unit, c->sample_v,
                 w->vm, w->vs, seed, SITE_V + 16u * (uint32_t)t, call, row0);
-        orc_act(w->vs, V, s->W, NULL, 0, NULL, H, B, s->hb, NULL, up, UNIT_BERNOULLI, c->sample_h,
+        orc_act(w->vs, V, s->W, NULL, 0, NULL, H, B, s->hb, NULL, up, hkind, c->sample_h,
                 w->hm, w->hs, seed, SITE_H + 16u * (uint32_t)t, call, row0);
         hstate = w->hs;
     }
@@ -336,37 +391,66 @@ void orc_rbm_train_step(const orc_rbm_cfg *c, orc_rbm_state *s, const float *X, 
     free(raw);
 }
 
+/* h_hat ~ Multinomial(total_count = M, logits = ones[K]).sample()  (rbm.py:58): counts of M uniform
+ * category draws, category = floor(u * K).  Stream: site SITE_FE + 16 t. */
+static void multinomial_uniform_counts(int K, int M, uint64_t seed, uint32_t call, uint32_t t, double *hhat) {
+    const orc_key key = make_key(seed, SITE_FE + 16u * t, call);
+    for (int k = 0; k < K; ++k) hhat[k] = 0.0;
+    for (int d = 0; d < M; ++d) {
+        int idx = (int)(uniform_at(key, (uint64_t)d) * (float)K);
+        if (idx > K - 1) idx = K - 1;
+        hhat[idx] += 1.0;
+    }
+}
+
 /* batch-mean free energy (double accumulation; tolerance-checked):
- * Bernoulli rbm.py:17-22, Gaussian rbm.py:109-116.  Xin = input AFTER /sigma. */
-double orc_rbm_free_energy(const orc_rbm_cfg *c, const orc_rbm_state *s, const float *Xin, int B,
-                           const int32_t *flip) {
+ * Bernoulli rbm.py:17-22, Gaussian rbm.py:109-116, Multinomial rbm.py:52-62 (a fresh random
+ * h_hat per evaluation; `t` selects its stream).  Xin = input AFTER /sigma. */
+double orc_rbm_free_energy_ex(const orc_rbm_cfg *c, const orc_rbm_state *s, const float *Xin, int B,
+                              const int32_t *flip, uint64_t seed, uint32_t call, uint32_t t) {
     const int V = c->V, H = c->H;
     double total = 0.0;
+    double *hhat = NULL;
+    if (c->h_unit == UNIT_MULTINOMIAL) {
+        hhat = (double *)malloc((size_t)H * sizeof(double));
+        multinomial_uniform_counts(H, c->n_samples, seed, call, t, hhat);
+    }
     for (int b = 0; b < B; ++b) {
         const float *x = Xin + (size_t)b * V;
-        double t = 0.0;
+        double tt = 0.0;
         for (int v = 0; v < V; ++v) {
             double xv = x[v];
             if (flip && flip[b] == v) xv = 1.0 - xv;                       /* base_rbm.py:503-509 */
             if (c->v_unit == UNIT_GAUSSIAN) {
                 const double mu = (double)s->vb[v] / (double)s->sigma[v];
-                t += 0.5 * (xv - mu) * (xv - mu);
+                tt += 0.5 * (xv - mu) * (xv - mu);
             } else {
-                t -= xv * (double)s->vb[v];
+                tt -= xv * (double)s->vb[v];
             }
         }
         for (int h = 0; h < H; ++h) {
-            double z = s->hb[h];
+            double z = hhat ? 0.0 : s->hb[h];
             for (int v = 0; v < V; ++v) {
                 double xv = x[v];
                 if (flip && flip[b] == v) xv = 1.0 - xv;
                 z += xv * (double)s->W[(size_t)v * H + h];
             }
-            t -= softplus_d(z);
+            tt -= hhat ? z * hhat[h] : softplus_d(z);                     /* rbm.py:57-60: T3 = -(vW).h_hat */
         }
-        total += t;
+        total += tt;
     }
-    return total / B;
+    double fe = total / B;
+    if (hhat) {
+        const double M = c->n_samples, K = H;
+        fe += -lgamma(M + K) + lgamma(M + 1.0) + lgamma(K);                /* rbm.py:61 */
+        free(hhat);
+    }
+    return fe;
+}
+
+double orc_rbm_free_energy(const orc_rbm_cfg *c, const orc_rbm_state *s, const float *Xin, int B,
+                           const int32_t *flip) {
+    return orc_rbm_free_energy_ex(c, s, Xin, B, flip, 0, 0, 0);
 }
 
 /* metrics of base_rbm.py:482-517 from a finished chain: out = [msre, pll, l2_loss, free_energy] */
@@ -391,9 +475,13 @@ void orc_rbm_metrics(const orc_rbm_cfg *c, const orc_rbm_state *s, const orc_rbm
         flip[b] = (int32_t)(wd[idx & 3] % (uint32_t)V);
         if (flip_out) flip_out[b] = flip[b];
     }
-    const double fe = orc_rbm_free_energy(c, s, w->Xin, B, NULL);
-    const double fe2 = orc_rbm_free_energy(c, s, w->Xin, B, flip);
-    const double d = fe2 - fe;
+    /* Bernoulli/Gaussian: the three evaluations of :511-516 coincide pairwise; Multinomial draws a
+     * fresh h_hat in each _free_energy() call (streams t = 0: free_energy_op, 1: F(x), 2: F(x~)) */
+    const int mn = c->h_unit == UNIT_MULTINOMIAL;
+    const double fe = orc_rbm_free_energy_ex(c, s, w->Xin, B, NULL, seed, call, 0);
+    const double fe1 = mn ? orc_rbm_free_energy_ex(c, s, w->Xin, B, NULL, seed, call, 1) : fe;
+    const double fe2 = orc_rbm_free_energy_ex(c, s, w->Xin, B, flip, seed, call, 2);
+    const double d = fe2 - fe1;
     out4[1] = (float)((double)V * -softplus_d(-d));       /* V * log_sigmoid(F(x~) - F(x))  :511-512 */
     out4[3] = (float)fe;
     free(flip);

@@ -22,7 +22,8 @@ class RbmCfg(C.Structure):
                 ('v_unit', C.c_int32), ('sample_v', C.c_int32), ('sample_h', C.c_int32),
                 ('dbm_first', C.c_int32), ('dbm_last', C.c_int32),
                 ('l2', C.c_float), ('sp_target', C.c_float), ('sp_cost', C.c_float),
-                ('sp_damping', C.c_float), ('dropout', C.c_float)]
+                ('sp_damping', C.c_float), ('dropout', C.c_float),
+                ('h_unit', C.c_int32), ('n_samples', C.c_int32)]
 
 
 class RbmState(C.Structure):
@@ -70,6 +71,9 @@ def lib():
                                          C.POINTER(RbmWork)]
         L.orc_rbm_free_energy.restype = C.c_double
         L.orc_rbm_free_energy.argtypes = [C.POINTER(RbmCfg), C.POINTER(RbmState), f32p, C.c_int, C.c_void_p]
+        L.orc_rbm_free_energy_ex.restype = C.c_double
+        L.orc_rbm_free_energy_ex.argtypes = [C.POINTER(RbmCfg), C.POINTER(RbmState), f32p, C.c_int, C.c_void_p,
+                                             C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_rbm_metrics.argtypes = [C.POINTER(RbmCfg), C.POINTER(RbmState), C.POINTER(RbmWork), C.c_int,
                                       C.c_uint64, C.c_uint32, C.c_int64, f32p, i32p]
         _lib = L
@@ -85,11 +89,11 @@ class OracleRBM(object):
 
     def __init__(self, n_visible, n_hidden, v_unit=0, sample_v_states=False, sample_h_states=True,
                  dbm_first=False, dbm_last=False, l2=1e-4, sparsity_target=0.1, sparsity_cost=0.,
-                 sparsity_damping=0.9, dropout=None):
+                 sparsity_damping=0.9, dropout=None, h_unit=0, n_samples=0):
         self.V, self.H = int(n_visible), int(n_hidden)
         self.cfg = RbmCfg(self.V, self.H, int(v_unit), int(bool(sample_v_states)), int(bool(sample_h_states)),
                           int(bool(dbm_first)), int(bool(dbm_last)), l2, sparsity_target, sparsity_cost,
-                          sparsity_damping, -1.0 if dropout is None else float(dropout))
+                          sparsity_damping, -1.0 if dropout is None else float(dropout), int(h_unit), int(n_samples))
         V, H = self.V, self.H
         z = lambda *s: np.zeros(s, dtype=np.float32)
         self.p = dict(W=z(V, H), vb=z(V), hb=z(H), dW=z(V, H), dvb=z(V), dhb=z(H), q_means=z(H),
@@ -158,7 +162,11 @@ class OracleRBM(object):
         X = np.ascontiguousarray(X, dtype=np.float32)
         if self.cfg.v_unit == 1:
             X = np.ascontiguousarray(X / self.p['sigma'][None, :], dtype=np.float32)
-        return lib().orc_rbm_free_energy(C.byref(self.cfg), C.byref(self._state()), X, len(X), None)
+        fe = lib().orc_rbm_free_energy_ex(C.byref(self.cfg), C.byref(self._state()), X, len(X), None,
+                                          self.seed, self.call, 0)
+        if self.cfg.h_unit == 2:          # the random h_hat consumes one call of the stream (bm_rbm_free_energy)
+            self.call += 1
+        return fe
 
     def gibbs(self, Hs, n_steps):
         """pure sampling sweep: n_steps of h->v->h from hidden states (bm_rbm_gibbs)."""
@@ -179,7 +187,8 @@ class OracleRBM(object):
                 self.cfg.v_unit, self.cfg.sample_v, None, _ptr(Vs), self.seed, 3 + 16 * t, self.call, self.row0)
             Hn = np.zeros_like(Hs)
             act(_ptr(Vs), V, _ptr(self.p['W']), None, 0, None, H, B, _ptr(self.p['hb']), None, up,
-                0, self.cfg.sample_h, None, _ptr(Hn), self.seed, 4 + 16 * t, self.call, self.row0)
+                16 + self.cfg.n_samples if self.cfg.h_unit == 2 else 0, self.cfg.sample_h, None, _ptr(Hn),
+                self.seed, 4 + 16 * t, self.call, self.row0)
             Hs = Hn
         self.call += 1
         return Hs, Vs

@@ -6,7 +6,8 @@ golden values that come FROM the reference are the known answers its own tests h
 (rbm/tests/test_rbm.py:64-67, utils doctests) — they are asserted literally in tests/test_oracle.py.
 The fixtures written here are regression pins of the CPU oracle (oracle/bm_oracle.c) on seeded
 inputs: parameters after 3 CD-k updates for the reference's test shape (12x8, 16 samples,
-dropout 0.9, both samplers on: test_rbm.py:14-22), a DBM train step, and AIS values.
+dropout 0.9, both samplers on: test_rbm.py:14-22), the same shape as a MultinomialRBM, a DBM train
+step, and AIS values.
 Run:  python tests/golden/make_golden.py
 """
 import os
@@ -34,6 +35,21 @@ def rbm_case():
                 transform=t.transform(X[:8], 1))
 
 
+def mrbm_case():
+    """MultinomialRBM (rbm.py:25-65): the reference test shape with a 10-draw multinomial hidden unit"""
+    V, H = 12, 8
+    X = RNG(seed=1337).rand(16, V).astype(np.float32)
+    t = orc.OracleRBM(V, H, sample_v_states=True, sample_h_states=True, h_unit=2, n_samples=10)
+    t.p['W'][...] = philox.tf_random_normal((V, H), 0.01, 1337)
+    t.set_seed(4242)
+    for _ in range(3):
+        t.train_step(X[:10], 0.01, 0.9, 1)
+        t.train_step(X[10:], 0.01, 0.9, 1)
+    w = t.chain(X[:10], 1)
+    return dict(W=t.p['W'], vb=t.p['vb'], hb=t.p['hb'], dW=t.p['dW'], q_means=t.p['q_means'],
+                h0_means=t.work['h0m'].copy(), h0_counts=t.work['h0s'].copy(), transform=t.transform(X[:8], 1))
+
+
 def dbm_case():
     V, nh, N, M = 20, [12, 16], 10, 10
     t = orc.OracleDBM(V, nh, n_particles=M, batch_size=N, max_mf_updates=5, mf_tol=1e-5, l2=1e-3, max_norm=1.5,
@@ -55,4 +71,5 @@ def dbm_case():
 if __name__ == '__main__':
     np.savez(os.path.join(HERE, 'rbm_12x8.npz'), **rbm_case())
     np.savez(os.path.join(HERE, 'dbm_20_12_16.npz'), **dbm_case())
+    np.savez(os.path.join(HERE, 'mrbm_12x8.npz'), **mrbm_case())
     print('wrote', os.listdir(HERE))

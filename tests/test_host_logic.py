@@ -15,8 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_w_init_shape_validation():
     """reference rbm/tests/test_rbm.py:29-36"""
-    from boltzmann_machines_amd import BernoulliRBM, GaussianRBM
-    for C in (BernoulliRBM, GaussianRBM):
+    from boltzmann_machines_amd import BernoulliRBM, GaussianRBM, MultinomialRBM
+    for C in (BernoulliRBM, MultinomialRBM, GaussianRBM):
         for bad in ((4, 2), (3, 3), (3, 2)):
             with pytest.raises(ValueError):
                 C(n_visible=4, n_hidden=3, W_init=np.zeros(bad))

@@ -101,6 +101,46 @@ def test_golden_fixtures_rbm():
         assert np.array_equal(g[k], now[k]), k
 
 
+def test_golden_fixtures_mrbm():
+    g = np.load(os.path.join(GOLD, 'mrbm_12x8.npz'))
+    now = make_golden.mrbm_case()
+    for k in g.files:
+        assert np.array_equal(g[k], now[k]), k
+
+
+def test_multinomial_layer_against_numpy():
+    """oracle softmax/multinomial row (layers.py:54-70) vs an independent NumPy restatement: the
+    means are n_samples * softmax(vW + hb) (float64 reference, 1e-6), the states are integer counts
+    of n_samples draws per row whose empirical distribution follows the softmax."""
+    V, H, B, M = 30, 17, 64, 1000
+    t = orc.OracleRBM(V, H, h_unit=2, n_samples=M, sample_h_states=True)
+    t.p['W'][...] = (philox.normal(3, 1, 0, V * H) * np.float32(0.3)).reshape(V, H)
+    t.p['hb'][...] = philox.normal(3, 2, 0, H) * np.float32(0.1)
+    t.set_seed(11)
+    X = (philox.uniform(3, 3, 0, B * V) < 0.3).astype(np.float32).reshape(B, V)
+    t.chain(X, 1)
+    z = X.astype(np.float64) @ t.p['W'].astype(np.float64) + t.p['hb'].astype(np.float64)
+    sm = np.exp(z - z.max(axis=1, keepdims=True))
+    sm /= sm.sum(axis=1, keepdims=True)
+    assert_allclose(t.work['h0m'], M * sm, rtol=2e-6)
+    counts = t.work['h0s']
+    assert np.all(counts == np.round(counts)) and np.all(counts >= 0) and np.all(counts.sum(axis=1) == M)
+    # chi-square style check of the pooled counts against the pooled probabilities
+    expected = M * sm
+    chi2 = ((counts - expected) ** 2 / np.maximum(expected, 1e-9)).sum()
+    dof = B * (H - 1)
+    assert abs(chi2 - dof) < 6 * np.sqrt(2 * dof), (chi2, dof)
+    # free energy of rbm.py:52-62 against NumPy with the oracle's own h_hat stream
+    fe = t.free_energy(X)
+    u = orc.uniform(11, 6, t.call - 1, M)
+    hhat = np.bincount(np.minimum((u * np.float32(H)).astype(np.int64), H - 1), minlength=H).astype(np.float64)
+    from scipy.special import gammaln
+    ref_fe = np.mean(-X.astype(np.float64) @ t.p['vb'].astype(np.float64)
+                     - (X.astype(np.float64) @ t.p['W'].astype(np.float64)) @ hhat)
+    ref_fe += -gammaln(M + H) + gammaln(M + 1) + gammaln(H)
+    assert_allclose(fe, ref_fe, rtol=1e-9)
+
+
 def test_golden_fixtures_dbm():
     g = np.load(os.path.join(GOLD, 'dbm_20_12_16.npz'))
     now = make_golden.dbm_case()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 from numpy.testing import assert_allclose, assert_almost_equal
 
-from boltzmann_machines_amd import BernoulliRBM, GaussianRBM
+from boltzmann_machines_amd import BernoulliRBM, GaussianRBM, MultinomialRBM
 from boltzmann_machines_amd.utils import RNG
 
 pytestmark = pytest.mark.gpu
@@ -41,7 +41,8 @@ def compare_transforms(rbm1, rbm2):
     assert_allclose(H1, H2)
 
 
-@pytest.mark.parametrize('C,dtype', [(BernoulliRBM, 'float32'), (BernoulliRBM, 'float64'), (GaussianRBM, 'float32')])
+@pytest.mark.parametrize('C,dtype', [(BernoulliRBM, 'float32'), (BernoulliRBM, 'float64'), (MultinomialRBM, 'float32'),
+                                     (GaussianRBM, 'float32')])
 def test_initialization(gpu_lib, dirs, C, dtype):
     """reference test_rbm.py:52-67 — the W-init known answer after init()."""
     rbm = C(max_epoch=2, model_path=dirs[0], dtype=dtype, **CONFIG)
@@ -50,7 +51,7 @@ def test_initialization(gpu_lib, dirs, C, dtype):
     assert_almost_equal(w, -0.0094548017 if dtype == 'float32' else -0.0077341544416)
 
 
-@pytest.mark.parametrize('C', [BernoulliRBM, GaussianRBM])
+@pytest.mark.parametrize('C', [BernoulliRBM, MultinomialRBM, GaussianRBM])
 def test_consistency(gpu_lib, dirs, C):
     """reference test_rbm.py:69-114 — twin models stay identical through fit, +1 epoch,
     load_model from disk, +1 epoch."""

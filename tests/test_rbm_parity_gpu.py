@@ -169,6 +169,31 @@ def test_against_committed_golden_fixture(gpu_lib):
     eng.close()
 
 
+def test_multinomial_against_committed_golden_fixture(gpu_lib):
+    """HIP path vs tests/golden/mrbm_12x8.npz (no oracle in the loop)"""
+    import os
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import RbmEngine, as_device
+    from boltzmann_machines_amd.utils import RNG, philox
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'mrbm_12x8.npz'))
+    V, H = 12, 8
+    X = RNG(seed=1337).rand(16, V).astype(np.float32)
+    eng = RbmEngine(V, H, max_batch=10, sample_v_states=True, sample_h_states=True, h_unit=2, n_samples=10)
+    eng.set('W', philox.tf_random_normal((V, H), 0.01, 1337))
+    eng.seed(4242)
+    Xd = as_device(X)
+    for _ in range(3):
+        eng.train_step(Xd, 10, 0.01, 0.9, 1, row=0)
+        eng.train_step(Xd, 6, 0.01, 0.9, 1, row=10)
+    for k in ('W', 'vb', 'hb', 'dW', 'q_means'):
+        assert np.array_equal(eng.get(k).view(np.uint32), g[k].view(np.uint32)), k
+    Hd = DeviceArray((8, H))
+    eng.transform(Xd, 8, 1, Hd)
+    eng.sync()
+    assert np.array_equal(Hd.numpy(), g['transform'])
+    eng.close()
+
+
 def _random_cases(n, seed):
     rng = np.random.RandomState(seed)
     for _ in range(n):
@@ -220,3 +245,76 @@ def test_short_last_batch_and_epoch_driver(gpu_lib):
         twin.train_step(X[s:s + bs], 0.05, 0.9, 2)
     assert_state_equal(eng, twin)
     eng.close()
+
+
+# ---- MultinomialRBM (reference rbm/rbm.py:25-65, layers.py:54-70)
+MN_CASES = [
+    # V, H (= states of the multinomial unit), B, k, n_samples, kwargs
+    (12, 8, 16, 1, 10, dict(sample_v_states=True)),                  # reference test shape
+    (100, 52, 37, 2, 100, dict(sample_v_states=True, l2=1e-3)),      # ragged tiles, default n_samples
+    (64, 300, 20, 1, 7, dict(sample_h_states=False)),                # means fed back instead of counts
+    (784, 1024, 128, 1, 100, dict(l2=1e-5, sample_v_states=True)),
+]
+
+
+@pytest.mark.parametrize('V,H,B,k,M,kw', MN_CASES)
+def test_multinomial_train_steps_bit_exact(gpu_lib, V, H, B, k, M, kw):
+    """softmax means, multinomial counts and the CD-k update built on them are bit-exact"""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, H, max_batch=B, w_std=0.1, h_unit=2, n_samples=M, **kw)
+    eng.seed(99); twin.set_seed(99)
+    for s in range(2):
+        X = synth_data(B, V, s)
+        eng.train_step(as_device(X), B, 0.01, 0.9, k)
+        twin.train_step(X, 0.01, 0.9, k)
+        assert_state_equal(eng, twin)
+    # hidden means after the chain (transform) and the sampling sweep
+    X = synth_data(B, V, 7)
+    Hd = DeviceArray((B, H))
+    eng.transform(as_device(X), B, k, Hd)
+    eng.sync()
+    g, c = Hd.numpy(), twin.transform(X, k)
+    assert np.array_equal(g.view(np.uint32), c.view(np.uint32))
+    np.testing.assert_allclose(g.sum(axis=1), M, rtol=1e-5)
+    Hs = twin.work['hs'].copy()
+    if kw.get('sample_h_states', True):
+        assert np.all(Hs == np.round(Hs)) and np.all(Hs.sum(axis=1) == M)      # counts of M draws
+    Hg, Vg = DeviceArray.from_numpy(Hs), DeviceArray((B, V))
+    eng.gibbs(Hg, Vg, B, 2)
+    eng.sync()
+    Hc, Vc = twin.gibbs(Hs, 2)
+    assert np.array_equal(Hg.numpy(), Hc) and np.array_equal(Vg.numpy(), Vc)
+    eng.close()
+
+
+def test_multinomial_metrics_and_free_energy(gpu_lib):
+    """rbm.py:52-62: free energy with a random h_hat per evaluation + the lgamma constant; PLL from
+    two more draws.  Tolerance-checked (double vs fp32 accumulation)."""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B, M = 40, 24, 32, 50
+    eng, twin = make_pair(V, H, max_batch=B, w_std=0.1, h_unit=2, n_samples=M, sample_v_states=True)
+    eng.seed(5); twin.set_seed(5)
+    X = synth_data(B, V, 1)
+    g = eng.metrics(as_device(X), B, 1)
+    c, _ = twin.metrics(X, 1)
+    np.testing.assert_allclose(g, c, rtol=2e-5, atol=1e-5)
+    fg = eng.free_energy(as_device(X), B)
+    fc = twin.free_energy(X)
+    np.testing.assert_allclose(fg, fc, rtol=2e-5)
+    # the h_hat draw advanced the stream on both sides: the next step still matches
+    eng.train_step(as_device(X), B, 0.01, 0.9, 1)
+    twin.train_step(X, 0.01, 0.9, 1)
+    assert_state_equal(eng, twin)
+    eng.close()
+
+
+def test_multinomial_rejects_bad_config(gpu_lib):
+    from boltzmann_machines_amd._ffi import Bm355Error
+    from boltzmann_machines_amd.engine import RbmEngine
+    with pytest.raises(Bm355Error):
+        RbmEngine(8, 8, max_batch=4, h_unit=2, n_samples=0)
+    with pytest.raises(Bm355Error):
+        RbmEngine(8, 9000, max_batch=4, h_unit=2, n_samples=10)
+    with pytest.raises(Bm355Error):
+        RbmEngine(8, 8, max_batch=4, h_unit=7)
