@@ -51,6 +51,18 @@ SIGNATURES = {
     'bm_h2d': [_vp, _vp, _sz],
     'bm_d2h': [_vp, _vp, _sz],
     'bm_dev_memset': [_vp, C.c_int, _sz],
+    'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
+    'bm_rbm64_destroy': [_vp],
+    'bm_rbm64_sync': [_vp],
+    'bm_rbm64_seed': [_vp, C.c_uint64],
+    'bm_rbm64_set_row_offset': [_vp, C.c_int64],
+    'bm_rbm64_set_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_rbm64_get_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_rbm64_train_step': [_vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32],
+    'bm_rbm64_train_step_metrics': [_vp, _vp, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double)],
+    'bm_rbm64_transform': [_vp, _vp, C.c_int32, C.c_int32, _vp],
+    'bm_rbm64_metrics': [_vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)],
+    'bm_rbm64_free_energy': [_vp, _vp, C.c_int32, C.POINTER(C.c_double)],
     'bm_rbm_create': [C.POINTER(RbmConfig), C.POINTER(_vp)],
     'bm_rbm_destroy': [_vp],
     'bm_rbm_sync': [_vp],

@@ -1,4 +1,6 @@
 // bm355.hip — the single translation unit of libbm355.so.  The kernels live in headers
-// (bm_kernels.h) shared by the RBM and DBM entry points, so both are compiled together.
+// (bm_kernels.h) shared by the RBM and DBM entry points, so both are compiled together; bm_rbm64.hip is the
+// float64 RBM path (own small kernels).
 #include "bm_rbm.hip"
 #include "bm_dbm.hip"
+#include "bm_rbm64.hip"

@@ -1,0 +1,456 @@
+// bm_rbm64.hip — the RBM hot path in float64 (bm_rbm64_* entry points of include/bm355.h).
+//
+// The reference's dtype is a constructor argument (base/mixin.py:15) and its own tests train a
+// float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  This is the compatibility path for
+// that dtype: the same graph (base_rbm.py:415-531) and the same canonical summation order as the
+// float32 engine, every operation in IEEE double, bit-identical to the float64 functions of
+// oracle/bm_oracle.c.  It is NOT the tuned path: plain vector-FMA kernels (one thread per output,
+// a sequential fma chain over k, operands through L1/L2); MI355X's FP64 vector rate makes a
+// 784x1024x512 CD-1 update a few hundred microseconds, ~2.5x the reference's own f32:f64 ratio
+// (examples/rbm_mnist.py:7-8).  Bernoulli hidden units; Bernoulli or Gaussian visible units.
+#include "bm_common.h"
+#include "bm_rng.h"
+
+namespace bm64 {
+using bm::PhiloxKey;
+
+// TF Uint64ToDouble: 52 mantissa bits from a word pair, [1,2) - 1
+__device__ __forceinline__ double u64_to_uniform(uint32_t x0, uint32_t x1) {
+    const unsigned long long u = (1023ull << 52) | (((unsigned long long)x0 & 0xfffffull) << 32) | (unsigned long long)x1;
+    return __longlong_as_double((long long)u) - 1.0;
+}
+// element idx of a float64 stream: 2 per Philox block
+__device__ __forceinline__ double uniform_at(const PhiloxKey &key, unsigned long long idx) {
+    uint32_t w[4];
+    bm::philox_block(key, idx >> 1, w);
+    return (idx & 1) ? u64_to_uniform(w[2], w[3]) : u64_to_uniform(w[0], w[1]);
+}
+__device__ __forceinline__ double normal_at(const PhiloxKey &key, unsigned long long idx) {
+    uint32_t w[4];
+    bm::philox_block(key, idx >> 1, w);
+    double u1 = u64_to_uniform(w[0], w[1]);
+    if (u1 < 1.0e-20) u1 = 1.0e-20;
+    const double v1 = 6.283185307179586476925286766559 * u64_to_uniform(w[2], w[3]);
+    const double r = sqrt(-2.0 * log(u1));
+    return (idx & 1) ? cos(v1) * r : sin(v1) * r;
+}
+
+// exp(-a), a in [0, 700]: Cody-Waite + degree-13 Taylor in Horner form, fma only (oracle: exp_neg_d)
+__device__ __forceinline__ double exp_neg(double a) {
+    const double t = a * -1.4426950408889634074;
+    const double n = rint(t);
+    double r = fma(n, -6.93147180369123816490e-01, -a);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const long long ni = (long long)n;
+    return __longlong_as_double(__double_as_longlong(p) + (ni << 52));
+}
+__device__ __forceinline__ double sigmoid(double x) {
+    double a = fabs(x);
+    if (a > 700.0) a = 700.0;
+    const double e = exp_neg(a);
+    const double d = 1.0 + e;
+    return (x >= 0.0) ? (1.0 / d) : (e / d);
+}
+__device__ __forceinline__ double softplus(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
+
+// z[j][i] = sum_k P[k][i] * Q[j][k] (k ascending fma chain), then the layer activation / draw.
+// One wave = 64 consecutive i of one row j: P is read coalesced, Q[j][k] is wave-uniform.
+struct ActArgs {
+    const double *P; int ldp;        // k-major [K][I]
+    const double *Q; int ldq;        // rows [J][K]
+    int K, I, J;
+    const double *bias, *sigma;
+    double mult;
+    int kind, sample;
+    double *means, *states;          // dense [J][I], may be null
+    PhiloxKey key; long long row0;
+};
+__global__ __launch_bounds__(256) void act_kernel(ActArgs a) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= a.I || j >= a.J) return;
+    const double *q = a.Q + (size_t)j * a.ldq, *p = a.P + i;
+    double z = 0.0;
+    for (int k = 0; k < a.K; ++k) z = fma(p[(size_t)k * a.ldp], q[k], z);
+    const double x = a.mult * z, b = a.mult * a.bias[i];
+    const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+    double s = m;
+    if (a.sample) {
+        const unsigned long long idx = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + (unsigned long long)i;
+        if (a.kind == BM_UNIT_BERNOULLI) s = (uniform_at(a.key, idx) < m) ? 1.0 : 0.0;
+        else s = normal_at(a.key, idx) * a.sigma[i] + m;
+    }
+    if (a.means) a.means[(size_t)j * a.I + i] = m;
+    if (a.states) a.states[(size_t)j * a.I + i] = s;
+}
+
+// raw CD gradient + update of W (and of the transpose Wt) in one pass: thread (j = visible, i = hidden)
+//   acc = sum_b h0m[b][i] X[b][j]  then  acc = fma(hm[b][i], -vs[b][j], acc)   (one chain)
+struct GradArgs {
+    const double *h0m, *hm, *X, *vs;     // [B][H], [B][H], [B][V] pitch ldx, [B][V]
+    int ldx, B, V, H;
+    double *W, *dW, *Wt;
+    const double *pen;
+    double N, l2, lr, mom;
+};
+__global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= a.H || j >= a.V) return;
+    double acc = 0.0;
+    for (int b = 0; b < a.B; ++b) acc = fma(a.h0m[(size_t)b * a.H + i], a.X[(size_t)b * a.ldx + j], acc);
+    for (int b = 0; b < a.B; ++b) acc = fma(a.hm[(size_t)b * a.H + i], -a.vs[(size_t)b * a.V + j], acc);
+    const size_t e = (size_t)j * a.H + i;
+    double g = acc / a.N;
+    g = g - a.l2 * a.W[e];
+    g = g - a.pen[i];
+    const double d = a.lr * (a.mom * a.dW[e] + g);
+    a.dW[e] = d;
+    const double w = a.W[e] + d;
+    a.W[e] = w;
+    a.Wt[(size_t)i * a.V + j] = w;
+}
+
+// column sums (sequential over rows) + bias / q_means update (base_rbm.py:450-474)
+struct BiasArgs {
+    const double *X, *vs, *h0m, *hm; int ldx, B, V, H;
+    double *vb, *dvb, *hb, *dhb, *q, *pen;
+    double N, lr, mom, damping, cost, target;
+};
+__global__ void bias_kernel(BiasArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.V) {
+        double s = 0.0;
+        for (int b = 0; b < a.B; ++b) s = s + (a.X[(size_t)b * a.ldx + c] - a.vs[(size_t)b * a.V + c]);
+        const double g = s / a.N;
+        const double d = a.lr * (a.mom * a.dvb[c] + g);
+        a.dvb[c] = d;
+        a.vb[c] = a.vb[c] + d;
+    } else if (c < a.V + a.H) {
+        const int h = c - a.V;
+        double sh = 0.0, sq = 0.0;
+        for (int b = 0; b < a.B; ++b) {
+            const double hm = a.hm[(size_t)b * a.H + h];
+            sh = sh + (a.h0m[(size_t)b * a.H + h] - hm);
+            sq = sq + hm;
+        }
+        const double qn = a.damping * a.q[h] + (1.0 - a.damping) * sq;
+        a.q[h] = qn;
+        const double pen = a.cost * (qn - a.target);
+        a.pen[h] = pen;
+        double g = sh / a.N;
+        g = g - pen;
+        const double d = a.lr * (a.mom * a.dhb[h] + g);
+        a.dhb[h] = d;
+        a.hb[h] = a.hb[h] + d;
+    }
+}
+
+__global__ void prep_kernel(const double *X, double *Y, const double *sigma, int rows, int cols, double keep,
+                            PhiloxKey key, unsigned long long flat0) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        double x = X[e];
+        if (sigma) x = x / sigma[e % (size_t)cols];                       // rbm.py:107
+        if (keep >= 0.0) x = (x / keep) * floor(keep + uniform_at(key, flat0 + e));   // tf.nn.dropout
+        Y[e] = x;
+    }
+}
+__global__ void transpose_kernel(const double *W, double *Wt, int V, int H) {
+    const size_t n = (size_t)V * H;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        Wt[(e % (size_t)H) * V + e / (size_t)H] = W[e];
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__global__ void sqdiff_kernel(const double *A, const double *B, size_t n, double *out) {
+    double s = 0.0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const double d = B ? A[e] - B[e] : A[e];
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+__global__ void pll_index_kernel(int *out, int B, int V, PhiloxKey key, unsigned long long row0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned long long idx = row0 + b;
+    uint32_t w[4];
+    bm::philox_block(key, idx >> 2, w);
+    out[b] = (int)(w[idx & 3] % (uint32_t)V);
+}
+// free energy of rows (rbm.py:17-22 / :109-116), optionally of the row with column flip[b] flipped:
+// out[0] += F(x_b), out[1] += F(x~_b).  One workgroup per row; hidden units strided over the threads.
+__global__ __launch_bounds__(256) void free_energy_kernel(const double *X, int ldx, int B, int V, int H,
+                                                          const double *W, const double *vb, const double *hb,
+                                                          const double *sigma, const int *flip, double *out) {
+    const int b = blockIdx.x;
+    const double *x = X + (size_t)b * ldx;
+    const int fc = flip ? flip[b] : -1;
+    double t = 0.0, t2 = 0.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const double xv = x[v], xf = (v == fc) ? 1.0 - xv : xv;
+        if (sigma) {
+            const double mu = vb[v] / sigma[v];
+            t += 0.5 * (xv - mu) * (xv - mu);
+            t2 += 0.5 * (xf - mu) * (xf - mu);
+        } else {
+            t -= xv * vb[v];
+            t2 -= xf * vb[v];
+        }
+    }
+    const double delta = (fc >= 0) ? 1.0 - 2.0 * x[fc] : 0.0;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        double z = hb[h];
+        for (int v = 0; v < V; ++v) z = fma(x[v], W[(size_t)v * H + h], z);
+        t -= softplus(z);
+        if (fc >= 0) t2 -= softplus(z + delta * W[(size_t)fc * H + h]);
+    }
+    t = wave_sum(t); t2 = wave_sum(t2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 0, t); if (flip) atomicAdd(out + 1, t2); }
+}
+
+struct DBuf {
+    double *p = nullptr; size_t n = 0;
+    int alloc(size_t count) {
+        n = count;
+        if (hipMalloc((void **)&p, (count ? count : 1) * sizeof(double)) != hipSuccess) { bm::set_error("hipMalloc of %zu doubles failed", count); return 1; }
+        return hipMemset(p, 0, (count ? count : 1) * sizeof(double)) == hipSuccess ? 0 : 1;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5 };
+}  // namespace bm64
+
+struct bm_rbm64 {
+    bm_rbm_config cfg;
+    int V, H, maxB;
+    hipStream_t stream = nullptr;
+    bm64::DBuf W, Wt, dW, vb, hb, dvb, dhb, q, sigma, pen;
+    bm64::DBuf h0m, h0s, hm, hs, vm, vs, Xp;
+    int *flip = nullptr;
+    double *scal = nullptr;      // [4] msre, l2, F(x), F(x~)
+    uint64_t seed = 0; uint32_t call = 0; int64_t row0 = 0;
+    const double *Xin = nullptr; int Xin_ld = 0;
+    // hyper-parameters as doubles (a Python float is a double; the float fields of cfg would round them)
+    double l2, sp_target, sp_cost, sp_damping, dropout;
+};
+
+namespace bm64 {
+static PhiloxKey make_key(const bm_rbm64 *h, uint32_t site, int t) {
+    PhiloxKey k;
+    k.k0 = (uint32_t)h->seed; k.k1 = (uint32_t)(h->seed >> 32);
+    k.site = site + 16u * (uint32_t)t; k.call = h->call;
+    return k;
+}
+static void launch_act(bm_rbm64 *h, bool up, const double *in, int ldin, int B, double *means, double *states,
+                       int sample, uint32_t site, int t) {
+    ActArgs a;
+    memset(&a, 0, sizeof(a));
+    if (up) { a.P = h->W.p; a.ldp = h->H; a.K = h->V; a.I = h->H; a.bias = h->hb.p; a.kind = BM_UNIT_BERNOULLI;
+              a.mult = 1.0 + (h->cfg.dbm_first ? 1.0 : 0.0); }
+    else    { a.P = h->Wt.p; a.ldp = h->V; a.K = h->H; a.I = h->V; a.bias = h->vb.p; a.sigma = h->sigma.p; a.kind = h->cfg.v_unit;
+              a.mult = 1.0 + (h->cfg.dbm_last ? 1.0 : 0.0); }
+    a.Q = in; a.ldq = ldin; a.J = B; a.sample = sample; a.means = means; a.states = states;
+    a.key = make_key(h, site, t); a.row0 = h->row0;
+    hipLaunchKernelGGL(act_kernel, dim3((a.I + 63) / 64, (B + 3) / 4), dim3(256), 0, h->stream, a);
+}
+// input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426)
+static int run_chain(bm_rbm64 *h, const double *X_dev, int B, int k, double *hm_out) {
+    BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
+    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    const double *Xin = X_dev;
+    if (h->cfg.v_unit == BM_UNIT_GAUSSIAN || h->dropout >= 0.0) {
+        hipLaunchKernelGGL(prep_kernel, dim3(256), dim3(256), 0, h->stream, X_dev, h->Xp.p,
+                           (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), B, h->V,
+                           h->dropout >= 0.0 ? h->dropout : -1.0, make_key(h, SITE_DROPOUT, 0),
+                           (unsigned long long)h->row0 * (unsigned long long)h->V);
+        Xin = h->Xp.p;
+    }
+    h->Xin = Xin; h->Xin_ld = h->V;
+    launch_act(h, true, Xin, h->V, B, h->h0m.p, h->h0s.p, 1, SITE_H0, 0);
+    const double *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;
+    for (int t = 0; t < k; ++t) {
+        launch_act(h, false, hstate, h->H, B, h->vm.p, h->vs.p, h->cfg.sample_v_states, SITE_V, t);
+        launch_act(h, true, h->vs.p, h->V, B, (hm_out && t == k - 1) ? hm_out : h->hm.p, h->hs.p,
+                   h->cfg.sample_h_states, SITE_H, t);
+        hstate = h->hs.p;
+    }
+    return 0;
+}
+static void launch_update(bm_rbm64 *h, int B, double lr, double mom) {
+    BiasArgs b;
+    b.X = h->Xin; b.vs = h->vs.p; b.h0m = h->h0m.p; b.hm = h->hm.p; b.ldx = h->Xin_ld; b.B = B; b.V = h->V; b.H = h->H;
+    b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
+    b.N = (double)B; b.lr = lr; b.mom = mom;
+    b.damping = h->sp_damping; b.cost = h->sp_cost; b.target = h->sp_target;
+    hipLaunchKernelGGL(bias_kernel, dim3((h->V + h->H + 255) / 256), dim3(256), 0, h->stream, b);
+    GradArgs g;
+    g.h0m = h->h0m.p; g.hm = h->hm.p; g.X = h->Xin; g.vs = h->vs.p; g.ldx = h->Xin_ld; g.B = B; g.V = h->V; g.H = h->H;
+    g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p; g.pen = h->pen.p;
+    g.N = (double)B; g.l2 = h->l2; g.lr = lr; g.mom = mom;
+    hipLaunchKernelGGL(grad_kernel, dim3((h->H + 63) / 64, (h->V + 3) / 4), dim3(256), 0, h->stream, g);
+}
+static int metrics_from_chain(bm_rbm64 *h, int B, double *out4) {
+    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, (const double *)h->vm.p, (size_t)B * h->V, h->scal + 0);
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, (const double *)h->W.p, (const double *)nullptr, (size_t)h->V * h->H, h->scal + 1);
+    hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
+                       make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
+    hipLaunchKernelGGL(free_energy_kernel, dim3(B), dim3(256), 0, h->stream, h->Xin, h->Xin_ld, B, h->V, h->H,
+                       (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hb.p,
+                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), (const int *)h->flip, h->scal + 2);
+    double host[4];
+    BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    const double fe = host[2] / B, fe2 = host[3] / B, d = fe2 - fe;
+    out4[0] = host[0] / ((double)B * h->V);
+    out4[1] = (double)h->V * -(fmax(-d, 0.0) + log1p(exp(-fabs(d))));
+    out4[2] = h->l2 * (0.5 * host[1]);
+    out4[3] = fe;
+    return 0;
+}
+static DBuf *find(bm_rbm64 *h, const char *name) {
+    struct { const char *n; DBuf *b; } t[] = {{"W", &h->W}, {"vb", &h->vb}, {"hb", &h->hb}, {"dW", &h->dW}, {"dvb", &h->dvb},
+                                              {"dhb", &h->dhb}, {"q_means", &h->q}, {"sigma", &h->sigma}};
+    for (auto &e : t) if (!strcmp(e.n, name)) return e.b;
+    return nullptr;
+}
+}  // namespace bm64
+
+using namespace bm64;
+
+extern "C" {
+
+int bm_rbm64_create(const bm_rbm_config *cfg, const double *hyper5, bm_rbm64 **out) {
+    BM_CHECK(cfg && out, "null argument");
+    BM_CHECK(cfg->n_visible >= 1 && cfg->n_hidden >= 1, "bad layer sizes %d x %d", cfg->n_visible, cfg->n_hidden);
+    BM_CHECK(cfg->max_batch >= 1, "max_batch must be >= 1");
+    BM_CHECK(cfg->v_unit == BM_UNIT_BERNOULLI || cfg->v_unit == BM_UNIT_GAUSSIAN, "unknown visible unit %d", cfg->v_unit);
+    BM_CHECK(cfg->h_unit == BM_UNIT_BERNOULLI, "the float64 path has Bernoulli hidden units only (h_unit %d)", cfg->h_unit);
+    BM_CHECK(bm_device_count() > 0, "no HIP device visible: libbm355 has no CPU fallback");
+    bm_rbm64 *h = new bm_rbm64();
+    h->cfg = *cfg;
+    h->V = cfg->n_visible; h->H = cfg->n_hidden; h->maxB = cfg->max_batch;
+    h->l2 = hyper5 ? hyper5[0] : (double)cfg->l2;
+    h->sp_target = hyper5 ? hyper5[1] : (double)cfg->sparsity_target;
+    h->sp_cost = hyper5 ? hyper5[2] : (double)cfg->sparsity_cost;
+    h->sp_damping = hyper5 ? hyper5[3] : (double)cfg->sparsity_damping;
+    h->dropout = hyper5 ? hyper5[4] : (double)cfg->dropout;
+    const size_t V = h->V, H = h->H, B = h->maxB;
+    BM_HIP(hipStreamCreate(&h->stream));
+    BM_TRY(h->W.alloc(V * H)); BM_TRY(h->Wt.alloc(V * H)); BM_TRY(h->dW.alloc(V * H));
+    BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
+    BM_TRY(h->q.alloc(H)); BM_TRY(h->sigma.alloc(V)); BM_TRY(h->pen.alloc(H));
+    BM_TRY(h->h0m.alloc(B * H)); BM_TRY(h->h0s.alloc(B * H)); BM_TRY(h->hm.alloc(B * H)); BM_TRY(h->hs.alloc(B * H));
+    BM_TRY(h->vm.alloc(B * V)); BM_TRY(h->vs.alloc(B * V)); BM_TRY(h->Xp.alloc(B * V));
+    BM_HIP(hipMalloc((void **)&h->flip, B * sizeof(int)));
+    BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
+    std::vector<double> ones(V, 1.0);
+    BM_HIP(hipMemcpy(h->sigma.p, ones.data(), V * sizeof(double), hipMemcpyHostToDevice));
+    *out = h;
+    return 0;
+}
+
+int bm_rbm64_destroy(bm_rbm64 *h) {
+    if (!h) return 0;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DBuf *all[] = {&h->W, &h->Wt, &h->dW, &h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->pen,
+                   &h->h0m, &h->h0s, &h->hm, &h->hs, &h->vm, &h->vs, &h->Xp};
+    for (DBuf *b : all) b->release();
+    if (h->flip) (void)hipFree(h->flip);
+    if (h->scal) (void)hipFree(h->scal);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int bm_rbm64_sync(bm_rbm64 *h) { BM_HIP(hipStreamSynchronize(h->stream)); return 0; }
+int bm_rbm64_seed(bm_rbm64 *h, uint64_t seed) { h->seed = seed; h->call = 0; return 0; }
+int bm_rbm64_set_row_offset(bm_rbm64 *h, int64_t row0) { h->row0 = row0; return 0; }
+
+int bm_rbm64_set_param(bm_rbm64 *h, const char *name, const double *host, size_t n) {
+    DBuf *b = find(h, name);
+    BM_CHECK(b, "unknown variable '%s'", name);
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    BM_HIP(hipStreamSynchronize(h->stream));
+    BM_HIP(hipMemcpy(b->p, host, n * sizeof(double), hipMemcpyHostToDevice));
+    if (b == &h->W) {
+        hipLaunchKernelGGL(transpose_kernel, dim3(256), dim3(256), 0, h->stream, (const double *)h->W.p, h->Wt.p, h->V, h->H);
+        BM_HIP(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+int bm_rbm64_get_param(bm_rbm64 *h, const char *name, double *host, size_t n) {
+    DBuf *b = find(h, name);
+    BM_CHECK(b, "unknown variable '%s'", name);
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    BM_HIP(hipStreamSynchronize(h->stream));
+    BM_HIP(hipMemcpy(host, b->p, n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bm_rbm64_train_step(bm_rbm64 *h, const double *X_dev, int32_t B, double lr, double mom, int32_t k) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    launch_update(h, B, lr, mom);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+int bm_rbm64_train_step_metrics(bm_rbm64 *h, const double *X_dev, int32_t B, double lr, double mom, int32_t k, double *out4) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(metrics_from_chain(h, B, out4));
+    launch_update(h, B, lr, mom);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+int bm_rbm64_transform(bm_rbm64 *h, const double *X_dev, int32_t B, int32_t k, double *H_dev) {
+    BM_CHECK(H_dev, "null output");
+    BM_TRY(run_chain(h, X_dev, B, k, H_dev));
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+int bm_rbm64_metrics(bm_rbm64 *h, const double *X_dev, int32_t B, int32_t k, double *out4) {
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(metrics_from_chain(h, B, out4));
+    h->call++;
+    return 0;
+}
+int bm_rbm64_free_energy(bm_rbm64 *h, const double *X_dev, int32_t B, double *out1) {
+    BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
+    const double *Xin = X_dev;
+    if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {
+        hipLaunchKernelGGL(prep_kernel, dim3(256), dim3(256), 0, h->stream, X_dev, h->Xp.p, (const double *)h->sigma.p, B, h->V,
+                           -1.0, make_key(h, bm64::SITE_DROPOUT, 0), 0ull);
+        Xin = h->Xp.p;
+    }
+    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(free_energy_kernel, dim3(B), dim3(256), 0, h->stream, Xin, h->V, B, h->V, h->H,
+                       (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hb.p,
+                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), (const int *)nullptr, h->scal + 2);
+    double host[4];
+    BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    *out1 = host[2] / B;
+    return 0;
+}
+
+}  // extern "C"

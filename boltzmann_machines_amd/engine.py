@@ -23,6 +23,8 @@ def as_device(X):
 
 
 class RbmEngine(object):
+    dtype = np.float32
+
     def __init__(self, n_visible, n_hidden, v_unit=_ffi.UNIT_BERNOULLI, sample_v_states=False,
                  sample_h_states=True, dbm_first=False, dbm_last=False, max_batch=10, l2=1e-4,
                  sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, dropout=None,
@@ -137,6 +139,83 @@ class RbmEngine(object):
         ms = C.c_float()
         check(self.lib.bm_rbm_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+class RbmEngine64(object):
+    """float64 RBM handle (bm_rbm64_*, include/bm355.h): same method names as RbmEngine, float64
+    device arrays and scalars.  Compatibility path for dtype='float64' models (base/mixin.py:15)."""
+
+    dtype = np.float64
+
+    def __init__(self, n_visible, n_hidden, v_unit=_ffi.UNIT_BERNOULLI, sample_v_states=False,
+                 sample_h_states=True, dbm_first=False, dbm_last=False, max_batch=10, l2=1e-4,
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, dropout=None,
+                 h_unit=_ffi.UNIT_BERNOULLI, n_samples=0):
+        self.lib = _ffi.load()
+        self.V, self.H, self.max_batch = int(n_visible), int(n_hidden), int(max_batch)
+        drop = -1.0 if dropout is None else float(dropout)
+        cfg = _ffi.RbmConfig(self.V, self.H, int(v_unit), int(bool(sample_v_states)),
+                             int(bool(sample_h_states)), int(bool(dbm_first)), int(bool(dbm_last)),
+                             self.max_batch, float(l2), float(sparsity_target), float(sparsity_cost),
+                             float(sparsity_damping), drop, int(h_unit), int(n_samples))
+        hyper = (C.c_double * 5)(float(l2), float(sparsity_target), float(sparsity_cost), float(sparsity_damping), drop)
+        self._h = C.c_void_p()
+        check(self.lib.bm_rbm64_create(C.byref(cfg), hyper, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.bm_rbm64_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape(self, name):
+        if name in ('W', 'dW'):
+            return (self.V, self.H)
+        return (self.V,) if name in ('vb', 'dvb', 'sigma') else (self.H,)
+
+    def set(self, name, value):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64), self._shape(name)))
+        check(self.lib.bm_rbm64_set_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get(self, name):
+        a = np.empty(self._shape(name), dtype=np.float64)
+        check(self.lib.bm_rbm64_get_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def seed(self, seed):
+        check(self.lib.bm_rbm64_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def set_row_offset(self, row0):
+        check(self.lib.bm_rbm64_set_row_offset(self._h, int(row0)))
+
+    def sync(self):
+        check(self.lib.bm_rbm64_sync(self._h))
+
+    def train_step(self, Xd, B, lr, momentum, k, row=0):
+        check(self.lib.bm_rbm64_train_step(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k))
+
+    def train_step_metrics(self, Xd, B, lr, momentum, k, row=0):
+        out = (C.c_double * 4)()
+        check(self.lib.bm_rbm64_train_step_metrics(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def transform(self, Xd, B, k, Hd, row=0, out_row=0):
+        check(self.lib.bm_rbm64_transform(self._h, Xd.offset_ptr(row * self.V), B, k, Hd.offset_ptr(out_row * self.H)))
+
+    def metrics(self, Xd, B, k, row=0):
+        out = (C.c_double * 4)()
+        check(self.lib.bm_rbm64_metrics(self._h, Xd.offset_ptr(row * self.V), B, k, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def free_energy(self, Xd, B, row=0):
+        out = C.c_double()
+        check(self.lib.bm_rbm64_free_energy(self._h, Xd.offset_ptr(row * self.V), B, C.byref(out)))
+        return float(out.value)
 
 
 class DbmEngine(object):

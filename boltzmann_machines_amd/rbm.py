@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _ffi
 from .base import EngineModel, is_attribute_name, run_on_engine
-from .engine import RbmEngine, as_device
+from .engine import RbmEngine, RbmEngine64, as_device
 from .utils import batch_iter, epoch_iter, make_list_from, write_during_training
 from .utils import philox
 
@@ -32,7 +32,7 @@ def assert_len(obj, name, desired_len):
 
 
 class _HostVars(object):
-    """float64 models: variables exist on the host only (no fp64 device path)."""
+    """models without a device path for their dtype (float64 MultinomialRBM): variables on the host only."""
 
     def __init__(self, variables):
         self.vars = variables
@@ -170,8 +170,10 @@ class BaseRBM(EngineModel):
 
     def _make_engine(self):
         variables = self._initial_variables()
-        if np.dtype(self.dtype) == np.float32:
-            self._engine = RbmEngine(self.n_visible, self.n_hidden, v_unit=self._V_UNIT,
+        f64 = np.dtype(self.dtype) == np.float64 and self._H_UNIT == _ffi.UNIT_BERNOULLI
+        if np.dtype(self.dtype) == np.float32 or f64:
+            self._engine = (RbmEngine64 if f64 else RbmEngine)(
+                                     self.n_visible, self.n_hidden, v_unit=self._V_UNIT,
                                      sample_v_states=self.sample_v_states, sample_h_states=self.sample_h_states,
                                      dbm_first=self.dbm_first, dbm_last=self.dbm_last, max_batch=self.batch_size,
                                      l2=self.l2, sparsity_target=self.sparsity_target,
@@ -186,9 +188,14 @@ class BaseRBM(EngineModel):
         return False
 
     def _on_device(self):
-        if not isinstance(self._engine, RbmEngine):
-            raise NotImplementedError("the MI355X engine computes in float32 (dtype='%s' requested)" % self.dtype)
+        if not isinstance(self._engine, (RbmEngine, RbmEngine64)):
+            raise NotImplementedError("no device path for %s with dtype='%s'" % (self.__class__.__name__, self.dtype))
         return self._engine
+
+    def _to_device(self, X):
+        """host array -> DeviceArray in the engine's dtype"""
+        dt = self._engine.dtype
+        return _ffi.DeviceArray.from_numpy(np.ascontiguousarray(X, dtype=dt), dt)
 
     def _upload_variables(self, d):
         for name, _ in self._VAR_SCOPES:
@@ -196,7 +203,7 @@ class BaseRBM(EngineModel):
                 self._engine.set(name, d[name])
 
     def _seed_engine(self, seed):
-        if isinstance(self._engine, RbmEngine):
+        if isinstance(self._engine, (RbmEngine, RbmEngine64)):
             self._engine.seed(seed)
 
     def _variables(self):
@@ -210,7 +217,7 @@ class BaseRBM(EngineModel):
         rebuild = {'batch_size', 'l2', 'dropout', 'sample_v_states', 'sample_h_states', 'sparsity_target',
                    'sparsity_cost', 'sparsity_damping', 'dbm_first', 'dbm_last'}
         super(BaseRBM, self).set_params(**params)
-        if self._engine is not None and isinstance(self._engine, RbmEngine) and rebuild & set(params):
+        if self._engine is not None and isinstance(self._engine, (RbmEngine, RbmEngine64)) and rebuild & set(params):
             self._pending_vars = self._variables()
             self._engine.close()
             self._engine = None
@@ -268,13 +275,12 @@ class BaseRBM(EngineModel):
         return np.mean(val_fes) - np.mean(train_fes)
 
     def _fit(self, X, X_val=None, *args, **kwargs):
-        X = np.ascontiguousarray(X, dtype=np.float32)
-        Xd = as_device(X)
+        self._on_device()
+        Xd = self._to_device(X)
         N = len(X)
         Xvd, Nv = None, 0
         if X_val is not None:
-            X_val = np.ascontiguousarray(X_val, dtype=np.float32)
-            Xvd, Nv = as_device(X_val), len(X_val)
+            Xvd, Nv = self._to_device(X_val), len(X_val)
         for self.epoch_ in epoch_iter(start_epoch=self.epoch_, max_epoch=self.max_epoch, verbose=self.verbose):
             val_results = {}
             feg = None
@@ -324,10 +330,9 @@ class BaseRBM(EngineModel):
         (reference base_rbm.py:687-700 with the op of :438-440)."""
         np_dtype = np_dtype or self._np_dtype
         eng = self._on_device()
-        X = np.ascontiguousarray(X, dtype=np.float32)
         N = len(X)
-        Xd = as_device(X)
-        Hd = _ffi.DeviceArray((N, self.n_hidden))
+        Xd = self._to_device(X)
+        Hd = _ffi.DeviceArray((N, self.n_hidden), eng.dtype)
         _, _, k = self._feed()
         for start in range(0, N, self.batch_size):
             eng.transform(Xd, min(self.batch_size, N - start), k, Hd, row=start, out_row=start)

@@ -151,6 +151,33 @@ int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6);
 int bm_rbm_timer_start(bm_rbm *h);
 int bm_rbm_timer_stop(bm_rbm *h, float *out_ms);
 
+/* ---- float64 RBM path ---------------------------------------------------------------------
+ * The reference's dtype is a constructor argument (base/mixin.py:15, DtypeMixin) and its own
+ * tests train a float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  Same fetch sites as
+ * the float32 entry points above, every buffer and scalar in double; Bernoulli hidden units,
+ * Bernoulli or Gaussian visible units (cfg->h_unit must be BM_UNIT_BERNOULLI).  Variables as in
+ * bm_rbm_set_param.  Compatibility path (plain FP64 vector kernels), not the tuned one. */
+typedef struct bm_rbm64 bm_rbm64;
+/* hyper5 = {l2, sparsity_target, sparsity_cost, sparsity_damping, dropout (<0: off)} as doubles (a Python
+ * float is a double; the float fields of cfg would round them); NULL: take them from cfg */
+int bm_rbm64_create(const bm_rbm_config *cfg, const double *hyper5, bm_rbm64 **out);
+int bm_rbm64_destroy(bm_rbm64 *h);
+int bm_rbm64_sync(bm_rbm64 *h);
+int bm_rbm64_seed(bm_rbm64 *h, uint64_t seed);                                  /* tf_model.py:20-21 */
+int bm_rbm64_set_row_offset(bm_rbm64 *h, int64_t row0);
+int bm_rbm64_set_param(bm_rbm64 *h, const char *name, const double *host, size_t n);   /* tf_model.py:22-28 */
+int bm_rbm64_get_param(bm_rbm64 *h, const char *name, double *host, size_t n);         /* tf_model.py:183-202 */
+int bm_rbm64_train_step(bm_rbm64 *h, const double *X_dev, int32_t B,                    /* base_rbm.py:566 */
+                        double learning_rate, double momentum, int32_t n_gibbs_steps);
+int bm_rbm64_train_step_metrics(bm_rbm64 *h, const double *X_dev, int32_t B,            /* base_rbm.py:554-564 */
+                                double learning_rate, double momentum, int32_t n_gibbs_steps, double *out4);
+int bm_rbm64_transform(bm_rbm64 *h, const double *X_dev, int32_t B, int32_t n_gibbs_steps,   /* base_rbm.py:697 */
+                       double *H_dev);
+int bm_rbm64_metrics(bm_rbm64 *h, const double *X_dev, int32_t B, int32_t n_gibbs_steps,     /* base_rbm.py:578 */
+                     double *out4);
+int bm_rbm64_free_energy(bm_rbm64 *h, const double *X_dev, int32_t B, double *out1);          /* base_rbm.py:605,612 */
+
+
 /* ------------------------------------------------------------------- DBM */
 typedef struct bm_dbm bm_dbm;
 

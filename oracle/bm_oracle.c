@@ -796,3 +796,237 @@ void orc_dbm_log_proba(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X, f
         out[r] = (float)(e + ent);
     }
 }
+
+/* ======================================================================= float64 RBM path
+ * The reference's dtype is a constructor argument (base/mixin.py:15) and its own tests train a
+ * float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  Same graph as the float32 functions
+ * above (base_rbm.py:415-531), every operation in IEEE double; canonical order unchanged.
+ * RNG: TF draws a float64 uniform from a word pair (Uint64ToDouble), 2 per Philox block. */
+static double u64_to_uniform_d(uint32_t x0, uint32_t x1) {
+    union { uint64_t u; double d; } v;
+    v.u = ((uint64_t)1023 << 52) | (((uint64_t)x0 & 0xfffffu) << 32) | (uint64_t)x1;
+    return v.d - 1.0;
+}
+static double uniform_at_d(orc_key key, uint64_t idx) {
+    uint32_t w[4];
+    philox_block(key, idx >> 1, w);
+    return (idx & 1) ? u64_to_uniform_d(w[2], w[3]) : u64_to_uniform_d(w[0], w[1]);
+}
+static double normal_at_d(orc_key key, uint64_t idx) {      /* BoxMullerDouble: one pair per block */
+    uint32_t w[4];
+    philox_block(key, idx >> 1, w);
+    double u1 = u64_to_uniform_d(w[0], w[1]);
+    if (u1 < 1.0e-20) u1 = 1.0e-20;
+    const double v1 = 6.283185307179586476925286766559 * u64_to_uniform_d(w[2], w[3]);
+    const double r = sqrt(-2.0 * log(u1));
+    return (idx & 1) ? cos(v1) * r : sin(v1) * r;
+}
+void orc_uniform_d(uint64_t seed, uint32_t site, uint32_t call, uint64_t idx0, uint64_t n, double *out) {
+    orc_key k = make_key(seed, site, call);
+    for (uint64_t i = 0; i < n; ++i) out[i] = uniform_at_d(k, idx0 + i);
+}
+
+/* exp(-a), a in [0, 700]: Cody-Waite + degree-13 Taylor in Horner form, fma only */
+static double exp_neg_d(double a) {
+    const double t = a * -1.4426950408889634074;
+    const double n = rint(t);
+    double r = fma(n, -6.93147180369123816490e-01, -a);      /* ln2_hi */
+    r = fma(n, -1.90821492927058770002e-10, r);               /* ln2_lo */
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    union { uint64_t u; double d; } v;
+    v.d = p;
+    v.u += ((uint64_t)(int64_t)n) << 52;
+    return v.d;
+}
+double orc_sigmoid_d(double x) {
+    double a = fabs(x);
+    if (a > 700.0) a = 700.0;
+    const double e = exp_neg_d(a);
+    const double d = 1.0 + e;
+    return (x >= 0.0) ? (1.0 / d) : (e / d);
+}
+
+typedef struct { double *W, *vb, *hb, *dW, *dvb, *dhb, *q, *sigma; } orc_rbm_state_d;
+typedef struct { double *Xin, *h0m, *h0s, *vm, *vs, *hm, *hs; } orc_rbm_work_d;
+
+/* z[j][i] = sum_k Q[j][k] * Pk[k][i], then the layer activation / draw (layers.py:34-36,47-51,84-89) */
+static void act_d(const double *Q, int K, const double *Pk, int I, int J, const double *bias, const double *sigma,
+                  double mult, int kind, int sample, double *means, double *states,
+                  uint64_t seed, uint32_t site, uint32_t call, int64_t row0) {
+    const orc_key key = make_key(seed, site, call);
+#pragma omp parallel
+    {
+        double *acc = (double *)malloc((size_t)I * sizeof(double));
+#pragma omp for schedule(static)
+        for (int j = 0; j < J; ++j) {
+            for (int i = 0; i < I; ++i) acc[i] = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double q = Q[(size_t)j * K + k];
+                const double *p = Pk + (size_t)k * I;
+                for (int i = 0; i < I; ++i) acc[i] = fma(p[i], q, acc[i]);
+            }
+            for (int i = 0; i < I; ++i) {
+                const double x = mult * acc[i];
+                const double b = mult * bias[i];
+                const double m = (kind == UNIT_BERNOULLI) ? orc_sigmoid_d(x + b) : (x * sigma[i] + b);
+                double s = m;
+                if (sample) {
+                    const uint64_t idx = (uint64_t)(row0 + j) * (uint64_t)I + (uint64_t)i;
+                    if (kind == UNIT_BERNOULLI) s = (uniform_at_d(key, idx) < m) ? 1.0 : 0.0;
+                    else s = normal_at_d(key, idx) * sigma[i] + m;
+                }
+                if (means) means[(size_t)j * I + i] = m;
+                if (states) states[(size_t)j * I + i] = s;
+            }
+        }
+        free(acc);
+    }
+}
+
+/* hy = {l2, sparsity_target, sparsity_cost, sparsity_damping, dropout (<0: off)} as doubles */
+void orc_rbm_chain_d(const orc_rbm_cfg *c, const double *hy, const orc_rbm_state_d *s, const double *X, int B, int k,
+                     uint64_t seed, uint32_t call, int64_t row0, orc_rbm_work_d *w) {
+    const int V = c->V, H = c->H;
+    const size_t nX = (size_t)B * V;
+    for (size_t e = 0; e < nX; ++e) {
+        double x = X[e];
+        if (c->v_unit == UNIT_GAUSSIAN) x = x / s->sigma[e % (size_t)V];
+        w->Xin[e] = x;
+    }
+    if (hy[4] >= 0.0) {
+        const orc_key key = make_key(seed, SITE_DROPOUT, call);
+        const double keep = hy[4];
+        for (size_t e = 0; e < nX; ++e) {
+            const double u = uniform_at_d(key, (uint64_t)row0 * (uint64_t)V + e);
+            w->Xin[e] = (w->Xin[e] / keep) * floor(keep + u);
+        }
+    }
+    const double up = 1.0 + (c->dbm_first ? 1.0 : 0.0), down = 1.0 + (c->dbm_last ? 1.0 : 0.0);
+    double *Wt = (double *)malloc((size_t)V * H * sizeof(double));
+    for (int v = 0; v < V; ++v) for (int h = 0; h < H; ++h) Wt[(size_t)h * V + v] = s->W[(size_t)v * H + h];
+    act_d(w->Xin, V, s->W, H, B, s->hb, NULL, up, UNIT_BERNOULLI, 1, w->h0m, w->h0s, seed, SITE_H0, call, row0);
+    const double *hstate = c->sample_h ? w->h0s : w->h0m;
+    for (int t = 0; t < k; ++t) {
+        act_d(hstate, H, Wt, V, B, s->vb, s->sigma, down, c->v_unit, c->sample_v, w->vm, w->vs,
+              seed, SITE_V + 16u * (uint32_t)t, call, row0);
+        act_d(w->vs, V, s->W, H, B, s->hb, NULL, up, UNIT_BERNOULLI, c->sample_h, w->hm, w->hs,
+              seed, SITE_H + 16u * (uint32_t)t, call, row0);
+        hstate = w->hs;
+    }
+    free(Wt);
+}
+
+/* chain + raw sums + update (base_rbm.py:443-478), one call = session.run(train_op) */
+void orc_rbm_train_step_d(const orc_rbm_cfg *c, const double *hy, orc_rbm_state_d *s, const double *X, int B,
+                          double lr, double mom, int k, uint64_t seed, uint32_t call, int64_t row0,
+                          orc_rbm_work_d *w) {
+    const int V = c->V, H = c->H;
+    orc_rbm_chain_d(c, hy, s, X, B, k, seed, call, row0, w);
+    const double N = (double)B, l2 = hy[0];
+    double *sv = (double *)calloc((size_t)V + 2 * (size_t)H, sizeof(double)), *sh = sv + V, *sq = sh + H;
+    for (int b = 0; b < B; ++b) {
+        for (int v = 0; v < V; ++v) sv[v] = sv[v] + (w->Xin[(size_t)b * V + v] - w->vs[(size_t)b * V + v]);
+        for (int h = 0; h < H; ++h) {
+            sh[h] = sh[h] + (w->h0m[(size_t)b * H + h] - w->hm[(size_t)b * H + h]);
+            sq[h] = sq[h] + w->hm[(size_t)b * H + h];
+        }
+    }
+    double *pen = (double *)malloc((size_t)H * sizeof(double));
+    for (int v = 0; v < V; ++v) {
+        const double g = sv[v] / N;
+        const double d = lr * (mom * s->dvb[v] + g);
+        s->dvb[v] = d;
+        s->vb[v] = s->vb[v] + d;
+    }
+    const double damp = hy[3], cost = hy[2], target = hy[1];
+    for (int h = 0; h < H; ++h) {
+        const double qn = damp * s->q[h] + (1.0 - damp) * sq[h];
+        s->q[h] = qn;
+        pen[h] = cost * (qn - target);
+        double g = sh[h] / N;
+        g = g - pen[h];
+        const double d = lr * (mom * s->dhb[h] + g);
+        s->dhb[h] = d;
+        s->hb[h] = s->hb[h] + d;
+    }
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < V; ++v) {
+        for (int h = 0; h < H; ++h) {
+            double acc = 0.0;                          /* one chain: positive rows, then negated negative rows */
+            for (int b = 0; b < B; ++b) acc = fma(w->h0m[(size_t)b * H + h], w->Xin[(size_t)b * V + v], acc);
+            for (int b = 0; b < B; ++b) acc = fma(w->hm[(size_t)b * H + h], -w->vs[(size_t)b * V + v], acc);
+            const size_t e = (size_t)v * H + h;
+            double g = acc / N;
+            g = g - l2 * s->W[e];
+            g = g - pen[h];
+            const double d = lr * (mom * s->dW[e] + g);
+            s->dW[e] = d;
+            s->W[e] = s->W[e] + d;
+        }
+    }
+    free(pen); free(sv);
+}
+
+double orc_rbm_free_energy_d(const orc_rbm_cfg *c, const orc_rbm_state_d *s, const double *Xin, int B,
+                             const int32_t *flip) {
+    const int V = c->V, H = c->H;
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double *x = Xin + (size_t)b * V;
+        double t = 0.0;
+        for (int v = 0; v < V; ++v) {
+            double xv = x[v];
+            if (flip && flip[b] == v) xv = 1.0 - xv;
+            if (c->v_unit == UNIT_GAUSSIAN) { const double mu = s->vb[v] / s->sigma[v]; t += 0.5 * (xv - mu) * (xv - mu); }
+            else t -= xv * s->vb[v];
+        }
+        for (int h = 0; h < H; ++h) {
+            double z = s->hb[h];
+            for (int v = 0; v < V; ++v) {
+                double xv = x[v];
+                if (flip && flip[b] == v) xv = 1.0 - xv;
+                z += xv * s->W[(size_t)v * H + h];
+            }
+            t -= softplus_d(z);
+        }
+        total += t;
+    }
+    return total / B;
+}
+
+/* out = [msre, pll, l2_loss, free_energy] from a finished chain (base_rbm.py:482-517) */
+void orc_rbm_metrics_d(const orc_rbm_cfg *c, const double *hy, const orc_rbm_state_d *s, const orc_rbm_work_d *w,
+                       int B, uint64_t seed, uint32_t call, int64_t row0, double *out4) {
+    const int V = c->V, H = c->H;
+    double se = 0.0, l2 = 0.0;
+    for (size_t e = 0; e < (size_t)B * V; ++e) { const double d = w->Xin[e] - w->vm[e]; se += d * d; }
+    for (size_t e = 0; e < (size_t)V * H; ++e) l2 += s->W[e] * s->W[e];
+    out4[0] = se / ((double)B * V);
+    out4[2] = hy[0] * (0.5 * l2);
+    int32_t *flip = (int32_t *)malloc((size_t)B * sizeof(int32_t));
+    const orc_key key = make_key(seed, SITE_PLL, call);
+    for (int b = 0; b < B; ++b) {
+        const uint64_t idx = (uint64_t)row0 + (uint64_t)b;
+        uint32_t wd[4];
+        philox_block(key, idx >> 2, wd);
+        flip[b] = (int32_t)(wd[idx & 3] % (uint32_t)V);
+    }
+    const double fe = orc_rbm_free_energy_d(c, s, w->Xin, B, NULL);
+    const double fe2 = orc_rbm_free_energy_d(c, s, w->Xin, B, flip);
+    out4[1] = (double)V * -softplus_d(-(fe2 - fe));
+    out4[3] = fe;
+    free(flip);
+}

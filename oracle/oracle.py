@@ -194,6 +194,93 @@ class OracleRBM(object):
         return Hs, Vs
 
 
+f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
+
+
+class OracleRBM64(object):
+    """float64 twin of a bm_rbm64 handle (oracle/bm_oracle.c, float64 RBM path)."""
+
+    def __init__(self, n_visible, n_hidden, v_unit=0, sample_v_states=False, sample_h_states=True,
+                 dbm_first=False, dbm_last=False, l2=1e-4, sparsity_target=0.1, sparsity_cost=0.,
+                 sparsity_damping=0.9, dropout=None):
+        self.V, self.H = int(n_visible), int(n_hidden)
+        self.cfg = RbmCfg(self.V, self.H, int(v_unit), int(bool(sample_v_states)), int(bool(sample_h_states)),
+                          int(bool(dbm_first)), int(bool(dbm_last)), l2, sparsity_target, sparsity_cost,
+                          sparsity_damping, -1.0 if dropout is None else float(dropout), 0, 0)
+        self.hy = np.array([l2, sparsity_target, sparsity_cost, sparsity_damping,
+                            -1.0 if dropout is None else float(dropout)], dtype=np.float64)
+        V, H = self.V, self.H
+        z = lambda *s: np.zeros(s, dtype=np.float64)
+        self.p = dict(W=z(V, H), vb=z(V), hb=z(H), dW=z(V, H), dvb=z(V), dhb=z(H), q_means=z(H), sigma=np.ones(V))
+        self.seed = self.call = self.row0 = 0
+        self.work = None
+        L = lib()
+        L.orc_rbm_chain_d.argtypes = [C.POINTER(RbmCfg), f64p, C.POINTER(RbmState), f64p, C.c_int, C.c_int,
+                                      C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(RbmWork)]
+        L.orc_rbm_train_step_d.argtypes = [C.POINTER(RbmCfg), f64p, C.POINTER(RbmState), f64p, C.c_int, C.c_double,
+                                           C.c_double, C.c_int, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(RbmWork)]
+        L.orc_rbm_free_energy_d.restype = C.c_double
+        L.orc_rbm_free_energy_d.argtypes = [C.POINTER(RbmCfg), C.POINTER(RbmState), f64p, C.c_int, C.c_void_p]
+        L.orc_rbm_metrics_d.argtypes = [C.POINTER(RbmCfg), f64p, C.POINTER(RbmState), C.POINTER(RbmWork), C.c_int,
+                                        C.c_uint64, C.c_uint32, C.c_int64, f64p]
+        L.orc_sigmoid_d.restype = C.c_double
+        L.orc_sigmoid_d.argtypes = [C.c_double]
+
+    def set_seed(self, seed):
+        self.seed, self.call = int(seed), 0
+
+    def _state(self):
+        p = self.p
+        return RbmState(*[_ptr(p[n]) for n in ('W', 'vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means', 'sigma')])
+
+    def _work(self, B):
+        V, H = self.V, self.H
+        z = lambda *s: np.zeros(s, dtype=np.float64)
+        self.work = dict(Xin=z(B, V), h0m=z(B, H), h0s=z(B, H), vm=z(B, V), vs=z(B, V), hm=z(B, H), hs=z(B, H))
+        return RbmWork(*[_ptr(self.work[n]) for n in ('Xin', 'h0m', 'h0s', 'vm', 'vs', 'hm', 'hs')])
+
+    def chain(self, X, k):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        w = self._work(len(X))
+        lib().orc_rbm_chain_d(C.byref(self.cfg), self.hy, C.byref(self._state()), X, len(X), k,
+                              self.seed, self.call, self.row0, C.byref(w))
+        return w
+
+    def train_step(self, X, lr, momentum, k):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        w = self._work(len(X))
+        lib().orc_rbm_train_step_d(C.byref(self.cfg), self.hy, C.byref(self._state()), X, len(X), lr, momentum, k,
+                                   self.seed, self.call, self.row0, C.byref(w))
+        self.call += 1
+
+    def transform(self, X, k):
+        self.chain(X, k)
+        self.call += 1
+        return self.work['hm'].copy()
+
+    def metrics(self, X, k):
+        w = self.chain(X, k)
+        out = np.zeros(4, dtype=np.float64)
+        lib().orc_rbm_metrics_d(C.byref(self.cfg), self.hy, C.byref(self._state()), C.byref(w), len(X),
+                                self.seed, self.call, self.row0, out)
+        self.call += 1
+        return out
+
+    def free_energy(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if self.cfg.v_unit == 1:
+            X = np.ascontiguousarray(X / self.p['sigma'][None, :])
+        return lib().orc_rbm_free_energy_d(C.byref(self.cfg), C.byref(self._state()), X, len(X), None)
+
+
+def uniform_d(seed, site, call, n, idx0=0):
+    out = np.zeros(n, dtype=np.float64)
+    f = lib().orc_uniform_d
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, f64p]
+    f(seed, site, call, idx0, n, out)
+    return out
+
+
 def philox_words(seed, site, call, block0, nblocks):
     out = np.zeros(4 * nblocks, dtype=np.uint32)
     lib().orc_philox_words(seed, site, call, block0, nblocks, out)

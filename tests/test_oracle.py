@@ -101,6 +101,23 @@ def test_golden_fixtures_rbm():
         assert np.array_equal(g[k], now[k]), k
 
 
+def test_f64_numerics_and_rng():
+    """oracle float64 pieces against independent references: sigmoid to 2 ulp of the exact value, the
+    uniform stream against utils/philox.py (TF Uint64ToDouble)"""
+    from boltzmann_machines_amd.utils import philox
+    L = orc.lib()
+    orc.OracleRBM64(2, 2)          # registers the double signatures
+    xs = np.concatenate([np.linspace(-40, 40, 2001), [-800., -700., 700., 800., 0., -0.]])
+    got = np.array([L.orc_sigmoid_d(float(x)) for x in xs])
+    with np.errstate(over='ignore'):
+        exact = 1.0 / (1.0 + np.exp(-np.clip(xs, -700, 700)))
+    assert np.all(np.abs(got - exact) <= 4 * np.spacing(exact))
+    u = orc.uniform_d(5, 2, 3, 9)
+    w = philox.philox_blocks(5, 2, 3, 0, 5)
+    ref = philox._u32x2_to_f64(w[:, [0, 2]].reshape(-1), w[:, [1, 3]].reshape(-1))[:9]
+    assert np.array_equal(u, ref)
+
+
 def test_golden_fixtures_mrbm():
     g = np.load(os.path.join(GOLD, 'mrbm_12x8.npz'))
     now = make_golden.mrbm_case()

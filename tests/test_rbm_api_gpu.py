@@ -51,12 +51,13 @@ def test_initialization(gpu_lib, dirs, C, dtype):
     assert_almost_equal(w, -0.0094548017 if dtype == 'float32' else -0.0077341544416)
 
 
-@pytest.mark.parametrize('C', [BernoulliRBM, MultinomialRBM, GaussianRBM])
-def test_consistency(gpu_lib, dirs, C):
+@pytest.mark.parametrize('C,dtype', [(BernoulliRBM, 'float32'), (BernoulliRBM, 'float64'), (MultinomialRBM, 'float32'),
+                                     (GaussianRBM, 'float32')])
+def test_consistency(gpu_lib, dirs, C, dtype):
     """reference test_rbm.py:69-114 — twin models stay identical through fit, +1 epoch,
-    load_model from disk, +1 epoch."""
-    rbm1 = C(max_epoch=2, model_path=dirs[0], **CONFIG)
-    rbm2 = C(max_epoch=2, model_path=dirs[1], **CONFIG)
+    load_model from disk, +1 epoch (same class / dtype list as the reference)."""
+    rbm1 = C(max_epoch=2, model_path=dirs[0], dtype=dtype, **CONFIG)
+    rbm2 = C(max_epoch=2, model_path=dirs[1], dtype=dtype, **CONFIG)
     rbm1.fit(X); rbm2.fit(X)
     compare_weights(rbm1, rbm2); compare_transforms(rbm1, rbm2)
     rbm1.set_params(max_epoch=rbm1.max_epoch + 1).fit(X)
@@ -119,9 +120,9 @@ def test_errors(gpu_lib, dirs):
         rbm.set_params(nope=1)
     with pytest.raises(RuntimeError):
         GaussianRBM.load_model(dirs[0])                      # class mismatch (tf_model.py:149-150)
-    r64 = BernoulliRBM(n_visible=4, n_hidden=3, dtype='float64', model_path=dirs[1], verbose=False).init()
-    with pytest.raises(NotImplementedError):
-        r64.fit(np.zeros((4, 4)))
+    m64 = MultinomialRBM(n_visible=4, n_hidden=3, dtype='float64', model_path=dirs[1], verbose=False).init()
+    with pytest.raises(NotImplementedError):             # float64 device path: Bernoulli hidden units only
+        m64.fit(np.zeros((4, 4)))
 
 
 def test_scalar_logs_and_checkpoint_files(gpu_lib, dirs):
