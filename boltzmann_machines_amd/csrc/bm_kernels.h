@@ -345,9 +345,11 @@ __device__ __forceinline__ void cs_stash(const ColRegs &r, float *sA, float *sB,
     }
 }
 
+// negB: Bm holds the NEGATED second operand (act_kernel's `negmeans`): a + (-b) == a - b and
+// -(sum of -b) == sum of b exactly, so the results are bit-identical to the plain form.
 __device__ __forceinline__ void block_colsum(const float *A, int lda, const float *Bm, int ldb,
                                              int c0, int ncols, int nrows, bool want2,
-                                             float *smem, f32x4 &sum1, f32x4 &sum2) {
+                                             float *smem, f32x4 &sum1, f32x4 &sum2, bool negB = false) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     float *sA = smem, *sB = smem + CS_ROWS * CS_LD;
@@ -384,7 +386,7 @@ __device__ __forceinline__ void block_colsum(const float *A, int lda, const floa
             for (int u = 0; u < 8; ++u) {
                 const int o = (4 * (s + u) + g) * CS_LD + co;
                 e[u] = sB[o];
-                d[u] = sA[o] - e[u];
+                d[u] = negB ? sA[o] + e[u] : sA[o] - e[u];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -394,6 +396,7 @@ __device__ __forceinline__ void block_colsum(const float *A, int lda, const floa
         }
         __syncthreads();
     }
+    if (negB) sum2 = -sum2;
 }
 
 __global__ __launch_bounds__(NT) void colsum_kernel(ColSumArgs a) {
@@ -449,6 +452,7 @@ __global__ void rbm_bias_kernel(RbmBiasArgs a) {
 struct RbmBiasFusedArgs {
     const float *X, *vs, *h0m, *hm;     // [B][V] pitch ldx / ldv, [B][H] pitch ldh0 / ldh
     int ldx, ldv, ldh0, ldh, B;
+    int hm_negated;                     // 1: `hm` points at -h_k (the negmeans buffer)
     float *raw_tail;                    // [V | H | H] raw sums are still published (metrics / tests)
     int raw_only;                       // 1: publish the raw sums only (data-parallel phase 1), no update
     RbmBiasArgs u;
@@ -477,7 +481,7 @@ __device__ __forceinline__ void rbm_bias_fused_block(const RbmBiasFusedArgs &a, 
         }
     } else {
         const int c0 = (wv - nv) * 64;
-        block_colsum(a.h0m, a.ldh0, a.hm, a.ldh, c0, a.u.H, a.B, true, smem, s1, s2);  // sum(h0 - h_k), sum(h_k)
+        block_colsum(a.h0m, a.ldh0, a.hm, a.ldh, c0, a.u.H, a.B, true, smem, s1, s2, a.hm_negated != 0);  // sum(h0 - h_k), sum(h_k)
         if ((lane & 15) == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -51,6 +51,7 @@ struct bm_rbm {
     // input of the last run_chain() (after /sigma and dropout) and its pitch
     const float *Xin = nullptr;
     int Xin_ld = 0;
+    bool hm_is_neg = false;    // the last run_chain() wrote -h_k (hneg) instead of h_k (hm)
     // optional per-kernel-class event timing
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; };
@@ -95,7 +96,7 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.mult = 1.0f + (h->cfg.dbm_first ? 1.0f : 0.0f);
     a.bmult = a.mult;
     a.kind = BM_UNIT_BERNOULLI;
-    a.sample = sample;
+    a.sample = states ? sample : 0;               // no consumer of the states: no draw
     a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
@@ -139,7 +140,10 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426). Leaves
 // h0m/h0s, vm/vs (last step), hm/hs (last step) and Xin in the handle.
 // If hm_out != null the last step's h_means are written there (dense, pitch H).
-static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out) {
+// need_vm: the last step's visible MEANS are wanted (msre metric); a plain update only consumes the
+// visible states, and nothing consumes the hidden STATES of the last step: those stores (and their
+// share of the kernel-boundary L2 writeback) are skipped.
+static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
     const float *Xin = X_dev;
@@ -159,10 +163,15 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out)
     launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0);      // :421-422
     const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
     for (int t = 0; t < k; ++t) {                                                 // :367-378
-        launch_down(h, hstate, h->hs.ld, B, h->vm.p, h->vs.p, h->vm.ld, h->cfg.sample_v_states, SITE_V, t);
-        const bool last_out = hm_out && t == k - 1;
-        launch_up(h, h->vs.p, h->vs.ld, B, last_out ? hm_out : h->hm.p, h->hs.p, last_out ? h->H : h->hm.ld,
-                  h->cfg.sample_h_states, SITE_H, t, (!hm_out && t == k - 1) ? h->hneg.p : nullptr);
+        const bool last = t == k - 1;
+        launch_down(h, hstate, h->hs.ld, B, (need_vm && last) ? h->vm.p : nullptr, h->vs.p, h->vm.ld,
+                    h->cfg.sample_v_states, SITE_V, t);
+        const bool last_out = hm_out && last;
+        // plain update, last step: only -h_k is consumed (outer products and column sums)
+        const bool neg_only = last && !hm_out && !need_vm && !h->multinomial();
+        h->hm_is_neg = neg_only;
+        launch_up(h, h->vs.p, h->vs.ld, B, last_out ? hm_out : (neg_only ? nullptr : h->hm.p), last ? nullptr : h->hs.p,
+                  last_out ? h->H : h->hm.ld, h->cfg.sample_h_states, SITE_H, t, (!hm_out && last) ? h->hneg.p : nullptr);
         hstate = h->hs.p;
     }
     return 0;
@@ -181,7 +190,10 @@ static void fill_bias(bm_rbm *h, float N, float lr, float mom, RbmBiasArgs &b) {
 static int fill_bias_fused(bm_rbm *h, int B, float lr, float mom, RbmBiasFusedArgs &a) {
     memset(&a, 0, sizeof(a));
     a.X = h->Xin; a.ldx = h->Xin_ld; a.vs = h->vs.p; a.ldv = h->vs.ld;
-    a.h0m = h->h0m.p; a.ldh0 = h->h0m.ld; a.hm = h->hm.p; a.ldh = h->hm.ld; a.B = B;
+    a.h0m = h->h0m.p; a.ldh0 = h->h0m.ld; a.B = B;
+    // the last up-pass of a plain update leaves only -h_k behind (run_chain)
+    if (h->hm_is_neg) { a.hm = h->hneg.p; a.ldh = h->hneg.ld; a.hm_negated = 1; }
+    else              { a.hm = h->hm.p; a.ldh = h->hm.ld; }
     a.raw_tail = h->grad.p + h->grad_tail();
     RbmBiasArgs &b = a.u;
     b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
@@ -425,7 +437,7 @@ int bm_rbm_seed(bm_rbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 
 int bm_rbm_set_row_offset(bm_rbm *h, int64_t row0) { h->row0 = row0; return 0; }
 
 int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, false));
     launch_update_fused(h, B, lr, mom);
     h->call++;
     BM_HIP(hipGetLastError());
@@ -452,7 +464,7 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, 
 }
 
 int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, false));
     rbm_grad(h, B, 0, (float)B, 0.f, 0.f, true);     // raw outer products + raw column sums, one launch
     h->call++;
     BM_HIP(hipGetLastError());
