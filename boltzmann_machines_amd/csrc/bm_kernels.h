@@ -100,9 +100,25 @@ __device__ __forceinline__ void draw4(const ActArgs &a, unsigned long long flat,
     }
 }
 
+// Output stores of the hot kernels (BM_NT_STORES, default on): streaming ("nt") stores.  Results
+// are consumed by the NEXT kernel, after the kernel-boundary L2 writeback + invalidate of the 8
+// non-coherent XCD L2s, so caching them write-back only queues them up for that flush.
+#ifndef BM_NT_STORES
+#define BM_NT_STORES 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store4(float *p, float x, float y, float z, float w) {
+    if (BM_NT_STORES) __builtin_nontemporal_store((f32x4){x, y, z, w}, reinterpret_cast<f32x4 *>(p));
+    else *reinterpret_cast<float4 *>(p) = make_float4(x, y, z, w);
+}
+__device__ __forceinline__ void stream_store2(float *p, float x, float y) {
+    if (BM_NT_STORES) __builtin_nontemporal_store((f32x2){x, y}, reinterpret_cast<f32x2 *>(p));
+    else *reinterpret_cast<float2 *>(p) = make_float2(x, y);
+}
+
 __device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int nvalid, bool v4) {
     if (v4) {
-        *reinterpret_cast<float4 *>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+        stream_store4(dst + o, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (r < nvalid) dst[o + r] = v[r];
@@ -693,10 +709,10 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
             wt[n][e] = wv[e];
         }
         if (side.vec8) {
-            *reinterpret_cast<float4 *>(a.W + o) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            *reinterpret_cast<float4 *>(a.W + o + 4) = make_float4(wv[4], wv[5], wv[6], wv[7]);
-            *reinterpret_cast<float4 *>(a.dW + o) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-            *reinterpret_cast<float4 *>(a.dW + o + 4) = make_float4(dv[4], dv[5], dv[6], dv[7]);
+            stream_store4(a.W + o, wv[0], wv[1], wv[2], wv[3]);
+            stream_store4(a.W + o + 4, wv[4], wv[5], wv[6], wv[7]);
+            stream_store4(a.dW + o, dv[0], dv[1], dv[2], dv[3]);
+            stream_store4(a.dW + o + 4, dv[4], dv[5], dv[6], dv[7]);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -711,7 +727,7 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
             if (ib0 + e >= a.I) break;
             float *dst = a.Wt + (size_t)(ib0 + e) * a.ldwt + ja;
             if (pair) {
-                *reinterpret_cast<float2 *>(dst) = make_float2(wt[0][e], wt[1][e]);
+                stream_store2(dst, wt[0][e], wt[1][e]);
             } else {
                 if (jok[0]) dst[0] = wt[0][e];
                 if (jok[1]) dst[1] = wt[1][e];
