@@ -45,7 +45,11 @@ namespace bm {
 // Side work hooks of the main loop: fill() runs in the shadow of the pipeline fill (the first
 // global round trip), drain() is issued before the MFMAs of the last two chunks (loads the
 // epilogue needs: their latency hides under ~2k cycles of matrix work).  Default: none.
-struct NoSide { __device__ __forceinline__ void fill() {} __device__ __forceinline__ void drain() {} };
+struct NoSide {
+    static constexpr bool kFinalSync = true;     // a following pipeline may refill the LDS ring
+    __device__ __forceinline__ void fill() {}
+    __device__ __forceinline__ void drain() {}
+};
 
 // compile-time ablation mask (template parameter ABL, 0 in the product; tools/probe_act.hip
 // instantiates other values to price each pipeline stage)
@@ -73,7 +77,10 @@ struct Geo {
     // k-major Q: NJ == 2 interleaves the two j sub-tiles like the i side (sub-tile n holds
     // j = base + 2*l15 + n: ONE ds_read_b64 per k-step, stride == 32 mod 64); NJ == 1 reads b32
     static constexpr int Q_STRIDE_KM = (NJ == 2) ? ((TJ % 64 == 0) ? TJ + 32 : TJ) : ((TJ % 32 == 0) ? TJ + 16 : TJ);
-    static constexpr int P_BUF = BK * P_STRIDE;
+    // x-major P (MI == 1 only: W itself as the prop-down operand, no maintained transpose): same
+    // row stride and conflict rules as the x-major Q
+    static constexpr int P_STRIDE_XM = BK + 2;
+    static constexpr int P_BUF = (MI == 1 && TI * P_STRIDE_XM > BK * P_STRIDE) ? TI * P_STRIDE_XM : BK * P_STRIDE;
     static constexpr int Q_BUF = (BK * Q_STRIDE_KM > TJ * Q_STRIDE_XM) ? BK * Q_STRIDE_KM : TJ * Q_STRIDE_XM;
     static constexpr int SMEM_FLOATS = NBUF * (P_BUF + Q_BUF);
     static constexpr int NVP = TI * BK / (4 * NT);       // float4 per thread per chunk, P tile
@@ -208,10 +215,12 @@ template <class G> struct Frags {
     float q[G::BK / 4][G::NJ];     // q[kk][n] = Q[j = 16n + l15][k = 4kk+g]
 };
 
-template <int QL, class G, int ABL = 0>
+template <int QL, class G, int ABL = 0, int PL = KM>
 __device__ __forceinline__ void read_frags(Frags<G> &f, const float *sP, const float *sQ, int wi, int wj, int lane) {
+    static_assert(PL == KM || G::MI == 1, "x-major P needs MI == 1 (no interleaved sub-tiles)");
     const int g = lane >> 4, l15 = lane & 15;
-    const float *pP = sP + g * G::P_STRIDE + wi * (16 * G::MI) + G::MI * l15;
+    const float *pP = (PL == KM) ? sP + g * G::P_STRIDE + wi * (16 * G::MI) + G::MI * l15
+                                 : sP + (wi * 16 + l15) * G::P_STRIDE_XM + g;
     const float *pQ = (QL == KM) ? sQ + g * G::Q_STRIDE_KM + wj * 16 * G::NJ + ((G::NJ == 2) ? 2 * l15 : l15)
                                  : sQ + (wj * 16 * G::NJ + l15) * G::Q_STRIDE_XM + g;
 #pragma unroll
@@ -223,7 +232,7 @@ __device__ __forceinline__ void read_frags(Frags<G> &f, const float *sP, const f
             const float2 t = *reinterpret_cast<const float2 *>(pP + kk * 4 * G::P_STRIDE);
             f.p[kk][0] = t.x; f.p[kk][G::MI - 1] = t.y;
         } else {
-            f.p[kk][0] = pP[kk * 4 * G::P_STRIDE];
+            f.p[kk][0] = (PL == KM) ? pP[kk * 4 * G::P_STRIDE] : pP[kk * 4];
         }
         if (QL == KM && G::NJ == 2) {
             const float2 t = *reinterpret_cast<const float2 *>(pQ + kk * 4 * G::Q_STRIDE_KM);
@@ -298,30 +307,30 @@ __device__ __forceinline__ const float *sel_p(const float *a, const float *b, in
     return (const float *)(ua ^ ((ua ^ ub) & (uintptr_t)(intptr_t)m));
 }
 
-template <int QL, class G, bool FAST, bool SEG2>
+template <int QL, class G, bool FAST, bool SEG2, int PL = KM>
 __device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, int nch1, int i0, int j0, int c, int tid) {
     constexpr int BK = G::BK;
     if (!SEG2) {
-        g2r<KM, G::TI, BK, G::NT, FAST>(r.p, kr.P1.ptr, kr.P1.ld, kr.P1.nx, kr.P1.vec, i0, c * BK, kr.K1, tid);
+        g2r<PL, G::TI, BK, G::NT, FAST>(r.p, kr.P1.ptr, kr.P1.ld, kr.P1.nx, kr.P1.vec, i0, c * BK, kr.K1, tid);
         g2r<QL, G::TJ, BK, G::NT, FAST>(r.q, kr.Q1.ptr, kr.Q1.ld, kr.Q1.nx, kr.Q1.vec, j0, c * BK, kr.K1, tid);
     } else {
         const int m = -(int)((c >= nch1) & (kr.K2 > 0));   // all-ones in segment 2 (wave-uniform)
         const int kc = c - (nch1 & m);
         const int K = sel_i(kr.K1, kr.K2, m);
-        g2r<KM, G::TI, BK, G::NT, FAST>(r.p, sel_p(kr.P1.ptr, kr.P2.ptr, m), sel_i(kr.P1.ld, kr.P2.ld, m),
+        g2r<PL, G::TI, BK, G::NT, FAST>(r.p, sel_p(kr.P1.ptr, kr.P2.ptr, m), sel_i(kr.P1.ld, kr.P2.ld, m),
                                         sel_i(kr.P1.nx, kr.P2.nx, m), sel_i(kr.P1.vec, kr.P2.vec, m), i0, kc * BK, K, tid);
         g2r<QL, G::TJ, BK, G::NT, FAST>(r.q, sel_p(kr.Q1.ptr, kr.Q2.ptr, m), sel_i(kr.Q1.ld, kr.Q2.ld, m),
                                         sel_i(kr.Q1.nx, kr.Q2.nx, m), sel_i(kr.Q1.vec, kr.Q2.vec, m), j0, kc * BK, K, tid);
     }
 }
 
-template <int QL, class G, bool FAST, bool SEG2>
+template <int QL, class G, bool FAST, bool SEG2, int PL = KM>
 __device__ __forceinline__ void store_chunk(const ChunkRegs<G> &r, const KRange &kr, int nch1, int c,
                                             float *sP, float *sQ, int tid) {
     constexpr int BK = G::BK;
     const int m = SEG2 ? -(int)((c >= nch1) & (kr.K2 > 0)) : 0;
     const int kz = sel_i(kr.K1, kr.K2, m) - (c - (nch1 & m)) * BK;
-    r2s<KM, G::TI, BK, G::NT, G::P_STRIDE, FAST>(r.p, sP, tid, kz);
+    r2s<PL, G::TI, BK, G::NT, (PL == KM) ? G::P_STRIDE : G::P_STRIDE_XM, FAST>(r.p, sP, tid, kz);
     r2s<QL, G::TJ, BK, G::NT, (QL == KM) ? G::Q_STRIDE_KM : G::Q_STRIDE_XM, FAST>(r.q, sQ, tid, kz);
 }
 
@@ -353,14 +362,14 @@ __device__ __forceinline__ void plan_offsets(uint32_t (&off)[TX * BK / (4 * NTH)
     }
 }
 
-template <int QL, class G>
+template <int QL, class G, int PL = KM>
 __device__ __forceinline__ void make_plan(LoadPlan<G> &pl, const Operand &P, const Operand &Q, int i0, int j0, int tid) {
-    plan_offsets<KM, G::TI, G::BK, G::NT>(pl.p, P.ld, P.nx, i0, tid);
+    plan_offsets<PL, G::TI, G::BK, G::NT>(pl.p, P.ld, P.nx, i0, tid);
     plan_offsets<QL, G::TJ, G::BK, G::NT>(pl.q, Q.ld, Q.nx, j0, tid);
 }
 
 // chunk c (must be a FULL chunk of its segment; c >= nch: prefetch overrun, any full chunk does)
-template <int QL, class G, bool SEG2>
+template <int QL, class G, bool SEG2, int PL = KM>
 __device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &kr, const LoadPlan<G> &pl1,
                                                 const LoadPlan<G> &pl2, int nch1, int nch, int c) {
     constexpr int BK = G::BK;
@@ -369,7 +378,8 @@ __device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &k
     const int kc = cl - (nch1 & m);
     const int ldp = SEG2 ? sel_i(kr.P1.ld, kr.P2.ld, m) : kr.P1.ld;
     const int ldq = SEG2 ? sel_i(kr.Q1.ld, kr.Q2.ld, m) : kr.Q1.ld;
-    const char *pb = (const char *)((SEG2 ? sel_p(kr.P1.ptr, kr.P2.ptr, m) : kr.P1.ptr) + (size_t)kc * BK * ldp);
+    const char *pb = (const char *)((SEG2 ? sel_p(kr.P1.ptr, kr.P2.ptr, m) : kr.P1.ptr) +
+                                    ((PL == KM) ? (size_t)kc * BK * ldp : (size_t)kc * BK));
     const char *qb = (const char *)((SEG2 ? sel_p(kr.Q1.ptr, kr.Q2.ptr, m) : kr.Q1.ptr) +
                                     ((QL == KM) ? (size_t)kc * BK * ldq : (size_t)kc * BK));
 #pragma unroll
@@ -386,9 +396,9 @@ __device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &k
     }
 }
 
-template <int QL, class G>
+template <int QL, class G, int PL = KM>
 __device__ __forceinline__ void store_chunk_slim(const ChunkRegs<G> &r, float *sP, float *sQ, int tid) {
-    r2s<KM, G::TI, G::BK, G::NT, G::P_STRIDE, false>(r.p, sP, tid, 0);
+    r2s<PL, G::TI, G::BK, G::NT, (PL == KM) ? G::P_STRIDE : G::P_STRIDE_XM, false>(r.p, sP, tid, 0);
     r2s<QL, G::TJ, G::BK, G::NT, (QL == KM) ? G::Q_STRIDE_KM : G::Q_STRIDE_XM, false>(r.q, sQ, tid, 0);
 }
 
@@ -408,7 +418,7 @@ __device__ __forceinline__ void store_chunk_slim(const ChunkRegs<G> &r, float *s
 // (clamped loads, K-tail zero fill) for chunks that touch the end of a segment.
 // `side.fill()` (the lane's Philox blocks in act_kernel) runs while the first loads are in
 // flight, when the wave would otherwise idle for one memory round trip.
-template <int QL, class G, bool FAST, bool SEG2, int ABL = 0, class Side = NoSide>
+template <int QL, class G, bool FAST, bool SEG2, int ABL = 0, int PL = KM, class Side = NoSide>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRange &kr, int i0, int j0, float *smem,
                                          Side &side, long long *stamps = nullptr) {
 #ifdef BM_PROBE
@@ -427,26 +437,26 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     Frags<G> fa, fb;
     LoadPlan<G> pl1, pl2;
     if (FAST) {
-        make_plan<QL, G>(pl1, kr.P1, kr.Q1, i0, j0, tid);
-        if (SEG2) make_plan<QL, G>(pl2, kr.P2, kr.Q2, i0, j0, tid);
+        make_plan<QL, G, PL>(pl1, kr.P1, kr.Q1, i0, j0, tid);
+        if (SEG2) make_plan<QL, G, PL>(pl2, kr.P2, kr.Q2, i0, j0, tid);
     }
     BM_MSTAMP(0);
     {   // pipeline fill: the four chunk loads go out back to back (ONE memory round trip);
         // chunks 0/1 pass through two prologue-only sets, chunks 2/3 land in the loop's sets
         ChunkRegs<G> ga, gb;
-        load_chunk<QL, G, FAST, SEG2>(ga, kr, nch1, i0, j0, 0, tid);
-        load_chunk<QL, G, FAST, SEG2>(gb, kr, nch1, i0, j0, 1, tid);
-        load_chunk<QL, G, FAST, SEG2>(g0, kr, nch1, i0, j0, 2, tid);
-        load_chunk<QL, G, FAST, SEG2>(g1, kr, nch1, i0, j0, 3, tid);
+        load_chunk<QL, G, FAST, SEG2, PL>(ga, kr, nch1, i0, j0, 0, tid);
+        load_chunk<QL, G, FAST, SEG2, PL>(gb, kr, nch1, i0, j0, 1, tid);
+        load_chunk<QL, G, FAST, SEG2, PL>(g0, kr, nch1, i0, j0, 2, tid);
+        load_chunk<QL, G, FAST, SEG2, PL>(g1, kr, nch1, i0, j0, 3, tid);
         __builtin_amdgcn_sched_barrier(0);
         side.fill();
         __builtin_amdgcn_sched_barrier(0);
-        store_chunk<QL, G, FAST, SEG2>(ga, kr, nch1, 0, sP, sQ, tid);
-        store_chunk<QL, G, FAST, SEG2>(gb, kr, nch1, 1, sP + P_BUF, sQ + Q_BUF, tid);
+        store_chunk<QL, G, FAST, SEG2, PL>(ga, kr, nch1, 0, sP, sQ, tid);
+        store_chunk<QL, G, FAST, SEG2, PL>(gb, kr, nch1, 1, sP + P_BUF, sQ + Q_BUF, tid);
     }
     BM_MSTAMP(1);
     __syncthreads();
-    read_frags<QL, G, ABL>(fa, sP, sQ, wi, wj, lane);
+    read_frags<QL, G, ABL, PL>(fa, sP, sQ, wi, wj, lane);
     BM_MSTAMP(2);
     int cc = 0, b1 = 1, b2 = 2;   // LDS slots of chunk cc+1 / cc+2
     // Issue order of one step.  Instruction counts per wave and step:
@@ -455,7 +465,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     // masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
     constexpr int NM = (BK / 4) * G::MI * G::NJ;
     constexpr int NRG = BK / 8, RPG = (QL == KM && G::NJ == 2) ? 2 : 1 + G::NJ;
-    constexpr int NW = G::NVP + ((QL == XM) ? 2 * G::NVQ : G::NVQ);
+    constexpr int NW = ((PL == XM) ? 2 * G::NVP : G::NVP) + ((QL == XM) ? 2 * G::NVQ : G::NVQ);
     constexpr int NL = G::NVP + G::NVQ;
     constexpr int MR = (NM >= 64) ? 2 : 1;            // MFMAs per read group
     constexpr int MW = (NM >= 32) ? 2 : 1;            // MFMAs per DS write
@@ -505,9 +515,9 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     // careful step: clamped loads, K-tail zero fill
 #define BM_STEP(FC, FN, G_)                                                                       \
     {                                                                                             \
-        if (!BM_ABL(3)) read_frags<QL, G, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
-        if (!BM_ABL(2)) store_chunk<QL, G, FAST, SEG2>(G_, kr, nch1, cc + 2, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid); \
-        if (!BM_ABL(0)) load_chunk<QL, G, FAST, SEG2>(G_, kr, nch1, i0, j0, cc + 4, tid);         \
+        if (!BM_ABL(3)) read_frags<QL, G, ABL, PL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
+        if (!BM_ABL(2)) store_chunk<QL, G, FAST, SEG2, PL>(G_, kr, nch1, cc + 2, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid); \
+        if (!BM_ABL(0)) load_chunk<QL, G, FAST, SEG2, PL>(G_, kr, nch1, i0, j0, cc + 4, tid);         \
         mfma_frags<G, ABL>(acc, FC);                                                              \
         BM_STEP_TAIL                                                                              \
     }
@@ -523,11 +533,11 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #define BM_STEP_SLIM(FC, FN, G_)                                                                  \
     {                                                                                             \
         BM_PSTAMP(0)                                                                              \
-        if (!BM_ABL(3)) read_frags<QL, G, ABL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
+        if (!BM_ABL(3)) read_frags<QL, G, ABL, PL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
         BM_PSTAMP(1)                                                                              \
-        if (!BM_ABL(2)) store_chunk_slim<QL, G>(G_, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid);       \
+        if (!BM_ABL(2)) store_chunk_slim<QL, G, PL>(G_, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid);       \
         BM_PSTAMP(2)                                                                              \
-        if (!BM_ABL(0)) load_chunk_slim<QL, G, SEG2>(G_, kr, pl1, pl2, nch1, nch, cc + 4);        \
+        if (!BM_ABL(0)) load_chunk_slim<QL, G, SEG2, PL>(G_, kr, pl1, pl2, nch1, nch, cc + 4);        \
         BM_PSTAMP(3)                                                                              \
         mfma_frags<G, ABL>(acc, FC);                                                              \
         BM_PSTAMP(4)                                                                              \
@@ -590,13 +600,13 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     const int nq_last = (klast + 15) / 16;
     side.drain();
     if (nch >= 2) {
-        if (!BM_ABL(3)) read_frags<QL, G, ABL>(fb, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane);
+        if (!BM_ABL(3)) read_frags<QL, G, ABL, PL>(fb, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane);
         mfma_frags<G, ABL>(acc, fa);
         mfma_frags_head<G, ABL>(acc, fb, nq_last);
     } else {
         mfma_frags_head<G, ABL>(acc, fa, nq_last);
     }
-    __syncthreads();           // the LDS ring may be refilled by a following pipeline
+    if (Side::kFinalSync) __syncthreads();     // the LDS ring may be refilled by a following pipeline
     BM_MSTAMP(4);
 #ifdef BM_PROBE
     if (BM_ABL(7) && stamps && lane == 0 && (w == 0 || w == 3)) {

@@ -23,6 +23,8 @@ namespace bm {
 // ------------------------------------------------------------------ act_kernel
 struct ActArgs {
     Operand P1, Q1; int K1;      // segment 1:  z += sum_k P1[i][k] Q1[j][k]
+    int p_xm;                    // 1: P1 is stored x-major [i][k] (W itself for the prop-down: no transpose kept);
+                                 //    single segment, geometries with MI == 1
     Operand P2, Q2; int K2;      // segment 2 (K2 == 0: absent), chained onto the same accumulator
     int I, J;                    // output is [J rows][I cols], ld = ldo
     const float *bias;           // [I]
@@ -130,6 +132,7 @@ template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
 
 // act_kernel's side work for the main loop's pipeline fill
 template <int E, class Rng> struct ActSide {
+    static constexpr bool kFinalSync = false;    // one pipeline per kernel: waves enter the epilogue as they finish
     const float *bias, *sigma;
     int ib0, I, with_rng;
     float bs[E], sg[E];
@@ -149,7 +152,7 @@ template <int E, class Rng> struct ActSide {
     __device__ __forceinline__ void drain() {}
 };
 
-template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0>
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
@@ -194,9 +197,9 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
             }
     }
 #ifdef BM_PROBE
-    mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+    mainloop<XM, G, FAST, SEG2, ABL, PL>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
 #else
-    mainloop<XM, G, FAST, SEG2, ABL>(acc, kr, i0, j0, smem, side);
+    mainloop<XM, G, FAST, SEG2, ABL, PL>(acc, kr, i0, j0, smem, side);
 #endif
     const float (&bs)[E] = side.bs;
     const float (&sg)[E] = side.sg;
@@ -573,6 +576,7 @@ struct DivBy {
 // grad_kernel's side work: the W / dW values of the lane's outputs are fetched at the start of
 // the pipeline drain, so the read-modify-write epilogue does not start with a memory round trip
 struct GradSide {
+    static constexpr bool kFinalSync = true;     // form 1 runs two pipelines through the same LDS ring
     const float *W, *dW; int ldw, I, J, ib0, jb[2]; bool on, vec8;
     float4 w[2][2], d[2][2];
     __device__ __forceinline__ void fill() {}
@@ -1222,9 +1226,17 @@ template <class G> static inline int tile_grid(int I, int J) { return ((I + G::T
 template <class G, int MINB>
 static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
     const bool seg2 = a.K2 > 0;
-    const bool fast = operand_fast(a.P1, KM, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
+    const int pl = a.p_xm ? XM : KM;
+    const bool fast = operand_fast(a.P1, pl, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
                       (!seg2 || (operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2)));
     const dim3 grid(tile_grid<G>(a.I, a.J)), blk(G::NT);
+    if constexpr (G::MI == 1) {
+        if (a.p_xm) {                       // x-major P: single segment only (RBM prop-down from W)
+            if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, XM>), grid, blk, 0, st, a);
+            else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, XM>), grid, blk, 0, st, a);
+            return;
+        }
+    }
     if (seg2) {
         if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true>), grid, blk, 0, st, a);
         else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false>), grid, blk, 0, st, a);
@@ -1233,6 +1245,7 @@ static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
         else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false>), grid, blk, 0, st, a);
     }
 }
+
 // ---- act_kernel geometry choice ---------------------------------------------------------
 // Three geometries compute bit-identical results (tests run all of them); which one is fastest
 // depends on how the output tiles fill the 256 CUs and on the K length, and did not follow a
@@ -1248,6 +1261,7 @@ static inline int act_geo_override() {
     return v;
 }
 static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
+    if (a.p_xm && geo != 1) geo = 8;        // x-major P exists for the MI == 1 geometries only
     if (geo == 8)      launch_act_geo<GeoAct8, 1>(a, st);
     else if (geo == 1) launch_act_geo<GeoActS, 2>(a, st);
     else               launch_act_geo<GeoAct, 1>(a, st);
@@ -1264,7 +1278,7 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
     if (ov) { launch_act_as(ov, a, st); return; }
     static std::mutex mu;
     static std::map<std::array<long long, 6>, ActTune> table;
-    const std::array<long long, 6> key = {a.I, a.J, a.K1, a.K2, (long long)((a.sample ? 1 : 0) | (a.kind << 1) | (a.prev ? 8 : 0) | (a.rowacc ? 16 : 0) | (a.acc_init ? 32 : 0)), 0LL};
+    const std::array<long long, 6> key = {a.I, a.J, a.K1, a.K2, (long long)((a.sample ? 1 : 0) | (a.kind << 1) | (a.prev ? 8 : 0) | (a.rowacc ? 16 : 0) | (a.acc_init ? 32 : 0) | (a.p_xm ? 64 : 0)), 0LL};
     int geo;
     ActTune::Sample *smp = nullptr;
     {

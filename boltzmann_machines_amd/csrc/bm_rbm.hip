@@ -32,8 +32,9 @@ struct bm_rbm {
     int V, H, maxB;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // variables (padded pitch, see pad_ld); Wt = W^T kept in sync by every writer of W
-    Mat W, Wt, dW;                     // [V][H], [H][V], [V][H]
+    // variables (padded pitch, see pad_ld).  No transposed copy of W: the prop-down reads W itself as an
+    // x-major operand (ActArgs::p_xm), which saves 3.2 MB of writes per update at 784 x 1024
+    Mat W, dW;                         // [V][H], [V][H]
     DevBuf vb, hb, dvb, dhb, q, sigma;
     // chain workspaces
     Mat h0m, h0s, hm, hs, hneg;        // [maxB][H]; hneg = -hm (negative-phase operand of the outer products)
@@ -122,7 +123,8 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
     ProfScope _ps(h, KC_DOWN);
     ActArgs a;
     memset(&a, 0, sizeof(a));
-    a.P1 = make_operand(h->Wt.p, h->Wt.ld, h->V);  // Wt[k=h][i=v], KM
+    a.P1 = make_operand(h->W.p, h->W.ld, h->V);    // W[i=v][k=h], x-major P
+    a.p_xm = 1;
     a.Q1 = make_operand(hs, ldh, B);               // h[j=b][k=h], XM
     a.K1 = h->H;
     a.I = h->V; a.J = B;
@@ -235,8 +237,8 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
     g.I = h->H; g.J = h->V;
     g.form = 0; g.fused = fused;
     g.raw = h->grad.p; g.raw2 = nullptr;
-    g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p;
-    g.ldw = h->W.ld; g.ldwt = h->Wt.ld;
+    g.W = h->W.p; g.dW = h->dW.p; g.Wt = nullptr;
+    g.ldw = h->W.ld; g.ldwt = 0;
     g.pen = with_bias ? nullptr : h->pen.p;
     g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
     if (with_bias) {
@@ -341,7 +343,7 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipEventCreate(&h->ev0));
     BM_HIP(hipEventCreate(&h->ev1));
-    BM_TRY(h->W.alloc(V, H)); BM_TRY(h->Wt.alloc(H, V)); BM_TRY(h->dW.alloc(V, H));
+    BM_TRY(h->W.alloc(V, H)); BM_TRY(h->dW.alloc(V, H));
     BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
     BM_TRY(h->q.alloc(H)); BM_TRY(h->sigma.alloc(V));
     BM_TRY(h->h0m.alloc(B, H)); BM_TRY(h->h0s.alloc(B, H)); BM_TRY(h->hm.alloc(B, H)); BM_TRY(h->hs.alloc(B, H)); BM_TRY(h->hneg.alloc(B, H));
@@ -362,7 +364,7 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
 int bm_rbm_destroy(bm_rbm *h) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->stream);
-    Mat *mats[] = {&h->W, &h->Wt, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
+    Mat *mats[] = {&h->W, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
     DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->pen, &h->rowacc, &h->hhat};
     for (DevBuf *b : all) b->release();
@@ -395,12 +397,6 @@ int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
     if (nm == "W" || nm == "dW") {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
         BM_TRY((nm == "W" ? h->W : h->dW).upload(host));
-        if (nm == "W") {   // keep the transposed copy in sync
-            std::vector<float> t(n);
-            for (int v = 0; v < h->V; ++v)
-                for (int c = 0; c < h->H; ++c) t[(size_t)c * h->V + v] = host[(size_t)v * h->H + c];
-            BM_TRY(h->Wt.upload(t.data()));
-        }
         return 0;
     }
     DevBuf *b = find_vec(h, nm);
@@ -413,9 +409,9 @@ int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
 int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n) {
     const std::string nm(name ? name : "");
     BM_HIP(hipStreamSynchronize(h->stream));
-    if (nm == "W" || nm == "dW" || nm == "Wt") {
+    if (nm == "W" || nm == "dW") {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
-        return (nm == "W" ? h->W : nm == "dW" ? h->dW : h->Wt).download(host);
+        return (nm == "W" ? h->W : h->dW).download(host);
     }
     DevBuf *b = find_vec(h, nm);
     BM_CHECK(b, "unknown RBM variable '%s'", name ? name : "(null)");
@@ -478,8 +474,8 @@ int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float lr, float mom) {
     ApplyWArgs a;
     memset(&a, 0, sizeof(a));
     a.raw = h->grad.p; a.raw2 = nullptr;
-    a.W = h->W.p; a.dW = h->dW.p; a.Wt = h->Wt.p;
-    a.I = h->H; a.J = h->V; a.ldw = h->W.ld; a.ldwt = h->Wt.ld; a.form = 0;
+    a.W = h->W.p; a.dW = h->dW.p; a.Wt = nullptr;
+    a.I = h->H; a.J = h->V; a.ldw = h->W.ld; a.ldwt = 0; a.form = 0;
     a.N = (float)B_global; a.M = a.N; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
     if (h->cfg.sparsity_cost != 0.f) {      // the W update needs the penalty: bias update first
         hipLaunchKernelGGL(rbm_bias_kernel, dim3((h->V + h->H + 255) / 256), dim3(256), 0, h->stream, b);
