@@ -550,6 +550,7 @@ struct GradArgs {
     // only when the W update does not need the penalty they produce (sparsity_cost == 0).
     int nbias;
     RbmBiasFusedArgs bias;
+    int fetch_at_fill;                // 1: read W/dW of the lane's outputs during the pipeline fill (set by launch_grad)
 #ifdef BM_PROBE
     long long *dbg;
 #endif
@@ -579,8 +580,10 @@ struct GradSide {
     static constexpr bool kFinalSync = true;     // form 1 runs two pipelines through the same LDS ring
     const float *W, *dW; int ldw, I, J, ib0, jb[2]; bool on, vec8;
     float4 w[2][2], d[2][2];
-    __device__ __forceinline__ void fill() {}
-    __device__ __forceinline__ void drain() {
+    bool at_fill;
+    __device__ __forceinline__ void fill() { if (at_fill) fetch(); }
+    __device__ __forceinline__ void drain() { if (!at_fill) fetch(); }
+    __device__ __forceinline__ void fetch() {
         if (!on || ib0 >= I) return;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -648,10 +651,10 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     side.jb[0] = j0 + wj * 32 + lane_j<KM, G>(l15, 0);
     side.jb[1] = j0 + wj * 32 + lane_j<KM, G>(l15, 1);
     side.vec8 = (ib0 + 7 < a.I) && ((a.ldw & 3) == 0);            // 16-byte aligned run of 8 (ib0 % 8 == 0)
-#ifndef BM_GRAD_PREFETCH
-#define BM_GRAD_PREFETCH 0
-#endif
-    side.on = BM_GRAD_PREFETCH && a.fused != 0;
+    // When are W/dW of the lane's outputs read?  In the epilogue by default; fetching them in the pipeline
+    // fill (fetch_at_fill) or at the start of the drain only moved the time or lost (launch_grad).
+    side.at_fill = true;
+    side.on = a.fused != 0 && a.fetch_at_fill != 0;
     KRange kr;
     kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
     if (a.form == 0) {
@@ -663,16 +666,14 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     } else {
         // DBM: pos/N - neg/M with N != M needs the two sums separately
         kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0;
-        side.on = false;
         mainloop<KM, G, FAST, false>(pos, kr, i0, j0, smem, side);
         kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
-        side.on = BM_GRAD_PREFETCH && a.fused != 0;
         mainloop<KM, G, FAST, false>(neg, kr, i0, j0, smem, side);
     }
 
     BM_GSTAMP(1);
     if (ib0 >= a.I) return;
-    if (!BM_GRAD_PREFETCH) { side.on = a.fused != 0; side.drain(); }
+    if (!a.fetch_at_fill) { side.on = a.fused != 0; side.fetch(); }
     const DivBy divN(a.N), divM(a.M);
     float wt[2][8];                 // updated W values of both j (adjacent columns of Wt)
     bool jok[2];
@@ -1323,7 +1324,11 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
     launch_act_as(geo, a, st);
 }
 
-static inline void launch_grad(const GradArgs &g, hipStream_t st) {
+static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
+    static int fetch_env = -1;          // BM355_GRAD_FETCH=0|1 overrides (experiments)
+    if (fetch_env < 0) { const char *e = getenv("BM355_GRAD_FETCH"); fetch_env = e ? 2 + atoi(e) : 0; }
+    GradArgs g = g_in;
+    g.fetch_at_fill = fetch_env >= 2 ? fetch_env - 2 : 0;      // measured (same box, 784x1024x512): epilogue 66.6 us/update, fill 67.5
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
     const dim3 grid(tile_grid<GeoGrad>(g.I, g.J) + g.nbias), blk(NT);
