@@ -318,3 +318,24 @@ def test_multinomial_rejects_bad_config(gpu_lib):
         RbmEngine(8, 9000, max_batch=4, h_unit=2, n_samples=10)
     with pytest.raises(Bm355Error):
         RbmEngine(8, 8, max_batch=4, h_unit=7)
+
+
+def test_long_run_stays_bit_exact(gpu_lib):
+    """300 consecutive CD-1 updates (the launch tuner changes the act_kernel geometry during the first
+    launches of each shape; lr/momentum/k schedules change mid-run): parameters still bit-identical."""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B = 200, 96, 48
+    eng, twin = make_pair(V, H, max_batch=B, sample_v_states=True, l2=1e-4, sparsity_cost=1e-3, dropout=0.9)
+    eng.seed(2024); twin.set_seed(2024)
+    X = synth_data(4 * B, V, 0)
+    Xd = as_device(X)
+    for step in range(300):
+        lr, mom, k = (0.05, 0.5, 1) if step < 150 else (0.01, 0.9, 2)
+        row = (step % 4) * B
+        eng.train_step(Xd, B, lr, mom, k, row=row)
+        twin.train_step(X[row:row + B], lr, mom, k)
+        if step in (0, 8, 9, 10, 149, 150):
+            assert_state_equal(eng, twin)
+    assert_state_equal(eng, twin)
+    assert np.all(np.isfinite(eng.get('W')))
+    eng.close()
