@@ -40,6 +40,7 @@ struct bm_dbm {
     DevBuf wnorm[MAXL];
     unsigned *flag = nullptr;                      // mean-field residual cell (= &ctl->maxdiff)
     MfCtl *ctl = nullptr;                          // device-side loop control
+    DevBuf mfblk;                                  // [L * BM_MF_SLOTS] per-workgroup residual slots (single-GPU mean field)
     Mat xw0;                                       // [N][n1] hoisted X.W0 of the current minibatch
     double *scal = nullptr;
     // AIS / ELBO workspaces (allocated on demand)
@@ -101,7 +102,8 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
 //   out_means  : Hout receives means (sample == 0) or samples (per-layer flags)
 static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout, Mat *Hout,
                         bool update_v, bool sample, int t, int64_t row0,
-                        unsigned *maxdiff = nullptr, const Mat *xw0 = nullptr, const int *skip = nullptr) {
+                        unsigned *maxdiff = nullptr, const Mat *xw0 = nullptr, const int *skip = nullptr,
+                        float *mfblk = nullptr) {
     const int L = h->L;
     for (int i = 0; i < L; ++i) {
         LayerIn below = (i == 0) ? vin : LayerIn{Hout[i - 1].p, Hout[i - 1].ld};       // NEW below   :400-402
@@ -110,6 +112,7 @@ static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout
         ActArgs e;
         memset(&e, 0, sizeof(e));
         e.skip = skip;
+        e.maxdiff_blk = (maxdiff && mfblk) ? mfblk + (size_t)i * BM_MF_SLOTS : nullptr;
         if (i == 0 && xw0 && above.p) {
             // mean-field: X.W0 is loop invariant — start the chain from the hoisted partial sum and
             // stream only the top-down segment (bit-identical to recomputing X.W0 every sweep)
@@ -192,7 +195,8 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
             ++step;
         }
     } else {
-        hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(1), 0, h->stream, h->ctl, h->cfg.mf_tol, 1);
+        hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, 1,
+                           h->mfblk.p, h->L * BM_MF_SLOTS);
         int enq = 0;
         MfCtl host;
         host.done = 0; host.steps = 0;
@@ -202,8 +206,9 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
                 // sweep number enq+s runs only if all before it ran, so its ping-pong parity is static
                 Mat *src = ((enq + s) & 1) ? h->mu_alt : h->mu, *dst = ((enq + s) & 1) ? h->mu : h->mu_alt;
                 gibbs_sweep(h, N, LayerIn{X_dev, h->V}, src, nullptr, dst, false, false, 0, 0, h->flag,
-                            hoist ? &h->xw0 : nullptr, &h->ctl->done);
-                hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(1), 0, h->stream, h->ctl, h->cfg.mf_tol, 0);
+                            hoist ? &h->xw0 : nullptr, &h->ctl->done, h->mfblk.p);
+                hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, 0,
+                                   h->mfblk.p, h->L * BM_MF_SLOTS);
             }
             enq += g;
             BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
@@ -375,6 +380,7 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
         BM_TRY(h->grad.alloc(off + nsums));
         h->sums_p = h->grad.p + off;
     }
+    BM_TRY(h->mfblk.alloc((size_t)BM_DBM_MAX_LAYERS * BM_MF_SLOTS));
     BM_HIP(hipMalloc((void **)&h->ctl, sizeof(MfCtl)));
     BM_HIP(hipMemset(h->ctl, 0, sizeof(MfCtl)));
     h->flag = &h->ctl->maxdiff;
@@ -402,6 +408,7 @@ int bm_dbm_destroy(bm_dbm *h) {
     DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->alogw, &h->adot, &h->rowtmp};
     for (DevBuf *b : bs) b->release();
     if (h->ctl) (void)hipFree(h->ctl);
+    h->mfblk.release();
     h->xw0.release();
     if (h->scal) (void)hipFree(h->scal);
     (void)hipEventDestroy(h->ev0);

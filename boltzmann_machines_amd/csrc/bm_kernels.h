@@ -9,6 +9,7 @@
 //                   canonical sequential order) + bias / q_means updates.
 //   elementwise / reduction helpers for dropout, msre, l2, free energy, PLL.
 #pragma once
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <array>
@@ -42,6 +43,8 @@ struct ActArgs {
     long long row0;              // global row of local row 0 (rank-invariant bitmaps)
     const float *prev;           // mean-field: previous mu (same layout as means) or null
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
+    float *maxdiff_blk;          // or (launches of <= BM_MF_SLOTS workgroups): one slot per workgroup, reduced by
+                                 // mf_ctl_kernel - hundreds of same-address atomics cost ~4 us per sweep kernel
     // optional per-row reductions of the epilogue (AIS log-weights dbm.py:650-660,713-720; ELBO :741-745)
     float *rowacc;               // [J] += sum_i softplus(beta_b*(z+b)) - softplus(beta_a*(z+b))   (AIS)
                                  //     or sum_i z * dot_mat[j][i]                                  (ELBO, dot_mat set)
@@ -66,6 +69,8 @@ struct ActArgs {
 #else
 #define BM_STAMP(n) do {} while (0)
 #endif
+
+constexpr int BM_MF_SLOTS = 1024;      // per-workgroup residual slots per layer (ActArgs::maxdiff_blk)
 
 // draw for 4 consecutive outputs starting at flat index `flat` (multiple of 4 on the fast path)
 __device__ __forceinline__ void draw4(const ActArgs &a, unsigned long long flat, int ib, int nvalid,
@@ -134,12 +139,17 @@ template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
 template <int E, class Rng> struct ActSide {
     static constexpr bool kFinalSync = false;    // one pipeline per kernel: waves enter the epilogue as they finish
     const float *bias, *sigma;
+    const float *prev_row;       // mean-field: &prev[j][ib0] when the row is valid, else null
     int ib0, I, with_rng;
-    float bs[E], sg[E];
+    float bs[E], sg[E], pv[E];   // pv: previous mu of the lane's outputs (mean-field residual)
     Rng rng;
     __device__ __forceinline__ void fill() {
         const float *sp = sigma ? sigma : bias;     // unconditional loads + select: no branch, no early wait
         const bool has_sigma = sigma != nullptr;
+        if (prev_row) {                             // wave-uniform per kernel (null for all lanes or row-dependent)
+#pragma unroll
+            for (int e = 0; e < E; ++e) pv[e] = (ib0 + e < I) ? prev_row[e] : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int i = (ib0 + e < I) ? ib0 + e : I - 1;
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     // the epilogue inputs (bias, sigma) and, when a draw follows, the lane's Philox block(s).
     ActSide<E, typename PhiloxFor<G::MI>::type> side;
     side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
+    side.prev_row = (a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
     side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
     f32x4 acc[G::MI][1];
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
             if (a.prev) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) dmax = fmaxf(dmax, fabsf(m[r] - a.prev[o + r]));
+                    if (r < nvalid) dmax = fmaxf(dmax, fabsf(m[r] - side.pv[4 * hlf + r]));
             }
             const bool v4 = al_out && nvalid == 4;
             if (a.means) store4(a.means, o, m, nvalid, v4 && (((uintptr_t)a.means & 15u) == 0));
@@ -264,10 +275,20 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
             if (a.states) store4(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
         }
     }
-    if (a.maxdiff) {
+    if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
+                               // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
+        __shared__ float s_wavemax[G::NT / 64];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
-        if (lane == 0 && dmax > 0.f) atomicMax(a.maxdiff, __float_as_uint(dmax));
+        if (lane == 0) s_wavemax[w] = dmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_wavemax[q]);
+            if (a.maxdiff_blk && gridDim.x <= BM_MF_SLOTS) a.maxdiff_blk[blockIdx.x] = m;
+            else if (m > 0.f) atomicMax(a.maxdiff, __float_as_uint(m));
+        }
     }
     if (a.rowacc || a.rowdot_out) {           // wave-uniform
         float racc = 0.f, rdot = 0.f;
@@ -1197,13 +1218,23 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
 // and latch `done` when the residual no longer exceeds the tolerance; `init` evaluates the
 // step-0 condition from the residual between the persistent mu and the init values.
 struct MfCtl { unsigned maxdiff; int done; int steps; };
-__global__ void mf_ctl_kernel(MfCtl *c, float tol, int init) {
+// blk [nblk]: per-workgroup residuals of the sweep's act_kernel launches (read, then zeroed for the next sweep)
+__global__ __launch_bounds__(256) void mf_ctl_kernel(MfCtl *c, float tol, int init, float *blk, int nblk) {
+    __shared__ float s_m[4];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < nblk; e += 256) { m = fmaxf(m, blk[e]); blk[e] = 0.f; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float resid = fmaxf(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])), __uint_as_float(c->maxdiff));
     if (init) {
         c->steps = 0;
-        c->done = !(__uint_as_float(c->maxdiff) > tol);
+        c->done = !(resid > tol);
     } else if (!c->done) {
         c->steps += 1;
-        c->done = !(__uint_as_float(c->maxdiff) > tol);
+        c->done = !(resid > tol);
     }
     c->maxdiff = 0u;
 }
@@ -1248,33 +1279,41 @@ static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
 }
 
 // ---- act_kernel geometry choice ---------------------------------------------------------
-// Three geometries compute bit-identical results (tests run all of them); which one is fastest
+// Four geometries compute bit-identical results (tests run all of them); which one is fastest
 // depends on how the output tiles fill the 256 CUs and on the K length, and did not follow a
 // simple rule in measurements (784x1024x512: 8-wave; AIS 20000 chains and 3072x5000: 32x32
-// tiles; DBM 784-512-1024 mean-field: 64x32).  So the launcher measures: the first 9 launches
+// tiles with BK = 32, four workgroups per CU; DBM 784-512-1024 mean-field: 64x32).  So the
+// launcher measures: the first 12 launches
 // of every distinct shape rotate through the candidates bracketed by HIP events on the
 // engine stream (they are REAL launches of the caller's work - no extra launches, no side
 // effects, no synchronisation: the events are polled on later launches), then the fastest is
-// used.  BM355_ACT_GEO=4|8|1 forces one geometry (experiments, tests).
+// used.  BM355_ACT_GEO=4|8|1|3 forces one geometry (experiments, tests).
 static inline int act_geo_override() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("BM355_ACT_GEO"); v = e ? atoi(e) : 0; }
     return v;
 }
 static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
-    if (a.p_xm && geo != 1) geo = 8;        // x-major P exists for the MI == 1 geometries only
+    if (a.p_xm && geo == 4) geo = 8;        // x-major P exists for the MI == 1 geometries only
     if (geo == 8)      launch_act_geo<GeoAct8, 1>(a, st);
     else if (geo == 1) launch_act_geo<GeoActS, 2>(a, st);
+    else if (geo == 3) launch_act_geo<GeoActS32, 4>(a, st);
     else               launch_act_geo<GeoAct, 1>(a, st);
 }
 struct ActTune {
-    static constexpr int NC = 3, R = 3;
+    static constexpr int NC = 4, R = 3;
     int best = 0, nlaunch = 0, ndone = 0;
-    float tmin[NC] = {1e30f, 1e30f, 1e30f};
+    float tmin[NC] = {1e30f, 1e30f, 1e30f, 1e30f};
     struct Sample { hipEvent_t e0 = nullptr, e1 = nullptr; int cand = 0; bool pending = false; } s[NC * R];
 };
+static inline void tune_log(const ActArgs &a, long long flags, const ActTune &T) {      // BM355_TUNE_LOG=1
+    static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
+    if (log)
+        fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f)\n",
+                a.I, a.J, a.K1, a.K2, flags, T.best, 1e3f * T.tmin[0], 1e3f * T.tmin[1], 1e3f * T.tmin[2], 1e3f * T.tmin[3]);
+}
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1};
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3};
     const int ov = act_geo_override();
     if (ov) { launch_act_as(ov, a, st); return; }
     static std::mutex mu;
@@ -1300,6 +1339,7 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
                 int b = 0;
                 for (int c = 1; c < ActTune::NC; ++c) if (T.tmin[c] < T.tmin[b]) b = c;
                 T.best = cand_geo[b];
+                tune_log(a, key[4], T);
             }
         }
         if (T.best) {
@@ -1311,7 +1351,20 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
             if (hipEventCreate(&smp->e0) != hipSuccess || hipEventCreate(&smp->e1) != hipSuccess) { smp = nullptr; T.best = geo = 4; }
             ++T.nlaunch;
         } else {
-            geo = (tile_grid<GeoAct>(a.I, a.J) <= 512) ? 8 : 1;      // samples still in flight
+            // all sampling launches are enqueued but some results are still in flight (the host runs
+            // ahead of the GPU): wait for them ONCE, so the choice is made after exactly NC*R launches
+            for (auto &q : T.s) {
+                if (!q.pending) continue;
+                (void)hipEventSynchronize(q.e1);
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess && ms < T.tmin[q.cand]) T.tmin[q.cand] = ms;
+                (void)hipEventDestroy(q.e0); (void)hipEventDestroy(q.e1);
+                q.pending = false; ++T.ndone;
+            }
+            int b = 0;
+            for (int c = 1; c < ActTune::NC; ++c) if (T.tmin[c] < T.tmin[b]) b = c;
+            geo = T.best = cand_geo[b];
+            tune_log(a, key[4], T);
         }
         if (smp) {
             (void)hipEventRecord(smp->e0, st);

@@ -53,7 +53,7 @@ print('GEOMETRY_OK')
 '''
 
 
-@pytest.mark.parametrize('geo', ['8', '4', '1'])
+@pytest.mark.parametrize('geo', ['8', '4', '1', '3'])
 def test_forced_geometry_bit_exact(gpu_lib, geo):
     env = dict(os.environ, BM355_ACT_GEO=geo)
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT)], env=env, capture_output=True, text=True,
