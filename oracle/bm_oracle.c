@@ -12,6 +12,10 @@
  *   - metrics (msre, pll, l2)       base_rbm.py:482-517
  *   - DBM Gibbs sweep / MF / PCD / train op / AIS / ELBO
  *                                   boltzmann_machines/dbm.py:385-759
+ *   - MultinomialRBM hidden layer + free energy
+ *                                   rbm/rbm.py:25-65, layers.py:54-70
+ *   - the float64 RBM path (dtype of base/mixin.py:15; rbm/tests/test_rbm.py:53-56,70-73)
+ *                                   end of this file
  *
  * The arithmetic of the reference lives in TensorFlow 1.3 (requirements.txt:11),
  * which is not in /root/reference and cannot run here; its op semantics are
