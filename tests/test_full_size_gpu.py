@@ -1,0 +1,66 @@
+"""-m gpu: the BASELINE.json configurations at their FULL sizes (configs[2], [3], [4]; configs[0]/[1]
+are cases of test_rbm_parity_gpu.py).  The OpenMP oracle needs ~10 s for one full update of each; AIS
+at 20 000 chains is checked through a size-independent property (a chain's value depends only on
+its own global index, so any slice of chains can be recomputed alone)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import test_dbm_parity_gpu as D
+from tests.helpers import assert_state_equal, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_gaussian_rbm_3072x5000_batch256(gpu_lib):
+    """Gaussian-Bernoulli RBM 3072 x 5000, batch 256 (examples/dbm_cifar_naive.py:83-98): one CD-1 update
+    (visible means fed back, so every value is bit-pinned) and the hidden means of 3 more chains."""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B = 3072, 5000, 256
+    eng, twin = make_pair(V, H, max_batch=B, w_std=0.0008, v_unit=1, sample_v_states=False, l2=0.01)
+    eng.seed(5); twin.set_seed(5)
+    X = orc.normal(87654321, 43, 0, B * V).reshape(B, V)
+    eng.train_step(as_device(X), B, 5e-4, 0.9, 1)
+    twin.train_step(X, 5e-4, 0.9, 1)
+    assert_state_equal(eng, twin)
+    rows = X[[0, 100, 255]]
+    Hd = DeviceArray((3, H))
+    eng.transform(as_device(rows), 3, 1, Hd)
+    eng.sync()
+    assert np.array_equal(Hd.numpy().view(np.uint32), twin.transform(rows, 1).view(np.uint32))
+    eng.close()
+
+
+def test_config3_dbm_784_512_1024_batch512_pcd5(gpu_lib):
+    """2-layer DBM 784-512-1024, 512 rows + 512 particles, PCD-5, up to 50 mean-field sweeps
+    (examples/dbm_mnist.py:250-284): one full update, bit-exact incl. the executed sweep count."""
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N = 784, [512, 1024], 512
+    kw = dict(max_mf_updates=50, mf_tol=1e-7, l2=1e-7, max_norm=6., sparsity_target=[0.2, 0.1],
+              sparsity_cost=[1e-4, 5e-5])
+    eng, twin = D.make_pair(V, nh, N, N, **kw)
+    eng.seed(42); twin.set_seed(42)
+    X = D.data(N, V, 1)
+    g = eng.train_step(as_device(X), 2e-3, 0.9, 5, want_msre=True)
+    c = twin.train_step(X, 2e-3, 0.9, 5, want_msre=True)
+    assert g[0] == c[0] and g[0] > 1, (g, c)                      # same number of mean-field sweeps
+    np.testing.assert_allclose(g[1], c[1], rtol=1e-5)
+    D.assert_equal(eng, twin, ['W', 'W_1', 'vb', 'hb', 'hb_1', 'dW', 'dW_1', 'v', 'h', 'h_1', 'mu', 'mu_1'])
+    eng.close()
+
+
+def test_config4_ais_20000_chains_slice_property(gpu_lib):
+    """AIS on the 784-512-1024 DBM with 20 000 chains (12 betas here): chains [7000, 7016) and the last 8
+    of the full run equal the oracle's standalone evaluation of just those chains."""
+    V, nh, N, R = 784, [512, 1024], 64, 20000
+    eng, twin = D.make_pair(V, nh, N, N)
+    full = eng.ais(n_betas=12, n_runs=R, k=1, seed=2222, chain0=0)
+    assert full.shape == (R,) and np.all(np.isfinite(full))
+    for c0, n in ((7000, 16), (R - 8, 8)):
+        ref = twin.ais(n_betas=12, n_runs=n, k=1, seed=2222, chain0=c0)
+        np.testing.assert_allclose(full[c0:c0 + n], ref, rtol=1e-5)
+    # and sharding the chains as 8 ranks would (2500 each) reproduces the single-run values exactly
+    part = eng.ais(n_betas=12, n_runs=2500, k=1, seed=2222, chain0=5000)
+    np.testing.assert_allclose(part, full[5000:7500], rtol=1e-6)
+    eng.close()
