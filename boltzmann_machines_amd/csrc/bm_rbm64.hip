@@ -4,10 +4,9 @@
 // float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  This is the compatibility path for
 // that dtype: the same graph (base_rbm.py:415-531) and the same canonical summation order as the
 // float32 engine, every operation in IEEE double, bit-identical to the float64 functions of
-// oracle/bm_oracle.c.  It is NOT the tuned path: plain vector-FMA kernels (one thread per output,
-// a sequential fma chain over k, operands through L1/L2); MI355X's FP64 vector rate makes a
-// 784x1024x512 CD-1 update a few hundred microseconds, ~2.5x the reference's own f32:f64 ratio
-// (examples/rbm_mnist.py:7-8).  Bernoulli hidden units; Bernoulli or Gaussian visible units.
+// oracle/bm_oracle.c.  It is NOT the tuned path: plain vector-FMA kernels (8 outputs per thread, each a
+// sequential fma chain over k, operands through L1/L2): a 784x1024x512 CD-1 update takes a few
+// hundred microseconds.  Bernoulli hidden units; Bernoulli or Gaussian visible units.
 #include "bm_common.h"
 #include "bm_rng.h"
 
@@ -79,22 +78,43 @@ struct ActArgs {
     double *means, *states;          // dense [J][I], may be null
     PhiloxKey key; long long row0;
 };
+constexpr int RB = 4;        // rows per thread (register blocking: every P element is loaded once per RB rows)
 __global__ __launch_bounds__(256) void act_kernel(ActArgs a) {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= a.I || j >= a.J) return;
-    const double *q = a.Q + (size_t)j * a.ldq, *p = a.P + i;
-    double z = 0.0;
-    for (int k = 0; k < a.K; ++k) z = fma(p[(size_t)k * a.ldp], q[k], z);
-    const double x = a.mult * z, b = a.mult * a.bias[i];
-    const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (x * a.sigma[i] + b);
-    double s = m;
-    if (a.sample) {
-        const unsigned long long idx = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + (unsigned long long)i;
-        if (a.kind == BM_UNIT_BERNOULLI) s = (uniform_at(a.key, idx) < m) ? 1.0 : 0.0;
-        else s = normal_at(a.key, idx) * a.sigma[i] + m;
+    // (readfirstlane: the wave index is uniform, so the Q rows are read with scalar loads)
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RB;
+    if (j0 >= a.J) return;
+    const bool live = i < a.I;
+    if (!live) return;
+    const double *p = a.P + i;
+    const double *q[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) q[r] = a.Q + (size_t)min(j0 + r, a.J - 1) * a.ldq;     // wave-uniform rows
+    double z[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) z[r] = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < a.K; ++k) {
+        const double pv = p[(size_t)k * a.ldp];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) z[r] = fma(pv, q[r][k], z[r]);
     }
-    if (a.means) a.means[(size_t)j * a.I + i] = m;
-    if (a.states) a.states[(size_t)j * a.I + i] = s;
+    const double b = a.mult * a.bias[i];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int j = j0 + r;
+        if (j >= a.J) break;
+        const double x = a.mult * z[r];
+        const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+        double s = m;
+        if (a.sample) {
+            const unsigned long long idx = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + (unsigned long long)i;
+            if (a.kind == BM_UNIT_BERNOULLI) s = (uniform_at(a.key, idx) < m) ? 1.0 : 0.0;
+            else s = normal_at(a.key, idx) * a.sigma[i] + m;
+        }
+        if (a.means) a.means[(size_t)j * a.I + i] = m;
+        if (a.states) a.states[(size_t)j * a.I + i] = s;
+    }
 }
 
 // raw CD gradient + update of W (and of the transpose Wt) in one pass: thread (j = visible, i = hidden)
@@ -107,20 +127,44 @@ struct GradArgs {
     double N, l2, lr, mom;
 };
 __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), j = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= a.H || j >= a.V) return;
-    double acc = 0.0;
-    for (int b = 0; b < a.B; ++b) acc = fma(a.h0m[(size_t)b * a.H + i], a.X[(size_t)b * a.ldx + j], acc);
-    for (int b = 0; b < a.B; ++b) acc = fma(a.hm[(size_t)b * a.H + i], -a.vs[(size_t)b * a.V + j], acc);
-    const size_t e = (size_t)j * a.H + i;
-    double g = acc / a.N;
-    g = g - a.l2 * a.W[e];
-    g = g - a.pen[i];
-    const double d = a.lr * (a.mom * a.dW[e] + g);
-    a.dW[e] = d;
-    const double w = a.W[e] + d;
-    a.W[e] = w;
-    a.Wt[(size_t)i * a.V + j] = w;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RB;
+    if (i >= a.H || j0 >= a.V) return;
+    int jj[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) jj[r] = min(j0 + r, a.V - 1);
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+#pragma unroll 8
+    for (int b = 0; b < a.B; ++b) {
+        const double pv = a.h0m[(size_t)b * a.H + i];
+        const double *x = a.X + (size_t)b * a.ldx;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = fma(pv, x[jj[r]], acc[r]);
+    }
+#pragma unroll 8
+    for (int b = 0; b < a.B; ++b) {
+        const double pv = a.hm[(size_t)b * a.H + i];
+        const double *v = a.vs + (size_t)b * a.V;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = fma(pv, -v[jj[r]], acc[r]);
+    }
+    const double pen = a.pen[i];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int j = j0 + r;
+        if (j >= a.V) break;
+        const size_t e = (size_t)j * a.H + i;
+        double g = acc[r] / a.N;
+        g = g - a.l2 * a.W[e];
+        g = g - pen;
+        const double d = a.lr * (a.mom * a.dW[e] + g);
+        a.dW[e] = d;
+        const double w = a.W[e] + d;
+        a.W[e] = w;
+        a.Wt[(size_t)i * a.V + j] = w;
+    }
 }
 
 // column sums (sequential over rows) + bias / q_means update (base_rbm.py:450-474)
@@ -269,7 +313,7 @@ static void launch_act(bm_rbm64 *h, bool up, const double *in, int ldin, int B, 
               a.mult = 1.0 + (h->cfg.dbm_last ? 1.0 : 0.0); }
     a.Q = in; a.ldq = ldin; a.J = B; a.sample = sample; a.means = means; a.states = states;
     a.key = make_key(h, site, t); a.row0 = h->row0;
-    hipLaunchKernelGGL(act_kernel, dim3((a.I + 63) / 64, (B + 3) / 4), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(act_kernel, dim3((a.I + 63) / 64, (B + 4 * RB - 1) / (4 * RB)), dim3(256), 0, h->stream, a);
 }
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426)
 static int run_chain(bm_rbm64 *h, const double *X_dev, int B, int k, double *hm_out) {
@@ -305,7 +349,7 @@ static void launch_update(bm_rbm64 *h, int B, double lr, double mom) {
     g.h0m = h->h0m.p; g.hm = h->hm.p; g.X = h->Xin; g.vs = h->vs.p; g.ldx = h->Xin_ld; g.B = B; g.V = h->V; g.H = h->H;
     g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p; g.pen = h->pen.p;
     g.N = (double)B; g.l2 = h->l2; g.lr = lr; g.mom = mom;
-    hipLaunchKernelGGL(grad_kernel, dim3((h->H + 63) / 64, (h->V + 3) / 4), dim3(256), 0, h->stream, g);
+    hipLaunchKernelGGL(grad_kernel, dim3((h->H + 63) / 64, (h->V + 4 * RB - 1) / (4 * RB)), dim3(256), 0, h->stream, g);
 }
 static int metrics_from_chain(bm_rbm64 *h, int B, double *out4) {
     BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
