@@ -93,6 +93,11 @@ class DBM(EngineModel):
     # ---- composition from pre-trained RBMs (reference dbm.py:207-231) ------------------
     def load_rbms(self, rbms):
         if rbms is not None:
+            for rbm in rbms:
+                if getattr(rbm, '_H_UNIT', _ffi.UNIT_BERNOULLI) != _ffi.UNIT_BERNOULLI:
+                    raise NotImplementedError('DBM layers are Bernoulli (hidden) and Bernoulli / Gaussian (visible): '
+                                              'a %s cannot be stacked (multinomial DBM layers are outside the '
+                                              'hot-path scope, SURVEY.md 8f-4)' % rbm.__class__.__name__)
             self._rbms = rbms
             self.n_layers_ = len(self._rbms)
             self.n_visible_ = self._rbms[0].n_visible
