@@ -93,8 +93,9 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_train_step_metrics(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k, out))
         return np.array(out[:], dtype=np.float32)
 
-    def train_epoch(self, Xd, N, batch, lr, momentum, k):
-        check(self.lib.bm_rbm_train_epoch(self._h, Xd.ptr, N, batch, lr, momentum, k))
+    def train_epoch(self, Xd, N, batch, lr, momentum, k, row=0):
+        """N rows starting at `row`, consecutive batches of `batch` rows, driven from C (no Python per batch)"""
+        check(self.lib.bm_rbm_train_epoch(self._h, Xd.offset_ptr(row * self.V), N, batch, lr, momentum, k))
 
     def grad_step(self, Xd, B, k, row=0):
         check(self.lib.bm_rbm_grad_step(self._h, Xd.offset_ptr(row * self.V), B, k))

@@ -238,16 +238,27 @@ class BaseRBM(EngineModel):
         results = {m: [] for m in names}
         lr, mom, k = self._feed()
         every = self.metrics_config['train_metrics_every_iter']
+        # runs of batches without a metrics fetch go to the engine as ONE call (bm_rbm_train_epoch loops in
+        # C: same launches, same RNG call counters, no Python per batch)
+        run_start, fused = None, hasattr(eng, 'train_epoch')
         for start in range(0, N, self.batch_size):
             B = min(self.batch_size, N - start)
             self.iter_ += 1
             if self.iter_ % every == 0:
+                if run_start is not None:
+                    eng.train_epoch(Xd, start - run_start, self.batch_size, lr, mom, k, row=run_start)
+                    run_start = None
                 out = eng.train_step_metrics(Xd, B, lr, mom, k, row=start)
                 vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
                 for m in names:
                     results[m].append(vals[m])
+            elif fused:
+                if run_start is None:
+                    run_start = start
             else:
                 eng.train_step(Xd, B, lr, mom, k, row=start)
+        if run_start is not None:
+            eng.train_epoch(Xd, N - run_start, self.batch_size, lr, mom, k, row=run_start)
         return {m: (np.mean(r) if r else None) for m, r in results.items()}
 
     def _run_val_metrics(self, Xvd, N):
