@@ -189,8 +189,18 @@ def main():
                 eng.apply_step(B * world, LR, MOM)
         kt = eng.kernel_times()
         eng.profile(False)
-        kern = {name: {'avg_us': round(1e3 * ms / n, 3), 'launches_per_step': n // n_prof}
+        # an event pair around a launch also times its two markers.  The unbracketed update was timed above
+        # (ev_ms): the markers' cost per launch is (sum of the bracketed launches - that) / launches, taken off
+        # so that the per-kernel figures are comparable with rocprofv3's kernel-trace durations
+        n_launch = sum(n for _, (ms, n) in kt.items() if n)
+        sum_us = 1e3 * sum(ms for _, (ms, n) in kt.items() if n) / n_prof
+        bracket_us = 0.0
+        if not use_dp and n_launch:
+            bracket_us = max(0.0, (sum_us - 1e3 * ev_ms / args.steps) / (n_launch / n_prof))
+        kern = {name: {'avg_us': round(1e3 * ms / n - bracket_us, 3), 'avg_us_with_markers': round(1e3 * ms / n, 3),
+                       'launches_per_step': n // n_prof}
                 for name, (ms, n) in kt.items() if n}
+        kern['event_pair_overhead_us'] = round(bracket_us, 3)
     barrier()
 
     if rank == 0:
