@@ -107,6 +107,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--k', type=int, default=1, help='n_gibbs_steps of CD-k')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--native-comm', action='store_true',
+                    help='data-parallel all-reduce through the library\'s own RCCL communicator (bm_comm_*) instead of '
+                         'torch.distributed; torch (gloo) then only carries the 128-byte id and the timing barrier')
     ap.add_argument('--force-dp', action='store_true',
                     help='take the data-parallel code path (grad_step -> all-reduce -> apply_step) even at N=1')
     args = ap.parse_args()
@@ -132,7 +135,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if args.native_comm:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     k = args.k
     X, W = synth(rank, B * N_BATCHES)
@@ -145,7 +151,11 @@ def main():
     if use_dp:
         from boltzmann_machines_amd import parallel
         dev = torch.device('cuda', local_rank)
-        dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.torch_allreduce_on_engine_stream(eng, dev))
+        if args.native_comm:
+            comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+            dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.native_allreduce_on_engine_stream(eng, comm))
+        else:
+            dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.torch_allreduce_on_engine_stream(eng, dev))
 
         def step(i):
             dp.train_step(Xd, LR, MOM, k, row=(i % N_BATCHES) * B)     # grad_step -> RCCL all-reduce -> apply_step
@@ -171,7 +181,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if args.native_comm else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -220,7 +230,8 @@ def main():
             'config': {'workload': 'BernoulliRBM 784x1024 CD-%d batch=512 fp32 (BASELINE configs[1])' % k,
                        'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
                        'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
-                       'parallelism': 'dp%d' % world, 'dp_path': bool(use_dp)},
+                       'parallelism': 'dp%d' % world, 'dp_path': bool(use_dp),
+                       'collective': ('bm_comm (in-library RCCL)' if args.native_comm else 'torch.distributed nccl') if use_dp else None},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
                          'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4),
                          'traffic': pmc_traffic() if k == 1 else None,

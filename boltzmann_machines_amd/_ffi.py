@@ -51,6 +51,13 @@ SIGNATURES = {
     'bm_h2d': [_vp, _vp, _sz],
     'bm_d2h': [_vp, _vp, _sz],
     'bm_dev_memset': [_vp, C.c_int, _sz],
+    'bm_comm_unique_id': [_vp],
+    'bm_comm_init': [C.c_int32, C.c_int32, _vp, C.POINTER(_vp)],
+    'bm_comm_destroy': [_vp],
+    'bm_comm_allreduce_sum': [_vp, _vp, _sz, _vp],
+    'bm_comm_allgather': [_vp, _vp, _vp, _sz, _vp],
+    'bm_rbm_allreduce_grads': [_vp, _vp],
+    'bm_dbm_allreduce_grads': [_vp, _vp],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],
     'bm_rbm64_sync': [_vp],

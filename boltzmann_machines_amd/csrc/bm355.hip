@@ -4,3 +4,4 @@
 #include "bm_rbm.hip"
 #include "bm_dbm.hip"
 #include "bm_rbm64.hip"
+#include "bm_comm.hip"

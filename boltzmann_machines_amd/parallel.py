@@ -115,3 +115,60 @@ def torch_allreduce_max():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return allreduce_max
+
+
+class NativeComm(object):
+    """RCCL communicator owned by libbm355.so (`bm_comm_*`, include/bm355.h): the all-reduce of the fused
+    `grad` buffer is enqueued on the engine's HIP stream by the library itself - no torch in the data path.
+    Only the 128-byte id travels through the host (here: any initialised torch.distributed backend,
+    e.g. gloo; MPI or a shared file would do as well)."""
+
+    def __init__(self, rank, world, id_bytes):
+        import ctypes as C
+        from . import _ffi
+        self._ffi, self.rank, self.world = _ffi, rank, world
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id_bytes))
+        self._c = C.c_void_p()
+        _ffi.check(_ffi.load().bm_comm_init(rank, world, buf, C.byref(self._c)))
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _ffi
+        buf = (C.c_char * 128)()
+        _ffi.check(_ffi.load().bm_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch_rendezvous(cls, rank, world):
+        """rank 0 creates the id, torch.distributed (already initialised, any backend) broadcasts it"""
+        import torch.distributed as dist
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls(rank, world, box[0])
+
+    def allreduce_grads(self, engine):
+        """in-place all-reduce(sum) of the engine's fused grad buffer on the engine's stream"""
+        from .engine import DbmEngine
+        lib = self._ffi.load()
+        f = lib.bm_dbm_allreduce_grads if isinstance(engine, DbmEngine) else lib.bm_rbm_allreduce_grads
+        self._ffi.check(f(engine._h, self._c))
+
+    def close(self):
+        if getattr(self, '_c', None) is not None and self._c:
+            self._ffi.load().bm_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def native_allreduce_on_engine_stream(engine, comm):
+    """`allreduce_` for DataParallelRBM / DataParallelDBM over the library's own RCCL communicator"""
+    def allreduce_():
+        comm.allreduce_grads(engine)
+    return allreduce_

@@ -260,6 +260,23 @@ int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host);
 int bm_dbm_timer_start(bm_dbm *h);
 int bm_dbm_timer_stop(bm_dbm *h, float *out_ms);
 
+
+/* ---- RCCL inside the library (bm_comm_init / bm_allreduce_grads; §8e: one exchange step
+ * per update).  The host only transports the 128-byte id from rank 0 to the other ranks.  librccl is
+ * dlopen'ed at first use (BM355_RCCL_LIB overrides the name); the single-GPU path does not need it.
+ * boltzmann_machines_amd/parallel.py can drive either these or torch.distributed (bench.py default). */
+typedef struct bm_comm bm_comm;
+int bm_comm_unique_id(void *out_id128);                                   /* ncclGetUniqueId, rank 0 */
+int bm_comm_init(int32_t rank, int32_t nranks, const void *id128, bm_comm **out);   /* on the current device */
+int bm_comm_destroy(bm_comm *c);
+/* in-place all-reduce(sum) / all-gather of device floats, enqueued on `stream` (a hipStream_t) */
+int bm_comm_allreduce_sum(bm_comm *c, float *buf_dev, size_t count, void *stream);
+int bm_comm_allgather(bm_comm *c, const float *send_dev, float *recv_dev, size_t count_per_rank, void *stream);
+/* the exchange step of data-parallel training: all-reduce of the handle's fused "grad" buffer on the
+ * handle's stream, between bm_*_grad_step and bm_*_apply_step (no host synchronisation) */
+int bm_rbm_allreduce_grads(bm_rbm *h, bm_comm *c);
+int bm_dbm_allreduce_grads(bm_dbm *h, bm_comm *c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,3 +92,47 @@ def test_dp_world2_on_gpu(gpu_lib, tmp_path):
     for step in range(3):
         ref.train_step(Xg, 0.05, 0.5, K)
     np.testing.assert_allclose(r0['W'], ref.p['W'], rtol=2e-5, atol=2e-7)
+
+
+NATIVE_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import ctypes as C
+import numpy as np
+assert 'torch' not in sys.modules
+from boltzmann_machines_amd import _ffi, parallel
+from boltzmann_machines_amd._ffi import DeviceArray
+from boltzmann_machines_amd.engine import RbmEngine, as_device
+from tests.test_parallel_gpu import _inputs, V, H, BL, K, KW
+W, Xg = _inputs()
+comm = parallel.NativeComm(0, 1, parallel.NativeComm.unique_id())
+e1 = RbmEngine(V, H, max_batch=BL, **KW)
+e2 = RbmEngine(V, H, max_batch=BL, **KW)
+for e in (e1, e2):
+    e.set('W', W); e.seed(7)
+dp = parallel.DataParallelRBM(e2, 0, 1, BL, parallel.native_allreduce_on_engine_stream(e2, comm))
+Xd = as_device(Xg[:BL])
+for step in range(3):
+    e1.train_step(Xd, BL, 0.05, 0.5, K)
+    dp.train_step(Xd, 0.05, 0.5, K)
+for n in ('W', 'vb', 'hb', 'dW', 'q_means'):
+    assert np.array_equal(e1.get(n).view(np.uint32), e2.get(n).view(np.uint32)), n
+a = DeviceArray.from_numpy(np.arange(10, dtype=np.float32))
+b = DeviceArray((10,))
+_ffi.check(_ffi.load().bm_comm_allgather(comm._c, a.ptr, b.ptr, 10, C.c_void_p(e2.stream())))
+e2.sync()
+assert np.array_equal(b.numpy(), np.arange(10, dtype=np.float32))
+comm.close(); e1.close(); e2.close()
+assert 'torch' not in sys.modules
+print('NATIVE_COMM_OK')
+"""
+
+
+def test_native_rccl_comm_world1(gpu_lib):
+    """the library's own RCCL communicator (bm_comm_*), world 1 on the test box, in a process that never
+    imports torch: init, the all-reduce of the fused grad buffer on the engine stream between grad_step and
+    apply_step (== the fused train_step bit for bit), all-gather, destroy."""
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', NATIVE_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'NATIVE_COMM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
