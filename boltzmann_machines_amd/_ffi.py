@@ -101,6 +101,7 @@ SIGNATURES = {
     'bm_dbm_get_param': [_vp, C.c_char_p, _vp, _sz],
     'bm_dbm_dev_ptr': [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)],
     'bm_dbm_train_step': [_vp, _vp, _f32, _f32, _i32, _ip, _fp],
+    'bm_dbm_metrics': [_vp, _vp, _i32, _ip, _fp],
     'bm_dbm_grad_step': [_vp, _vp, _i32, _ip],
     'bm_dbm_apply_step': [_vp, _i32, _i32, _f32, _f32],
     'bm_dbm_set_mf_allreduce': [_vp, _vp, _vp],
@@ -126,11 +127,19 @@ def load(rebuild=True):
         return _lib
     path = _build.LIB
     if rebuild and _build.needs_build():
+        import shutil
+        have_hipcc = bool(shutil.which('hipcc')) or os.path.exists('/opt/rocm/bin/hipcc')
         try:
             _build.build()
-        except Exception as e:  # stale-but-present library on a box without hipcc is still usable
-            if not os.path.exists(path):
-                raise Bm355Error('libbm355.so is missing and could not be built: %s' % e)
+        except Exception as e:
+            # A present-but-older library is used ONLY on a box without hipcc (nothing can be rebuilt
+            # there).  With a compiler, a failed build means the sources are broken: binding the stale
+            # library would silently run code that no longer matches them.
+            if have_hipcc or not os.path.exists(path):
+                raise Bm355Error('libbm355.so could not be built from the current sources: %s' % e)
+            import warnings
+            warnings.warn('libbm355.so is older than its sources and hipcc is not available; using the existing '
+                          'library (%s)' % e)
     if not os.path.exists(path):
         raise Bm355Error('libbm355.so not found at %s (run __graft_entry__.build())' % path)
     lib = C.CDLL(path)

@@ -14,8 +14,10 @@ Differences that are deliberate (DESIGN.md "boundary"):
   - variables live in HBM behind a C-ABI handle for the lifetime of the Python
     object; they are written to `<model_filepath>.npz` where the reference runs
     the TF Saver, and re-read from there only by `load_model`.
-  - dtype: the device path is fp32 (the reference default).  'float64' models
-    can be constructed/initialised (the W-init known answer of
+  - dtype: the tuned device path is fp32 (the reference default).  'float64'
+    Bernoulli / Gaussian RBMs run on the device through `bm_rbm64_*`
+    (rbm.py -> RbmEngine64).  A float64 MultinomialRBM or DBM can be
+    constructed/initialised (the W-init known answer of
     rbm/tests/test_rbm.py:67 holds) but `fit`/`transform` raise.
 """
 import json
@@ -185,7 +187,9 @@ class EngineModel(BaseModel, DtypeMixin):
     def _ensure_engine(self):
         if self._engine is None:
             if np.dtype(self.dtype) != np.float32 and self._needs_device():
-                raise NotImplementedError("the MI355X engine computes in float32 (dtype='%s' requested)" % self.dtype)
+                raise NotImplementedError("%s has no device path for dtype='%s': float64 runs for Bernoulli/Gaussian "
+                                          "RBMs (bm_rbm64_*), everything else computes in float32"
+                                          % (self.__class__.__name__, self.dtype))
             self._make_engine()
             if self._pending_vars is not None:
                 self._upload_variables(self._pending_vars)

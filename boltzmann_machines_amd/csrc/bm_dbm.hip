@@ -46,7 +46,8 @@ struct bm_dbm {
     // AIS / ELBO workspaces (allocated on demand)
     int ais_rows = 0;
     Mat ax, ax2, av, ah2;
-    DevBuf alogw, adot, rowtmp;
+    DevBuf apart_v, apart_h, apart_x[2], rowtmp;   // per-16-column slot partial sums (ActArgs::rowacc / rowdot_out)
+    double *alogw = nullptr;                       // [ais_rows] log-weights, accumulated in double in a fixed order
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0, prow0 = 0;
@@ -315,6 +316,8 @@ static void launch_dbm_grad(bm_dbm *h, const float *X_dev, int i, int fused, flo
     launch_grad(g, h->stream);
 }
 
+static int recon_msre(bm_dbm *h, const float *X_dev, float *out_msre);
+
 static void launch_dbm_maxnorm(bm_dbm *h, int i) {
     MaxNormArgs m;
     m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = h->n[i + 1]; m.J = h->n[i]; m.ldw = h->W[i].ld; m.ldwt = h->Wt[i].ld;
@@ -405,8 +408,9 @@ int bm_dbm_destroy(bm_dbm *h) {
     }
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
-    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->alogw, &h->adot, &h->rowtmp};
+    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp};
     for (DevBuf *b : bs) b->release();
+    if (h->alogw) (void)hipFree(h->alogw);
     if (h->ctl) (void)hipFree(h->ctl);
     h->mfblk.release();
     h->xw0.release();
@@ -513,19 +517,38 @@ int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float lr, float mom, int32_
     int nmf = 0;
     BM_TRY(mean_field(h, X_dev, &nmf));                       // :517
     particles_update(h, k, true);                             // :521
-    if (out_msre) {                                           // :625-630 (W before the update)
-        reconstruct_from_mu(h, h->recon.p, h->recon.ld);
-        BM_HIP(hipMemsetAsync(h->scal, 0, sizeof(double), h->stream));
-        hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, X_dev, h->V, (const float *)h->recon.p,
-                           h->recon.ld, h->N, h->V, h->scal);
-        double s = 0.0;
-        BM_HIP(hipMemcpyAsync(&s, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        BM_HIP(hipStreamSynchronize(h->stream));
-        *out_msre = (float)(s / ((double)h->N * h->V));
-    }
+    if (out_msre) BM_TRY(recon_msre(h, X_dev, out_msre));     // :625-630 (W before the update)
     BM_TRY(apply_update(h, X_dev, lr, mom));
     if (out_n_mf) *out_n_mf = nmf;
     h->call++;
+    return 0;
+}
+
+// msre of sigma(mu0 W0^T + vb) against X (dbm.py:625-630), mu from the last mean_field()
+static int recon_msre(bm_dbm *h, const float *X_dev, float *out_msre) {
+    reconstruct_from_mu(h, h->recon.p, h->recon.ld);
+    BM_HIP(hipMemsetAsync(h->scal, 0, sizeof(double), h->stream));
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, X_dev, h->V, (const float *)h->recon.p,
+                       h->recon.ld, h->N, h->V, h->scal);
+    double s = 0.0;
+    BM_HIP(hipMemcpyAsync(&s, h->scal, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    *out_msre = (float)(s / ((double)h->N * h->V));
+    return 0;
+}
+
+// session.run([msre, n_mf_updates]) of _run_val_metrics (dbm.py:813): both tensors are built under
+// tf.control_dependencies([v_update, v_new_update] + H_updates + H_new_updates + mu_updates) (:521-523),
+// so the fetch runs the mean-field on X AND advances the fantasy particles by n_gibbs_steps; no parameter update.
+int bm_dbm_metrics(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf, float *out_msre) {
+    BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    int nmf = 0;
+    BM_TRY(mean_field(h, X_dev, &nmf));
+    particles_update(h, k, true);
+    if (out_msre) BM_TRY(recon_msre(h, X_dev, out_msre));
+    if (out_n_mf) *out_n_mf = nmf;
+    h->call++;
+    BM_HIP(hipGetLastError());
     return 0;
 }
 
@@ -608,9 +631,11 @@ int bm_dbm_sample_v(bm_dbm *h, int32_t k, float *V_dev) {
         Mat *x = Hout; Hout = Hout2; Hout2 = x;
         Mat *y = vout; vout = vout2; vout2 = y;
     }
-    // v <- v_means (the last vout is now vout2 after the swap)
-    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)vout2->p, vout2->ld, h->v.p, h->v.ld,
-                       h->M, h->V);
+    // v <- v_means (the last vout is now vout2 after the swap).  k == 0: no sweep ran, v keeps its value
+    // (the reference's op list is empty then, dbm.py:641-648; oracle: orc_dbm_sample_v)
+    if (k > 0)
+        hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)vout2->p, vout2->ld, h->v.p, h->v.ld,
+                           h->M, h->V);
     if (V_dev)
         hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)h->v.p, h->v.ld, V_dev, h->V,
                            h->M, h->V);
@@ -621,14 +646,23 @@ int bm_dbm_sample_v(bm_dbm *h, int32_t k, float *V_dev) {
     return 0;
 }
 
+static inline int nslots(int n) { return (n + 15) / 16; }
+
 static int ensure_ais(bm_dbm *h, int rows) {
     if (rows <= h->ais_rows) return 0;
     Mat *ms[] = {&h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
-    h->alogw.release(); h->adot.release(); h->rowtmp.release();
+    DevBuf *bs[] = {&h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp};
+    for (DevBuf *b : bs) b->release();
+    if (h->alogw) { (void)hipFree(h->alogw); h->alogw = nullptr; }
+    const int H2 = h->L >= 2 ? h->n[2] : 1;
     BM_TRY(h->ax.alloc(rows, h->n[1])); BM_TRY(h->ax2.alloc(rows, h->n[1]));
-    BM_TRY(h->av.alloc(rows, h->V)); BM_TRY(h->ah2.alloc(rows, h->L >= 2 ? h->n[2] : 1));
-    BM_TRY(h->alogw.alloc(rows)); BM_TRY(h->adot.alloc(2 * (size_t)rows)); BM_TRY(h->rowtmp.alloc(rows));
+    BM_TRY(h->av.alloc(rows, h->V)); BM_TRY(h->ah2.alloc(rows, H2));
+    BM_TRY(h->apart_v.alloc((size_t)nslots(h->V > h->n[1] ? h->V : h->n[1]) * rows));   // AIS: V slots; ELBO: n1 slots
+    BM_TRY(h->apart_h.alloc((size_t)nslots(H2 > h->n[1] ? H2 : h->n[1]) * rows));
+    BM_TRY(h->apart_x[0].alloc((size_t)nslots(h->n[1]) * rows)); BM_TRY(h->apart_x[1].alloc((size_t)nslots(h->n[1]) * rows));
+    BM_TRY(h->rowtmp.alloc(rows));
+    BM_HIP(hipMalloc((void **)&h->alogw, (size_t)rows * sizeof(double)));
     h->ais_rows = rows;
     return 0;
 }
@@ -642,7 +676,7 @@ __global__ void ais_init_kernel(float *X, int ld, int rows, int cols, PhiloxKey 
     }
 }
 
-// rowdot[j] = sum_i X[j][i] * vec[i]  (one wave per row)
+// rowdot[j] = sum_i X[j][i] * vec[i]  (one wave per row; fixed lane-strided order + butterfly: deterministic)
 __global__ __launch_bounds__(256) void rowdot_kernel(const float *X, int ld, int rows, int cols, const float *vec, float *out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -653,6 +687,19 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float *X, int ld, int
     if (lane == 0) out[row] = s;
 }
 
+// One AIS score: logw[j] += sum_slots pv + sum_slots ph + (beta_b - beta_a) * sum_slots pd   (dbm.py:650-660)
+// from the slot partials act_kernel left (ActArgs::rowacc / rowdot_out), slots in ascending order, in double.
+__global__ void ais_score_kernel(double *logw, int J, int ld, const float *pv, int nv, const float *ph, int nh,
+                                 const float *pd, int nd, float dbeta) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    double s = 0.0, d = 0.0;
+    for (int q = 0; q < nv; ++q) s += (double)pv[(size_t)q * ld + j];
+    for (int q = 0; q < nh; ++q) s += (double)ph[(size_t)q * ld + j];
+    for (int q = 0; q < nd; ++q) d += (double)pd[(size_t)q * ld + j];
+    logw[j] += s + (double)dbeta * d;
+}
+
 int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0,
                float *values_host) {
     BM_CHECK(h->L == 2, "AIS is implemented for 2-layer DBMs only (dbm.py:925)");
@@ -661,8 +708,11 @@ int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t s
     BM_TRY(ensure_ais(h, n_runs));
     const int R = n_runs, V = h->V, H1 = h->n[1], H2 = h->n[2];
     const float db = 1.0f / (float)n_betas;                               // delta_beta (dbm.py:929)
-    float *rdot_cur = h->adot.p, *rdot_next = h->adot.p + R;
-    BM_HIP(hipMemsetAsync(h->alogw.p, 0, (size_t)R * sizeof(float), h->stream));
+    // x.hb0 of the current / next state as slot partials (pitch ldp); x0's comes from rowdot_kernel as ONE slot
+    const int ldp = h->ais_rows;
+    float *rdot_cur = h->apart_x[0].p, *rdot_next = h->apart_x[1].p;
+    int nd_cur = 1;
+    BM_HIP(hipMemsetAsync(h->alogw, 0, (size_t)R * sizeof(double), h->stream));
     Mat *x = &h->ax, *xn = &h->ax2;
     hipLaunchKernelGGL(ais_init_kernel, dim3(512), dim3(256), 0, h->stream, x->p, x->ld, R, H1,
                        dkey(h, SITE_AIS_X0, 0, seed, 0), (unsigned long long)chain0);
@@ -677,28 +727,32 @@ int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t s
             ActArgs e;
             // v~ <- P(v | h = x): sigma(beta*x W0^T + beta*vb)  — and the visible softplus term of log p*
             memset(&e, 0, sizeof(e));
-            if (sc) { e.rowacc = h->alogw.p; e.beta_a = ba; e.beta_b = bb; e.rowdot_in = rdot_cur; }
+            if (sc) { e.rowacc = h->apart_v.p; e.ld_part = ldp; e.beta_a = ba; e.beta_b = bb; }
             const int smp_v = transit && h->cfg.sample_v_states;
             layer_update(h, -1, R, LayerIn{nullptr, 0}, LayerIn{x->p, x->ld}, bc, bc, smp_v,
                          (transit && !smp_v) ? h->av.p : nullptr, (transit && smp_v) ? h->av.p : nullptr, h->av.ld,
                          dkey(h, SITE_DBM_V, t, seed, step), chain0, nullptr, nullptr, &e);
             // h2~ <- P(h2 | h = x): sigma(beta*x W1 + beta*hb1)  — and the top softplus term
             memset(&e, 0, sizeof(e));
-            if (sc) { e.rowacc = h->alogw.p; e.beta_a = ba; e.beta_b = bb; }
+            if (sc) { e.rowacc = h->apart_h.p; e.ld_part = ldp; e.beta_a = ba; e.beta_b = bb; }
             const int smp_2 = transit && h->cfg.sample_h_states[1];
             layer_update(h, 1, R, LayerIn{x->p, x->ld}, LayerIn{nullptr, 0}, bc, bc, smp_2,
                          (transit && !smp_2) ? h->ah2.p : nullptr, (transit && smp_2) ? h->ah2.p : nullptr, h->ah2.ld,
                          dkey(h, SITE_DBM_H + 1, t, seed, step), chain0, nullptr, nullptr, &e);
+            if (sc)     // both softplus terms + (bb - ba) * x.hb0, slots in fixed order, into the double log-weights
+                hipLaunchKernelGGL(ais_score_kernel, dim3((R + 255) / 256), dim3(256), 0, h->stream, h->alogw, R, ldp,
+                                   (const float *)h->apart_v.p, nslots(V), (const float *)h->apart_h.p, nslots(H2),
+                                   (const float *)rdot_cur, nd_cur, bb - ba);
             if (!transit) break;
             // x^ <- P(h | v~, h2~): sigma(beta*(v W0 + h2 W1^T) + beta*hb0); also x^.hb0 for the next score
-            BM_HIP(hipMemsetAsync(rdot_next, 0, (size_t)R * sizeof(float), h->stream));
             memset(&e, 0, sizeof(e));
-            e.rowdot_out = rdot_next; e.dot_vec = h->hb[0].p;
+            e.rowdot_out = rdot_next; e.ld_part = ldp; e.dot_vec = h->hb[0].p;
             const int smp_x = h->cfg.sample_h_states[0];
             layer_update(h, 0, R, LayerIn{h->av.p, h->av.ld}, LayerIn{h->ah2.p, h->ah2.ld}, bc, bc, smp_x,
                          nullptr, xn->p, xn->ld, dkey(h, SITE_DBM_H + 0, t, seed, step), chain0, nullptr, nullptr, &e);
             Mat *tm = x; x = xn; xn = tm;
             float *tr = rdot_cur; rdot_cur = rdot_next; rdot_next = tr;
+            nd_cur = nslots(H1);
         }
         return 0;
     };
@@ -713,20 +767,22 @@ int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t s
         beta = beta + db;
     }
     BM_TRY(visit(true, prev, 1.0f, false, 0.f, step++));                     // +log p_1(x_M) - log p_prev(x_M)  (:728)
-    std::vector<float> w(R);
-    BM_HIP(hipMemcpyAsync(w.data(), h->alogw.p, (size_t)R * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    std::vector<double> w(R);
+    BM_HIP(hipMemcpyAsync(w.data(), h->alogw, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    const float logZ0 = (float)(V + H1 + H2) * logf(2.0f);                   // (:731-734)
-    for (int r = 0; r < R; ++r) values_host[r] = w[r] + logZ0;
+    const double logZ0 = (double)(V + H1 + H2) * (double)logf(2.0f);         // (:731-734)
+    for (int r = 0; r < R; ++r) values_host[r] = (float)(w[r] + logZ0);
     BM_HIP(hipGetLastError());
     return 0;
 }
 
-// per-row bias terms and entropies of the ELBO (dbm.py:746-756), one wave per row
+// per-row bias terms and entropies of the ELBO (dbm.py:746-756), one wave per row; p0 / p1: slot partials of
+// sum((X W0) * mu0) and sum((mu0 W1) * mu1) from the two propagations (pitch ldp), added in slot order
 __global__ __launch_bounds__(256) void elbo_row_kernel(const float *X, int ldx, int V, const float *vb,
                                                        const float *mu0, int ld0, int H1, const float *hb0,
                                                        const float *mu1, int ld1, int H2, const float *hb1,
-                                                       int rows, float *acc) {
+                                                       int rows, const float *p0, int n0, const float *p1, int n1, int ldp,
+                                                       float *out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float s = 0.f;
@@ -745,7 +801,12 @@ __global__ __launch_bounds__(256) void elbo_row_kernel(const float *X, int ldx, 
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) atomicAdd(acc + row, s);
+    if (lane == 0) {
+        double e = 0.0;
+        for (int q = 0; q < n0; ++q) e += (double)p0[(size_t)q * ldp + row];
+        for (int q = 0; q < n1; ++q) e += (double)p1[(size_t)q * ldp + row];
+        out[row] = (float)(e + (double)s);
+    }
 }
 
 int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host) {
@@ -753,20 +814,21 @@ int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host) {
     BM_CHECK(out_host, "null output");
     BM_TRY(mean_field(h, X_dev, nullptr));
     BM_TRY(ensure_ais(h, h->N));
-    BM_HIP(hipMemsetAsync(h->rowtmp.p, 0, (size_t)h->N * sizeof(float), h->stream));
-    // sum((X W0) * mu0) and sum((mu0 W1) * mu1) as dot-epilogues of the two propagations
+    // sum((X W0) * mu0) and sum((mu0 W1) * mu1) as dot-epilogues of the two propagations (slot partials)
+    const int ldp = h->ais_rows;
     ActArgs e;
     memset(&e, 0, sizeof(e));
-    e.rowacc = h->rowtmp.p; e.dot_mat = h->mu[0].p; e.ld_dot = h->mu[0].ld;
+    e.rowacc = h->apart_v.p; e.ld_part = ldp; e.dot_mat = h->mu[0].p; e.ld_dot = h->mu[0].ld;
     layer_update(h, 0, h->N, LayerIn{X_dev, h->V}, LayerIn{nullptr, 0}, 1.f, 1.f, 0, nullptr, nullptr, h->mu[0].ld,
                  dkey(h, 0, 0, h->seed, h->call), 0, nullptr, nullptr, &e);
     memset(&e, 0, sizeof(e));
-    e.rowacc = h->rowtmp.p; e.dot_mat = h->mu[1].p; e.ld_dot = h->mu[1].ld;
+    e.rowacc = h->apart_h.p; e.ld_part = ldp; e.dot_mat = h->mu[1].p; e.ld_dot = h->mu[1].ld;
     layer_update(h, 1, h->N, LayerIn{h->mu[0].p, h->mu[0].ld}, LayerIn{nullptr, 0}, 1.f, 1.f, 0, nullptr, nullptr,
                  h->mu[1].ld, dkey(h, 0, 0, h->seed, h->call), 0, nullptr, nullptr, &e);
     hipLaunchKernelGGL(elbo_row_kernel, dim3((h->N + 3) / 4), dim3(256), 0, h->stream, X_dev, h->V, h->V,
                        (const float *)h->vb.p, (const float *)h->mu[0].p, h->mu[0].ld, h->n[1], (const float *)h->hb[0].p,
-                       (const float *)h->mu[1].p, h->mu[1].ld, h->n[2], (const float *)h->hb[1].p, h->N, h->rowtmp.p);
+                       (const float *)h->mu[1].p, h->mu[1].ld, h->n[2], (const float *)h->hb[1].p, h->N,
+                       (const float *)h->apart_v.p, nslots(h->n[1]), (const float *)h->apart_h.p, nslots(h->n[2]), ldp, h->rowtmp.p);
     BM_HIP(hipMemcpyAsync(out_host, h->rowtmp.p, (size_t)h->N * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     h->call++;

@@ -45,12 +45,18 @@ struct ActArgs {
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
     float *maxdiff_blk;          // or (launches of <= BM_MF_SLOTS workgroups): one slot per workgroup, reduced by
                                  // mf_ctl_kernel - hundreds of same-address atomics cost ~4 us per sweep kernel
-    // optional per-row reductions of the epilogue (AIS log-weights dbm.py:650-660,713-720; ELBO :741-745)
-    float *rowacc;               // [J] += sum_i softplus(beta_b*(z+b)) - softplus(beta_a*(z+b))   (AIS)
-                                 //     or sum_i z * dot_mat[j][i]                                  (ELBO, dot_mat set)
+    // optional per-row reductions of the epilogue (AIS log-weights dbm.py:650-660,713-720; ELBO :741-745).
+    // DETERMINISTIC: no atomics.  Every aligned group of 16 output columns ("slot" s = i / 16) of row j
+    // gets ONE partial sum, computed in a fixed order that does not depend on the tile geometry
+    // (quads of 4 consecutive i summed left to right, then (q0+q1)+(q2+q3)), stored at
+    // part[s * ld_part + j]; the consumer kernel (ais_score_kernel / elbo_row_kernel) adds the
+    // ceil(I/16) slots of a row in ascending order.  Round 1 used fp32 atomicAdd from every tile:
+    // order - and therefore the low bits of log Z - varied from run to run.
+    float *rowacc;               // [ceil(I/16)][ld_part]: sum_i softplus(beta_b*(z+b)) - softplus(beta_a*(z+b))  (AIS)
+                                 //     or sum_i z * dot_mat[j][i]                                                 (ELBO, dot_mat set)
     float beta_a, beta_b;
-    const float *rowdot_in;      // [J]: rowacc[j] += (beta_b - beta_a) * rowdot_in[j], added once per row (AIS x.hb0 term)
-    float *rowdot_out;           // [J] += sum_i states[j][i] * dot_vec[i]
+    float *rowdot_out;           // [ceil(I/16)][ld_part]: sum_i states[j][i] * dot_vec[i]
+    int ld_part;                 // pitch of the partial-sum buffers (>= J)
     const float *dot_vec;        // [I]
     const float *dot_mat;        // [J][I] pitch ld_dot
     int ld_dot;
@@ -291,32 +297,41 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
         }
     }
     if (a.rowacc || a.rowdot_out) {           // wave-uniform
+        // per-lane quads (4 consecutive i, left to right); MI == 2: the lane's two quads are added
         float racc = 0.f, rdot = 0.f;
         if (j < a.J) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int i = ib0 + e;
-                if (i >= a.I) break;
-                if (a.rowacc) {
-                    if (a.dot_mat) {
-                        racc += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
-                    } else {
-                        const float t = z[e] + bs[e];
-                        racc += softplus(a.beta_b * t) - softplus(a.beta_a * t);
+            for (int hlf = 0; hlf < NH; ++hlf) {
+                float qa = 0.f, qd = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = 4 * hlf + r, i = ib0 + e;
+                    if (i >= a.I) break;
+                    if (a.rowacc) {
+                        if (a.dot_mat) {
+                            qa += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
+                        } else {
+                            const float t = z[e] + bs[e];
+                            qa += softplus(a.beta_b * t) - softplus(a.beta_a * t);
+                        }
                     }
+                    // the state of this element as it was just stored by this lane
+                    if (a.rowdot_out) qd += a.states[(size_t)j * a.ldo + i] * a.dot_vec[i];
                 }
-                if (a.rowdot_out) {
-                    // recompute the state of this element from what was stored (states were just written)
-                    rdot += a.states[(size_t)j * a.ldo + i] * a.dot_vec[i];
-                }
+                racc = (hlf == 0) ? qa : racc + qa;
+                rdot = (hlf == 0) ? qd : rdot + qd;
             }
-            if (a.rowacc && a.rowdot_in && ib0 == 0) racc += (a.beta_b - a.beta_a) * a.rowdot_in[j];
         }
-        racc += __shfl_xor(racc, 16); racc += __shfl_xor(racc, 32);
-        rdot += __shfl_xor(rdot, 16); rdot += __shfl_xor(rdot, 32);
-        if (g == 0 && j < a.J) {
-            if (a.rowacc) atomicAdd(a.rowacc + j, racc);
-            if (a.rowdot_out) atomicAdd(a.rowdot_out + j, rdot);
+        // 16-column slot sums: MI == 1: lanes g = 0..3 hold q0..q3 -> (q0+q1)+(q2+q3);
+        // MI == 2: lanes g hold (q_2g + q_2g+1); g in {0,1} / {2,3} are the wave's two slots
+        racc += __shfl_xor(racc, 16);
+        rdot += __shfl_xor(rdot, 16);
+        if (G::MI == 1) { racc += __shfl_xor(racc, 32); rdot += __shfl_xor(rdot, 32); }
+        const bool writer = (G::MI == 1) ? (g == 0) : ((g & 1) == 0);
+        const int slot = (i0 + wi * (16 * G::MI)) / 16 + ((G::MI == 2) ? (g >> 1) : 0);
+        if (writer && j < a.J && slot * 16 < a.I) {
+            if (a.rowacc) a.rowacc[(size_t)slot * a.ld_part + j] = racc;
+            if (a.rowdot_out) a.rowdot_out[(size_t)slot * a.ld_part + j] = rdot;
         }
     }
     BM_STAMP(2);
@@ -1283,11 +1298,15 @@ static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
 // depends on how the output tiles fill the 256 CUs and on the K length, and did not follow a
 // simple rule in measurements (784x1024x512: 8-wave; AIS 20000 chains and 3072x5000: 32x32
 // tiles with BK = 32, four workgroups per CU; DBM 784-512-1024 mean-field: 64x32).  So the
-// launcher measures: the first 12 launches
-// of every distinct shape rotate through the candidates bracketed by HIP events on the
-// engine stream (they are REAL launches of the caller's work - no extra launches, no side
-// effects, no synchronisation: the events are polled on later launches), then the fastest is
-// used.  BM355_ACT_GEO=4|8|1|3 forces one geometry (experiments, tests).
+// launcher measures, ONCE per distinct shape and process, SYNCHRONOUSLY at the first launch of
+// that shape: every candidate runs the caller's contraction on the caller's (read-only)
+// operands with all OUTPUTS redirected to a scratch pool (so the tuning launches have no side
+// effects: no double-counted row accumulators, no early write of a mean-field result), timed
+// with one HIP event pair around TUNE_REP back-to-back launches, best of TUNE_ROUNDS rounds.
+// After that the launch path is one table lookup: no event, no allocation, no synchronisation
+// (round 1 rotated the candidates through the first 12 real launches, which put slower
+// geometries and event markers into short timed runs).  BM355_ACT_GEO=4|8|1|3 forces one
+// geometry (experiments, tests); BM355_TUNE_LOG=1 prints the decisions.
 static inline int act_geo_override() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("BM355_ACT_GEO"); v = e ? atoi(e) : 0; }
@@ -1301,78 +1320,88 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     else               launch_act_geo<GeoAct, 1>(a, st);
 }
 struct ActTune {
-    static constexpr int NC = 4, R = 3;
-    int best = 0, nlaunch = 0, ndone = 0;
-    float tmin[NC] = {1e30f, 1e30f, 1e30f, 1e30f};
-    struct Sample { hipEvent_t e0 = nullptr, e1 = nullptr; int cand = 0; bool pending = false; } s[NC * R];
+    static constexpr int NC = 4;
+    int best = 0;
+    float t_us[NC] = {0.f, 0.f, 0.f, 0.f};
 };
-static inline void tune_log(const ActArgs &a, long long flags, const ActTune &T) {      // BM355_TUNE_LOG=1
+// scratch pool of the tuning launches (per process and device; grown on demand, never on the hot path)
+struct TuneScratch {
+    float *p = nullptr; size_t cap = 0; int dev = -1;
+    float *get(size_t nfloats) {
+        int d = 0; (void)hipGetDevice(&d);
+        if (p && (d != dev || nfloats > cap)) { (void)hipFree(p); p = nullptr; cap = 0; }
+        if (!p) {
+            if (hipMalloc((void **)&p, nfloats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return nullptr; }
+            cap = nfloats; dev = d;
+        }
+        return p;
+    }
+};
+static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3};
+    constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
+    static TuneScratch pool;
+    const size_t mat = ((size_t)a.J * (size_t)a.ldo + 3) & ~(size_t)3;
+    const size_t rowv = (((size_t)((a.I + 15) / 16) * (size_t)(a.ld_part > a.J ? a.ld_part : a.J)) + 3) & ~(size_t)3;   // slot partials
+    float *s = pool.get(3 * mat + 2 * rowv + BM_MF_SLOTS + 4);
+    T.best = a.p_xm ? 8 : 4;
+    if (!s) return;                                  // no memory for the scratch outputs: keep the default
+    ActArgs t = a;
+    t.skip = nullptr;
+    if (a.means) t.means = s;
+    if (a.states) t.states = s + mat;
+    if (a.negmeans) t.negmeans = s + 2 * mat;
+    if (a.rowacc) t.rowacc = s + 3 * mat;
+    if (a.rowdot_out) t.rowdot_out = s + 3 * mat + rowv;
+    if (a.maxdiff_blk) t.maxdiff_blk = s + 3 * mat + 2 * rowv;
+    if (a.maxdiff) t.maxdiff = reinterpret_cast<unsigned *>(s + 3 * mat + 2 * rowv + BM_MF_SLOTS);
+#ifdef BM_PROBE
+    t.dbg = nullptr;
+#endif
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
+    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f};
+    for (int round = 0; round < TUNE_ROUNDS; ++round) {
+        for (int c = 0; c < ActTune::NC; ++c) {
+            if (a.p_xm && cand_geo[c] == 4) continue;             // not instantiated for an x-major P
+            launch_act_as(cand_geo[c], t, st);                    // warm (instruction cache, clocks)
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < TUNE_REP; ++r) launch_act_as(cand_geo[c], t, st);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 1e3f * ms / TUNE_REP < best_us[c]) best_us[c] = 1e3f * ms / TUNE_REP;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    int b = -1;
+    for (int c = 0; c < ActTune::NC; ++c) {
+        T.t_us[c] = best_us[c];
+        if (best_us[c] < 1e29f && (b < 0 || best_us[c] < best_us[b])) b = c;
+    }
+    if (b >= 0) T.best = cand_geo[b];
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f)\n",
-                a.I, a.J, a.K1, a.K2, flags, T.best, 1e3f * T.tmin[0], 1e3f * T.tmin[1], 1e3f * T.tmin[2], 1e3f * T.tmin[3]);
+                a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0], T.t_us[1], T.t_us[2], T.t_us[3]);
 }
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3};
     const int ov = act_geo_override();
     if (ov) { launch_act_as(ov, a, st); return; }
     static std::mutex mu;
     static std::map<std::array<long long, 6>, ActTune> table;
-    const std::array<long long, 6> key = {a.I, a.J, a.K1, a.K2, (long long)((a.sample ? 1 : 0) | (a.kind << 1) | (a.prev ? 8 : 0) | (a.rowacc ? 16 : 0) | (a.acc_init ? 32 : 0) | (a.p_xm ? 64 : 0)), 0LL};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const long long flags = (long long)((a.sample ? 1 : 0) | (a.kind << 1) | (a.prev ? 16 : 0) | (a.rowacc ? 32 : 0) |
+                                        (a.acc_init ? 64 : 0) | (a.p_xm ? 128 : 0) | (a.rowdot_out ? 256 : 0) |
+                                        (a.dot_mat ? 512 : 0) | (a.negmeans ? 1024 : 0));
+    const std::array<long long, 6> key = {a.I, a.J, a.K1, a.K2, flags, (long long)dev};
     int geo;
-    ActTune::Sample *smp = nullptr;
     {
         std::lock_guard<std::mutex> lk(mu);
         ActTune &T = table[key];
-        if (!T.best) {
-            for (auto &q : T.s) {
-                if (!q.pending) continue;
-                if (hipEventQuery(q.e1) != hipSuccess) { (void)hipGetLastError(); continue; }   // not ready: clear the sticky status
-                {
-                    float ms = 0.f;
-                    if (hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess && ms < T.tmin[q.cand]) T.tmin[q.cand] = ms;
-                    (void)hipEventDestroy(q.e0); (void)hipEventDestroy(q.e1);
-                    q.pending = false; ++T.ndone;
-                }
-            }
-            if (T.ndone == ActTune::NC * ActTune::R) {
-                int b = 0;
-                for (int c = 1; c < ActTune::NC; ++c) if (T.tmin[c] < T.tmin[b]) b = c;
-                T.best = cand_geo[b];
-                tune_log(a, key[4], T);
-            }
-        }
-        if (T.best) {
-            geo = T.best;
-        } else if (T.nlaunch < ActTune::NC * ActTune::R) {
-            smp = &T.s[T.nlaunch];
-            smp->cand = T.nlaunch % ActTune::NC;
-            geo = cand_geo[smp->cand];
-            if (hipEventCreate(&smp->e0) != hipSuccess || hipEventCreate(&smp->e1) != hipSuccess) { smp = nullptr; T.best = geo = 4; }
-            ++T.nlaunch;
-        } else {
-            // all sampling launches are enqueued but some results are still in flight (the host runs
-            // ahead of the GPU): wait for them ONCE, so the choice is made after exactly NC*R launches
-            for (auto &q : T.s) {
-                if (!q.pending) continue;
-                (void)hipEventSynchronize(q.e1);
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, q.e0, q.e1) == hipSuccess && ms < T.tmin[q.cand]) T.tmin[q.cand] = ms;
-                (void)hipEventDestroy(q.e0); (void)hipEventDestroy(q.e1);
-                q.pending = false; ++T.ndone;
-            }
-            int b = 0;
-            for (int c = 1; c < ActTune::NC; ++c) if (T.tmin[c] < T.tmin[b]) b = c;
-            geo = T.best = cand_geo[b];
-            tune_log(a, key[4], T);
-        }
-        if (smp) {
-            (void)hipEventRecord(smp->e0, st);
-            launch_act_as(geo, a, st);
-            (void)hipEventRecord(smp->e1, st);
-            smp->pending = true;
-            return;
-        }
+        if (!T.best) tune_act_shape(a, st, T, flags);
+        geo = T.best;
     }
     launch_act_as(geo, a, st);
 }

@@ -513,6 +513,16 @@ int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1) {
                            h->Xs.ld, B, h->V);
         Xin = h->Xs.p; ldx = h->Xs.ld;
     }
+    bool dropped = false;
+    if (h->cfg.dropout >= 0.f) {
+        // free_energy_op is built from self._X_batch AFTER tf.nn.dropout replaced it (base_rbm.py:417-418,
+        // :516): the `feg` metric sees the dropped input like msre / pll do
+        hipLaunchKernelGGL(dropout_kernel, dim3(256), dim3(256), 0, h->stream, Xin, ldx, h->Xd.p, h->Xd.ld, B, h->V,
+                           h->cfg.dropout, make_key(h, SITE_DROPOUT, 0),
+                           (unsigned long long)h->row0 * (unsigned long long)h->V);
+        Xin = h->Xd.p; ldx = h->Xd.ld;
+        dropped = true;
+    }
     BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
     BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 3 * (size_t)h->maxB * sizeof(float), h->stream));
     launch_fe(h, Xin, ldx, B, false);
@@ -520,7 +530,7 @@ int bm_rbm_free_energy(bm_rbm *h, const float *X_dev, int32_t B, float *out1) {
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     *out1 = (float)(host[2] / B + mn_fe_const(h));
-    if (h->multinomial()) h->call++;          // the random h_hat consumed one call of the stream
+    if (h->multinomial() || dropped) h->call++;   // the random h_hat / the dropout mask consumed one call of the stream
     return 0;
 }
 

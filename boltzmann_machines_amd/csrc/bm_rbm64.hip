@@ -481,9 +481,12 @@ int bm_rbm64_metrics(bm_rbm64 *h, const double *X_dev, int32_t B, int32_t k, dou
 int bm_rbm64_free_energy(bm_rbm64 *h, const double *X_dev, int32_t B, double *out1) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     const double *Xin = X_dev;
-    if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {
-        hipLaunchKernelGGL(prep_kernel, dim3(256), dim3(256), 0, h->stream, X_dev, h->Xp.p, (const double *)h->sigma.p, B, h->V,
-                           -1.0, make_key(h, bm64::SITE_DROPOUT, 0), 0ull);
+    const bool dropped = h->dropout >= 0.0;      // free_energy_op sees the dropped input (base_rbm.py:417-418, :516)
+    if (h->cfg.v_unit == BM_UNIT_GAUSSIAN || dropped) {
+        hipLaunchKernelGGL(prep_kernel, dim3(256), dim3(256), 0, h->stream, X_dev, h->Xp.p,
+                           (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), B, h->V,
+                           dropped ? h->dropout : -1.0, make_key(h, bm64::SITE_DROPOUT, 0),
+                           (unsigned long long)h->row0 * (unsigned long long)h->V);
         Xin = h->Xp.p;
     }
     BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
@@ -494,6 +497,7 @@ int bm_rbm64_free_energy(bm_rbm64 *h, const double *X_dev, int32_t B, double *ou
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     *out1 = host[2] / B;
+    if (dropped) h->call++;                      // the dropout mask consumed one call of the stream
     return 0;
 }
 

@@ -237,13 +237,15 @@ class DBM(EngineModel):
         return (np.mean(msres) if msres else None, np.mean(nmfs) if nmfs else None)
 
     def _run_val_metrics(self, X_val, Xvd):
+        # one fetch of [msre, n_mf_updates] per batch (reference dbm.py:810-816).  Both tensors sit under the
+        # control dependencies of the train graph (dbm.py:521-523): the fetch also advances the fantasy
+        # particles by n_gibbs_steps, exactly like the reference's validation pass does.
         msres, nmfs = [], []
-        Rd = _ffi.DeviceArray((self.batch_size, self.n_visible_))
+        _, _, k = self._feed()
         for start in range(0, len(X_val), self.batch_size):
-            nmfs.append(self._engine.mean_field(Xvd, row=start))
-            self._engine.reconstruct(Xvd, Rd, row=start)
-            self._engine.sync()
-            msres.append(np.mean((X_val[start:start + self.batch_size] - Rd.numpy()) ** 2))
+            nmf, msre = self._engine.metrics(Xvd, k, row=start)
+            msres.append(msre)
+            nmfs.append(nmf)
         return np.mean(msres), np.mean(nmfs)
 
     def _fit(self, X, X_val=None, *args, **kwargs):

@@ -305,6 +305,12 @@ class DbmEngine(object):
                                          C.byref(msre) if want_msre else None))
         return int(nmf.value), (float(msre.value) if want_msre else None)
 
+    def metrics(self, Xd, k, row=0):
+        """validation fetch (dbm.py:813): mean-field + k PCD sweeps + reconstruction msre, no update"""
+        nmf, msre = C.c_int32(), C.c_float()
+        check(self.lib.bm_dbm_metrics(self._h, Xd.offset_ptr(row * self.V), k, C.byref(nmf), C.byref(msre)))
+        return int(nmf.value), float(msre.value)
+
     def grad_step(self, Xd, k, row=0):
         nmf = C.c_int32()
         check(self.lib.bm_dbm_grad_step(self._h, Xd.offset_ptr(row * self.V), k, C.byref(nmf)))

@@ -222,6 +222,11 @@ int bm_dbm_dev_ptr(bm_dbm *h, const char *name, void **out_dev, size_t *out_n);
  * out_msre (host, may be NULL) the reconstruction msre (dbm.py:625-630). */
 int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float learning_rate, float momentum,
                       int32_t n_gibbs_steps, int32_t *out_n_mf, float *out_msre);
+/* session.run([msre, n_mf_updates]) at dbm.py:813 (_run_val_metrics): the two tensors are built under
+ * control dependencies on the mean-field AND the particle updates (dbm.py:521-523), so this fetch runs
+ * the mean-field on X_dev, advances the fantasy particles by n_gibbs_steps, and returns the
+ * reconstruction msre (dbm.py:625-630); no parameter update. */
+int bm_dbm_metrics(bm_dbm *h, const float *X_dev, int32_t n_gibbs_steps, int32_t *out_n_mf, float *out_msre);
 /* data-parallel halves, as for the RBM: phase 1 (mean-field, PCD, raw sums) leaves
  * [sum_b below^T mu_i | sum_m below^T H_i per layer | column sums of X, v, mu_i, H_i] in the
  * "grad" buffer (bm_dbm_dev_ptr); the caller all-reduces it; phase 2 applies the update of

@@ -162,9 +162,15 @@ class OracleRBM(object):
         X = np.ascontiguousarray(X, dtype=np.float32)
         if self.cfg.v_unit == 1:
             X = np.ascontiguousarray(X / self.p['sigma'][None, :], dtype=np.float32)
+        dropped = self.cfg.dropout >= 0.0
+        if dropped:
+            # free_energy_op reads self._X_batch AFTER tf.nn.dropout replaced it (base_rbm.py:417-418, :516)
+            keep = np.float32(self.cfg.dropout)
+            u = uniform(self.seed, 1, self.call, X.size, idx0=self.row0 * self.V).reshape(X.shape)
+            X = np.ascontiguousarray((X / keep) * np.floor(keep + u), dtype=np.float32)
         fe = lib().orc_rbm_free_energy_ex(C.byref(self.cfg), C.byref(self._state()), X, len(X), None,
                                           self.seed, self.call, 0)
-        if self.cfg.h_unit == 2:          # the random h_hat consumes one call of the stream (bm_rbm_free_energy)
+        if self.cfg.h_unit == 2 or dropped:   # the random h_hat / dropout mask consumes one call of the stream
             self.call += 1
         return fe
 
@@ -270,7 +276,15 @@ class OracleRBM64(object):
         X = np.ascontiguousarray(X, dtype=np.float64)
         if self.cfg.v_unit == 1:
             X = np.ascontiguousarray(X / self.p['sigma'][None, :])
-        return lib().orc_rbm_free_energy_d(C.byref(self.cfg), C.byref(self._state()), X, len(X), None)
+        dropped = self.hy[4] >= 0.0
+        if dropped:                           # base_rbm.py:417-418, :516 (see OracleRBM.free_energy)
+            keep = self.hy[4]
+            u = uniform_d(self.seed, 1, self.call, X.size, idx0=self.row0 * self.V).reshape(X.shape)
+            X = np.ascontiguousarray((X / keep) * np.floor(keep + u))
+        fe = lib().orc_rbm_free_energy_d(C.byref(self.cfg), C.byref(self._state()), X, len(X), None)
+        if dropped:
+            self.call += 1
+        return fe
 
 
 def uniform_d(seed, site, call, n, idx0=0):
@@ -406,6 +420,20 @@ class OracleDBM(object):
         self._sync_back(s)
         self.call += 1
         return n, (msre.value if want_msre else None)
+
+    def metrics(self, X, k):
+        """validation fetch (dbm.py:813 under the control dependencies of :521-523): mean-field, k PCD
+        sweeps on the particles, reconstruction msre; no parameter update."""
+        s = self._state()
+        L_ = _dbm_lib()
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        n = L_.orc_dbm_mean_field(C.byref(self.cfg), C.byref(s), X)
+        L_.orc_dbm_particles(C.byref(self.cfg), C.byref(s), k, 1, self.seed, self.call, self.prow0)
+        R = np.zeros((self.N, self.V), dtype=np.float32)
+        L_.orc_dbm_reconstruct_from_mu(C.byref(self.cfg), C.byref(s), R)
+        self._sync_back(s)
+        self.call += 1
+        return n, float(np.mean((X.astype(np.float64) - R.astype(np.float64)) ** 2))
 
     def reconstruct(self, X):
         s = self._state()

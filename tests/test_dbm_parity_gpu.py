@@ -184,3 +184,50 @@ def test_randomised_dbm_bit_exact(gpu_lib):
         except AssertionError as e:
             raise AssertionError('case %d V=%d nh=%r N=%d M=%d k=%d %r: %s' % (case, V, nh, N, M, k, kw, e))
         eng.close()
+
+
+def test_sample_v_zero_steps_keeps_particles(gpu_lib):
+    """k = 0 (the default of DBM.sample_v): no sweep runs, v is returned unchanged (dbm.py:641-648)."""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    V, nh, N, M = 20, [12, 16], 10, 10
+    eng, twin = make_pair(V, nh, N, M)
+    eng.seed(7); twin.set_seed(7)
+    before = eng.get('v')
+    Vd = DeviceArray((M, V))
+    eng.sample_v(0, Vd)
+    assert np.array_equal(Vd.numpy(), before) and np.array_equal(eng.get('v'), before)
+    assert np.array_equal(twin.sample_v(0), before)
+    eng.close()
+
+
+def test_validation_fetch_advances_particles(gpu_lib):
+    """bm_dbm_metrics = session.run([msre, n_mf_updates]) of _run_val_metrics (dbm.py:813): mean-field AND
+    n_gibbs_steps PCD sweeps (control dependencies, dbm.py:521-523), no parameter update."""
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 20, [12, 16], 10, 10
+    eng, twin = make_pair(V, nh, N, M, max_mf_updates=6, mf_tol=1e-6)
+    eng.seed(5); twin.set_seed(5)
+    W_before = eng.get('W')
+    for s in range(2):
+        X = data(N, V, s)
+        g = eng.metrics(as_device(X), 2)
+        c = twin.metrics(X, 2)
+        assert g[0] == c[0]
+        np.testing.assert_allclose(g[1], c[1], rtol=1e-5)
+    assert_equal(eng, twin, ['v', 'h', 'h_1', 'mu', 'mu_1'])
+    assert np.array_equal(eng.get('W'), W_before)
+    eng.close()
+
+
+def test_ais_is_deterministic_and_geometry_invariant(gpu_lib, monkeypatch):
+    """log-weights are accumulated from per-16-column partial sums in a fixed order (no atomics):
+    repeated runs are bit-identical, and so are runs with every tile geometry forced."""
+    V, nh, N, M = 52, [40, 36], 8, 8
+    eng, _ = make_pair(V, nh, N, M)
+    a = eng.ais(n_betas=30, n_runs=300, k=1, seed=11)
+    b = eng.ais(n_betas=30, n_runs=300, k=1, seed=11)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # a chain's value does not depend on which other chains run with it
+    c = eng.ais(n_betas=30, n_runs=100, k=1, seed=11, chain0=150)
+    assert np.array_equal(c.view(np.uint32), a[150:250].view(np.uint32))
+    eng.close()
