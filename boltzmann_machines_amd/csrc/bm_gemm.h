@@ -99,6 +99,8 @@ using GeoActS = Geo<2, 2, 1, 1, 64>;     // 32 x 32 tile, 4 waves of 16 x 16, 72
                                          // outputs too small to give every CU a larger tile
 using GeoActS32 = Geo<2, 2, 1, 1, 32>;   // the same with BK = 32: 36 KiB LDS, up to four workgroups per CU
 using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 4 waves of 32 x 32, 144 KiB LDS
+using GeoGrad8 = Geo<2, 4, 2, 1, 64>;    // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD: one wave's LDS / global issue
+                                         // overlaps its partner's MFMAs), 132 KiB LDS
 
 struct Operand {
     const float *ptr;

@@ -612,17 +612,17 @@ struct DivBy {
 
 // grad_kernel's side work: the W / dW values of the lane's outputs are fetched at the start of
 // the pipeline drain, so the read-modify-write epilogue does not start with a memory round trip
-struct GradSide {
+template <int NJ> struct GradSide {
     static constexpr bool kFinalSync = true;     // form 1 runs two pipelines through the same LDS ring
-    const float *W, *dW; int ldw, I, J, ib0, jb[2]; bool on, vec8;
-    float4 w[2][2], d[2][2];
+    const float *W, *dW; int ldw, I, J, ib0, jb[NJ]; bool on, vec8;
+    float4 w[NJ][2], d[NJ][2];
     bool at_fill;
     __device__ __forceinline__ void fill() { if (at_fill) fetch(); }
     __device__ __forceinline__ void drain() { if (!at_fill) fetch(); }
     __device__ __forceinline__ void fetch() {
         if (!on || ib0 >= I) return;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NJ; ++n) {
             if (jb[n] >= J) continue;
             const size_t o = (size_t)jb[n] * ldw + ib0;
             if (vec8) {
@@ -643,17 +643,18 @@ struct GradSide {
     }
 };
 
-template <bool FAST, int ABL = 0>
-__global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
-    using G = GeoGrad;
-    constexpr int TI = G::TI;
+template <class G, bool FAST, int ABL = 0>
+__global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
+    constexpr int TI = G::TI, NJ = G::NJ;
+    static_assert(G::MI == 2 && G::TI == 64 && G::TJ == 64, "grad_kernel: 64 x 64 tiles, 8 consecutive outputs per lane");
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
-    static_assert(G::SMEM_FLOATS >= CS_SMEM_FLOATS && G::NT == NT, "bias path reuses the tile LDS");
+    static_assert(G::SMEM_FLOATS >= CS_SMEM_FLOATS && G::NT >= NT, "bias path reuses the tile LDS");
     // the bias/colsum workgroups sit BEHIND the tile workgroups in dispatch order: 208 tiles
     // (784x1024) take 208 CUs for the whole launch, the short bias groups cycle through
     // the CUs that are left and finish inside the tiles' shadow.
     const int ntile_blocks = (int)gridDim.x - a.nbias;
     if ((int)blockIdx.x >= ntile_blocks) {
+        if (G::NT > NT && threadIdx.x >= NT) return;      // the column-sum body is written for NT threads (whole waves leave)
         rbm_bias_fused_block(a.bias, (int)blockIdx.x - ntile_blocks, smem);
         return;
     }
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     block_to_tile(tiles_j, ti, tj, 0, a.nbias);
     const int i0 = ti * TI, j0 = tj * TJ2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w & 1, wj = w >> 1;
+    const int wi = w % G::WI, wj = w / G::WI;
     const int g = lane >> 4, l15 = lane & 15;
     const int ib0 = i0 + wi * 32 + g * 8;
 
@@ -677,15 +678,15 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
 #define BM_GSTAMP(n) do {} while (0)
 #endif
     BM_GSTAMP(0);
-    f32x4 pos[2][2], neg[2][2];
+    f32x4 pos[2][NJ], neg[2][NJ];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) pos[t][n] = neg[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    GradSide side;
+        for (int n = 0; n < NJ; ++n) pos[t][n] = neg[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    GradSide<NJ> side;
     side.W = a.W; side.dW = a.dW; side.ldw = a.ldw; side.I = a.I; side.J = a.J; side.ib0 = ib0;
-    side.jb[0] = j0 + wj * 32 + lane_j<KM, G>(l15, 0);
-    side.jb[1] = j0 + wj * 32 + lane_j<KM, G>(l15, 1);
+#pragma unroll
+    for (int n = 0; n < NJ; ++n) side.jb[n] = j0 + wj * (16 * NJ) + lane_j<KM, G>(l15, n);
     side.vec8 = (ib0 + 7 < a.I) && ((a.ldw & 3) == 0);            // 16-byte aligned run of 8 (ib0 % 8 == 0)
     // When are W/dW of the lane's outputs read?  In the epilogue by default; fetching them in the pipeline
     // fill (fetch_at_fill) or at the start of the drain only moved the time or lost (launch_grad).
@@ -711,10 +712,10 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
     if (ib0 >= a.I) return;
     if (!a.fetch_at_fill) { side.on = a.fused != 0; side.fetch(); }
     const DivBy divN(a.N), divM(a.M);
-    float wt[2][8];                 // updated W values of both j (adjacent columns of Wt)
-    bool jok[2];
+    float wt[NJ][8];                // updated W values of the lane's j (NJ == 2: adjacent columns of Wt)
+    bool jok[NJ];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NJ; ++n) {
         const int j = side.jb[n];
         jok[n] = j < a.J;
         if (!jok[n]) continue;
@@ -761,17 +762,17 @@ __global__ __launch_bounds__(NT, 1) void grad_kernel(GradArgs a) {
         }
     }
     if (a.fused && a.Wt) {                            // maintained transpose (prop-down P operand)
-        const int ja = side.jb[0];                    // the lane's two columns are adjacent: ja, ja + 1
-        const bool pair = jok[0] && jok[1] && ((a.ldwt & 1) == 0);     // (ja is even)
+        const int ja = side.jb[0];                    // NJ == 2: the lane's two columns are adjacent: ja, ja + 1
+        const bool pair = NJ == 2 && jok[0] && jok[NJ - 1] && ((a.ldwt & 1) == 0);     // (ja is even)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (ib0 + e >= a.I) break;
             float *dst = a.Wt + (size_t)(ib0 + e) * a.ldwt + ja;
             if (pair) {
-                stream_store2(dst, wt[0][e], wt[1][e]);
+                stream_store2(dst, wt[0][e], wt[NJ - 1][e]);
             } else {
                 if (jok[0]) dst[0] = wt[0][e];
-                if (jok[1]) dst[1] = wt[1][e];
+                if (NJ == 2 && jok[NJ - 1]) dst[1] = wt[NJ - 1][e];
             }
         }
     }
@@ -1406,16 +1407,75 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
     launch_act_as(geo, a, st);
 }
 
-static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
-    static int fetch_env = -1;          // BM355_GRAD_FETCH=0|1 overrides (experiments)
-    if (fetch_env < 0) { const char *e = getenv("BM355_GRAD_FETCH"); fetch_env = e ? 2 + atoi(e) : 0; }
-    GradArgs g = g_in;
-    g.fetch_at_fill = fetch_env >= 2 ? fetch_env - 2 : 0;      // measured (same box, 784x1024x512): epilogue 66.6 us/update, fill 67.5
+// ---- grad_kernel geometry choice: 4 waves of 32 x 32 or 8 waves of 32 x 16 (bit-identical results), measured
+// once per shape like the act geometries (tune_act_shape), on scratch copies of every buffer the kernel writes.
+// BM355_GRAD_GEO=4|8 forces one.
+template <class G>
+static inline void launch_grad_geo(const GradArgs &g, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
-    const dim3 grid(tile_grid<GeoGrad>(g.I, g.J) + g.nbias), blk(NT);
-    if (fast) hipLaunchKernelGGL((grad_kernel<true>), grid, blk, 0, st, g);
-    else      hipLaunchKernelGGL((grad_kernel<false>), grid, blk, 0, st, g);
+    const dim3 grid(tile_grid<G>(g.I, g.J) + g.nbias), blk(G::NT);
+    if (fast) hipLaunchKernelGGL((grad_kernel<G, true>), grid, blk, 0, st, g);
+    else      hipLaunchKernelGGL((grad_kernel<G, false>), grid, blk, 0, st, g);
+}
+static inline void launch_grad_as(int geo, const GradArgs &g, hipStream_t st) {
+    if (geo == 8) launch_grad_geo<GeoGrad8>(g, st);
+    else          launch_grad_geo<GeoGrad>(g, st);
+}
+static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
+    // the tile workgroups only: scratch W / dW / raw (the update is not idempotent), no bias groups
+    static TuneScratch pool;
+    const size_t mat = (((size_t)g.J * (size_t)g.ldw) + 3) & ~(size_t)3;
+    float *s = pool.get(4 * mat);
+    if (!s) return 4;
+    GradArgs t = g;
+    t.nbias = 0; t.pen = nullptr; t.Wt = nullptr;
+    t.W = s; t.dW = s + mat; t.raw = s + 2 * mat; t.raw2 = s + 3 * mat;
+    (void)hipMemsetAsync(s, 0, 4 * mat * sizeof(float), st);
+#ifdef BM_PROBE
+    t.dbg = nullptr;
+#endif
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return 4; }
+    const int cand[2] = {4, 8};
+    float best_us[2] = {1e30f, 1e30f};
+    for (int round = 0; round < 3; ++round)
+        for (int c = 0; c < 2; ++c) {
+            launch_grad_as(cand[c], t, st);
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < 4; ++r) launch_grad_as(cand[c], t, st);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 250.f * ms < best_us[c]) best_us[c] = 250.f * ms;
+        }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const int best = (best_us[1] < best_us[0]) ? 8 : 4;
+    static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
+    if (log)
+        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> %d waves (us: 4w %.1f, 8w %.1f)\n",
+                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1]);
+    return best;
+}
+static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
+    static int fetch_env = -1, geo_env = -1;          // BM355_GRAD_FETCH=0|1, BM355_GRAD_GEO=4|8 override (experiments)
+    if (fetch_env < 0) { const char *e = getenv("BM355_GRAD_FETCH"); fetch_env = e ? 2 + atoi(e) : 0; }
+    if (geo_env < 0) { const char *e = getenv("BM355_GRAD_GEO"); geo_env = e ? atoi(e) : 0; }
+    GradArgs g = g_in;
+    g.fetch_at_fill = fetch_env >= 2 ? fetch_env - 2 : 0;      // measured (same box, 784x1024x512): epilogue 66.6 us/update, fill 67.5
+    int geo = geo_env;
+    if (!geo) {
+        static std::mutex mu;
+        static std::map<std::array<long long, 7>, int> table;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1)), (long long)g.ldw, (long long)dev};
+        std::lock_guard<std::mutex> lk(mu);
+        int &b = table[key];
+        if (!b) b = tune_grad_shape(g, st);
+        geo = b;
+    }
+    launch_grad_as(geo, g, st);
 }
 
 static inline void launch_fe_hidden(const FeArgs &f, hipStream_t st) {

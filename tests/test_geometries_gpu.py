@@ -53,9 +53,10 @@ print('GEOMETRY_OK')
 '''
 
 
-@pytest.mark.parametrize('geo', ['8', '4', '1', '3'])
+@pytest.mark.parametrize('geo', ['8', '4', '1', '3', 'g4', 'g8'])
 def test_forced_geometry_bit_exact(gpu_lib, geo):
-    env = dict(os.environ, BM355_ACT_GEO=geo)
+    # 'g4' / 'g8': the two grad_kernel geometries (4 waves of 32 x 32, 8 waves of 32 x 16) through BM355_GRAD_GEO
+    env = dict(os.environ, BM355_GRAD_GEO=geo[1:]) if geo.startswith('g') else dict(os.environ, BM355_ACT_GEO=geo)
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT)], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and 'GEOMETRY_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -140,7 +140,7 @@ int main(int argc, char **argv) {
         }
 #define GRUN(MASK, NAME) { \
             const dim3 gg(tile_grid<GeoGrad>(g.I, g.J)); \
-            float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<true, MASK>), gg, dim3(NT), 0, st, g); }); \
+            float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad, true, MASK>), gg, dim3(NT), 0, st, g); }); \
             std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
             double s1 = 0, s2 = 0; for (int b = 0; b < 208; ++b) { s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
             printf("grad %-26s %6.2f us | mainloop %6.0f epilogue %5.0f\n", NAME, us, s1/208, s2/208); }
