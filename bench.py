@@ -1,24 +1,34 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json metric on MI355X: Gibbs-steps/sec of the CD-k loop,
-784x1024 Bernoulli RBM, batch 512 per GPU, fp32 MFMA.
+784x1024 Bernoulli RBM, batch 512 per GPU, fp32 MFMA — plus the other BASELINE configurations.
 
-    python bench.py --gpus N --steps K --warmup W [--k 1] [--no-cpu]
+    python bench.py --gpus N --steps K --warmup W [--config rbm|gibbs|grbm|dbm|ais] [--k 1] [--no-cpu]
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one CD-k update (base_rbm.py:566 `session.run(train_op)`) of one
-512-row minibatch per GPU, already resident in HBM = k Gibbs steps.
-N > 1 is data-parallel, weak scaling (512 rows per GPU): each rank runs the
-chain + raw outer products on its rows, ONE RCCL all-reduce(sum) of the fused
+--config rbm (default) is BASELINE.json's metric on configs[1]: one "step" = one CD-k update
+(base_rbm.py:566 `session.run(train_op)`) of one 512-row minibatch per GPU, already resident in HBM
+= k Gibbs steps.  N > 1 is data-parallel, weak scaling (512 rows per GPU): each rank
+runs the chain + raw outer products on its rows, ONE RCCL all-reduce(sum) of the fused
 [dW|dvb|dhb|q] buffer over xGMI, then every rank applies the identical update.
 value = N * k * K / t  (512-row Gibbs steps per second, whole job).
 
-The JSON line also carries
-  roofline     : fp32-MFMA roofline of the CD-k update.  achieved = algorithmic
-                 GEMM flops (2k+3)*2*B*V*H per update / HIP-event time of the
-                 update's kernels on the engine stream; `kernels` holds the
-                 per-kernel-class durations from a second, event-instrumented pass.
-  cpu_baseline : the CPU oracle (restatement of the reference maths, NOT TF1
-                 itself) timed on this box's host cores on a bounded sample.
+Other configurations (one JSON line each, same contract; they are the driver-reproducible form of the
+numbers DESIGN.md quotes for BASELINE configs[2..4] and of SURVEY §8d(ii)):
+  gibbs : pure sampling sweep (bm_rbm_gibbs, base_rbm.py:367-413) on the same 784x1024, batch 512 RBM;
+          a step = 10 (or --k) block-Gibbs sweeps h->v->h in one call; reports MFMA fraction AND algorithmic GB/s.
+  grbm  : configs[2] Gaussian-Bernoulli RBM 3072x5000, PCD-5, batch 256 (1-layer DBM path, README.md:96).
+  dbm   : configs[3] DBM 784-512-1024, 512 rows + 512 particles per GPU, <= 50 mean-field sweeps, PCD-5;
+          N > 1: data-parallel through the library's own RCCL communicator (bm_comm_*).
+  ais   : configs[4] AIS log Z, 20 000 chains x 1000 betas; a step = one full run; N > 1 shards the chains
+          (strong scaling) and ends with ONE all-gather of the log-weights.
+
+The JSON line carries
+  roofline     : fp32-MFMA roofline.  achieved = algorithmic GEMM flops per step (SURVEY §8d formulas) /
+                 HIP-event time of the step's kernels on the engine stream; `kernels` holds the
+                 per-kernel-class durations from a second, event-instrumented pass (rbm only).
+  cpu_baseline : CPU restatements of the reference maths (NOT TF1 itself, which cannot run here) timed on
+                 this box's host cores on a bounded sample: the canonical-order OpenMP C oracle and a
+                 NumPy + BLAS (sgemm) restatement; CPU model, core count and threads are stated.
 """
 import argparse
 import json
@@ -34,64 +44,112 @@ sys.path.insert(0, ROOT)
 V, H, B = 784, 1024, 512
 LR, MOM, L2 = 0.05, 0.9, 1e-5            # examples/rbm_mnist.py:160,166,55
 PEAK_FP32_MFMA = 157.3                    # TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM = 8000.0                         # GB/s (spec), MI355X_MICROARCH.md
 N_BATCHES = 20                            # synthetic batches resident in HBM, cycled
 
 
-def synth(seed, rows):
+def synth(seed, rows, v=V, h=H):
     from boltzmann_machines_amd.utils import philox
-    u = philox.uniform(87654321, 42 + seed, 0, rows * V).reshape(rows, V)
+    u = philox.uniform(87654321, 42 + seed, 0, rows * v).reshape(rows, v)
     X = (u < 0.1307).astype(np.float32)   # MNIST mean intensity; MNIST itself is not available offline
-    W = philox.tf_random_normal((V, H), 0.01, 1337)     # reference W_init (base_rbm.py:277-279)
+    W = philox.tf_random_normal((v, h), 0.01, 1337)     # reference W_init (base_rbm.py:277-279)
     return X, W
 
 
-def _cpu_worker(k, threads, budget_s, q):
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_info():
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def _cpu_worker(kind, v, h, b, k, threads, budget_s, q):
     os.environ['OMP_NUM_THREADS'] = str(threads)
+    os.environ['OPENBLAS_NUM_THREADS'] = str(threads)
     os.environ['OMP_WAIT_POLICY'] = 'passive'
-    from oracle import oracle as orc
-    X, W = synth(0, B)
-    twin = orc.OracleRBM(V, H, l2=L2, sample_v_states=True)
-    twin.p['W'][...] = W
-    twin.set_seed(1337)
-    twin.train_step(X, LR, MOM, k)        # warm-up (thread pool, page faults)
+    X, W = synth(0, b, v, h)
+    if kind == 'oracle':
+        from oracle import oracle as orc
+        twin = orc.OracleRBM(v, h, l2=L2, sample_v_states=True)
+        twin.p['W'][...] = W
+        twin.set_seed(1337)
+        step = lambda: twin.train_step(X, LR, MOM, k)
+    else:
+        from oracle import cpu_blas
+        m = cpu_blas.BlasRBM(W, l2=L2, sample_v=True, sample_h=True, seed=1337)
+        step = lambda: m.train_step(X, LR, MOM, k)
+    step()                                # warm-up (thread pool, page faults)
     n, t0 = 0, time.time()
     while time.time() - t0 < budget_s:
-        twin.train_step(X, LR, MOM, k)
+        step()
         n += 1
     q.put((n, time.time() - t0))
 
 
-def cpu_baseline(k, budget_s=6.0):
-    """The CPU oracle (restatement of the reference maths) timed on this box's host cores, in
-    fresh processes so that the OpenMP team size can be chosen; the best of three team sizes is
-    reported with its thread count."""
+def _cpu_rate(kind, v, h, b, k, threads, budget_s):
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_cpu_worker, args=(kind, v, h, b, k, threads, budget_s, q))
+    p.start()
+    n, dt = q.get()
+    p.join()
+    return n * k / dt, n, dt
+
+
+def cpu_baseline(k, budget_s=2.5):
+    """CPU restatements of the reference maths timed on this box's host cores, each in a fresh process
+    so that the thread-team size can be chosen.  Two restatements: (a) the canonical-order OpenMP C
+    oracle (oracle/bm_oracle.c: the parity checker; sequential fma chains, so it cannot use a blocked
+    sgemm) and (b) NumPy float32 + the BLAS numpy links (sgemm for the five GEMMs, oracle/cpu_blas.py).
+    `value` is the faster of the two at the north-star shape; both, and the cfg1 shape (784x128, batch
+    100: the shape BASELINE.json assigns to the reference's CPU path), are listed in `detail`."""
+    model, ncpu = cpu_info()
+    teams = sorted({min(16, ncpu), min(64, ncpu), ncpu})
+    detail = {}
     best = None
-    for threads in sorted({min(16, ncpu), min(64, ncpu), ncpu}):
-        ctx = mp.get_context('spawn')
-        q = ctx.Queue()
-        p = ctx.Process(target=_cpu_worker, args=(k, threads, budget_s, q))
-        p.start()
-        n, dt = q.get()
-        p.join()
-        rate = n * k / dt
-        if best is None or rate > best[0]:
-            best = (rate, threads, n, dt)
-    rate, threads, n, dt = best
+    for name, (v, h, b) in (('784x1024_b512', (V, H, B)), ('784x128_b100', (784, 128, 100))):
+        for kind in ('oracle', 'blas'):
+            top = None
+            for threads in (teams if name == '784x1024_b512' else teams[:2]):
+                rate, n, dt = _cpu_rate(kind, v, h, b, k, threads, budget_s)
+                if top is None or rate > top[0]:
+                    top = (rate, threads, n, dt)
+            detail['%s_%s' % (name, kind)] = {'gibbs_steps_per_s': round(top[0], 2), 'threads': top[1],
+                                              'updates_timed': top[2], 'seconds': round(top[3], 2)}
+            if name == '784x1024_b512' and (best is None or top[0] > best[0]):
+                best = top + (kind,)
+    rate, threads, n, dt, kind = best
+    try:
+        blas = np.__config__.show(mode='dicts')['Build Dependencies']['blas']
+        blas = '%s %s' % (blas.get('name'), blas.get('version'))
+    except Exception:
+        blas = 'unknown'
     return {'value': round(rate, 3), 'unit': 'Gibbs-steps/s (512-row)', 'cores': threads, 'kind': 'port',
-            'sample': '%d CD-%d updates of the same 784x1024 batch-512 workload in %.1f s, OpenMP C oracle '
-                      '(oracle/bm_oracle.c, restatement of base_rbm.py:415-479; TF1.3 cannot run here), best of '
-                      'OMP team sizes 16/64/%d' % (n, k, dt, ncpu)}
+            'cpu_model': model, 'nproc': ncpu, 'blas': blas, 'restatement': kind,
+            'sample': '%d CD-%d updates of the same 784x1024 batch-512 workload in %.1f s with the %s restatement '
+                      '(best of the OpenMP C oracle and NumPy+BLAS, thread teams %s); TF1.3 / python2 cannot run here'
+                      % (n, k, dt, kind, '/'.join(str(t) for t in teams)),
+            'detail': detail}
 
 
-def pmc_traffic():
-    """HBM-side bytes per CD-1 update from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of this same command, tools/profile_r1.sh + tools/summarize_profile.py); None
-    when no profile has been collected for this tree.  Counters cannot be read live from inside the
-    process, so this is the one roofline field that comes from profiles/."""
+def pmc_traffic(config):
+    """HBM-side bytes per step from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    runs of this same command, tools/profile_r2.sh + tools/summarize_profile.py); None when no profile has
+    been collected for this configuration.  Counters cannot be read live from inside the process, so this
+    is the one roofline field that comes from profiles/."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+    pats = ['r*_%s_pmc.json' % config] + (['r[0-9]_pmc.json'] if config == 'rbm' else [])
+    files = []
+    for p in pats:
+        files += glob.glob(os.path.join(ROOT, 'profiles', p))
+    files = sorted(files)
     if not files:
         return None
     try:
@@ -100,23 +158,350 @@ def pmc_traffic():
         return None
 
 
+# ------------------------------------------------------------------------------------ workloads
+class Workload(object):
+    """One benchmark configuration.  step(i) enqueues one step on the engine stream."""
+    name = ''
+    scaling = 'weak'
+
+    def precondition_steps(self, seconds):
+        return 0
+
+    def reset(self):
+        pass
+
+
+class RbmCD(Workload):
+    name = 'rbm'
+
+    def __init__(self, args, rank, world, local_rank, dist):
+        import torch
+        from boltzmann_machines_amd.engine import RbmEngine, as_device
+        self.k, self.world, self.rank = args.k, world, rank
+        self.X, self.W = synth(rank, B * N_BATCHES)
+        self.eng = eng = RbmEngine(V, H, max_batch=B, l2=L2, sample_v_states=True, sample_h_states=True)
+        eng.set('W', self.W)
+        eng.seed(1337)
+        eng.set_row_offset(rank * B)
+        self.Xd = as_device(self.X)
+        self.use_dp = world > 1 or args.force_dp
+        self.native = args.native_comm
+        if self.use_dp:
+            from boltzmann_machines_amd import parallel
+            dev = torch.device('cuda', local_rank)
+            if args.native_comm:
+                self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+                ar = parallel.native_allreduce_on_engine_stream(eng, self.comm)
+            else:
+                ar = parallel.torch_allreduce_on_engine_stream(eng, dev)
+            self.dp = parallel.DataParallelRBM(eng, rank, world, B, ar)
+
+    def step(self, i):
+        if self.use_dp:
+            self.dp.train_step(self.Xd, LR, MOM, self.k, row=(i % N_BATCHES) * B)   # grad_step -> all-reduce -> apply_step
+        else:
+            self.eng.train_step(self.Xd, B, LR, MOM, self.k, row=(i % N_BATCHES) * B)
+
+    def precondition_steps(self, seconds):
+        return int(seconds * 12500)
+
+    def reset(self):
+        for name in ('vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means'):
+            self.eng.set(name, 0.0)
+        self.eng.set('W', self.W)
+        self.eng.seed(1337)
+
+    def kernel_pass(self, steps, ev_ms):
+        """second, instrumented pass: per-kernel-class durations (HIP events on the engine stream)"""
+        eng, k = self.eng, self.k
+        n_prof = min(steps, 200)
+        eng.profile(True)
+        if not self.use_dp:
+            for i in range(n_prof):
+                self.step(i)
+        else:   # kernels only (no collective) so that other ranks need not participate
+            for i in range(n_prof):
+                eng.grad_step(self.Xd, B, k, row=(i % N_BATCHES) * B)
+                eng.apply_step(B * self.world, LR, MOM)
+        kt = eng.kernel_times()
+        eng.profile(False)
+        # an event pair around a launch also times its two markers.  The unbracketed update was timed
+        # (ev_ms): the markers' cost per launch is (sum of the bracketed launches - that) / launches, taken off
+        # so that the per-kernel figures are comparable with rocprofv3's kernel-trace durations
+        n_launch = sum(n for _, (ms, n) in kt.items() if n)
+        sum_us = 1e3 * sum(ms for _, (ms, n) in kt.items() if n) / n_prof
+        bracket_us = 0.0
+        if not self.use_dp and n_launch:
+            bracket_us = max(0.0, (sum_us - 1e3 * ev_ms / steps) / (n_launch / n_prof))
+        kern = {name: {'avg_us': round(1e3 * ms / n - bracket_us, 3), 'avg_us_with_markers': round(1e3 * ms / n, 3),
+                       'launches_per_step': n // n_prof}
+                for name, (ms, n) in kt.items() if n}
+        kern['event_pair_overhead_us'] = round(bracket_us, 3)
+        return kern
+
+    def report(self, args, world, dt, ev_ms):
+        k = self.k
+        F = 2.0 * B * V * H
+        flops = (2 * k + 3) * F
+        kern = self.kernel_pass(args.steps, ev_ms)
+        up_us = kern.get('act_up', {}).get('avg_us')
+        return {
+            'metric': 'Gibbs-steps/sec (CD-k, 784x1024 RBM, batch 512)',
+            'value': round(world * k * args.steps / dt, 2),
+            'unit': 'Gibbs-steps/s (512-row block sweeps h->v->h incl. CD-%d update)' % k,
+            'config': {'workload': 'BernoulliRBM 784x1024 CD-%d batch=512 fp32 (BASELINE configs[1])' % k,
+                       'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
+                       'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
+                       'parallelism': 'dp%d' % world, 'dp_path': bool(self.use_dp),
+                       'collective': ('bm_comm (in-library RCCL)' if self.native else 'torch.distributed nccl') if self.use_dp else None},
+            'flops_per_step': flops,
+            'roofline_extra': {
+                'traffic': pmc_traffic('rbm') if k == 1 else None,
+                'scope': 'whole CD-%d update = (2k+3)*2*B*V*H = %.3f GFLOP per launch sequence, '
+                         'HIP events on the engine stream over the timed region' % (k, flops / 1e9),
+                'dominant_kernel': 'act_kernel (propagation GEMM + sigmoid + Philox Bernoulli, 3 of the 4 launches)',
+                'dominant_kernel_tflops': round(F / (up_us * 1e-6) / 1e12, 3) if up_us else None,
+                'kernels': kern},
+        }
+
+
+class RbmGibbs(Workload):
+    """pure sampling sweep, SURVEY §8d(ii): bm_rbm_gibbs (base_rbm.py:367-413), no parameter update"""
+    name = 'gibbs'
+
+    def __init__(self, args, rank, world, local_rank, dist):
+        from boltzmann_machines_amd._ffi import DeviceArray
+        from boltzmann_machines_amd.engine import RbmEngine
+        from boltzmann_machines_amd.utils import philox
+        self.k = args.k if args.k > 1 else 10          # sweeps per call
+        _, W = synth(rank, 4)
+        self.eng = eng = RbmEngine(V, H, max_batch=B, sample_v_states=True, sample_h_states=True)
+        eng.set('W', W)
+        eng.seed(1337)
+        eng.set_row_offset(rank * B)
+        h0 = (philox.uniform(87654321, 7 + rank, 0, B * H) < 0.5).astype(np.float32).reshape(B, H)
+        self.Hd = DeviceArray.from_numpy(h0)
+        self.Vd = DeviceArray((B, V))
+
+    def step(self, i):
+        self.eng.gibbs(self.Hd, self.Vd, B, self.k)
+
+    def precondition_steps(self, seconds):
+        return int(seconds * 30000 / self.k)
+
+    def report(self, args, world, dt, ev_ms):
+        k = self.k
+        F = 2.0 * B * V * H
+        flops = k * 2 * F
+        # algorithmic bytes of one block sweep (SURVEY §8d): W read twice + states written and read once each way
+        bytes_sweep = 2 * 4.0 * V * H + 2 * 4.0 * B * (V + H)
+        gbps = k * bytes_sweep / (ev_ms / args.steps * 1e-3) / 1e9
+        return {
+            'metric': 'Gibbs-steps/sec (pure block-Gibbs sampling sweep, 784x1024 RBM, batch 512)',
+            'value': round(world * k * args.steps / dt, 2),
+            'unit': 'Gibbs-steps/s (512-row block sweeps h->v->h, sampling both ways, no update)',
+            'config': {'workload': 'BernoulliRBM 784x1024 sampling sweep batch=512 fp32 (SURVEY 8d-ii, bm_rbm_gibbs)',
+                       'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'sweeps_per_call': k,
+                       'parallelism': 'replicas%d' % world},
+            'flops_per_step': flops,
+            'roofline_extra': {
+                'scope': '%d sweeps per call, 2*2*B*V*H = %.3f GFLOP per sweep; the sweep is MFMA-bound (the 6.4 MB of W '
+                         'and the 3.7 MB of states are L2 / Infinity-Cache resident), the HBM figure is the secondary '
+                         'number north_star asks for' % (k, 2 * F / 1e9),
+                'hbm': {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': PEAK_HBM, 'unit': 'GB/s',
+                        'frac': round(gbps / PEAK_HBM, 4),
+                        'algorithmic_bytes_per_sweep': bytes_sweep, 'traffic': pmc_traffic('gibbs')}},
+        }
+
+
+class _DbmBase(Workload):
+    def _dp_setup(self, args, rank, world, dist):
+        self.comm = None
+        if world > 1 or args.force_dp:
+            from boltzmann_machines_amd import parallel
+            self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+            self.dp = parallel.DataParallelDBM(self.eng, rank, world,
+                                               parallel.native_allreduce_on_engine_stream(self.eng, self.comm), comm=self.comm)
+
+
+class Grbm(_DbmBase):
+    """BASELINE configs[2]: Gaussian-Bernoulli RBM 3072x5000, PCD-5, batch 256 (examples/dbm_cifar_naive.py:83-98;
+    the reference RBM class has no PCD: realised as the 1-layer DBM path, README.md:96)"""
+    name = 'grbm'
+    GV, GH, GN, GK = 3072, 5000, 256, 5
+
+    def __init__(self, args, rank, world, local_rank, dist):
+        from boltzmann_machines_amd.engine import DbmEngine, as_device
+        from boltzmann_machines_amd.utils import philox
+        V_, H_, N_ = self.GV, self.GH, self.GN
+        self.world = world
+        self.eng = eng = DbmEngine(V_, [H_], v_unit=1, sample_v_states=True, n_particles=N_, batch_size=N_,
+                                   max_mf_updates=1, l2=0.01)
+        eng.set('W', philox.tf_random_normal((V_, H_), 0.0008, 1337))
+        eng.set('v', philox.normal(1, 1 + rank, 0, N_ * V_).reshape(N_, V_))
+        X = philox.normal(1, 100 + rank, 0, 4 * N_ * V_).reshape(4 * N_, V_).astype(np.float32)
+        self.Xd = as_device(X)
+        eng.seed(1)
+        self.nmf = []
+        self._dp_setup(args, rank, world, dist)
+
+    def step(self, i):
+        row = (i % 4) * self.GN
+        if self.comm is not None:
+            self.nmf.append(self.dp.train_step(self.Xd, 5e-4, 0.9, self.GK, row=row))
+        else:
+            self.nmf.append(self.eng.train_step(self.Xd, 5e-4, 0.9, self.GK, row=row)[0])
+
+    def precondition_steps(self, seconds):
+        return int(seconds * 500)
+
+    def reset(self):
+        self.nmf = []
+
+    def report(self, args, world, dt, ev_ms):
+        F = 2.0 * self.GN * self.GV * self.GH
+        T = float(np.mean(self.nmf[-args.steps:])) if self.nmf else 0.0
+        flops = (2 * self.GK + 3) * F          # SURVEY §8d: prop-up of data 1F, 5 sweeps 10F, 2 outer products 2F
+        return {
+            'metric': 'Gibbs-steps/sec (PCD-5, 3072x5000 Gaussian-Bernoulli RBM, batch 256)',
+            'value': round(world * self.GK * args.steps / dt, 2),
+            'unit': 'Gibbs-steps/s (256-particle block sweeps incl. the PCD-5 update)',
+            'config': {'workload': 'Gaussian-Bernoulli RBM 3072x5000 PCD-5 batch=256 fp32 (BASELINE configs[2])',
+                       'n_visible': self.GV, 'n_hidden': self.GH, 'batch_per_gpu': self.GN, 'n_particles_per_gpu': self.GN,
+                       'n_gibbs_steps': self.GK, 'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world},
+            'flops_per_step': flops,
+            'roofline_extra': {'scope': 'whole PCD-5 update = (2*5+3)*2*B*V*H = %.1f GFLOP (SURVEY 8d)' % (flops / 1e9),
+                               'traffic': pmc_traffic('grbm')},
+        }
+
+
+class Dbm(_DbmBase):
+    """BASELINE configs[3]: 2-layer DBM 784-512-1024, mean-field + PCD-5 (examples/dbm_mnist.py:250-284)"""
+    name = 'dbm'
+    DV, H1, H2, DN, DK = 784, 512, 1024, 512, 5
+
+    def __init__(self, args, rank, world, local_rank, dist):
+        from boltzmann_machines_amd.engine import DbmEngine, as_device
+        from boltzmann_machines_amd.utils import philox
+        V_, N_ = self.DV, self.DN
+        self.world = world
+        self.eng = eng = DbmEngine(V_, [self.H1, self.H2], n_particles=N_, batch_size=N_, max_mf_updates=50, mf_tol=1e-7,
+                                   l2=1e-7, max_norm=6., sparsity_target=[0.2, 0.1], sparsity_cost=[1e-4, 5e-5])
+        eng.set('W', philox.tf_random_normal((V_, self.H1), 0.01, 1337))
+        eng.set('W_1', philox.tf_random_normal((self.H1, self.H2), 0.01, 1111))
+        eng.set('v', (philox.uniform(1, 1 + rank, 0, N_ * V_) < 0.13).reshape(N_, V_))
+        X = (philox.uniform(1, 200 + rank, 0, 4 * N_ * V_) < 0.13).astype(np.float32).reshape(4 * N_, V_)
+        self.Xd = as_device(X)
+        eng.seed(1)
+        self.nmf = []
+        self._dp_setup(args, rank, world, dist)
+
+    def step(self, i):
+        row = (i % 4) * self.DN
+        if self.comm is not None:
+            self.nmf.append(self.dp.train_step(self.Xd, 2e-3, 0.9, self.DK, row=row))
+        else:
+            self.nmf.append(self.eng.train_step(self.Xd, 2e-3, 0.9, self.DK, row=row)[0])
+
+    def precondition_steps(self, seconds):
+        return int(seconds * 700)
+
+    def reset(self):
+        self.nmf = []
+
+    def report(self, args, world, dt, ev_ms):
+        V_, H1, H2, N_, k = self.DV, self.H1, self.H2, self.DN, self.DK
+        T = float(np.mean(self.nmf[-args.steps:])) if self.nmf else 0.0
+        # SURVEY §8d (X.W0 hoisted out of the sweeps): MF + PCD + gradients (msre is not fetched here)
+        flops = 2.0 * N_ * V_ * H1 + T * (4.0 * N_ * H1 * H2) + k * N_ * (4.0 * V_ * H1 + 4.0 * H1 * H2) \
+            + 2.0 * (N_ + N_) * (V_ * H1 + H1 * H2)
+        return {
+            'metric': 'DBM updates/sec (784-512-1024, mean-field + PCD-5, 512 rows + 512 particles per GPU)',
+            'value': round(world * args.steps / dt, 2),
+            'unit': 'updates/s x GPUs (each update = 512 rows + 512 particles per GPU; weak scaling)',
+            'config': {'workload': '2-layer DBM 784-512-1024 mean-field (<=50 sweeps, tol 1e-7) + PCD-5 fp32 (BASELINE configs[3])',
+                       'layers': [V_, H1, H2], 'batch_per_gpu': N_, 'particles_per_gpu': N_, 'n_gibbs_steps': k,
+                       'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world,
+                       'collective': 'bm_comm (in-library RCCL): all-reduce(max) of the mean-field residual per sweep + '
+                                     'one all-reduce(sum) of the fused gradient buffer' if self.comm is not None else None},
+            'flops_per_step': flops,
+            'roofline_extra': {'scope': 'whole update, SURVEY 8d formula with T = %.1f executed mean-field sweeps = %.2f GFLOP'
+                                        % (T, flops / 1e9), 'traffic': pmc_traffic('dbm')},
+        }
+
+
+class Ais(_DbmBase):
+    """BASELINE configs[4]: AIS log Z, 20 000 chains x 1000 betas on the 784-512-1024 DBM (dbm.py:650-736)"""
+    name = 'ais'
+    scaling = 'strong'
+    DV, H1, H2 = 784, 512, 1024
+
+    def __init__(self, args, rank, world, local_rank, dist):
+        from boltzmann_machines_amd import parallel
+        from boltzmann_machines_amd.engine import DbmEngine
+        from boltzmann_machines_amd.utils import philox
+        self.R, self.nb, self.k = args.ais_runs, args.ais_betas, max(args.k, 1)
+        self.rank, self.world = rank, world
+        self.eng = eng = DbmEngine(self.DV, [self.H1, self.H2], n_particles=8, batch_size=8)
+        eng.set('W', philox.tf_random_normal((self.DV, self.H1), 0.01, 1337))
+        eng.set('W_1', philox.tf_random_normal((self.H1, self.H2), 0.01, 1111))
+        self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world) if (world > 1 or args.force_dp) else None
+        self.start, self.stop = parallel.shard(self.R, rank, world)
+        self.last = None
+
+    def step(self, i):
+        if self.comm is not None:
+            self.last = self.eng.ais_sharded(self.comm, self.nb, self.R, self.k, 2222)    # shard + ONE all-gather
+        else:
+            self.last = self.eng.ais(self.nb, self.R, self.k, 2222)
+
+    def report(self, args, world, dt, ev_ms):
+        from boltzmann_machines_amd.utils import log_mean_exp
+        flops = self.k * 4.0 * self.R * self.H1 * (self.DV + self.H2) * self.nb / world     # per GPU and run (SURVEY 8d, deduplicated)
+        return {
+            'metric': 'AIS beta-steps/sec (20000 chains, 784-512-1024 DBM)',
+            'value': round(self.nb * args.steps / dt, 2),
+            'unit': 'beta-steps/s over all %d chains (one step of this bench = one full %d-beta run)' % (self.R, self.nb),
+            'config': {'workload': 'AIS log Z, %d chains x %d betas, k=%d, DBM 784-512-1024 fp32 (BASELINE configs[4])'
+                                   % (self.R, self.nb, self.k),
+                       'chains_per_gpu': self.stop - self.start, 'parallelism': 'chains/%d' % world,
+                       'collective': 'bm_comm all-gather of the per-chain log-weights (once per run)' if self.comm else None,
+                       'log_Z_estimate': float(log_mean_exp(self.last.astype(np.float64))) if self.last is not None else None},
+            'flops_per_step': flops,
+            'roofline_extra': {'scope': 'one run = n_betas * 4*M*H1*(V+H2) = %.2f TFLOP per GPU (SURVEY 8d, shared pre-activations)'
+                                        % (flops / 1e12), 'traffic': pmc_traffic('ais')},
+        }
+
+
+WORKLOADS = {w.name: w for w in (RbmCD, RbmGibbs, Grbm, Dbm, Ais)}
+DEFAULTS = {'rbm': (2000, 100), 'gibbs': (300, 30), 'grbm': (30, 5), 'dbm': (40, 5), 'ais': (2, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--k', type=int, default=1, help='n_gibbs_steps of CD-k')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', choices=sorted(WORKLOADS), default='rbm')
+    ap.add_argument('--k', type=int, default=1, help='n_gibbs_steps of CD-k (rbm), sweeps per call (gibbs), AIS transitions per beta')
+    ap.add_argument('--ais-runs', type=int, default=20000)
+    ap.add_argument('--ais-betas', type=int, default=1000)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--precondition-s', type=float, default=0.4,
-                    help='seconds of untimed updates BEFORE the W warm-up steps (launch tuning, instruction caches, '
-                         'clock ramp of an idle GPU); parameters and RNG are reset afterwards, so the warm-up and the '
-                         'timed steps start from the documented initial state.  0 disables')
+                    help='seconds (approximate: a fixed step count) of untimed steps BEFORE the W warm-up steps (launch '
+                         'tuning, instruction caches, clock ramp of an idle GPU); parameters and RNG are reset afterwards, '
+                         'so the warm-up and the timed steps start from the documented initial state.  0 disables')
     ap.add_argument('--native-comm', action='store_true',
-                    help='data-parallel all-reduce through the library\'s own RCCL communicator (bm_comm_*) instead of '
-                         'torch.distributed; torch (gloo) then only carries the 128-byte id and the timing barrier')
+                    help='rbm: data-parallel all-reduce through the library\'s own RCCL communicator (bm_comm_*) instead of '
+                         'torch.distributed; torch (gloo) then only carries the 128-byte id and the timing barrier '
+                         '(dbm / grbm / ais always use bm_comm)')
     ap.add_argument('--force-dp', action='store_true',
                     help='take the data-parallel code path (grad_step -> all-reduce -> apply_step) even at N=1')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = DEFAULTS[args.config][0]
+    if args.warmup is None:
+        args.warmup = DEFAULTS[args.config][1]
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -127,45 +512,25 @@ def main():
 
     import torch
     from boltzmann_machines_amd import _ffi
-    from boltzmann_machines_amd.engine import RbmEngine, as_device
     lib = _ffi.load()
     if lib.bm_device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
     torch.cuda.set_device(local_rank)
     _ffi.check(lib.bm_set_device(local_rank))
     dist = None
-    use_dp = world > 1 or args.force_dp
-    if use_dp:
+    native = args.native_comm or args.config not in ('rbm', 'gibbs')
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        if args.native_comm:
+        if native:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    args.native_comm = native
 
-    k = args.k
-    X, W = synth(rank, B * N_BATCHES)
-    eng = RbmEngine(V, H, max_batch=B, l2=L2, sample_v_states=True, sample_h_states=True)
-    eng.set('W', W)
-    eng.seed(1337)
-    eng.set_row_offset(rank * B)
-    Xd = as_device(X)
-
-    if use_dp:
-        from boltzmann_machines_amd import parallel
-        dev = torch.device('cuda', local_rank)
-        if args.native_comm:
-            comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
-            dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.native_allreduce_on_engine_stream(eng, comm))
-        else:
-            dp = parallel.DataParallelRBM(eng, rank, world, B, parallel.torch_allreduce_on_engine_stream(eng, dev))
-
-        def step(i):
-            dp.train_step(Xd, LR, MOM, k, row=(i % N_BATCHES) * B)     # grad_step -> RCCL all-reduce -> apply_step
-    else:
-        def step(i):
-            eng.train_step(Xd, B, LR, MOM, k, row=(i % N_BATCHES) * B)
+    wl = WORKLOADS[args.config](args, rank, world, local_rank, dist)
+    eng = wl.eng
 
     def barrier():
         eng.sync()
@@ -176,91 +541,48 @@ def main():
 
     # Precondition the device: a GPU box that has been idle needs a few hundred ms of work before its clocks and
     # caches are in the state a training job runs in (a 25-step run from cold measured 74 us/update against 66.7
-    # steady).  Untimed; the model is then put back to its initial state.
+    # steady).  A FIXED number of steps (every rank of a data-parallel run must issue the same number of
+    # collectives); untimed; the model is then put back to its initial state.
     if args.precondition_s > 0:
-        # a FIXED number of updates (~ precondition_s at the steady 1-GPU rate): every rank of a data-parallel run
-        # must issue the same number of collectives
-        for i in range(int(args.precondition_s * 12500)):
-            step(i)
+        for i in range(wl.precondition_steps(args.precondition_s)):
+            wl.step(i)
         eng.sync()
-        for name in ('vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means'):
-            eng.set(name, 0.0)
-        eng.set('W', W)
-        eng.seed(1337)
+        wl.reset()
     for i in range(args.warmup):
-        step(i)
+        wl.step(i)
     barrier()
     t0 = time.perf_counter()
     eng.timer_start()
     for i in range(args.steps):
-        step(i)
+        wl.step(i)
     ev_ms = eng.timer_stop()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if args.native_comm else 'cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if native else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # second, instrumented pass: per-kernel-class durations (HIP events on the engine stream)
-    kern = {}
-    if rank == 0:
-        n_prof = min(args.steps, 200)
-        eng.profile(True)
-        if not use_dp:
-            for i in range(n_prof):
-                step(i)
-        else:   # kernels only (no collective) so that other ranks need not participate
-            for i in range(n_prof):
-                eng.grad_step(Xd, B, k, row=(i % N_BATCHES) * B)
-                eng.apply_step(B * world, LR, MOM)
-        kt = eng.kernel_times()
-        eng.profile(False)
-        # an event pair around a launch also times its two markers.  The unbracketed update was timed above
-        # (ev_ms): the markers' cost per launch is (sum of the bracketed launches - that) / launches, taken off
-        # so that the per-kernel figures are comparable with rocprofv3's kernel-trace durations
-        n_launch = sum(n for _, (ms, n) in kt.items() if n)
-        sum_us = 1e3 * sum(ms for _, (ms, n) in kt.items() if n) / n_prof
-        bracket_us = 0.0
-        if not use_dp and n_launch:
-            bracket_us = max(0.0, (sum_us - 1e3 * ev_ms / args.steps) / (n_launch / n_prof))
-        kern = {name: {'avg_us': round(1e3 * ms / n - bracket_us, 3), 'avg_us_with_markers': round(1e3 * ms / n, 3),
-                       'launches_per_step': n // n_prof}
-                for name, (ms, n) in kt.items() if n}
-        kern['event_pair_overhead_us'] = round(bracket_us, 3)
+    rep = wl.report(args, world, dt, ev_ms) if rank == 0 else None
     barrier()
 
     if rank == 0:
-        F = 2.0 * B * V * H
-        flops_update = (2 * k + 3) * F
-        ms_step = 1e3 * dt / args.steps
-        achieved = flops_update / (ev_ms / args.steps * 1e-3) / 1e12
-        # dominant kernel = prop-up act_kernel (k+1 launches per update): its own roofline point
-        up_us = kern.get('act_up', {}).get('avg_us')
+        flops = rep.pop('flops_per_step')
+        extra = rep.pop('roofline_extra')
+        achieved = flops / (ev_ms / args.steps * 1e-3) / 1e12
         out = {
-            'metric': 'Gibbs-steps/sec (CD-k, 784x1024 RBM, batch 512)',
-            'value': round(world * k * args.steps / dt, 2),
-            'unit': 'Gibbs-steps/s (512-row block sweeps h->v->h incl. CD-%d update)' % k,
+            'metric': rep['metric'], 'value': rep['value'], 'unit': rep['unit'],
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_step, 5), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(1e3 * dt / args.steps, 5), 'higher_is_better': True, 'scaling': wl.scaling,
             'precondition_s': args.precondition_s,
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BernoulliRBM 784x1024 CD-%d batch=512 fp32 (BASELINE configs[1])' % k,
-                       'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
-                       'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
-                       'parallelism': 'dp%d' % world, 'dp_path': bool(use_dp),
-                       'collective': ('bm_comm (in-library RCCL)' if args.native_comm else 'torch.distributed nccl') if use_dp else None},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4),
-                         'traffic': pmc_traffic() if k == 1 else None,
-                         'scope': 'whole CD-%d update = (2k+3)*2*B*V*H = %.3f GFLOP per launch sequence, '
-                                  'HIP events on the engine stream over the timed region' % (k, flops_update / 1e9),
-                         'dominant_kernel': 'act_kernel (propagation GEMM + sigmoid + Philox Bernoulli, 3 of the 4 launches)',
-                         'dominant_kernel_tflops': round(F / (up_us * 1e-6) / 1e12, 3) if up_us else None,
-                         'kernels': kern},
+            'config': rep['config'],
+            'roofline': dict({'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
+                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4), 'traffic': extra.pop('traffic', None)},
+                             **extra),
         }
-        if not args.no_cpu and world == 1:
-            out['cpu_baseline'] = cpu_baseline(k)
+        if not args.no_cpu and world == 1 and args.config == 'rbm':
+            out['cpu_baseline'] = cpu_baseline(args.k)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

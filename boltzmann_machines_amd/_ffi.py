@@ -56,6 +56,8 @@ SIGNATURES = {
     'bm_comm_destroy': [_vp],
     'bm_comm_allreduce_sum': [_vp, _vp, _sz, _vp],
     'bm_comm_allgather': [_vp, _vp, _vp, _sz, _vp],
+    'bm_comm_allreduce_max': [_vp, _vp, _sz, _vp],
+    'bm_comm_rank': [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     'bm_rbm_allreduce_grads': [_vp, _vp],
     'bm_dbm_allreduce_grads': [_vp, _vp],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
@@ -105,6 +107,8 @@ SIGNATURES = {
     'bm_dbm_grad_step': [_vp, _vp, _i32, _ip],
     'bm_dbm_apply_step': [_vp, _i32, _i32, _f32, _f32],
     'bm_dbm_set_mf_allreduce': [_vp, _vp, _vp],
+    'bm_dbm_set_comm': [_vp, _vp],
+    'bm_dbm_ais_sharded': [_vp, _vp, _i32, _i32, _i32, _u64, _vp],
     'bm_dbm_stream': [_vp, C.POINTER(_vp)],
     'bm_dbm_mean_field': [_vp, _vp, _vp, _ip],
     'bm_dbm_reconstruct': [_vp, _vp, _vp],

@@ -190,6 +190,19 @@ class EngineModel(BaseModel, DtypeMixin):
                 raise NotImplementedError("%s has no device path for dtype='%s': float64 runs for Bernoulli/Gaussian "
                                           "RBMs (bm_rbm64_*), everything else computes in float32"
                                           % (self.__class__.__name__, self.dtype))
+            # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher): bind this process to its GPU
+            # and join the job's communicator before the handle is created (boltzmann_machines_amd/parallel.py)
+            from . import parallel
+            self._rank, local_rank, self._world = parallel.dist_env()
+            self._comm = None
+            if self._world > 1:
+                from . import _ffi
+                try:
+                    _ffi.check(_ffi.load().bm_set_device(local_rank))
+                    self._comm = parallel.default_comm()
+                except _ffi.Bm355Error:
+                    if self._needs_device():
+                        raise
             self._make_engine()
             if self._pending_vars is not None:
                 self._upload_variables(self._pending_vars)
@@ -203,6 +216,8 @@ class EngineModel(BaseModel, DtypeMixin):
 
     # ---- persistence (reference tf_model.py:117-162) ----------------------------
     def _save_model(self, global_step=None):
+        if getattr(self, '_world', 1) > 1 and getattr(self, '_rank', 0) != 0:
+            return                      # data-parallel replicas are identical: rank 0 writes the checkpoint
         for dirpath in (self._train_summary_dirpath, self._val_summary_dirpath):
             if not os.path.exists(dirpath):
                 os.makedirs(dirpath)
@@ -240,7 +255,7 @@ class EngineModel(BaseModel, DtypeMixin):
     # :584-589, dbm.py:636-639): one JSON line per record under logs/train or logs/val ----------
     def _log_scalars(self, kind, step, values):
         values = {k: float(v) for k, v in values.items() if v is not None}
-        if not values:
+        if not values or (getattr(self, '_world', 1) > 1 and getattr(self, '_rank', 0) != 0):
             return
         d = self._train_summary_dirpath if kind == 'train' else self._val_summary_dirpath
         if not os.path.exists(d):

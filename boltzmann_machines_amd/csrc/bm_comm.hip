@@ -105,6 +105,20 @@ int bm_comm_allreduce_sum(bm_comm *c, float *buf_dev, size_t count, void *stream
     return 0;
 }
 
+// in-place all-reduce(max) (the mean-field residual of a data-parallel DBM: one float per sweep)
+int bm_comm_allreduce_max(bm_comm *c, float *buf_dev, size_t count, void *stream) {
+    BM_CHECK(c && c->comm && buf_dev, "null argument");
+    BM_NCCL(bmcomm::g_api.AllReduce(buf_dev, buf_dev, count, bmcomm::kFloat32, bmcomm::kMax, c->comm, (hipStream_t)stream));
+    return 0;
+}
+
+int bm_comm_rank(bm_comm *c, int32_t *out_rank, int32_t *out_nranks) {
+    BM_CHECK(c, "null argument");
+    if (out_rank) *out_rank = c->rank;
+    if (out_nranks) *out_nranks = c->nranks;
+    return 0;
+}
+
 // all-gather of `count` floats per rank (AIS log-weights, equal chain counts per rank)
 int bm_comm_allgather(bm_comm *c, const float *send_dev, float *recv_dev, size_t count, void *stream) {
     BM_CHECK(c && c->comm && send_dev && recv_dev, "null argument");

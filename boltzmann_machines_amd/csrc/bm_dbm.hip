@@ -35,8 +35,10 @@ struct bm_dbm {
     DevBuf grad;                                   // data-parallel payload: [pos_i | neg_i per layer | sums]
     float *sums_p = nullptr;                       // column sums inside `grad`: [V | V | (n_i | n_i) per layer]
     size_t raw_off[MAXL][2];                       // offsets of the raw pos / neg outer products of layer i
-    float (*mf_reduce)(float, void *) = nullptr;   // max over ranks of the mean-field residual (data-parallel)
-    void *mf_ctx = nullptr;
+    float (*mf_reduce)(float, void *) = nullptr;   // max over ranks of the mean-field residual through a HOST callback
+    void *mf_ctx = nullptr;                        // (bm_dbm_set_mf_allreduce: collectives the library does not own)
+    bm_comm *comm = nullptr;                       // bm_dbm_set_comm: the residual is all-reduced (max) ON DEVICE, on the
+                                                   // engine stream, by the library's own RCCL communicator
     DevBuf wnorm[MAXL];
     unsigned *flag = nullptr;                      // mean-field residual cell (= &ctl->maxdiff)
     MfCtl *ctl = nullptr;                          // device-side loop control
@@ -196,8 +198,21 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
             ++step;
         }
     } else {
-        hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, 1,
-                           h->mfblk.p, h->L * BM_MF_SLOTS);
+        // loop control of one sweep: local (one kernel) or global (residual all-reduced over the ranks in stream
+        // order: every rank enqueues the same sequence and latches the same `done`, so no host round trip is
+        // needed and the ranks stay in lockstep)
+        auto ctl_step = [&](int init) -> int {
+            if (!h->comm) {
+                hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, init,
+                                   h->mfblk.p, h->L * BM_MF_SLOTS);
+                return 0;
+            }
+            hipLaunchKernelGGL(mf_resid_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->mfblk.p, h->L * BM_MF_SLOTS);
+            BM_TRY(bm_comm_allreduce_max(h->comm, &h->ctl->resid, 1, (void *)h->stream));
+            hipLaunchKernelGGL(mf_latch_kernel, dim3(1), dim3(64), 0, h->stream, h->ctl, h->cfg.mf_tol, init);
+            return 0;
+        };
+        BM_TRY(ctl_step(1));
         int enq = 0;
         MfCtl host;
         host.done = 0; host.steps = 0;
@@ -208,8 +223,7 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
                 Mat *src = ((enq + s) & 1) ? h->mu_alt : h->mu, *dst = ((enq + s) & 1) ? h->mu : h->mu_alt;
                 gibbs_sweep(h, N, LayerIn{X_dev, h->V}, src, nullptr, dst, false, false, 0, 0, h->flag,
                             hoist ? &h->xw0 : nullptr, &h->ctl->done, h->mfblk.p);
-                hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, 0,
-                                   h->mfblk.p, h->L * BM_MF_SLOTS);
+                BM_TRY(ctl_step(0));
             }
             enq += g;
             BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
@@ -552,6 +566,12 @@ int bm_dbm_metrics(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf, 
     return 0;
 }
 
+int bm_dbm_set_comm(bm_dbm *h, bm_comm *c) {
+    BM_CHECK(h, "null argument");
+    h->comm = c;
+    return 0;
+}
+
 int bm_dbm_set_mf_allreduce(bm_dbm *h, float (*fn)(float, void *), void *ctx) {
     h->mf_reduce = fn; h->mf_ctx = ctx;
     return 0;
@@ -700,11 +720,11 @@ __global__ void ais_score_kernel(double *logw, int J, int ld, const float *pv, i
     logw[j] += s + (double)dbeta * d;
 }
 
-int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0,
-               float *values_host) {
+// the AIS run itself: leaves the per-chain log-weights (without log Z_0) in h->alogw [n_runs] (device, double)
+static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0) {
     BM_CHECK(h->L == 2, "AIS is implemented for 2-layer DBMs only (dbm.py:925)");
     BM_CHECK(h->cfg.v_unit == BM_UNIT_BERNOULLI, "AIS needs Bernoulli visible units (dbm.py:926-927)");
-    BM_CHECK(n_betas >= 2 && n_runs >= 1 && k >= 1 && values_host, "bad AIS arguments");
+    BM_CHECK(n_betas >= 2 && n_runs >= 1 && k >= 1, "bad AIS arguments");
     BM_TRY(ensure_ais(h, n_runs));
     const int R = n_runs, V = h->V, H1 = h->n[1], H2 = h->n[2];
     const float db = 1.0f / (float)n_betas;                               // delta_beta (dbm.py:929)
@@ -767,12 +787,70 @@ int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t s
         beta = beta + db;
     }
     BM_TRY(visit(true, prev, 1.0f, false, 0.f, step++));                     // +log p_1(x_M) - log p_prev(x_M)  (:728)
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+static double ais_log_Z0(const bm_dbm *h) {                                  // (:731-734)
+    return (double)(h->V + h->n[1] + h->n[2]) * (double)logf(2.0f);
+}
+
+int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0,
+               float *values_host) {
+    BM_CHECK(values_host, "null output");
+    BM_TRY(ais_core(h, n_betas, n_runs, k, seed, chain0));
+    const int R = n_runs;
     std::vector<double> w(R);
     BM_HIP(hipMemcpyAsync(w.data(), h->alogw, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    const double logZ0 = (double)(V + H1 + H2) * (double)logf(2.0f);         // (:731-734)
+    const double logZ0 = ais_log_Z0(h);
     for (int r = 0; r < R; ++r) values_host[r] = (float)(w[r] + logZ0);
-    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// values[r] = (float)(logw[r] + log Z_0) for r < n, 0 in the padding up to npad
+__global__ void ais_finish_kernel(const double *logw, float *out, int n, int npad, double logZ0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < npad) out[r] = (r < n) ? (float)(logw[r] + logZ0) : 0.f;
+}
+
+// Chain-sharded AIS: this rank runs chains [start, stop) of n_runs_total (contiguous slices, the
+// remainder spread over the first ranks), no communication during the sweep, then ONE all-gather of the
+// per-chain values over the library's communicator; every rank returns all n_runs_total values.
+int bm_dbm_ais_sharded(bm_dbm *h, bm_comm *c, int32_t n_betas, int32_t n_runs_total, int32_t k, uint64_t seed,
+                       float *values_host) {
+    BM_CHECK(h && c && values_host, "null argument");
+    int32_t rank = 0, world = 1;
+    BM_TRY(bm_comm_rank(c, &rank, &world));
+    BM_CHECK(n_runs_total >= 1, "bad AIS arguments");
+    auto shard = [&](int r, int &a, int &b) {
+        const int q = n_runs_total / world, rem = n_runs_total % world;
+        a = r * q + (r < rem ? r : rem);
+        b = a + q + (r < rem ? 1 : 0);
+    };
+    int a = 0, b = 0;
+    shard(rank, a, b);
+    const int n = b - a, npad = (n_runs_total + world - 1) / world;
+    float *send = nullptr, *recv = nullptr;
+    BM_HIP(hipMalloc((void **)&send, (size_t)npad * sizeof(float)));
+    BM_HIP(hipMalloc((void **)&recv, (size_t)npad * world * sizeof(float)));
+    int rc = 0;
+    if (n > 0) rc = ais_core(h, n_betas, n, k, seed, a);
+    if (!rc) {
+        hipLaunchKernelGGL(ais_finish_kernel, dim3((npad + 255) / 256), dim3(256), 0, h->stream, (const double *)h->alogw, send,
+                           n, npad, ais_log_Z0(h));
+        rc = bm_comm_allgather(c, send, recv, (size_t)npad, (void *)h->stream);
+    }
+    std::vector<float> all((size_t)npad * world);
+    if (!rc && hipMemcpyAsync(all.data(), recv, all.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = 1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = 1;
+    (void)hipFree(send); (void)hipFree(recv);
+    if (rc) { if (rc == 1) bm::set_error("bm_dbm_ais_sharded: device copy / synchronisation failed"); return rc; }
+    for (int r = 0; r < world; ++r) {
+        int ra, rb;
+        shard(r, ra, rb);
+        memcpy(values_host + ra, all.data() + (size_t)r * npad, (size_t)(rb - ra) * sizeof(float));
+    }
     return 0;
 }
 

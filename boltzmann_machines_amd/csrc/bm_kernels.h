@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
 // device-side mean-field loop control (dbm.py:449-452): after each sweep, advance the counter
 // and latch `done` when the residual no longer exceeds the tolerance; `init` evaluates the
 // step-0 condition from the residual between the persistent mu and the init values.
-struct MfCtl { unsigned maxdiff; int done; int steps; };
+struct MfCtl { unsigned maxdiff; int done; int steps; float resid; };
 // blk [nblk]: per-workgroup residuals of the sweep's act_kernel launches (read, then zeroed for the next sweep)
 __global__ __launch_bounds__(256) void mf_ctl_kernel(MfCtl *c, float tol, int init, float *blk, int nblk) {
     __shared__ float s_m[4];
@@ -1253,6 +1253,34 @@ __global__ __launch_bounds__(256) void mf_ctl_kernel(MfCtl *c, float tol, int in
         c->done = !(resid > tol);
     }
     c->maxdiff = 0u;
+}
+
+// Data-parallel form of mf_ctl_kernel, split around the all-reduce(max) of the residual over the ranks
+// (the loop condition of dbm.py:449-452 is over ALL rows of the global minibatch):
+//   mf_resid_kernel: local residual of the sweep -> c->resid (slots and the atomic cell are reset)
+//   [ncclAllReduce(max) of c->resid on the same stream]
+//   mf_latch_kernel: the counter / `done` update of mf_ctl_kernel from the reduced value
+__global__ __launch_bounds__(256) void mf_resid_kernel(MfCtl *c, float *blk, int nblk) {
+    __shared__ float s_m[4];
+    float m = 0.f;
+    for (int e = threadIdx.x; e < nblk; e += 256) { m = fmaxf(m, blk[e]); blk[e] = 0.f; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    c->resid = fmaxf(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])), __uint_as_float(c->maxdiff));
+    c->maxdiff = 0u;
+}
+__global__ void mf_latch_kernel(MfCtl *c, float tol, int init) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (init) {
+        c->steps = 0;
+        c->done = !(c->resid > tol);
+    } else if (!c->done) {
+        c->steps += 1;
+        c->done = !(c->resid > tol);
+    }
 }
 
 // ||A - B||_inf over a [rows][cols] window -> atomicMax on float bits (mean-field cond, dbm.py:449-452)

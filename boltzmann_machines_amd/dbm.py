@@ -190,6 +190,16 @@ class DBM(EngineModel):
                                  sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping)
         if self._pending_vars is None:          # fresh model (load_model uploads its checkpoint instead)
             self._upload_variables(self._initial_variables())
+        # Multi-GPU job (one process per GPU): rank r owns rows [r*batch_size, ...) of every global
+        # minibatch of world*batch_size rows and particles [r*n_particles, ...) of world*n_particles; one
+        # all-reduce(sum) of the fused gradient buffer per update, the mean-field residual all-reduced (max) on
+        # the device per sweep, replicas bit-identical.  Every rank must make the same public calls.
+        self._dp = None
+        if getattr(self, '_comm', None) is not None:
+            from . import parallel
+            self._dp = parallel.DataParallelDBM(self._engine, self._rank, self._world,
+                                                parallel.native_allreduce_on_engine_stream(self._engine, self._comm),
+                                                comm=self._comm)
 
     def _upload_variables(self, d):
         for name, _ in self._var_names():
@@ -217,15 +227,26 @@ class DBM(EngineModel):
         k = n_gibbs_steps if n_gibbs_steps is not None else pick(self.n_gibbs_steps)
         return float(pick(self.learning_rate)), float(pick(self.momentum)), int(k)
 
-    def _check_batches(self, X):
-        if len(X) % self.batch_size != 0:
+    def _check_batches(self, X, sharded=False):
+        unit = self.batch_size * (getattr(self, '_world', 1) if sharded else 1)
+        if len(X) % unit != 0:
             raise ValueError('DBM variational parameters have a fixed [batch_size, n] shape (dbm.py:345-348): '
-                             '{0} rows are not a multiple of batch_size={1}'.format(len(X), self.batch_size))
+                             '{0} rows are not a multiple of batch_size{2}={1}'
+                             .format(len(X), unit, ' x world_size' if unit != self.batch_size else ''))
 
     # ---- training loop (reference dbm.py:793-857) -------------------------------------------
     def _train_epoch(self, Xd, N):
         lr, mom, k = self._feed()
         msres, nmfs = [], []
+        if self._dp is not None:
+            # data-parallel: the global minibatch is world * batch_size rows, this rank's slice starts at
+            # rank * batch_size inside it (the msre summary is not fetched: it would be a rank-local number)
+            for start in range(0, N, self.batch_size * self._world):
+                self.iter_ += 1
+                nmf = self._dp.train_step(Xd, lr, mom, k, row=start + self._rank * self.batch_size)
+                if self.iter_ % self.train_metrics_every_iter == 0:
+                    nmfs.append(nmf)
+            return None, (np.mean(nmfs) if nmfs else None)
         for start in range(0, N, self.batch_size):
             self.iter_ += 1
             if self.iter_ % self.train_metrics_every_iter == 0:
@@ -242,7 +263,10 @@ class DBM(EngineModel):
         # particles by n_gibbs_steps, exactly like the reference's validation pass does.
         msres, nmfs = [], []
         _, _, k = self._feed()
-        for start in range(0, len(X_val), self.batch_size):
+        world, rank = getattr(self, '_world', 1), getattr(self, '_rank', 0)
+        # (data-parallel: each rank evaluates its slice of every world*batch_size block; msre is then this
+        # rank's share, n_mf_updates is global because the mean-field loop condition is)
+        for start in range(rank * self.batch_size, len(X_val), self.batch_size * world):
             nmf, msre = self._engine.metrics(Xvd, k, row=start)
             msres.append(msre)
             nmfs.append(nmf)
@@ -250,12 +274,12 @@ class DBM(EngineModel):
 
     def _fit(self, X, X_val=None, *args, **kwargs):
         X = np.ascontiguousarray(X, dtype=np.float32)
-        self._check_batches(X)
+        self._check_batches(X, sharded=True)
         Xd, N = as_device(X), len(X)
         Xvd = None
         if X_val is not None:
             X_val = np.ascontiguousarray(X_val, dtype=np.float32)
-            self._check_batches(X_val)
+            self._check_batches(X_val, sharded=True)
             Xvd = as_device(X_val)
         val_msre, val_n_mf_updates = None, None
         for self.epoch_ in epoch_iter(start_epoch=self.epoch_, max_epoch=self.max_epoch, verbose=self.verbose):
@@ -344,7 +368,12 @@ class DBM(EngineModel):
         (reference dbm.py:899-939).  Returns log_mean, (log_low, log_high), values."""
         assert self.n_layers_ == 2
         assert self.v_unit_ == _ffi.UNIT_BERNOULLI
-        values = self._engine.ais(n_betas, n_runs, n_gibbs_steps, seed=self._graph_seed)
+        if getattr(self, '_comm', None) is not None:
+            # multi-GPU job: the independent chains are sharded over the ranks (their index in the RNG stream is
+            # global), ONE all-gather of the per-chain values at the end; every rank returns all of them
+            values = self._engine.ais_sharded(self._comm, n_betas, n_runs, n_gibbs_steps, seed=self._graph_seed)
+        else:
+            values = self._engine.ais(n_betas, n_runs, n_gibbs_steps, seed=self._graph_seed)
         log_mean = log_mean_exp(values)
         log_std = log_std_exp(values, log_mean_exp_x=log_mean)
         log_high = log_sum_exp([log_std, log_mean])

@@ -319,6 +319,19 @@ class DbmEngine(object):
     def apply_step(self, N_global, M_global, lr, momentum):
         check(self.lib.bm_dbm_apply_step(self._h, N_global, M_global, lr, momentum))
 
+    def set_comm(self, comm):
+        """install (or, with None, remove) the library-owned RCCL communicator: the mean-field residual is then
+        all-reduced (max) on the device per sweep (bm_dbm_set_comm)"""
+        self._comm = comm
+        check(self.lib.bm_dbm_set_comm(self._h, comm._c if comm is not None else None))
+
+    def ais_sharded(self, comm, n_betas, n_runs_total, k, seed):
+        """this rank's slice of the chains + ONE all-gather (bm_dbm_ais_sharded); returns all n_runs_total values"""
+        out = np.empty(n_runs_total, dtype=np.float32)
+        check(self.lib.bm_dbm_ais_sharded(self._h, comm._c, n_betas, n_runs_total, k, int(seed),
+                                          out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def set_mf_allreduce(self, fn):
         """fn(local_max: float) -> global max over ranks (mean-field loop condition)"""
         self._mf_cb = _ffi.MF_REDUCE_FN(lambda x, ctx: float(fn(x))) if fn is not None else None

@@ -29,6 +29,17 @@ def dist_env():
     return int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 
 
+_default_comm = [None, False]
+
+
+def default_comm():
+    """process-wide communicator of a one-process-per-GPU job (NativeComm.from_env, created once); None at world 1"""
+    if not _default_comm[1]:
+        _default_comm[0] = NativeComm.from_env()
+        _default_comm[1] = True
+    return _default_comm[0]
+
+
 class DataParallelRBM(object):
     """Drives one rank's engine (RbmEngine, or any object with grad_step / apply_step /
     set_row_offset) through data-parallel CD-k updates."""
@@ -90,11 +101,15 @@ class DataParallelDBM(object):
     `grad_step` (mean-field with an all-reduce(max) of the residual per sweep, PCD, raw sums) ->
     ONE all-reduce(sum) of the fused buffer -> `apply_step` with the global N and M."""
 
-    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None):
+    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None, comm=None):
         self.engine, self.rank, self.world = engine, rank, world
         self.allreduce_ = allreduce_
         engine.set_row_offset(rank * engine.N, rank * engine.M)
-        if allreduce_max is not None and world > 1:
+        if comm is not None:
+            # the library's own communicator: residual all-reduce(max) on the device, in stream order
+            engine.set_comm(comm)
+        elif allreduce_max is not None and world > 1:
+            # collectives the library does not own (torch.distributed / gloo): host callback per sweep
             engine.set_mf_allreduce(allreduce_max)
 
     def train_step(self, X_local, lr, momentum, k, **kw):
@@ -140,6 +155,23 @@ class NativeComm(object):
         return bytes(buf)
 
     @classmethod
+    def from_env(cls):
+        """communicator of a job launched one process per GPU (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the
+        environment, e.g. by torch.distributed.run); the 128-byte id travels over torch.distributed when a process
+        group exists, else over a plain TCP socket on MASTER_PORT + 1.  None when WORLD_SIZE <= 1."""
+        rank, _, world = dist_env()
+        if world <= 1:
+            return None
+        try:
+            import sys
+            dist = sys.modules.get('torch.distributed')
+            if dist is not None and dist.is_initialized():
+                return cls.from_torch_rendezvous(rank, world)
+        except Exception:
+            pass
+        return cls(rank, world, socket_broadcast(cls.unique_id() if rank == 0 else None, rank, world))
+
+    @classmethod
     def from_torch_rendezvous(cls, rank, world):
         """rank 0 creates the id, torch.distributed (already initialised, any backend) broadcasts it"""
         import torch.distributed as dist
@@ -165,6 +197,43 @@ class NativeComm(object):
             self.close()
         except Exception:
             pass
+
+
+def socket_broadcast(payload, rank, world, addr=None, port=None, timeout=120.0):
+    """rank 0 sends `payload` (bytes) to every other rank over TCP (torch-free rendezvous for the RCCL id)"""
+    import socket
+    import time
+    addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(port or int(os.environ.get('MASTER_PORT', '29533')) + 1)
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            c.sendall(len(payload).to_bytes(4, 'little') + payload)
+            c.close()
+        srv.close()
+        return payload
+    t0 = time.time()
+    while True:
+        try:
+            c = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() - t0 > timeout:
+                raise
+            time.sleep(0.05)
+    buf = b''
+    while len(buf) < 4 or len(buf) < 4 + int.from_bytes(buf[:4], 'little'):
+        chunk = c.recv(4096)
+        if not chunk:
+            break
+        buf += chunk
+    c.close()
+    return buf[4:4 + int.from_bytes(buf[:4], 'little')]
 
 
 def native_allreduce_on_engine_stream(engine, comm):

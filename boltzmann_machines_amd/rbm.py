@@ -181,6 +181,14 @@ class BaseRBM(EngineModel):
                                      dropout=self.dropout, h_unit=self._H_UNIT,
                                      n_samples=getattr(self, 'n_samples', 0))
             self._upload_variables(variables)
+            # multi-GPU job (one process per GPU): data-parallel CD-k, rank r takes rows [r*batch_size, ...) of every
+            # global minibatch of world*batch_size rows; ONE all-reduce(sum) of the fused [dW|dvb|dhb|q] buffer per
+            # update through the library's communicator (parallel.DataParallelRBM)
+            self._dp = None
+            if getattr(self, '_comm', None) is not None and not f64:
+                from . import parallel
+                self._dp = parallel.DataParallelRBM(self._engine, self._rank, self._world, self.batch_size,
+                                                    parallel.native_allreduce_on_engine_stream(self._engine, self._comm))
         else:
             self._engine = _HostVars(variables)
 
@@ -238,6 +246,17 @@ class BaseRBM(EngineModel):
         results = {m: [] for m in names}
         lr, mom, k = self._feed()
         every = self.metrics_config['train_metrics_every_iter']
+        if getattr(self, '_dp', None) is not None:
+            # data-parallel epoch: global minibatches of world * batch_size rows (train metrics are not fetched:
+            # they would be rank-local numbers; validation metrics are evaluated on this rank's replica)
+            step_rows = self.batch_size * self._world
+            if N % step_rows:
+                raise ValueError('data-parallel fit: {0} rows are not a multiple of batch_size x world_size = {1}'
+                                 .format(N, step_rows))
+            for start in range(0, N, step_rows):
+                self.iter_ += 1
+                self._dp.train_step(Xd, lr, mom, k, row=start + self._rank * self.batch_size)
+            return {m: None for m in names}
         # runs of batches without a metrics fetch go to the engine as ONE call (bm_rbm_train_epoch loops in
         # C: same launches, same RNG call counters, no Python per batch)
         run_start, fused = None, hasattr(eng, 'train_epoch')

@@ -277,6 +277,19 @@ int bm_comm_destroy(bm_comm *c);
 /* in-place all-reduce(sum) / all-gather of device floats, enqueued on `stream` (a hipStream_t) */
 int bm_comm_allreduce_sum(bm_comm *c, float *buf_dev, size_t count, void *stream);
 int bm_comm_allgather(bm_comm *c, const float *send_dev, float *recv_dev, size_t count_per_rank, void *stream);
+int bm_comm_allreduce_max(bm_comm *c, float *buf_dev, size_t count, void *stream);
+int bm_comm_rank(bm_comm *c, int32_t *out_rank, int32_t *out_nranks);
+/* Data-parallel DBM (dbm.py:449-452 over the GLOBAL minibatch): with a communicator installed the mean-field
+ * residual of every sweep is all-reduced (max) on the device, on the handle's stream, and the device-side
+ * loop control latches the same `done` on every rank - no host callback, no host synchronisation per sweep.
+ * NULL removes it.  (bm_dbm_set_mf_allreduce remains for collectives the library does not own.) */
+int bm_dbm_set_comm(bm_dbm *h, bm_comm *c);
+/* Chain-sharded AIS (north_star): this rank runs its contiguous slice of the n_runs_total chains
+ * (the chain index in the RNG stream is global), zero communication during the sweep, ONE all-gather of the
+ * per-chain values at the end; values_host [n_runs_total] is filled on every rank.  Replaces the
+ * session.run(log_Z) of dbm.py:930 in a multi-GPU job. */
+int bm_dbm_ais_sharded(bm_dbm *h, bm_comm *c, int32_t n_betas, int32_t n_runs_total, int32_t n_gibbs_steps,
+                       uint64_t seed, float *values_host);
 /* the exchange step of data-parallel training: all-reduce of the handle's fused "grad" buffer on the
  * handle's stream, between bm_*_grad_step and bm_*_apply_step (no host synchronisation) */
 int bm_rbm_allreduce_grads(bm_rbm *h, bm_comm *c);

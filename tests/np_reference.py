@@ -96,6 +96,7 @@ class NumpyDBM(object):
         self.sp_damping = sp_damping
         self.seed, self.call, self.prow0 = 0, 0, 0
         self.ties = 0            # draws whose uniform was within 1e-6 of the probability
+        self.allreduce_max = None    # data-parallel: max over ranks of the mean-field residual (dbm.py:449-452 is over ALL rows)
 
     def W(self, i): return self.P['W' + _sfx(i)]
     def hb(self, i): return self.P['hb' + _sfx(i)]
@@ -152,7 +153,10 @@ class NumpyDBM(object):
             self.P['mu_new' + _sfx(i)] = mu_new[i].copy()
         mu = [self.P['mu' + _sfx(i)] for i in range(L)]
         step = 0
-        while step < self.max_mf and max(np.max(np.abs(u - w)) for u, w in zip(mu, mu_new)) > self.mf_tol:   # :449-452
+        def resid():
+            r = max(np.max(np.abs(u - w)) for u, w in zip(mu, mu_new))
+            return self.allreduce_max(r) if self.allreduce_max is not None else r
+        while step < self.max_mf and resid() > self.mf_tol:                    # :449-452
             _, out = self.gibbs_step(X, mu, update_v=False, sample=False)      # :455 (reads mu, overwrites mu_new)
             mu, mu_new = out, mu                                                # :457 swap
             step += 1
@@ -169,7 +173,15 @@ class NumpyDBM(object):
 
     def train_step(self, X, lr, mom, k):
         """session.run(train_op) (dbm.py:515-621); returns (n_mf, msre)."""
-        P, L, N, M = self.P, self.L, float(self.N), float(self.M)
+        n_mf, msre, S = self.raw_sums(X, k)
+        self.apply(S, float(self.N), float(self.M), lr, mom)
+        self.call += 1
+        return n_mf, msre
+
+    def raw_sums(self, X, k):
+        """mean-field + PCD, then the UN-normalised sums the update needs (what a data-parallel rank
+        contributes to the all-reduce): pos/neg outer products per layer and the column sums."""
+        P, L = self.P, self.L
         n_mf = self.mean_field(X)                                               # :517
         v, H = self.particles_update(k)                                         # :521
         P['v'] = v
@@ -177,17 +189,27 @@ class NumpyDBM(object):
             P['h' + _sfx(i)] = H[i]
         mu = [P['mu' + _sfx(i)] for i in range(L)]
         msre = np.mean((X - sigmoid(mu[0].dot(self.W(0).T) + P['vb'])) ** 2)    # :625-630 (W before the update)
-        dvb = np.mean(X, axis=0) - np.mean(v, axis=0)                           # :553
-        dW = [X.T.dot(mu[0]) / N - v.T.dot(H[0]) / M - self.l2 * self.W(0)]     # :558-561
-        for i in range(1, L):                                                   # :564-569
-            dW.append(mu[i - 1].T.dot(mu[i]) / N - H[i - 1].T.dot(H[i]) / M - self.l2 * self.W(i))
-        dhb = [np.mean(mu[i], axis=0) - np.mean(H[i], axis=0) for i in range(L)]   # :573-576
+        S = dict(sX=np.sum(X, axis=0), sv=np.sum(v, axis=0))
+        for i in range(L):
+            below_p, below_n = (X, v) if i == 0 else (mu[i - 1], H[i - 1])
+            S['pos%d' % i] = below_p.T.dot(mu[i])
+            S['neg%d' % i] = below_n.T.dot(H[i])
+            S['smu%d' % i] = np.sum(mu[i], axis=0)
+            S['sH%d' % i] = np.sum(H[i], axis=0)
+        return n_mf, msre, S
+
+    def apply(self, S, N, M, lr, mom):
+        """the parameter update of dbm.py:550-621 from (possibly all-reduced) raw sums and the GLOBAL N, M"""
+        P, L = self.P, self.L
+        dvb = S['sX'] / N - S['sv'] / M                                         # :553
+        dW = [S['pos%d' % i] / N - S['neg%d' % i] / M - self.l2 * self.W(i) for i in range(L)]    # :558-569
+        dhb = [S['smu%d' % i] / N - S['sH%d' % i] / M for i in range(L)]        # :573-576
         d = self.sp_damping
         for i in range(L):                                                      # :580-592
-            q_means = np.sum(H[i], axis=0)
+            q_means = S['sH%d' % i]
             q_update = d * P['q_means' + _sfx(i)] + (1 - d) * q_means[i]        # q_means[i]: scalar (layer index!)
             P['q_means' + _sfx(i)] = q_update
-            mu_means = np.sum(mu[i], axis=0)
+            mu_means = S['smu%d' % i]
             mu_update = d * P['mu_means' + _sfx(i)] + (1 - d) * mu_means[i]
             P['mu_means' + _sfx(i)] = mu_update
             pen = self.sp_cost[i] * (q_update - self.sp_target[i])
@@ -204,8 +226,6 @@ class NumpyDBM(object):
         for i in range(L):                                                      # :611-615
             P['dhb' + _sfx(i)] = lr * (mom * P['dhb' + _sfx(i)] + dhb[i])
             P['hb' + _sfx(i)] = self.hb(i) + P['dhb' + _sfx(i)]
-        self.call += 1
-        return n_mf, msre
 
     def sample_v(self, k):
         """_make_sample_v (dbm.py:641-648): k sampled sweeps (assigned), k mean sweeps, v <- v_means."""

@@ -310,3 +310,25 @@ def test_ais_brackets_exact_log_Z():
     # the float64 restatement agrees with ground truth too (fewer runs: pure Python)
     r = npm.ais(n_betas=2000, n_runs=256, k=1, seed=779)
     assert abs(log_mean_exp(r) - exact) < 0.05
+
+
+def test_blas_restatement_matches_oracle():
+    """oracle/cpu_blas.py (the NumPy + sgemm CPU baseline of bench.py) computes the same CD-k update as the
+    canonical-order C oracle when it is fed the pinned uniform stream."""
+    from oracle import cpu_blas
+    V, H, B = 30, 20, 14
+    X = (philox.uniform(3, 1, 0, B * V) < 0.3).astype(np.float32).reshape(B, V)
+    W0 = (philox.normal(3, 2, 0, V * H) * np.float32(0.1)).reshape(V, H)
+    t = orc.OracleRBM(V, H, l2=1e-3, sample_v_states=True, sparsity_cost=0.02)
+    t.p['W'][...] = W0
+    t.set_seed(99)
+    m = cpu_blas.BlasRBM(W0, l2=1e-3, sample_v=True, sp_cost=0.02)
+    for step in range(3):
+        us = [philox.uniform(99, 2, step, B * H).reshape(B, H), philox.uniform(99, 3, step, B * V).reshape(B, V),
+              philox.uniform(99, 4, step, B * H).reshape(B, H)]
+        t.train_step(X, 0.05, 0.7, 1)
+        r = m.train_step(X, 0.05, 0.7, 1, uniforms=us)
+        assert np.array_equal(t.work['vs'], r['vs'])
+        assert_allclose(t.work['hm'], r['hm'], rtol=2e-6, atol=1e-7)
+        for a, b in ((t.p['W'], m.W), (t.p['vb'], m.vb), (t.p['hb'], m.hb), (t.p['q_means'], m.q)):
+            assert_allclose(a, b, rtol=2e-5, atol=2e-7)

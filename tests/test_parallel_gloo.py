@@ -109,3 +109,117 @@ def test_shard():
     assert [shard(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
     assert [shard(20000, r, 8) for r in range(8)][-1] == (17500, 20000)
     assert shard(2, 1, 4) == (1, 2) and shard(2, 3, 4) == (2, 2)
+
+
+# ------------------------------------------------------------------ data-parallel DBM incl. the mean-field max
+class NumpyDbmAsEngine(object):
+    """adapts tests/np_reference.NumpyDBM (float64 restatement of dbm.py) to the engine interface that
+    parallel.DataParallelDBM drives: set_row_offset / set_mf_allreduce / grad_step / apply_step"""
+
+    def __init__(self, npm):
+        self.m, self.N, self.M = npm, npm.N, npm.M
+        self.S = None
+        self.keys = None
+
+    def set_row_offset(self, row0, particle0):
+        self.m.prow0 = particle0
+
+    def set_mf_allreduce(self, fn):
+        self.m.allreduce_max = fn
+
+    def grad_step(self, X, k):
+        n_mf, _, self.S = self.m.raw_sums(X, k)
+        self.m.call += 1
+        return n_mf
+
+    def flat(self):
+        self.keys = sorted(self.S)
+        return np.concatenate([self.S[k_].ravel() for k_ in self.keys])
+
+    def unflat(self, buf):
+        o = 0
+        for k_ in self.keys:
+            n = self.S[k_].size
+            self.S[k_] = buf[o:o + n].reshape(self.S[k_].shape)
+            o += n
+
+    def apply_step(self, N_global, M_global, lr, mom):
+        self.m.apply(self.S, float(N_global), float(M_global), lr, mom)
+
+
+def _dbm_model(N, M, rows=None, prow=None):
+    """NumpyDBM 14-10-8 with pinned weights; particles / mu for global rows [rows], particles [prow]"""
+    from tests import np_reference as ref
+    from oracle import oracle as orc
+    V, nh = 14, [10, 8]
+    n = [V] + nh
+    Ng, Mg = 8, 6                                     # global batch / particle count (2 ranks x 4 / 3)
+    P = {}
+    for i in range(2):
+        sfx = '' if i == 0 else '_1'
+        P['W' + sfx] = (orc.normal(9, 1 + i, 0, n[i] * n[i + 1]) * np.float32(0.3)).reshape(n[i], n[i + 1]).astype(np.float64)
+        P['hb' + sfx] = (orc.uniform(9, 5 + i, 0, n[i + 1]).astype(np.float64) - 0.5) * 0.4
+        Hp = (orc.uniform(9, 10 + i, 0, Mg * n[i + 1]) < 0.5).astype(np.float64).reshape(Mg, n[i + 1])
+        P['h' + sfx] = Hp[prow].copy()
+        for b in ('dW',):
+            P[b + sfx] = np.zeros((n[i], n[i + 1]))
+        for b in ('dhb', 'q_means', 'mu_means'):
+            P[b + sfx] = np.zeros(n[i + 1])
+        P['mu' + sfx] = np.zeros((len(range(*rows.indices(Ng))), n[i + 1]))
+    P['vb'] = (orc.uniform(9, 20, 0, V).astype(np.float64) - 0.5) * 0.4
+    P['dvb'] = np.zeros(V)
+    P['v'] = (orc.uniform(9, 21, 0, Mg * V) < 0.3).astype(np.float64).reshape(Mg, V)[prow].copy()
+    m = ref.NumpyDBM(P, 2, N, M, max_mf=6, mf_tol=1e-3, l2=1e-3, max_norm=1.2, sp_target=[0.2, 0.1], sp_cost=[1e-2, 5e-3])
+    m.seed = 77
+    X = (orc.uniform(9, 30, 0, 3 * Ng * V) < 0.25).astype(np.float64).reshape(3, Ng, V)
+    return m, X
+
+
+def _dbm_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from boltzmann_machines_amd import parallel
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    N, M = 4, 3
+    m, X = _dbm_model(N, M, rows=slice(rank * N, (rank + 1) * N), prow=slice(rank * M, (rank + 1) * M))
+    eng = NumpyDbmAsEngine(m)
+    calls = []
+
+    def allreduce_():
+        t = torch.from_numpy(eng.flat())
+        dist.all_reduce(t)
+        eng.unflat(t.numpy())
+
+    def allreduce_max(x):
+        calls.append(x)
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    dp = parallel.DataParallelDBM(eng, rank, world, allreduce_, allreduce_max=allreduce_max)
+    nmf = [dp.train_step(X[s][rank * N:(rank + 1) * N], 0.05, 0.5, 2) for s in range(3)]
+    np.savez(out + '.r%d' % rank, nmf=nmf, n_max_calls=len(calls), **{k_: v for k_, v in m.P.items()})
+    dist.destroy_process_group()
+
+
+def test_dp_dbm_world2_with_mean_field_max(tmp_path):
+    """DataParallelDBM over gloo, world 2: rank-sharded rows and particles, the mean-field loop condition
+    all-reduced (max) per sweep, ONE all-reduce(sum) of the raw sums, update with the global N and M ==
+    the same model trained by one process on the concatenated minibatch / particle set."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'dpdbm')
+    mp.spawn(_dbm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out + '.r0.npz'), np.load(out + '.r1.npz')
+    ref_m, X = _dbm_model(8, 6, rows=slice(0, 8), prow=slice(0, 6))
+    nmf = [ref_m.train_step(X[s], 0.05, 0.5, 2)[0] for s in range(3)]
+    assert list(r0['nmf']) == nmf and list(r1['nmf']) == nmf          # the GLOBAL residual decides the trip count
+    assert int(r0['n_max_calls']) == int(r1['n_max_calls']) >= sum(nmf)
+    for k_ in ('W', 'W_1', 'hb', 'hb_1', 'vb', 'dW', 'q_means', 'mu_means_1'):
+        assert np.array_equal(r0[k_], r1[k_]), k_                     # replicas identical
+        np.testing.assert_allclose(r0[k_], ref_m.P[k_], rtol=1e-10, atol=1e-13, err_msg=k_)
+    # sharded state = slices of the single-process state (sample bitmaps are functions of the GLOBAL row index)
+    for k_ in ('v', 'h', 'h_1'):
+        assert np.array_equal(np.concatenate([r0[k_], r1[k_]]), ref_m.P[k_]), k_
+    for k_ in ('mu', 'mu_1'):
+        np.testing.assert_allclose(np.concatenate([r0[k_], r1[k_]]), ref_m.P[k_], rtol=1e-10, atol=1e-13)

@@ -136,3 +136,49 @@ def test_native_rccl_comm_world1(gpu_lib):
     r = subprocess.run([sys.executable, '-c', NATIVE_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and 'NATIVE_COMM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+NATIVE_DBM_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+assert 'torch' not in sys.modules
+from boltzmann_machines_amd import parallel
+from boltzmann_machines_amd.engine import as_device
+from tests import test_dbm_parity_gpu as D
+V, nh, N, M = 20, [12, 16], 10, 10
+kw = dict(max_mf_updates=5, mf_tol=1e-5, l2=1e-3, max_norm=1.5, sparsity_target=[0.2, 0.1], sparsity_cost=[1e-2, 5e-3])
+comm = parallel.NativeComm(0, 1, parallel.NativeComm.unique_id())
+e1, _ = D.make_pair(V, nh, N, M, **kw)
+e2, _ = D.make_pair(V, nh, N, M, **kw)
+e1.seed(42); e2.seed(42)
+dp = parallel.DataParallelDBM(e2, 0, 1, parallel.native_allreduce_on_engine_stream(e2, comm), comm=comm)
+for s in range(3):
+    Xd = as_device(D.data(N, V, s))
+    n1, _ = e1.train_step(Xd, 0.05, 0.5, 2)
+    n2 = dp.train_step(Xd, 0.05, 0.5, 2)      # MF residual all-reduced (max) on the device, grads all-reduced (sum)
+    assert n1 == n2, (n1, n2)
+for nm in ('W', 'W_1', 'dW', 'hb', 'hb_1', 'vb', 'q_means', 'mu_means_1', 'v', 'h_1', 'mu', 'mu_1'):
+    assert np.array_equal(e1.get(nm).view(np.uint32), e2.get(nm).view(np.uint32)), nm
+# validation fetch and inference also run with the communicator installed
+assert e1.metrics(Xd, 2) == e2.metrics(Xd, 2)
+# chain-sharded AIS: shard + all-gather inside the library == the plain run
+a = e1.ais(20, 37, 1, 2222)
+b = e2.ais_sharded(comm, 20, 37, 1, 2222)
+assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+e2.set_comm(None)
+comm.close(); e1.close(); e2.close()
+assert 'torch' not in sys.modules
+print('NATIVE_DBM_OK')
+"""
+
+
+def test_native_comm_dbm_and_ais_world1(gpu_lib):
+    """DBM data-parallel step and chain-sharded AIS through the library's own RCCL communicator (world 1 on the
+    test box, torch-free process): device-side all-reduce(max) of the mean-field residual per sweep, one
+    all-reduce(sum) of the fused gradient buffer, one all-gather of the AIS values — bit-identical to the
+    fused single-GPU entry points."""
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', NATIVE_DBM_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'NATIVE_DBM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
