@@ -71,8 +71,14 @@ def cpu_info():
 
 def _cpu_worker(kind, v, h, b, k, threads, budget_s, q):
     os.environ['OMP_NUM_THREADS'] = str(threads)
-    os.environ['OPENBLAS_NUM_THREADS'] = str(threads)
     os.environ['OMP_WAIT_POLICY'] = 'passive'
+    # numpy (and its OpenBLAS pool) is already loaded when a spawned worker starts (it imports this module):
+    # the pool size is set at run time
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(limits=threads)
+    except Exception:
+        pass
     X, W = synth(0, b, v, h)
     if kind == 'oracle':
         from oracle import oracle as orc
@@ -111,13 +117,13 @@ def cpu_baseline(k, budget_s=2.5):
     `value` is the faster of the two at the north-star shape; both, and the cfg1 shape (784x128, batch
     100: the shape BASELINE.json assigns to the reference's CPU path), are listed in `detail`."""
     model, ncpu = cpu_info()
-    teams = sorted({min(16, ncpu), min(64, ncpu), ncpu})
+    teams = sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)})
     detail = {}
     best = None
     for name, (v, h, b) in (('784x1024_b512', (V, H, B)), ('784x128_b100', (784, 128, 100))):
         for kind in ('oracle', 'blas'):
             top = None
-            for threads in (teams if name == '784x1024_b512' else teams[:2]):
+            for threads in (teams if name == '784x1024_b512' else teams[:3]):
                 rate, n, dt = _cpu_rate(kind, v, h, b, k, threads, budget_s)
                 if top is None or rate > top[0]:
                     top = (rate, threads, n, dt)

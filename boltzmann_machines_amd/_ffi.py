@@ -35,7 +35,8 @@ class DbmConfig(C.Structure):
                 ('n_particles', C.c_int32), ('batch_size', C.c_int32), ('max_mf_updates', C.c_int32),
                 ('mf_tol', C.c_float), ('l2', C.c_float), ('max_norm', C.c_float),
                 ('sparsity_target', C.c_float * MAX_LAYERS), ('sparsity_cost', C.c_float * MAX_LAYERS),
-                ('sparsity_damping', C.c_float)]
+                ('sparsity_damping', C.c_float),
+                ('h_unit', C.c_int32 * MAX_LAYERS), ('n_samples', C.c_int32 * MAX_LAYERS)]
 
 
 _vp, _i32, _i64, _u64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t

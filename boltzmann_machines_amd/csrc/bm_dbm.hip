@@ -40,6 +40,9 @@ struct bm_dbm {
     bm_comm *comm = nullptr;                       // bm_dbm_set_comm: the residual is all-reduced (max) ON DEVICE, on the
                                                    // engine stream, by the library's own RCCL communicator
     DevBuf wnorm[MAXL];
+    Mat logits[MAXL];                              // Multinomial layers: row store of the logits / means [rows][n_i], on demand
+    int logit_rows[MAXL] = {0, 0, 0, 0};
+    bool multinomial(int layer) const { return layer >= 0 && cfg.h_unit[layer] == BM_UNIT_MULTINOMIAL; }
     unsigned *flag = nullptr;                      // mean-field residual cell (= &ctl->maxdiff)
     MfCtl *ctl = nullptr;                          // device-side loop control
     DevBuf mfblk;                                  // [L * BM_MF_SLOTS] per-workgroup residual slots (single-GPU mean field)
@@ -97,6 +100,31 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
     a.means = means; a.states = states; a.ldo = ldo;
     a.key = key; a.row0 = row0;
     a.prev = prev; a.maxdiff = maxdiff;
+    if (h->multinomial(layer) && a.kind != 2) {
+        // MultinomialLayer inside the stack (layers.py:54-70): the GEMM writes the logits mult*z + bmult*b, then one
+        // wave per row does the softmax (activation = n_samples * softmax) and, when sampling, the n_samples
+        // categorical draws (counts); same two kernels as the MultinomialRBM hidden layer (bm_rbm.hip launch_up)
+        float *lg = means; int ldl = ldo;
+        if (!lg) {                                 // sampled sweep: the means are not kept, they pass through a row store
+            if (h->logit_rows[layer] < J) {
+                h->logits[layer].release();
+                if (h->logits[layer].alloc(J, a.I)) return;
+                h->logit_rows[layer] = J;
+            }
+            lg = h->logits[layer].p; ldl = h->logits[layer].ld;
+        }
+        a.kind = 3; a.sample = 0; a.means = lg; a.ldo = ldl; a.states = nullptr; a.negmeans = nullptr;
+        a.prev = nullptr; a.maxdiff = nullptr; a.maxdiff_blk = nullptr;
+        launch_act(a, h->stream);
+        SmArgs m;
+        memset(&m, 0, sizeof(m));
+        m.L = lg; m.ld = ldl; m.I = a.I; m.J = J; m.M = h->cfg.n_samples[layer]; m.sample = sample;
+        m.states = (states && (sample || states != lg)) ? states : nullptr;
+        m.key = key; m.row0 = row0;
+        m.prev = prev; m.ld_prev = ldo; m.maxdiff = maxdiff; m.skip = a.skip;
+        hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(J), dim3(64), 2 * (size_t)a.I * sizeof(float), h->stream, m);
+        return;
+    }
     launch_act(a, h->stream);
 }
 
@@ -116,7 +144,7 @@ static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout
         memset(&e, 0, sizeof(e));
         e.skip = skip;
         e.maxdiff_blk = (maxdiff && mfblk) ? mfblk + (size_t)i * BM_MF_SLOTS : nullptr;
-        if (i == 0 && xw0 && above.p) {
+        if (i == 0 && xw0 && above.p && !h->multinomial(0)) {
             // mean-field: X.W0 is loop invariant — start the chain from the hoisted partial sum and
             // stream only the top-down segment (bit-identical to recomputing X.W0 every sweep)
             e.acc_init = xw0->p; e.ld_init = xw0->ld;
@@ -170,7 +198,7 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
                      dkey(h, 0, 0, h->seed, h->call), 0);
     }
     // hoisted loop invariant of the sweeps: z0 = X.W0 (raw chain, no activation)
-    const bool hoist = L >= 2;
+    const bool hoist = L >= 2 && !h->multinomial(0);
     if (hoist) {
         ActArgs e;
         memset(&e, 0, sizeof(e));
@@ -372,6 +400,12 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
     for (int i = 0; i < h->L; ++i) {
         BM_CHECK(cfg->n_hiddens[i] >= 1, "bad hidden size");
         BM_CHECK(cfg->n_hiddens[i] > i, "layer %d needs more than %d units (sparsity index, dbm.py:583)", i, i);
+        BM_CHECK(cfg->h_unit[i] == BM_UNIT_BERNOULLI || cfg->h_unit[i] == BM_UNIT_MULTINOMIAL, "unknown unit %d of hidden layer %d",
+                 cfg->h_unit[i], i);
+        if (cfg->h_unit[i] == BM_UNIT_MULTINOMIAL) {
+            BM_CHECK(cfg->n_samples[i] >= 1, "Multinomial layer %d: n_samples must be >= 1 (got %d)", i, cfg->n_samples[i]);
+            BM_CHECK(cfg->n_hiddens[i] <= 8192, "Multinomial layer %d: %d units > 8192 (softmax row staged in LDS)", i, cfg->n_hiddens[i]);
+        }
         h->n[i + 1] = cfg->n_hiddens[i];
     }
     BM_HIP(hipStreamCreate(&h->stream));
@@ -419,6 +453,7 @@ int bm_dbm_destroy(bm_dbm *h) {
         for (Mat *m : ms) m->release();
         DevBuf *bs[] = {&h->hb[i], &h->dhb[i], &h->q[i], &h->mm[i], &h->pen[i], &h->wnorm[i]};
         for (DevBuf *b : bs) b->release();
+        h->logits[i].release();
     }
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
@@ -724,6 +759,7 @@ __global__ void ais_score_kernel(double *logw, int J, int ld, const float *pv, i
 static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0) {
     BM_CHECK(h->L == 2, "AIS is implemented for 2-layer DBMs only (dbm.py:925)");
     BM_CHECK(h->cfg.v_unit == BM_UNIT_BERNOULLI, "AIS needs Bernoulli visible units (dbm.py:926-927)");
+    BM_CHECK(!h->multinomial(0) && !h->multinomial(1), "AIS needs Bernoulli hidden layers (dbm.py:926-927)");
     BM_CHECK(n_betas >= 2 && n_runs >= 1 && k >= 1, "bad AIS arguments");
     BM_TRY(ensure_ais(h, n_runs));
     const int R = n_runs, V = h->V, H1 = h->n[1], H2 = h->n[2];
@@ -889,6 +925,7 @@ __global__ __launch_bounds__(256) void elbo_row_kernel(const float *X, int ldx, 
 
 int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host) {
     BM_CHECK(h->L == 2, "log_proba is implemented for 2-layer DBMs only (dbm.py:741-756)");
+    BM_CHECK(!h->multinomial(0) && !h->multinomial(1), "log_proba needs Bernoulli hidden layers (dbm.py:947-948)");
     BM_CHECK(out_host, "null output");
     BM_TRY(mean_field(h, X_dev, nullptr));
     BM_TRY(ensure_ais(h, h->N));

@@ -908,11 +908,16 @@ struct SmArgs {
     float *L; int ld, I, J, M, sample;
     float *states, *negmeans;        // may be null
     PhiloxKey key; long long row0;
+    // DBM sweeps (a Multinomial layer inside the stack): mean-field residual max|means - prev| -> atomicMax on
+    // float bits, and the device-side "loop finished" flag of the mean-field loop (launch becomes a no-op)
+    const float *prev; int ld_prev; unsigned *maxdiff;
+    const int *skip;
 };
 __global__ __launch_bounds__(64) void softmax_multinomial_kernel(SmArgs a) {
     extern __shared__ float sm_dyn[];
     float *c = sm_dyn, *e = sm_dyn + a.I;
     const int row = blockIdx.x, lane = threadIdx.x;
+    if (a.skip && *a.skip) return;
     float *l = a.L + (size_t)row * a.ld;
     float mx = -3.402823466e38f;
     for (int i = lane; i < a.I; i += 64) mx = fmaxf(mx, l[i]);
@@ -938,11 +943,18 @@ __global__ __launch_bounds__(64) void softmax_multinomial_kernel(SmArgs a) {
     }
     __syncthreads();
     const float S = c[a.I - 1], Mf = (float)a.M;
+    float dmax = 0.f;
     for (int i = lane; i < a.I; i += 64) {
         const float m = Mf * (e[i] / S);
+        if (a.prev) dmax = fmaxf(dmax, fabsf(m - a.prev[(size_t)row * a.ld_prev + i]));
         l[i] = m;
         if (a.negmeans) a.negmeans[(size_t)row * a.ld + i] = -m;
         if (a.states && !a.sample) a.states[(size_t)row * a.ld + i] = m;
+    }
+    if (a.maxdiff) {            // wave-uniform
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        if (lane == 0 && dmax > 0.f) atomicMax(a.maxdiff, __float_as_uint(dmax));
     }
     if (!a.states || !a.sample) return;
     __syncthreads();

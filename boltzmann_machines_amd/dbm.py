@@ -7,8 +7,9 @@ Drop-in for boltzmann_machines/dbm.py of the reference: constructor keywords
 `n_layers_`, `n_visible_`, `n_hiddens_`, `n_samples_generated_`.  The TF graph
 (mean-field, PCD, train op, AIS, ELBO) is executed by libbm355 (csrc/bm_dbm.hip).
 
-Unit types: Bernoulli hidden layers, Bernoulli or Gaussian visible layer
-(Multinomial layers are out of the hot-path scope).
+Unit types: Bernoulli or Gaussian visible layer; Bernoulli or Multinomial hidden layers (the CIFAR
+model of examples/dbm_cifar.py is Gaussian-Bernoulli-Multinomial; `log_Z` / `log_proba` need all-Bernoulli
+layers like the reference, dbm.py:925-927, :947-948).
 """
 import numpy as np
 
@@ -43,6 +44,8 @@ class DBM(EngineModel):
         self._rbms = None
         self._W_init = self._vb_init = self._hb_init = None
         self.v_unit_ = _ffi.UNIT_BERNOULLI     # visible unit type (attribute: restored by load_model)
+        self.h_units_ = []                     # hidden layer kinds / multinomial draw counts (layers.py:39-70)
+        self.h_n_samples_ = []
         self._sigma_init = None
         self.load_rbms(rbms)
 
@@ -93,12 +96,11 @@ class DBM(EngineModel):
     # ---- composition from pre-trained RBMs (reference dbm.py:207-231) ------------------
     def load_rbms(self, rbms):
         if rbms is not None:
-            for rbm in rbms:
-                if getattr(rbm, '_H_UNIT', _ffi.UNIT_BERNOULLI) != _ffi.UNIT_BERNOULLI:
-                    raise NotImplementedError('DBM layers are Bernoulli (hidden) and Bernoulli / Gaussian (visible): '
-                                              'a %s cannot be stacked (multinomial DBM layers are outside the '
-                                              'hot-path scope, SURVEY.md 8f-4)' % rbm.__class__.__name__)
             self._rbms = rbms
+            # `self._h_layers = [rbm._h_layer for rbm in self._rbms]` (dbm.py:226): the hidden layer of every RBM
+            self.h_units_ = [int(getattr(rbm, '_H_UNIT', _ffi.UNIT_BERNOULLI)) for rbm in rbms]
+            self.h_n_samples_ = [int(getattr(rbm, 'n_samples', 0) or 0) if u == _ffi.UNIT_MULTINOMIAL else 0
+                                 for rbm, u in zip(rbms, self.h_units_)]
             self.n_layers_ = len(self._rbms)
             self.n_visible_ = self._rbms[0].n_visible
             self.n_hiddens_ = [rbm.n_hidden for rbm in self._rbms]
@@ -169,12 +171,24 @@ class DBM(EngineModel):
         for i in range(L):
             s, n = self._sfx(i), self.n_hiddens_[i]
             d['W' + s], d['hb' + s] = W_init[i], hb_init[i]
+            def h_init(site):       # BernoulliLayer.init: U[0,1) (layers.py:43-45); MultinomialLayer.init: the same
+                t = philox.uniform(seed, site, 0, M * n).reshape(M, n)      # divided by the sum over the WHOLE tensor
+                if self._h_unit(i) == _ffi.UNIT_MULTINOMIAL:                # (layers.py:59-63)
+                    t = (t / np.sum(t, dtype=np.float32)).astype(np.float32)
+                return t
             if self._h_particles_init is not None:
                 d['h' + s] = np.asarray(self._h_particles_init[i], dtype=np.float32).reshape(M, n)
             else:
-                d['h' + s] = philox.uniform(seed, _SITE_H_INIT + 2 * i, 0, M * n).reshape(M, n)
-            d['h_new' + s] = philox.uniform(seed, _SITE_H_INIT + 2 * i + 1, 0, M * n).reshape(M, n)
+                d['h' + s] = h_init(_SITE_H_INIT + 2 * i)
+            d['h_new' + s] = h_init(_SITE_H_INIT + 2 * i + 1)
         return d
+
+    def _h_unit(self, i):
+        return self.h_units_[i] if self.h_units_ else _ffi.UNIT_BERNOULLI
+
+    def _all_bernoulli(self):
+        return self.v_unit_ == _ffi.UNIT_BERNOULLI and all(self._h_unit(i) == _ffi.UNIT_BERNOULLI
+                                                           for i in range(self.n_layers_))
 
     # ---- engine hooks ---------------------------------------------------------------------
     def _make_engine(self):
@@ -187,7 +201,8 @@ class DBM(EngineModel):
                                  n_particles=self.n_particles, batch_size=self.batch_size,
                                  max_mf_updates=self.max_mf_updates, mf_tol=self.mf_tol, l2=self.l2,
                                  max_norm=self.max_norm, sparsity_target=self.sparsity_target,
-                                 sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping)
+                                 sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping,
+                                 h_units=self.h_units_ or None, n_samples=self.h_n_samples_ or None)
         if self._pending_vars is None:          # fresh model (load_model uploads its checkpoint instead)
             self._upload_variables(self._initial_variables())
         # Multi-GPU job (one process per GPU): rank r owns rows [r*batch_size, ...) of every global
@@ -367,7 +382,7 @@ class DBM(EngineModel):
         """AIS estimate of the log partition function of the 2-layer binary DBM
         (reference dbm.py:899-939).  Returns log_mean, (log_low, log_high), values."""
         assert self.n_layers_ == 2
-        assert self.v_unit_ == _ffi.UNIT_BERNOULLI
+        assert self._all_bernoulli()           # reference dbm.py:926-927: every layer is a BernoulliLayer
         if getattr(self, '_comm', None) is not None:
             # multi-GPU job: the independent chains are sharded over the ranks (their index in the RNG stream is
             # global), ONE all-gather of the per-chain values at the end; every rank returns all of them
@@ -384,7 +399,7 @@ class DBM(EngineModel):
     def log_proba(self, X_test, log_Z):
         """Variational lower bound on log p(x) for the 2-layer binary DBM (reference dbm.py:941-957)."""
         assert self.n_layers_ == 2
-        assert self.v_unit_ == _ffi.UNIT_BERNOULLI
+        assert self._all_bernoulli()           # reference dbm.py:947-948
         X_test = np.ascontiguousarray(X_test, dtype=np.float32)
         self._check_batches(X_test)
         Xd = as_device(X_test)

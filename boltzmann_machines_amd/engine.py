@@ -226,7 +226,8 @@ class DbmEngine(object):
 
     def __init__(self, n_visible, n_hiddens, v_unit=_ffi.UNIT_BERNOULLI, sample_v_states=True,
                  sample_h_states=None, n_particles=100, batch_size=100, max_mf_updates=10, mf_tol=1e-7,
-                 l2=0., max_norm=np.inf, sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9):
+                 l2=0., max_norm=np.inf, sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9,
+                 h_units=None, n_samples=None):
         self.lib = _ffi.load()
         self.V = int(n_visible)
         self.n_hiddens = [int(x) for x in n_hiddens]
@@ -243,6 +244,8 @@ class DbmEngine(object):
             cfg.sample_h_states[i] = int(bool(sh[i]))
             cfg.sparsity_target[i] = float(st[i])
             cfg.sparsity_cost[i] = float(sc[i])
+            cfg.h_unit[i] = int((h_units or [_ffi.UNIT_BERNOULLI] * self.L)[i])      # layers.py:39-70
+            cfg.n_samples[i] = int((n_samples or [0] * self.L)[i])
         cfg.n_particles, cfg.batch_size, cfg.max_mf_updates = self.M, self.N, int(max_mf_updates)
         cfg.mf_tol, cfg.l2, cfg.max_norm = float(mf_tol), float(l2), float(max_norm)
         cfg.sparsity_damping = float(sparsity_damping)

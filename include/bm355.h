@@ -200,6 +200,10 @@ typedef struct bm_dbm_config {
     float   sparsity_target[BM_DBM_MAX_LAYERS];
     float   sparsity_cost[BM_DBM_MAX_LAYERS];
     float   sparsity_damping;
+    /* hidden layer kinds (layers.py:39-70; the CIFAR DBM of examples/dbm_cifar.py is Gaussian-Bernoulli-
+     * Multinomial): BM_UNIT_BERNOULLI (0, default) or BM_UNIT_MULTINOMIAL with n_samples[i] draws per row */
+    int32_t h_unit[BM_DBM_MAX_LAYERS];
+    int32_t n_samples[BM_DBM_MAX_LAYERS];
 } bm_dbm_config;
 
 int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out);

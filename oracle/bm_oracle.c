@@ -498,7 +498,13 @@ typedef struct {
     int32_t v_unit, sample_v, sample_h[ORC_MAXL];
     int32_t N, M, max_mf;
     float mf_tol, l2, max_norm, sp_target[ORC_MAXL], sp_cost[ORC_MAXL], sp_damping;
+    int32_t h_unit[ORC_MAXL], n_samples[ORC_MAXL];   /* hidden layer kinds (layers.py:39-70): Bernoulli | Multinomial(n_samples) */
 } orc_dbm_cfg;
+
+/* activation kind of hidden layer i for orc_act2 (Multinomial: 16 + n_samples) */
+static int hkind(const orc_dbm_cfg *c, int i) {
+    return (c->h_unit[i] == UNIT_MULTINOMIAL) ? 16 + c->n_samples[i] : UNIT_BERNOULLI;
+}
 
 typedef struct {
     float *W[ORC_MAXL], *dW[ORC_MAXL], *hb[ORC_MAXL], *dhb[ORC_MAXL], *q[ORC_MAXL], *mm[ORC_MAXL];
@@ -522,7 +528,7 @@ static void dbm_sweep(const orc_dbm_cfg *c, const orc_dbm_state *s, int J, const
         float *Wt = NULL; const float *above = NULL; int Ka = 0;
         if (i + 1 < L) { Ka = dn(c, i + 2); Wt = transpose(s->W[i + 1], I, Ka); above = Hin[i + 1]; }
         const int smp = sample && c->sample_h[i];
-        orc_act2(below, Kb, s->W[i], above, Ka, Wt, I, J, s->hb[i], NULL, 1.0f, 1.0f, UNIT_BERNOULLI, smp,
+        orc_act2(below, Kb, s->W[i], above, Ka, Wt, I, J, s->hb[i], NULL, 1.0f, 1.0f, hkind(c, i), smp,
                  NULL, Hout[i], seed, SITE_DBM_H + (uint32_t)i + 16u * (uint32_t)t, call, row0);
         free(Wt);
     }
@@ -548,7 +554,7 @@ int orc_dbm_mean_field(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X) {
         const float *below = (i == 0) ? X : s->mu_new[i - 1];
         const float mult = (i == 0 || i < L - 1) ? 2.0f : 1.0f;
         orc_act2(below, dn(c, i), s->W[i], NULL, 0, NULL, dn(c, i + 1), N, s->hb[i], NULL, mult, 1.0f,
-                 UNIT_BERNOULLI, 0, s->mu_new[i], NULL, 0, 0, 0, 0);
+                 hkind(c, i), 0, s->mu_new[i], NULL, 0, 0, 0, 0);
     }
     float diff = 0.0f;
     for (int i = 0; i < L; ++i) {

@@ -322,7 +322,8 @@ class DbmCfg(C.Structure):
                 ('v_unit', C.c_int32), ('sample_v', C.c_int32), ('sample_h', C.c_int32 * MAXL),
                 ('N', C.c_int32), ('M', C.c_int32), ('max_mf', C.c_int32),
                 ('mf_tol', C.c_float), ('l2', C.c_float), ('max_norm', C.c_float),
-                ('sp_target', C.c_float * MAXL), ('sp_cost', C.c_float * MAXL), ('sp_damping', C.c_float)]
+                ('sp_target', C.c_float * MAXL), ('sp_cost', C.c_float * MAXL), ('sp_damping', C.c_float),
+                ('h_unit', C.c_int32 * MAXL), ('n_samples', C.c_int32 * MAXL)]
 
 
 class DbmState(C.Structure):
@@ -353,10 +354,13 @@ class OracleDBM(object):
 
     def __init__(self, n_visible, n_hiddens, v_unit=0, sample_v_states=True, sample_h_states=None,
                  n_particles=100, batch_size=100, max_mf_updates=10, mf_tol=1e-7, l2=0., max_norm=np.inf,
-                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9):
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, h_units=None, n_samples=None):
         self.V, self.nh = int(n_visible), [int(x) for x in n_hiddens]
         self.L, self.N, self.M = len(self.nh), int(batch_size), int(n_particles)
         c = DbmCfg()
+        for i in range(self.L):     # hidden layer kinds: 0 Bernoulli, 2 Multinomial(n_samples[i]) (layers.py:39-70)
+            c.h_unit[i] = int((h_units or [0] * self.L)[i])
+            c.n_samples[i] = int((n_samples or [0] * self.L)[i])
         c.L, c.V, c.v_unit, c.sample_v = self.L, self.V, int(v_unit), int(bool(sample_v_states))
         sh = sample_h_states or [True] * self.L
         st = sparsity_target if hasattr(sparsity_target, '__iter__') else [sparsity_target] * self.L

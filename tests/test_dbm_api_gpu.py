@@ -91,3 +91,35 @@ def test_errors(gpu_lib, tmp_path):
         dbm.transform(X)
     with pytest.raises(ValueError):
         dbm.fit(X[:15])                                                  # not a multiple of batch_size
+
+
+def test_gaussian_bernoulli_multinomial_stack(gpu_lib, tmp_path):
+    """the layer stack of examples/dbm_cifar.py in miniature: GaussianRBM -> BernoulliRBM/MultinomialRBM composed into
+    a G-B-M DBM (layers.py:54-70 inside dbm.py:385-427): fit, transform, reconstruct, sample_v, resume; log_Z and
+    log_proba refuse it like the reference (dbm.py:925-927, :947-948)."""
+    from boltzmann_machines_amd import GaussianRBM, MultinomialRBM
+    Xg = RNG(seed=2).randn(N, V).astype(np.float32)
+    g = GaussianRBM(n_visible=V, n_hidden=H1, dbm_first=True, sigma=1., learning_rate=1e-3, max_epoch=1, batch_size=BS,
+                    random_seed=5, verbose=False, model_path=str(tmp_path / 'g') + '/').fit(Xg)
+    Q = g.transform(Xg)
+    m = MultinomialRBM(n_visible=H1, n_hidden=H2, n_samples=6, dbm_last=True, learning_rate=1e-2, max_epoch=1, batch_size=BS,
+                       random_seed=6, verbose=False, model_path=str(tmp_path / 'm') + '/').fit(Q)
+    cfg = dict(rbms=[g, m], n_particles=BS, n_gibbs_steps=2, max_mf_updates=4, mf_tol=1e-4, learning_rate=1e-3, max_epoch=2,
+               batch_size=BS, l2=1e-4, random_seed=1337, verbose=False, model_path=str(tmp_path / 'gbm') + '/')
+    d1, d2 = DBM(**cfg), DBM(**dict(cfg, model_path=str(tmp_path / 'gbm2') + '/'))
+    assert d1.h_units_ == [0, 2] and d1.h_n_samples_ == [0, 6]
+    d1.fit(Xg); d2.fit(Xg)
+    w1, w2 = d1.get_tf_params('weights'), d2.get_tf_params('weights')
+    for k in ('W', 'W_1', 'hb', 'hb_1', 'vb'):
+        assert np.all(np.isfinite(w1[k])) and np.array_equal(w1[k], w2[k])
+    h_top = d1.get_tf_params('negative_particles')['h_1']
+    assert np.all(h_top.sum(axis=1) == 6)                                     # multinomial counts
+    T = d1.transform(Xg)
+    assert T.shape == (N, H2)
+    assert_allclose(T.sum(axis=1), 6.0, rtol=1e-5)                   # activation = n_samples * softmax
+    assert d1.reconstruct(Xg).shape == (N, V) and d1.sample_v(n_gibbs_steps=2).shape == (BS, V)
+    d3 = DBM.load_model(d1._model_dirpath)
+    assert d3.h_units_ == [0, 2] and d3.h_n_samples_ == [0, 6]
+    assert_allclose(d3.get_tf_params('weights')['W_1'], w1['W_1'])
+    with pytest.raises(AssertionError):
+        d1.log_Z(n_betas=5, n_runs=4)

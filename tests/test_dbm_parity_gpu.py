@@ -231,3 +231,40 @@ def test_ais_is_deterministic_and_geometry_invariant(gpu_lib, monkeypatch):
     c = eng.ais(n_betas=30, n_runs=100, k=1, seed=11, chain0=150)
     assert np.array_equal(c.view(np.uint32), a[150:250].view(np.uint32))
     eng.close()
+
+
+@pytest.mark.parametrize('V,nh,hu,ns,vu', [
+    (24, [16, 12], [0, 2], [0, 9], 1),          # Gaussian - Bernoulli - Multinomial: the layer stack of examples/dbm_cifar.py
+    (20, [12, 16, 8], [2, 0, 2], [7, 0, 5], 0),  # Multinomial first and last, Bernoulli in between
+    (18, [10], [2], [6], 0),
+])
+def test_multinomial_layers_bit_exact(gpu_lib, V, nh, hu, ns, vu):
+    """Multinomial hidden layers inside the DBM (layers.py:54-70): mean-field, PCD, train op and sample_v against the
+    oracle, bit-exact (logits GEMM + one-wave-per-row softmax / categorical counts)."""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    N = M = 10
+    kw = dict(max_mf_updates=5, mf_tol=1e-5, l2=1e-3, max_norm=1.5, sparsity_cost=[1e-2] * len(nh), sparsity_target=[0.2] * len(nh),
+              h_units=hu, n_samples=ns, v_unit=vu, sample_v_states=(vu == 0))
+    eng, twin = make_pair(V, nh, N, M, **kw)
+    eng.seed(42); twin.set_seed(42)
+    names = ['vb', 'dvb', 'v']
+    for i in range(len(nh)):
+        sfx = '' if i == 0 else '_%d' % i
+        names += [b + sfx for b in ('W', 'dW', 'hb', 'dhb', 'q_means', 'mu_means', 'mu', 'h')]
+    for s in range(2):
+        X = data(N, V, s) if vu == 0 else orc.normal(87654321, 500 + s, 0, N * V).reshape(N, V)
+        n1, m1 = eng.train_step(as_device(X), 0.02, 0.5, 2, want_msre=True)
+        n2, m2 = twin.train_step(X, 0.02, 0.5, 2, want_msre=True)
+        assert n1 == n2
+        np.testing.assert_allclose(m1, m2, rtol=1e-5)
+        assert_equal(eng, twin, names)
+    # the counts of a multinomial layer sum to n_samples in every row
+    for i, (u, n) in enumerate(zip(hu, ns)):
+        if u == 2:
+            h = eng.get('h' + ('' if i == 0 else '_%d' % i))
+            assert np.all(h.sum(axis=1) == n) and np.all(h == np.round(h))
+    Vd = DeviceArray((M, V))
+    eng.sample_v(2, Vd)
+    assert np.array_equal(Vd.numpy().view(np.uint32), twin.sample_v(2).view(np.uint32))
+    eng.close()

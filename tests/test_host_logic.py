@@ -125,12 +125,3 @@ def test_no_cpu_fallback_without_gpu():
     from boltzmann_machines_amd import BernoulliRBM
     with pytest.raises(_ffi.Bm355Error):
         BernoulliRBM(n_visible=8, n_hidden=4, verbose=False, model_path='/tmp/bm355_nogpu/').fit(np.zeros((4, 8)))
-
-
-def test_dbm_rejects_multinomial_layers():
-    """a MultinomialRBM cannot be stacked into the DBM engine: loud error, no silent Bernoulli substitute"""
-    from boltzmann_machines_amd import DBM, BernoulliRBM, MultinomialRBM
-    b = BernoulliRBM(n_visible=6, n_hidden=4)
-    m = MultinomialRBM(n_visible=4, n_hidden=3, n_samples=5)
-    with pytest.raises(NotImplementedError):
-        DBM(rbms=[b, m])

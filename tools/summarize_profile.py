@@ -1,61 +1,96 @@
 #!/usr/bin/env python
-"""Condense gpurun_out/prof_rN (written by tools/profile_r1.sh) into profiles/:
-kernel-trace stats, the PMC counters per kernel, and the HBM traffic figure that
-bench.py reports as roofline.traffic (FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM
-prescribes for wide coalesced reads on gfx950, plus WRITE_SIZE; both are in KiB)."""
+"""Condense gpurun_out/prof_rN/<config> (written by tools/profile_r2.sh) into profiles/:
+kernel-trace stats, the PMC counters per kernel, and the HBM traffic figure that bench.py reports as
+roofline.traffic (FETCH_SIZE doubled as MI355X_MICROARCH.md section HBM prescribes for wide coalesced
+reads on gfx950, plus WRITE_SIZE; both are in KiB), per STEP of the bench command.
+
+    python tools/summarize_profile.py gpurun_out/prof_r2 r2 [configs...]
+"""
 import collections
 import csv
+import glob
 import json
 import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r1'
-tag = sys.argv[2] if len(sys.argv) > 2 else 'r1'
+src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r2'
+tag = sys.argv[2] if len(sys.argv) > 2 else 'r2'
+configs = sys.argv[3:] or ['rbm', 'gibbs', 'grbm', 'dbm', 'ais']
 os.makedirs('profiles', exist_ok=True)
 
 
-totals = collections.defaultdict(float)      # counter -> sum over every dispatch of the engine's kernels
-ndisp = collections.defaultdict(int)         # kernel -> dispatches seen in the FETCH pass
+def find(d, pat):
+    f = glob.glob(os.path.join(d, '**', pat), recursive=True)
+    return f[0] if f else None
 
 
-def agg(path):
-    rows = list(csv.DictReader(open(path)))
-    a = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in rows:
-        if 'bm::' not in r['Kernel_Name']:
-            continue
-        a[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
-        totals[r['Counter_Name']] += float(r['Counter_Value'])
-        if r['Counter_Name'] == 'FETCH_SIZE':
-            ndisp[r['Kernel_Name']] += 1
-    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in a.items()}
+def bench_steps(log):
+    """steps + warmup + precondition launches are all profiled: per-step figures use the counted dispatches"""
+    try:
+        return json.loads(open(log).read().strip().splitlines()[-1])
+    except Exception:
+        return None
 
 
-shutil.copy(os.path.join(src, 'stats/s_kernel_stats.csv'), 'profiles/%s_kernel_stats.csv' % tag)
-stats = {r['Name']: r for r in csv.DictReader(open(os.path.join(src, 'stats/s_kernel_stats.csv')))}
-pmc = {}
-for sub, f in (('fetch', 'f'), ('write', 'w'), ('sq', 'q')):
-    for k, d in agg(os.path.join(src, sub, f + '_counter_collection.csv')).items():
-        pmc.setdefault(k, {}).update(d)
-# one grad_kernel dispatch per CD-1 update: per-update traffic = all engine dispatches / updates
-n_updates = max(1, sum(n for k, n in ndisp.items() if 'grad_kernel' in k))
-traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_updates
-lines = ['# rocprofv3 summary %s — `python bench.py` (BernoulliRBM 784x1024, CD-1, batch 512, 1x MI355X)' % tag, '',
-         '| kernel | calls | avg us (kernel-trace) | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | LDS bank-conflict cycles |',
-         '|---|---|---|---|---|---|---|---|']
-for k, d in sorted(pmc.items()):
-    st = stats.get(k, {})
-    busy = 100.0 * d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / max(d.get('SQ_BUSY_CYCLES', 1) / 32.0, 1)
-    fetch2 = 2 * d.get('FETCH_SIZE', 0) * 1024 / 1e6
-    lines.append('| `%s` | %s | %.2f | %.0f | %.1f | %.0f | %.1f | %.0f |' % (
-        k.split('(')[0], st.get('Calls', '?'), float(st.get('AverageNs', 0)) / 1e3, d.get('FETCH_SIZE', 0), fetch2,
-        d.get('WRITE_SIZE', 0), busy, d.get('SQ_LDS_BANK_CONFLICT', 0)))
-lines += ['', 'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs).',
-          'HBM-side traffic per CD-1 update (all engine dispatches of the counter pass / %d updates, FETCH doubled + WRITE): %.1f MB' % (n_updates, traffic / 1e6),
-          '(the working set is Infinity-Cache resident; these are L2-miss side counters, not DRAM bytes).', '']
-open('profiles/%s_summary.md' % tag, 'w').write('\n'.join(lines))
-json.dump({'traffic_bytes_per_update': traffic, 'pmc': pmc}, open('profiles/%s_pmc.json' % tag, 'w'), indent=1)
-if os.path.exists(os.path.join(src, 'bench_default.json')):
-    shutil.copy(os.path.join(src, 'bench_default.json'), 'profiles/%s_bench.json' % tag)
-print('\n'.join(lines))
+for cfg in configs:
+    d = os.path.join(src, cfg)
+    if not os.path.isdir(d):
+        continue
+    totals = collections.defaultdict(float)
+    ndisp = collections.defaultdict(int)
+
+    def agg(path):
+        rows = list(csv.DictReader(open(path)))
+        a = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows:
+            if 'bm::' not in r['Kernel_Name'] and 'bm64::' not in r['Kernel_Name']:
+                continue
+            a[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+            totals[r['Counter_Name']] += float(r['Counter_Value'])
+            if r['Counter_Name'] == 'FETCH_SIZE':
+                ndisp[r['Kernel_Name']] += 1
+        return {k: {c: sum(v) / len(v) for c, v in dd.items()} for k, dd in a.items()}
+
+    sfile = find(os.path.join(d, 'stats'), '*kernel_stats.csv')
+    stats = {}
+    if sfile:
+        shutil.copy(sfile, 'profiles/%s_%s_kernel_stats.csv' % (tag, cfg))
+        stats = {r['Name']: r for r in csv.DictReader(open(sfile))}
+    pmc = {}
+    for sub in ('fetch', 'write', 'sq'):
+        f = find(os.path.join(d, sub), '*counter_collection.csv')
+        if f:
+            for k, dd in agg(f).items():
+                pmc.setdefault(k, {}).update(dd)
+    # steps seen by the counter pass: one marker kernel per step
+    marker = {'rbm': 'grad_kernel', 'gibbs': None, 'grbm': 'maxnorm_kernel', 'dbm': 'dbm_bias_kernel', 'ais': 'ais_init_kernel'}[cfg]
+    if marker:
+        per = {'dbm_bias_kernel': 3}.get(marker, 1)
+        n_steps = max(1, sum(n for k, n in ndisp.items() if marker in k) // per)
+    else:       # gibbs: 2 act launches per sweep, 10 sweeps per step
+        n_steps = max(1, sum(n for k, n in ndisp.items() if 'act_kernel' in k) // 20)
+    traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_steps
+    lines = ['# rocprofv3 summary %s / %s - `python bench.py --config %s` on 1x MI355X' % (tag, cfg, cfg), '',
+             '| kernel | calls | avg us (kernel-trace) | total % | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | LDS bank-conflict cycles |',
+             '|---|---|---|---|---|---|---|---|---|']
+    names = sorted(set(pmc) | {k for k in stats if 'bm::' in k or 'bm64::' in k},
+                   key=lambda k: -float(stats.get(k, {}).get('TotalDurationNs', 0) or 0))
+    for k in names:
+        dd, st = pmc.get(k, {}), stats.get(k, {})
+        busy = 100.0 * dd.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / max(dd.get('SQ_BUSY_CYCLES', 1) / 32.0, 1)
+        lines.append('| `%s` | %s | %.2f | %s | %.0f | %.1f | %.0f | %s | %s |' % (
+            k.split('(')[0], st.get('Calls', '?'), float(st.get('AverageNs', 0) or 0) / 1e3, st.get('Percentage', '?'),
+            dd.get('FETCH_SIZE', 0), 2 * dd.get('FETCH_SIZE', 0) * 1024 / 1e6, dd.get('WRITE_SIZE', 0),
+            ('%.1f' % busy) if 'SQ_BUSY_CYCLES' in dd else '-', ('%.0f' % dd['SQ_LDS_BANK_CONFLICT']) if 'SQ_LDS_BANK_CONFLICT' in dd else '-'))
+    lines += ['', 'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs).',
+              'HBM-side traffic per bench step (all engine dispatches of the counter pass / %d steps, FETCH doubled + WRITE): %.1f MB' % (n_steps, traffic / 1e6),
+              '(working sets up to 256 MB are Infinity-Cache resident; these are L2-miss side counters, not DRAM bytes).', '']
+    b = os.path.join(src, cfg + '.bench.json')
+    if os.path.exists(b) and os.path.getsize(b) > 10:
+        shutil.copy(b, 'profiles/%s_%s_bench.json' % (tag, cfg))
+        lines += ['bench line of the same tree: `%s`' % open(b).read().strip()[:700], '']
+    open('profiles/%s_%s_summary.md' % (tag, cfg), 'w').write('\n'.join(lines))
+    json.dump({'traffic_bytes_per_update': traffic, 'steps_in_counter_pass': n_steps, 'pmc': pmc},
+              open('profiles/%s_%s_pmc.json' % (tag, cfg), 'w'), indent=1)
+    print('\n'.join(lines))
