@@ -45,7 +45,8 @@ struct bm_dbm {
     bool multinomial(int layer) const { return layer >= 0 && cfg.h_unit[layer] == BM_UNIT_MULTINOMIAL; }
     unsigned *flag = nullptr;                      // mean-field residual cell (= &ctl->maxdiff)
     MfCtl *ctl = nullptr;                          // device-side loop control
-    DevBuf mfblk;                                  // [L * BM_MF_SLOTS] per-workgroup residual slots (single-GPU mean field)
+    DevBuf mfblk;                                  // [2][MAXL * BM_MF_SLOTS] per-workgroup residual slots of the mean-field
+                                                   // sweeps, double-buffered by sweep parity (ActArgs::chk_ctl)
     Mat xw0;                                       // [N][n1] hoisted X.W0 of the current minibatch
     double *scal = nullptr;
     // AIS / ELBO workspaces (allocated on demand)
@@ -134,7 +135,7 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
 static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout, Mat *Hout,
                         bool update_v, bool sample, int t, int64_t row0,
                         unsigned *maxdiff = nullptr, const Mat *xw0 = nullptr, const int *skip = nullptr,
-                        float *mfblk = nullptr) {
+                        float *mfblk = nullptr, const float *chk_slots = nullptr) {
     const int L = h->L;
     for (int i = 0; i < L; ++i) {
         LayerIn below = (i == 0) ? vin : LayerIn{Hout[i - 1].p, Hout[i - 1].ld};       // NEW below   :400-402
@@ -144,6 +145,9 @@ static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout
         memset(&e, 0, sizeof(e));
         e.skip = skip;
         e.maxdiff_blk = (maxdiff && mfblk) ? mfblk + (size_t)i * BM_MF_SLOTS : nullptr;
+        if (i == 0 && chk_slots) {     // the sweep's first kernel evaluates the loop control of the previous sweep
+            e.chk_ctl = h->ctl; e.chk_slots = chk_slots; e.chk_n = L * BM_MF_SLOTS; e.chk_tol = h->cfg.mf_tol;
+        }
         if (i == 0 && xw0 && above.p && !h->multinomial(0)) {
             // mean-field: X.W0 is loop invariant — start the chain from the hoisted partial sum and
             // stream only the top-down segment (bit-identical to recomputing X.W0 every sweep)
@@ -240,6 +244,15 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
             hipLaunchKernelGGL(mf_latch_kernel, dim3(1), dim3(64), 0, h->stream, h->ctl, h->cfg.mf_tol, init);
             return 0;
         };
+        // Self-controlled sweeps (single GPU, Bernoulli layers, grids that fit the residual slots): the loop-control
+        // update of sweep s-1 is evaluated by the first kernel of sweep s (ActArgs::chk_ctl) from the slot set of
+        // the other parity; only the LAST sweep of a group needs the one-workgroup control kernel.  Otherwise
+        // (communicator installed, Multinomial layers, > BM_MF_SLOTS workgroups possible) one control step per sweep.
+        bool self_ctl = !h->comm;
+        for (int i = 0; i < L; ++i)
+            self_ctl = self_ctl && !h->multinomial(i) && ((h->n[i + 1] + 31) / 32) * ((N + 31) / 32) <= BM_MF_SLOTS;
+        const size_t set_sz = (size_t)MAXL * BM_MF_SLOTS;
+        if (self_ctl) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * set_sz * sizeof(float), h->stream));
         BM_TRY(ctl_step(1));
         int enq = 0;
         MfCtl host;
@@ -248,10 +261,20 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
             const int g = (h->cfg.max_mf_updates - enq < MF_GROUP) ? h->cfg.max_mf_updates - enq : MF_GROUP;
             for (int s = 0; s < g; ++s) {
                 // sweep number enq+s runs only if all before it ran, so its ping-pong parity is static
-                Mat *src = ((enq + s) & 1) ? h->mu_alt : h->mu, *dst = ((enq + s) & 1) ? h->mu : h->mu_alt;
-                gibbs_sweep(h, N, LayerIn{X_dev, h->V}, src, nullptr, dst, false, false, 0, 0, h->flag,
-                            hoist ? &h->xw0 : nullptr, &h->ctl->done, h->mfblk.p);
-                BM_TRY(ctl_step(0));
+                const int sw = enq + s;
+                Mat *src = (sw & 1) ? h->mu_alt : h->mu, *dst = (sw & 1) ? h->mu : h->mu_alt;
+                if (self_ctl) {
+                    float *mine = h->mfblk.p + (size_t)(sw & 1) * set_sz, *prev = h->mfblk.p + (size_t)((sw & 1) ^ 1) * set_sz;
+                    gibbs_sweep(h, N, LayerIn{X_dev, h->V}, src, nullptr, dst, false, false, 0, 0, h->flag,
+                                hoist ? &h->xw0 : nullptr, &h->ctl->done, mine, s > 0 ? prev : nullptr);
+                    if (s == g - 1)      // Check(last sweep of the group); it also clears the slots it read
+                        hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, 0,
+                                           mine, h->L * BM_MF_SLOTS);
+                } else {
+                    gibbs_sweep(h, N, LayerIn{X_dev, h->V}, src, nullptr, dst, false, false, 0, 0, h->flag,
+                                hoist ? &h->xw0 : nullptr, &h->ctl->done, h->mfblk.p);
+                    BM_TRY(ctl_step(0));
+                }
             }
             enq += g;
             BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
@@ -431,7 +454,7 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
         BM_TRY(h->grad.alloc(off + nsums));
         h->sums_p = h->grad.p + off;
     }
-    BM_TRY(h->mfblk.alloc((size_t)BM_DBM_MAX_LAYERS * BM_MF_SLOTS));
+    BM_TRY(h->mfblk.alloc(2 * (size_t)BM_DBM_MAX_LAYERS * BM_MF_SLOTS));
     BM_HIP(hipMalloc((void **)&h->ctl, sizeof(MfCtl)));
     BM_HIP(hipMemset(h->ctl, 0, sizeof(MfCtl)));
     h->flag = &h->ctl->maxdiff;

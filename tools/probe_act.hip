@@ -69,6 +69,18 @@ int main(int argc, char **argv) {
     RUN(33, "mfma + reads + writes")
     RUN(9, "mfma + writes + barrier")
     RUN(4, "mfma + reads + gloads + barrier")
+    printf("---- 8-wave geometry (the one the tuner picks at this shape)\n");
+    RUNG(GeoAct8, 1, 0, "8w full")
+    RUNG(GeoAct8, 1, 16, "8w no-epilogue")
+    RUNG(GeoAct8, 1, 1, "8w no-gload")
+    RUNG(GeoAct8, 1, 4, "8w no-ldswrite")
+    RUNG(GeoAct8, 1, 5, "8w no-gload no-ldswrite")
+    RUNG(GeoAct8, 1, 8, "8w no-ldsread")
+    RUNG(GeoAct8, 1, 13, "8w no-gload/write/read")
+    RUNG(GeoAct8, 1, 32, "8w no-barrier")
+    RUNG(GeoAct8, 1, 45, "8w only mfma (+epilogue)")
+    RUNG(GeoAct8, 1, 2, "8w no-mfma")
+    RUNG(GeoAct8, 1, 63, "8w nothing")
     {   // phase-ordered step with stamps (wave 0 and wave 3 of every workgroup, step 4)
         RUN(128, "phase-ordered steps")
         std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost));
