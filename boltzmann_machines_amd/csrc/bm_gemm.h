@@ -3,10 +3,21 @@
 // All contractions of the reference hot path (tf.matmul at base_rbm.py:329-337,
 // :447-448; dbm.py:390-425, :553-570, :650-694) are small dense fp32 GEMMs whose
 // result feeds a nonlinearity + a Bernoulli draw or a parameter update.  They are
-// computed with v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain) so that
-// the result of every dot product is BIT-IDENTICAL to the sequential chain
-//     acc = 0; for k in 0..K-1: acc = fmaf(p[k], q[k], acc)
-// which is the order the CPU oracle uses ("canonical order").
+// computed with v_mfma_f32_16x16x4_f32 (exact fp32: the instruction is the fma chain
+// acc = fmaf(a[g], b[g], acc) for g = 0..3 over the four k the lanes' 16-groups hold).
+//
+// "Canonical order"  — the order in which the products of one dot product
+// enter the chain, identical in oracle/bm_oracle.c, so that every result is BIT-IDENTICAL
+// between the CPU oracle and the GPU:
+//     for each aligned block of 16 k (m = 0, 1, ...):  for j = 0..3:  for g = 0..3:
+//         k = 16 m + 4 g + j;   acc = fmaf(p[k], q[k], acc)            (k >= K skipped)
+// i.e. MFMA step j of block m takes k = 16m + 4g + j from lane group g.  (Round 1 used plain
+// ascending k, which needs lane group g to hold k = 4 step + g: four DIFFERENT 16-byte chunks
+// of a k-contiguous row per lane.  With this order a lane's four steps are ONE 16-byte chunk
+// (k = 16m + 4g + {0,1,2,3}): one ds_read_b128 instead of four ds_read_b32, at twice the LDS
+// rate, and the chunk can be placed in LDS by the LDS-DMA engine, which moves whole 16-byte
+// pieces and cannot transpose within them.)  Segment 2 of a two-segment contraction starts
+// its own block structure at its k = 0.
 //
 // Geometry (wave64, gfx950), a compile-time parameter pack Geo<WI, WJ, MI, NJ, BK>:
 //   workgroup = WI x WJ waves; a wave owns MI x NJ MFMA tiles of 16 x 16 outputs, i.e.
@@ -18,24 +29,27 @@
 //       i = base + 8g + 2r + t  (r = register, t = tile) of output row j:
 //       two 16-byte stores and exactly two Philox blocks per lane.
 //   With MI = 1 a lane holds the 4 consecutive outputs i = base + 4g + r (one Philox block).
-//   K is streamed in BK chunks through a 3-slot LDS ring; global->VGPR loads run four
-//   chunks ahead (the whole problem is L2/MALL resident, the loop is latency- not
-//   bandwidth-limited).
 //
-// Operand storage:
-//   P is always k-major  [k][i] (i contiguous): W for prop-up, the maintained
-//     transpose Wt for prop-down, the hidden means for the outer products.
-//   Q is k-major [k][j] (outer products: X, v) or x-major [j][k] (propagations:
-//     rows of X / h, k contiguous).
-// LDS strides make every fragment read conflict free:
-//   P  MI=2 (ds_read_b64, 64 banks): stride == 32 (mod 64): lanes 0-15 cover 32
-//      consecutive dwords of row k, lanes 16-31 the other 32 banks with row k+1.
-//   P  MI=1 / Q KM (ds_read_b32, 32 banks): stride == 16 (mod 32).
-//   Q XM (ds_read_b32, half-wave passes over 32 banks): stride BK+2 == 2 (mod 4): bank =
-//      (2j + k) mod 32 is a bijection on 16 j x 2 k.  The b64 stores of an x-major tile go out
-//      in passes of 16 lanes; xm_slot() gives 16 consecutive lanes the first (or second) 8
-//      float4 of TWO adjacent rows, whose dwords 4c+{0,1} (+2 for the odd row) cover all 32
-//      banks (16 lanes of ONE row collide 2-way: rocprofv3 SQ_LDS_BANK_CONFLICT).
+// Data movement: K is streamed in BK chunks through a 4-slot LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: global -> LDS without passing through VGPRs; 1 KiB per wave
+// instruction, destination = wave-uniform base + 16 * lane).  The probe (tools/probe_act.hip)
+// priced round 1's VGPR -> ds_write staging at 2.0 of 13.4 us per propagation kernel and 1.9 of
+// 25.3 us per outer-product kernel: the LDS write port ingests ds_write data at ~70 B/clk, and
+// those cycles come out of the same pipe the fragment reads use.  DMA runs three chunks ahead
+// (counted s_waitcnt vmcnt + raw s_barrier: a __syncthreads() would drain the DMA queue).
+//
+// LDS images (no padding: a DMA piece is 1 KiB of consecutive LDS; bank conflicts are avoided
+// by XOR-swizzling WHICH global 16-byte chunk a lane fetches — tools/bank_check.py proves every
+// fragment read conflict free under the bank model of MI355X_MICROARCH.md):
+//   x-major tile [x rows][BK floats]  (propagation Q operands, W itself as the prop-down P):
+//       chunk c of row r sits at slot c ^ fx(r), fx(r) = r & 15 (BK = 64) | (r >> 1) & 7 (BK = 32);
+//       fragment of block m: ONE ds_read_b128 of chunk 4m + g.
+//   k-major tile [BK rows k][TX floats]  (W for the prop-up, every outer-product operand):
+//       chunk c of row k sits at slot c ^ (S * ((k >> 2) & 1)),  S = 4 (b32 reads) | 8 (b64 reads);
+//       fragment of step (m, j): row k = 16m + 4g + j, b32 (one sub-tile) or b64 (two interleaved).
+// Chunks that touch the end of a K segment, and every chunk of shapes that do not allow 16-byte
+// loads (template FAST = false), pass through registers (clamped / guarded loads, zero fill) and are
+// written to the SAME images with ds_write_b128.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,8 +57,8 @@
 namespace bm {
 
 // Side work hooks of the main loop: fill() runs in the shadow of the pipeline fill (the first
-// global round trip), drain() is issued before the MFMAs of the last two chunks (loads the
-// epilogue needs: their latency hides under ~2k cycles of matrix work).  Default: none.
+// global round trip), drain() is issued before the MFMAs of the last chunk (loads the
+// epilogue needs).  Default: none.
 struct NoSide {
     static constexpr bool kFinalSync = true;     // a following pipeline may refill the LDS ring
     __device__ __forceinline__ void fill() {}
@@ -53,54 +67,55 @@ struct NoSide {
 
 // compile-time ablation mask (template parameter ABL, 0 in the product; tools/probe_act.hip
 // instantiates other values to price each pipeline stage)
+//   bit 0: no global -> LDS traffic   bit 1: VALU instead of MFMA   bit 3: no fragment reads
+//   bit 4: no epilogue (act_kernel)   bit 5: no barriers             bit 6: register path for every chunk
+//   bit 7: no ping-pong (8-wave geometries run lock-stepped like the 4-wave ones)
 #define BM_ABL(bit) ((ABL >> (bit)) & 1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-constexpr int NT = 256;   // threads per workgroup of the non-tile kernels (column sums, max-norm)
-constexpr int NBUF = 3;   // LDS ring depth
+constexpr int NT = 256;        // threads per workgroup of the non-tile kernels (column sums, max-norm)
+constexpr int NBUF = 4;        // LDS ring depth
+constexpr int PF = NBUF - 1;   // DMA prefetch distance in chunks
 
 enum : int { KM = 0, XM = 1 };
 
-// Tile geometry (see the header comment).  GeoAct: propagations at the north-star shape
-// (batch 512 x 1024 hidden -> 16 x 16 = 256 tiles, one per CU); GeoGrad: 64 x 64 outer-product
-// tiles (4 MFMAs per fragment pair, 208 tiles at 784 x 1024).
+// Tile geometry (see the header comment).
 template <int WI_, int WJ_, int MI_, int NJ_, int BK_>
 struct Geo {
     static constexpr int WI = WI_, WJ = WJ_, MI = MI_, NJ = NJ_, BK = BK_;
-    static constexpr int NT = 64 * WI * WJ;              // threads per workgroup
+    static constexpr int NW = WI * WJ;                   // waves per workgroup
+    static constexpr int NT = 64 * NW;                   // threads per workgroup
     static constexpr int TI = 16 * MI * WI;              // tile extent along i
     static constexpr int TJ = 16 * NJ * WJ;              // tile extent along j
     static constexpr int E = 4 * MI;                     // consecutive outputs per lane and j sub-tile
-    static constexpr int P_STRIDE = (MI == 2) ? ((TI % 64 == 0) ? TI + 32 : TI) : ((TI % 32 == 0) ? TI + 16 : TI);
-    static constexpr int Q_STRIDE_XM = BK + 2;
-    // k-major Q: NJ == 2 interleaves the two j sub-tiles like the i side (sub-tile n holds
-    // j = base + 2*l15 + n: ONE ds_read_b64 per k-step, stride == 32 mod 64); NJ == 1 reads b32
-    static constexpr int Q_STRIDE_KM = (NJ == 2) ? ((TJ % 64 == 0) ? TJ + 32 : TJ) : ((TJ % 32 == 0) ? TJ + 16 : TJ);
-    // x-major P (MI == 1 only: W itself as the prop-down operand, no maintained transpose): same
-    // row stride and conflict rules as the x-major Q
-    static constexpr int P_STRIDE_XM = BK + 2;
-    static constexpr int P_BUF = (MI == 1 && TI * P_STRIDE_XM > BK * P_STRIDE) ? TI * P_STRIDE_XM : BK * P_STRIDE;
-    static constexpr int Q_BUF = (BK * Q_STRIDE_KM > TJ * Q_STRIDE_XM) ? BK * Q_STRIDE_KM : TJ * Q_STRIDE_XM;
+    static constexpr int P_BUF = TI * BK;                // floats of one P / Q tile chunk (no padding)
+    static constexpr int Q_BUF = TJ * BK;
     static constexpr int SMEM_FLOATS = NBUF * (P_BUF + Q_BUF);
-    static constexpr int NVP = TI * BK / (4 * NT);       // float4 per thread per chunk, P tile
+    static constexpr int NPP = P_BUF * 4 / (1024 * NW);  // 1 KiB DMA pieces per wave and chunk, P tile
+    static constexpr int NPQ = Q_BUF * 4 / (1024 * NW);  // ... Q tile
+    static constexpr int NVP = TI * BK / (4 * NT);       // float4 per thread per chunk (register path), P tile
     static constexpr int NVQ = TJ * BK / (4 * NT);       // ... Q tile
+    static constexpr int SP = (MI == 2) ? 8 : 4;         // k-major swizzle strides (see header)
+    static constexpr int SQ = (NJ == 2) ? 8 : 4;
     static_assert(MI == 1 || MI == 2, "MI");
     static_assert(NJ == 1 || NJ == 2, "NJ");
-    static_assert(NVP >= 1 && NVP * 4 * NT == TI * BK, "P chunk must split evenly over the threads");
-    static_assert(NVQ >= 1 && NVQ * 4 * NT == TJ * BK, "Q chunk must split evenly over the threads");
-    static_assert(BK % 8 == 0, "BK");
+    static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(NPP >= 1 && NPP * 1024 * NW == P_BUF * 4, "P chunk must split into whole DMA pieces per wave");
+    static_assert(NPQ >= 1 && NPQ * 1024 * NW == Q_BUF * 4, "Q chunk must split into whole DMA pieces per wave");
+    static_assert(NVP >= 1 && NVP * 4 * NT == TI * BK && NVQ >= 1 && NVQ * 4 * NT == TJ * BK, "register path split");
+    static_assert(SMEM_FLOATS * 4 <= 160 * 1024 - 1024, "LDS");
 };
-using GeoAct = Geo<2, 2, 2, 1, 64>;      // 64 x 32 tile, 4 waves of 32 x 16, 108 KiB LDS
+using GeoAct = Geo<2, 2, 2, 1, 64>;      // 64 x 32 tile, 4 waves of 32 x 16, 96 KiB LDS
 using GeoAct8 = Geo<2, 4, 1, 1, 64>;     // 32 x 64 tile, 8 waves of 16 x 16 (two per SIMD), 96 KiB LDS:
                                          // more LDS traffic per MFMA but half the per-wave fill and
                                          // epilogue; wins while the launch is about one tile per CU
-using GeoActS = Geo<2, 2, 1, 1, 64>;     // 32 x 32 tile, 4 waves of 16 x 16, 72 KiB LDS (two per CU): for
+using GeoActS = Geo<2, 2, 1, 1, 64>;     // 32 x 32 tile, 4 waves of 16 x 16, 64 KiB LDS (two per CU): for
                                          // outputs too small to give every CU a larger tile
-using GeoActS32 = Geo<2, 2, 1, 1, 32>;   // the same with BK = 32: 36 KiB LDS, up to four workgroups per CU
-using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 4 waves of 32 x 32, 144 KiB LDS
-using GeoGrad8 = Geo<2, 4, 2, 1, 64>;    // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD: one wave's LDS / global issue
-                                         // overlaps its partner's MFMAs), 132 KiB LDS
+using GeoActS32 = Geo<2, 2, 1, 1, 32>;   // the same with BK = 32: 32 KiB LDS, up to four workgroups per CU
+using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 4 waves of 32 x 32, 128 KiB LDS
+using GeoGrad8 = Geo<2, 4, 2, 1, 64>;    // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD), 128 KiB LDS
 
 struct Operand {
     const float *ptr;
@@ -116,11 +131,21 @@ static inline Operand make_operand(const float *p, int ld, int nx) {
     return o;
 }
 
-// host: can this operand take the branch-free load path?
+// host: can this operand take the 16-byte (DMA) path?
 static inline bool operand_fast(const Operand &o, int layout, int K) {
     if (!o.ptr) return true;                      // absent segment
     if (!o.vec) return false;
-    return layout == KM ? (o.nx % 4 == 0) : (K % 4 == 0);
+    return layout == KM ? (o.nx % 4 == 0 && o.nx >= 4) : (K % 4 == 0);
+}
+
+// ---- LDS image addressing -------------------------------------------------------------------
+template <int BK> __device__ __forceinline__ int fx(int row) { return (BK == 64) ? (row & 15) : ((row >> 1) & 7); }
+template <int S> __device__ __forceinline__ int fk(int row) { return S * ((row >> 2) & 1); }
+
+// float offset of 16-byte chunk c4 of tile row `row`; L = layout, TX = floats per k-major row, S = its swizzle
+template <int L, int TX, int BK, int S>
+__device__ __forceinline__ int img_off(int row, int c4) {
+    return (L == XM) ? row * BK + ((c4 ^ fx<BK>(row)) << 2) : row * TX + ((c4 ^ fk<S>(row)) << 2);
 }
 
 __device__ __forceinline__ float4 load4_guard(const float *p, bool row_ok, int col, int ncols, bool vec) {
@@ -138,40 +163,22 @@ __device__ __forceinline__ float4 load4_guard(const float *p, bool row_ok, int c
     return v;
 }
 
-// float4 slot f of an x-major tile chunk -> (row, c4); see the bank note in the header
-template <int BK>
-__device__ __forceinline__ void xm_slot(int f, int &row, int &c4) {
-    constexpr int C = BK / 4;                  // float4 per row
-    static_assert(C % 8 == 0, "xm_slot: rows of at least 8 float4");
-    const int blk = f / (2 * C), r = f % (2 * C);          // two rows per block of 2*C slots
-    const int q = r / 8;                                   // run of 8 lanes
-    row = 2 * blk + (q & 1);
-    c4 = (q >> 1) * 8 + (r & 7);
-}
-
-// global -> registers for one BK chunk of one operand tile (TX = tile extent along x,
-// NTH = threads of the workgroup).
-// FAST: every float4 is either fully inside or fully outside the operand (host
-// guarantees 16B alignment, ld % 4 == 0 and a contiguous extent % 4 == 0), so the
-// load is unconditional and branch free: indices are clamped into range; the K tail is
-// zeroed when the set is stored to LDS, and x-tail garbage only reaches outputs
-// i >= I / j >= J, which are never stored.
+// ---- register path (chunks that touch the end of a segment; every chunk when !FAST) ------------
+// global -> registers for one BK chunk of one operand tile.  float4 slot f = tid + n*NTH covers tile row
+// f / (row float4s), chunk f % (row float4s).  FAST: every float4 is either fully inside or fully outside
+// the operand, so the load is unconditional with clamped indices; the K tail is zeroed at the LDS store,
+// x-tail garbage only reaches outputs i >= I / j >= J, which are never stored.
 template <int L, int TX, int BK, int NTH, bool FAST>
 __device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NTH)], const float *ptr, int ld, int nx, int vec,
                                     int x0, int k0, int K, int tid) {
-    constexpr int NV = TX * BK / (4 * NTH);   // float4 per thread
+    constexpr int NV = TX * BK / (4 * NTH);
+    constexpr int RC = (L == KM) ? TX / 4 : BK / 4;      // float4 per tile row
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int f = tid + n * NTH;
-        int k, x;
-        if (L == KM) {
-            const int row = f / (TX / 4), c4 = f % (TX / 4);
-            k = k0 + row; x = x0 + c4 * 4;
-        } else {
-            int row, c4;
-            xm_slot<BK>(f, row, c4);
-            x = x0 + row; k = k0 + c4 * 4;
-        }
+        const int row = f / RC, c4 = f % RC;
+        const int k = (L == KM) ? k0 + row : k0 + c4 * 4;
+        const int x = (L == KM) ? x0 + c4 * 4 : x0 + row;
         if (FAST) {
             const int kc = (L == KM) ? min(k, K - 1) : min(k, K - 4);
             const int xc = (L == KM) ? min(x, nx - 4) : min(x, nx - 1);
@@ -185,70 +192,102 @@ __device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NTH)], const fl
     }
 }
 
-// registers -> LDS.  kz = K - k0 (rows/cols of this chunk at k >= K are zeroed; only the
-// FAST path needs it, the guarded loads already returned zeros).  STRIDE = LDS row stride
-// of this layout (k rows for KM, x rows for XM).
-template <int L, int TX, int BK, int NTH, int STRIDE, bool FAST>
+// registers -> LDS image.  kz = K - k0: rows / columns of this chunk at k >= K are zeroed.
+template <int L, int TX, int BK, int NTH, int S, bool ZF = true>
 __device__ __forceinline__ void r2s(const float4 (&reg)[TX * BK / (4 * NTH)], float *s, int tid, int kz) {
     constexpr int NV = TX * BK / (4 * NTH);
+    constexpr int RC = (L == KM) ? TX / 4 : BK / 4;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int f = tid + n * NTH;
+        const int row = f / RC, c4 = f % RC;
         float4 v = reg[n];
-        if (L == KM) {
-            const int row = f / (TX / 4), c4 = f % (TX / 4);
-            if (FAST && row >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 *d = reinterpret_cast<float2 *>(s + row * STRIDE + c4 * 4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+        if (!ZF) {
+        } else if (L == KM) {
+            if (row >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            int row, c4;
-            xm_slot<BK>(f, row, c4);
-            if (FAST && c4 * 4 >= kz) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float2 *d = reinterpret_cast<float2 *>(s + row * STRIDE + c4 * 4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+            const int k = c4 * 4;
+            if (k     >= kz) v.x = 0.f;
+            if (k + 1 >= kz) v.y = 0.f;
+            if (k + 2 >= kz) v.z = 0.f;
+            if (k + 3 >= kz) v.w = 0.f;
         }
+        *reinterpret_cast<float4 *>(s + img_off<L, TX, BK, S>(row, c4)) = v;
     }
 }
 
-// MFMA operand fragments of one BK chunk for this wave (48 VGPRs for GeoAct)
+// MFMA operand fragments of one BK chunk for this wave
 template <class G> struct Frags {
-    float p[G::BK / 4][G::MI];     // p[kk][t] = P[k = 4kk+g][i = base + MI*l15 + t]
-    float q[G::BK / 4][G::NJ];     // q[kk][n] = Q[j = 16n + l15][k = 4kk+g]
+    float p[G::BK / 4][G::MI];     // p[4m+j][t] = P[k = 16m + 4g + j][i = base + MI*l15 + t]
+    float q[G::BK / 4][G::NJ];     // q[4m+j][n] = Q[j' = lane_j(l15, n)][k = 16m + 4g + j]
 };
 
 template <int QL, class G, int ABL = 0, int PL = KM>
 __device__ __forceinline__ void read_frags(Frags<G> &f, const float *sP, const float *sQ, int wi, int wj, int lane) {
     static_assert(PL == KM || G::MI == 1, "x-major P needs MI == 1 (no interleaved sub-tiles)");
+    constexpr int BK = G::BK;
     const int g = lane >> 4, l15 = lane & 15;
-    const float *pP = (PL == KM) ? sP + g * G::P_STRIDE + wi * (16 * G::MI) + G::MI * l15
-                                 : sP + (wi * 16 + l15) * G::P_STRIDE_XM + g;
-    const float *pQ = (QL == KM) ? sQ + g * G::Q_STRIDE_KM + wj * 16 * G::NJ + ((G::NJ == 2) ? 2 * l15 : l15)
-                                 : sQ + (wj * 16 * G::NJ + l15) * G::Q_STRIDE_XM + g;
+    if (BM_ABL(3)) {
 #pragma unroll
-    for (int kk = 0; kk < G::BK / 4; ++kk) {
-        if (BM_ABL(3)) { f.p[kk][0] = 1.f; if (G::MI == 2) f.p[kk][G::MI - 1] = 2.f; f.q[kk][0] = 1.f; continue; }
-        // (hipcc fuses pairs of these into ds_read2st64_b64; keeping them as separate ds_read_b64
-        // was measured 34 % SLOWER in the loop, so the fused form stays)
-        if (G::MI == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(pP + kk * 4 * G::P_STRIDE);
-            f.p[kk][0] = t.x; f.p[kk][G::MI - 1] = t.y;
-        } else {
-            f.p[kk][0] = (PL == KM) ? pP[kk * 4 * G::P_STRIDE] : pP[kk * 4];
-        }
-        if (QL == KM && G::NJ == 2) {
-            const float2 t = *reinterpret_cast<const float2 *>(pQ + kk * 4 * G::Q_STRIDE_KM);
-            f.q[kk][0] = t.x; f.q[kk][G::NJ - 1] = t.y;
-        } else {
+        for (int kk = 0; kk < BK / 4; ++kk) { f.p[kk][0] = 1.f; f.p[kk][G::MI - 1] = 2.f; f.q[kk][0] = 1.f; f.q[kk][G::NJ - 1] = 1.f; }
+        return;
+    }
+    // ---- P
+    if (PL == XM) {
+        const int row = wi * 16 + l15;
 #pragma unroll
-            for (int n = 0; n < G::NJ; ++n)
-                f.q[kk][n] = (QL == KM) ? pQ[kk * 4 * G::Q_STRIDE_KM + 16 * n] : pQ[16 * n * G::Q_STRIDE_XM + kk * 4];
+        for (int m = 0; m < BK / 16; ++m) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(sP + img_off<XM, 0, BK, 0>(row, 4 * m + g));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f.p[4 * m + j][0] = v[j];
         }
+    } else {
+        const int col = wi * (16 * G::MI) + G::MI * l15;          // MI == 2: even, both floats in one chunk
+#pragma unroll
+        for (int m = 0; m < BK / 16; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * m + 4 * g + j;
+                const float *a = sP + row * G::TI + (((col >> 2) ^ fk<G::SP>(row)) << 2) + (col & 3);
+                if (G::MI == 2) {
+                    const f32x2v t = *reinterpret_cast<const f32x2v *>(a);
+                    f.p[4 * m + j][0] = t[0]; f.p[4 * m + j][G::MI - 1] = t[1];
+                } else {
+                    f.p[4 * m + j][0] = *a;
+                }
+            }
+    }
+    // ---- Q
+    if (QL == XM) {
+#pragma unroll
+        for (int n = 0; n < G::NJ; ++n) {
+            const int row = wj * (16 * G::NJ) + 16 * n + l15;
+#pragma unroll
+            for (int m = 0; m < BK / 16; ++m) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sQ + img_off<XM, 0, BK, 0>(row, 4 * m + g));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f.q[4 * m + j][n] = v[j];
+            }
+        }
+    } else {
+        const int col = wj * (16 * G::NJ) + G::NJ * l15;          // NJ == 2: sub-tile n holds j = base + 2*l15 + n
+#pragma unroll
+        for (int m = 0; m < BK / 16; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = 16 * m + 4 * g + j;
+                const float *a = sQ + row * G::TJ + (((col >> 2) ^ fk<G::SQ>(row)) << 2) + (col & 3);
+                if (G::NJ == 2) {
+                    const f32x2v t = *reinterpret_cast<const f32x2v *>(a);
+                    f.q[4 * m + j][0] = t[0]; f.q[4 * m + j][G::NJ - 1] = t[1];
+                } else {
+                    f.q[4 * m + j][0] = *a;
+                }
+            }
     }
 }
 
-// acc[t][n] += P-frag(t) x Q-frag(n)
+// acc[t][n] += P-frag(t) x Q-frag(n), every k block of the chunk
 template <class G, int ABL = 0>
 __device__ __forceinline__ void mfma_frags(f32x4 (&acc)[G::MI][G::NJ], const Frags<G> &f) {
 #pragma unroll
@@ -265,8 +304,8 @@ __device__ __forceinline__ void mfma_frags(f32x4 (&acc)[G::MI][G::NJ], const Fra
     }
 }
 
-// the same for the first `nq` groups of 4 k-steps only (last chunk of a contraction whose
-// K tail is shorter than BK: the zero-filled remainder would only add fma(0, 0, acc))
+// the same for the first `nq` blocks of 16 k only (last chunk of a contraction whose K tail is shorter than BK:
+// the zero-filled remainder would only add fma(0, 0, acc))
 template <class G, int ABL = 0>
 __device__ __forceinline__ void mfma_frags_head(f32x4 (&acc)[G::MI][G::NJ], const Frags<G> &f, int nq) {
 #pragma unroll
@@ -288,7 +327,7 @@ __device__ __forceinline__ void mfma_frags_head(f32x4 (&acc)[G::MI][G::NJ], cons
     }
 }
 
-// one register set = one BK chunk of both operand tiles, global -> VGPR staging
+// one register set = one BK chunk of both operand tiles (register path)
 template <class G> struct ChunkRegs {
     float4 p[G::NVP];
     float4 q[G::NVQ];
@@ -303,13 +342,85 @@ struct KRange {
     Operand P2, Q2; int K2;     // K2 == 0: absent
 };
 
-// branch-free wave-uniform selects (a branch inside a step would split its scheduling region)
+// branch-free wave-uniform selects
 __device__ __forceinline__ int sel_i(int a, int b, int m) { return a ^ ((a ^ b) & m); }
 __device__ __forceinline__ const float *sel_p(const float *a, const float *b, int m) {
     const uintptr_t ua = (uintptr_t)a, ub = (uintptr_t)b;
     return (const float *)(ua ^ ((ua ^ ub) & (uintptr_t)(intptr_t)m));
 }
 
+// ---- LDS-DMA plan: per-lane byte offsets (relative to the chunk base of the operand) of the 16-byte
+// global chunk this lane moves in each of the wave's pieces; piece n of wave w is piece p = w + n*NW of the
+// tile image (1 KiB = 64 consecutive 16-byte slots: lane l fills slot l of the piece).
+template <class G> struct DmaPlan {
+    uint32_t p[G::NPP], q[G::NPQ];
+};
+
+template <int L, int TX, int BK, int NW, int NP, int S>
+__device__ __forceinline__ void plan_offsets(uint32_t (&off)[NP], int ld, int nx, int x0, int wave, int lane) {
+    constexpr int RC = (L == KM) ? TX / 4 : BK / 4;      // 16-byte slots per image row
+    constexpr int R = 64 / RC;                           // image rows per piece
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+        const int pc = wave + n * NW;
+        const int row = pc * R + lane / RC, slot = lane % RC;
+        if (L == KM) {
+            const int c4 = slot ^ fk<S>(row);
+            off[n] = (uint32_t)(row * ld + min(x0 + c4 * 4, nx - 4)) * 4u;
+        } else {
+            const int c4 = slot ^ fx<BK>(row);
+            off[n] = (uint32_t)(min(x0 + row, nx - 1) * ld + c4 * 4) * 4u;
+        }
+    }
+}
+
+template <int QL, class G, int PL = KM>
+__device__ __forceinline__ void make_plan(DmaPlan<G> &pl, const Operand &P, const Operand &Q, int i0, int j0, int wave, int lane) {
+    plan_offsets<PL, G::TI, G::BK, G::NW, G::NPP, G::SP>(pl.p, P.ld, P.nx, i0, wave, lane);
+    plan_offsets<QL, G::TJ, G::BK, G::NW, G::NPQ, G::SQ>(pl.q, Q.ld, Q.nx, j0, wave, lane);
+}
+
+// One LDS-DMA wave instruction: 64 lanes x 16 bytes from each lane's `src` to lds_dst + 16 * lane.
+// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin hipcc (ROCm 7.2) treats every later
+// ds_read as a possible reader of the DMA's destination and puts `s_waitcnt vmcnt(0)` in front of it, i.e.
+// it drains the DMA queue in the very step that filled it.  The asm form is invisible to that bookkeeping:
+// completion is counted by hand (BM_WAIT_VM + barrier before the first read of a slot; cdna_hip_programming.md
+// "What hipcc does not do").  M0 (the DMA's LDS base) is written in the same statement that uses it.
+__device__ __forceinline__ void dma16(const char *src, float *lds_dst) {
+    unsigned keep;
+    const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+}
+
+// chunk c (a FULL chunk of its segment) -> LDS slot images sP / sQ, all pieces of this wave
+template <int QL, class G, bool SEG2, int PL = KM>
+__device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G> &pl1, const DmaPlan<G> &pl2, int nch1, int c,
+                                          float *sP, float *sQ, int wave) {
+    constexpr int BK = G::BK;
+    const int m = SEG2 ? -(int)(c >= nch1) : 0;           // all-ones in segment 2 (wave-uniform)
+    const int kc = c - (nch1 & m);
+    const int ldp = SEG2 ? sel_i(kr.P1.ld, kr.P2.ld, m) : kr.P1.ld;
+    const int ldq = SEG2 ? sel_i(kr.Q1.ld, kr.Q2.ld, m) : kr.Q1.ld;
+    const char *pb = (const char *)((SEG2 ? sel_p(kr.P1.ptr, kr.P2.ptr, m) : kr.P1.ptr) +
+                                    ((PL == KM) ? (size_t)kc * BK * ldp : (size_t)kc * BK));
+    const char *qb = (const char *)((SEG2 ? sel_p(kr.Q1.ptr, kr.Q2.ptr, m) : kr.Q1.ptr) +
+                                    ((QL == KM) ? (size_t)kc * BK * ldq : (size_t)kc * BK));
+#pragma unroll
+    for (int n = 0; n < G::NPP; ++n) {
+        const uint32_t o1 = pl1.p[n], o2 = SEG2 ? pl2.p[n] : 0u;
+        const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
+        dma16(pb + o, sP + (wave + n * G::NW) * 256);
+    }
+#pragma unroll
+    for (int n = 0; n < G::NPQ; ++n) {
+        const uint32_t o1 = pl1.q[n], o2 = SEG2 ? pl2.q[n] : 0u;
+        const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
+        dma16(qb + o, sQ + (wave + n * G::NW) * 256);
+    }
+}
+
+// register path: load chunk c (any chunk) / store it into the slot images with the K-tail zero fill
 template <int QL, class G, bool FAST, bool SEG2, int PL = KM>
 __device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, int nch1, int i0, int j0, int c, int tid) {
     constexpr int BK = G::BK;
@@ -327,58 +438,47 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, in
     }
 }
 
-template <int QL, class G, bool FAST, bool SEG2, int PL = KM>
+template <int QL, class G, bool SEG2, int PL = KM>
 __device__ __forceinline__ void store_chunk(const ChunkRegs<G> &r, const KRange &kr, int nch1, int c,
                                             float *sP, float *sQ, int tid) {
     constexpr int BK = G::BK;
     const int m = SEG2 ? -(int)((c >= nch1) & (kr.K2 > 0)) : 0;
     const int kz = sel_i(kr.K1, kr.K2, m) - (c - (nch1 & m)) * BK;
-    r2s<PL, G::TI, BK, G::NT, (PL == KM) ? G::P_STRIDE : G::P_STRIDE_XM, FAST>(r.p, sP, tid, kz);
-    r2s<QL, G::TJ, BK, G::NT, (QL == KM) ? G::Q_STRIDE_KM : G::Q_STRIDE_XM, FAST>(r.q, sQ, tid, kz);
+    r2s<PL, G::TI, BK, G::NT, G::SP>(r.p, sP, tid, kz);
+    r2s<QL, G::TJ, BK, G::NT, G::SQ>(r.q, sQ, tid, kz);
 }
 
-// ---- steady-state ("slim") chunk path -------------------------------------------------------
-// One wave issues its instructions strictly in order and an MFMA holds the wave for its 32
-// cycles (tools/ubench.hip: MFMA + n VALU = 41 + 4.4 n cycles in one wave), so every VALU
-// instruction inside the K loop is paid in full.  For chunks that lie completely inside K the
-// loads therefore use per-thread byte offsets computed ONCE per kernel (x clamps folded in)
-// on top of a wave-uniform chunk base (SGPR arithmetic), and the LDS stores skip the K-tail
-// zero fill.  Chunks that touch the end of a segment go through load_chunk/store_chunk above.
-template <class G> struct LoadPlan {
-    uint32_t p[G::NVP], q[G::NVQ];     // byte offsets relative to the chunk base of the operand
+// ---- register staging of FULL chunks ("REG" steady steps; the alternative to LDS-DMA, chosen per shape by
+// measurement: a DMA wave instruction holds the issuing wave ~75 cycles, which the 4-wave outer-product kernel
+// - one wave per SIMD, 8 pieces per wave and step - cannot hide, while global_load_dwordx4 + ds_write_b128 cost it
+// less issue time).  Per-thread byte offsets are computed once per kernel on top of a wave-uniform chunk base.
+template <class G> struct RegPlan {
+    uint32_t p[G::NVP], q[G::NVQ];
 };
-
 template <int L, int TX, int BK, int NTH>
-__device__ __forceinline__ void plan_offsets(uint32_t (&off)[TX * BK / (4 * NTH)], int ld, int nx, int x0, int tid) {
+__device__ __forceinline__ void reg_offsets(uint32_t (&off)[TX * BK / (4 * NTH)], int ld, int nx, int x0, int tid) {
     constexpr int NV = TX * BK / (4 * NTH);
+    constexpr int RC = (L == KM) ? TX / 4 : BK / 4;
 #pragma unroll
     for (int n = 0; n < NV; ++n) {
         const int f = tid + n * NTH;
-        if (L == KM) {
-            const int row = f / (TX / 4), c4 = f % (TX / 4);
-            off[n] = (uint32_t)(row * ld + min(x0 + c4 * 4, nx - 4)) * 4u;
-        } else {
-            int row, c4;
-            xm_slot<BK>(f, row, c4);
-            off[n] = (uint32_t)(min(x0 + row, nx - 1) * ld + c4 * 4) * 4u;
-        }
+        const int row = f / RC, c4 = f % RC;
+        off[n] = (L == KM) ? (uint32_t)(row * ld + min(x0 + c4 * 4, nx - 4)) * 4u
+                           : (uint32_t)(min(x0 + row, nx - 1) * ld + c4 * 4) * 4u;
     }
 }
-
 template <int QL, class G, int PL = KM>
-__device__ __forceinline__ void make_plan(LoadPlan<G> &pl, const Operand &P, const Operand &Q, int i0, int j0, int tid) {
-    plan_offsets<PL, G::TI, G::BK, G::NT>(pl.p, P.ld, P.nx, i0, tid);
-    plan_offsets<QL, G::TJ, G::BK, G::NT>(pl.q, Q.ld, Q.nx, j0, tid);
+__device__ __forceinline__ void make_reg_plan(RegPlan<G> &pl, const Operand &P, const Operand &Q, int i0, int j0, int tid) {
+    reg_offsets<PL, G::TI, G::BK, G::NT>(pl.p, P.ld, P.nx, i0, tid);
+    reg_offsets<QL, G::TJ, G::BK, G::NT>(pl.q, Q.ld, Q.nx, j0, tid);
 }
-
-// chunk c (must be a FULL chunk of its segment; c >= nch: prefetch overrun, any full chunk does)
+// chunk c (a FULL chunk of its segment) -> registers
 template <int QL, class G, bool SEG2, int PL = KM>
-__device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &kr, const LoadPlan<G> &pl1,
-                                                const LoadPlan<G> &pl2, int nch1, int nch, int c) {
+__device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &kr, const RegPlan<G> &pl1,
+                                                const RegPlan<G> &pl2, int nch1, int c) {
     constexpr int BK = G::BK;
-    const int cl = (c < nch) ? c : 0;
-    const int m = SEG2 ? -(int)(cl >= nch1) : 0;          // all-ones in segment 2 (wave-uniform)
-    const int kc = cl - (nch1 & m);
+    const int m = SEG2 ? -(int)(c >= nch1) : 0;           // all-ones in segment 2 (wave-uniform)
+    const int kc = c - (nch1 & m);
     const int ldp = SEG2 ? sel_i(kr.P1.ld, kr.P2.ld, m) : kr.P1.ld;
     const int ldq = SEG2 ? sel_i(kr.Q1.ld, kr.Q2.ld, m) : kr.Q1.ld;
     const char *pb = (const char *)((SEG2 ? sel_p(kr.P1.ptr, kr.P2.ptr, m) : kr.P1.ptr) +
@@ -398,30 +498,35 @@ __device__ __forceinline__ void load_chunk_slim(ChunkRegs<G> &r, const KRange &k
         r.q[n] = *reinterpret_cast<const float4 *>(qb + o);
     }
 }
-
 template <int QL, class G, int PL = KM>
 __device__ __forceinline__ void store_chunk_slim(const ChunkRegs<G> &r, float *sP, float *sQ, int tid) {
-    r2s<PL, G::TI, G::BK, G::NT, (PL == KM) ? G::P_STRIDE : G::P_STRIDE_XM, false>(r.p, sP, tid, 0);
-    r2s<QL, G::TJ, G::BK, G::NT, (QL == KM) ? G::Q_STRIDE_KM : G::Q_STRIDE_XM, false>(r.q, sQ, tid, 0);
+    r2s<PL, G::TI, G::BK, G::NT, G::SP, false>(r.p, sP, tid, 0);
+    r2s<QL, G::TJ, G::BK, G::NT, G::SQ, false>(r.q, sQ, tid, 0);
 }
 
-// acc += sum_k P[k][i] * Q[j][k] over the K range, k ascending (canonical order).
+enum : int { STG_DMA = 0, STG_REG = 1 };
+
+// counted waits / raw barrier (a __syncthreads() would insert vmcnt(0) and drain the DMA queue)
+#define BM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads / writes have completed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// acc += sum_k P[k][i] * Q[j][k] over the K range in canonical order (header).
 //
-// The loop is software-pipelined by hand over a 3-deep LDS ring.  In step c (between
-// barriers B(c-1) and B(c)) a wave
+// Pipeline: chunk c lives in LDS slot c % 4.  Step c (between barriers B(c-1) and B(c)):
+//   * starts chunk c+3 by LDS-DMA into slot (c+3) % 4 (last read for F(c-1) in step c-2),
 //   * runs the MFMAs of chunk c on fragments F(c) that are ALREADY in registers,
-//   * reads the fragments F(c+1) from LDS slot (c+1)%3 (published by B(c-1)),
-//   * stores chunk c+2 (global data that arrived in registers) to LDS slot (c+2)%3
-//     (last read for F(c-1), complete before B(c-2)),
-//   * re-issues the global loads of chunk c+4 into the register set just stored.
-// sched_group_barrier pins that issue order: hipcc otherwise issues the LDS traffic
-// AFTER the MFMAs and the two phases run back to back.  Steps come in two flavours, chosen
-// per PAIR of steps by a wave-uniform branch around the whole pair (so each flavour is one
-// scheduling region): the slim one for full chunks (see LoadPlan) and the careful one
-// (clamped loads, K-tail zero fill) for chunks that touch the end of a segment.
-// `side.fill()` (the lane's Philox blocks in act_kernel) runs while the first loads are in
-// flight, when the wave would otherwise idle for one memory round trip.
-template <int QL, class G, bool FAST, bool SEG2, int ABL = 0, int PL = KM, class Side = NoSide>
+//   * reads the fragments F(c+1) from slot (c+1) % 4,
+//   * waits until its own DMA pieces of chunk c+2 have landed (vmcnt(pieces of chunk c+3)), then B(c).
+// A chunk that touches the end of a segment (and every chunk when !FAST) goes through registers instead:
+// loaded at the start of step c-2, written to its slot at the end of that step.  The leading run of steps
+// whose DMA chunk and whose next-but-one chunk are both DMA chunks is straight-line code ("steady" steps:
+// sched_group_barrier pins the MFMA / DMA / LDS-read interleave); the rest takes the general step.
+// `side.fill()` (the lane's Philox blocks in act_kernel) runs while the first loads are in flight.
+template <int QL, class G, bool FAST, bool SEG2, int ABL = 0, int PL = KM, int STG = STG_DMA, class Side = NoSide>
 __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRange &kr, int i0, int j0, float *smem,
                                          Side &side, long long *stamps = nullptr) {
 #ifdef BM_PROBE
@@ -430,197 +535,239 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #define BM_MSTAMP(n) do {} while (0)
 #endif
     constexpr int BK = G::BK, P_BUF = G::P_BUF, Q_BUF = G::Q_BUF;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NPW = G::NPP + G::NPQ;              // DMA instructions per wave and chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (SGPR): LDS piece bases stay scalar
     const int wi = w % G::WI, wj = w / G::WI;
     float *sP = smem, *sQ = smem + NBUF * P_BUF;
     const int nch1 = (kr.K1 + BK - 1) / BK;
     const int nch = nch1 + (SEG2 ? (kr.K2 + BK - 1) / BK : 0);
     const int nfull1 = kr.K1 / BK, nfull2 = SEG2 ? kr.K2 / BK : 0;
-    ChunkRegs<G> g0, g1;      // named sets (never arrays: must stay in VGPRs)
+    // can chunk c be moved by DMA?  (a full chunk of its segment, 16-byte-legal operands)
+    auto is_full = [&](int c) -> bool {               // a full chunk of its segment
+        return (c < nfull1) | (SEG2 && c >= nch1 && c - nch1 < nfull2);
+    };
+    auto is_dma = [&](int c) -> bool {
+        if (!FAST || STG != STG_DMA || BM_ABL(6)) return false;
+        return is_full(c);
+    };
+    ChunkRegs<G> gr;             // register-path staging (one chunk)
     Frags<G> fa, fb;
-    LoadPlan<G> pl1, pl2;
-    if (FAST) {
-        make_plan<QL, G, PL>(pl1, kr.P1, kr.Q1, i0, j0, tid);
-        if (SEG2) make_plan<QL, G, PL>(pl2, kr.P2, kr.Q2, i0, j0, tid);
+    DmaPlan<G> pl1, pl2;
+    RegPlan<G> rp1, rp2;
+    ChunkRegs<G> g0, g1;         // REG staging: the two register sets of the steady steps (named, never arrays)
+    if (FAST && STG == STG_DMA) {
+        make_plan<QL, G, PL>(pl1, kr.P1, kr.Q1, i0, j0, w, lane);
+        if (SEG2) make_plan<QL, G, PL>(pl2, kr.P2, kr.Q2, i0, j0, w, lane);
+    }
+    // REG staging: leading run of steps c whose chunks c+2 (stored) and c+4 (loaded) are full chunks; chunks
+    // 0 .. 3 are then full as well and go through the same slim path in the fill
+    int n_reg = 0;
+    if (FAST && STG == STG_REG && !BM_ABL(6) && !BM_ABL(0)) {
+        while (n_reg + 4 < nch && is_full(n_reg + 4) && is_full(n_reg + 2)) ++n_reg;
+        n_reg &= ~1;
+        if (n_reg > 0 && !(is_full(0) && is_full(1) && is_full(2) && is_full(3))) n_reg = 0;
+        if (n_reg > 0) {
+            make_reg_plan<QL, G, PL>(rp1, kr.P1, kr.Q1, i0, j0, tid);
+            if (SEG2) make_reg_plan<QL, G, PL>(rp2, kr.P2, kr.Q2, i0, j0, tid);
+        }
     }
     BM_MSTAMP(0);
-    {   // pipeline fill: the four chunk loads go out back to back (ONE memory round trip);
-        // chunks 0/1 pass through two prologue-only sets, chunks 2/3 land in the loop's sets
+    if (n_reg > 0) {
+        // ---- pipeline fill, REG staging: the four chunk loads go out back to back (ONE memory round trip);
+        // chunks 0 / 1 pass through two prologue-only sets, chunks 2 / 3 land in the loop's sets
         ChunkRegs<G> ga, gb;
-        load_chunk<QL, G, FAST, SEG2, PL>(ga, kr, nch1, i0, j0, 0, tid);
-        load_chunk<QL, G, FAST, SEG2, PL>(gb, kr, nch1, i0, j0, 1, tid);
-        load_chunk<QL, G, FAST, SEG2, PL>(g0, kr, nch1, i0, j0, 2, tid);
-        load_chunk<QL, G, FAST, SEG2, PL>(g1, kr, nch1, i0, j0, 3, tid);
+        load_chunk_slim<QL, G, SEG2, PL>(ga, kr, rp1, rp2, nch1, 0);
+        load_chunk_slim<QL, G, SEG2, PL>(gb, kr, rp1, rp2, nch1, 1);
+        load_chunk_slim<QL, G, SEG2, PL>(g0, kr, rp1, rp2, nch1, 2);
+        load_chunk_slim<QL, G, SEG2, PL>(g1, kr, rp1, rp2, nch1, 3);
         __builtin_amdgcn_sched_barrier(0);
         side.fill();
         __builtin_amdgcn_sched_barrier(0);
-        store_chunk<QL, G, FAST, SEG2, PL>(ga, kr, nch1, 0, sP, sQ, tid);
-        store_chunk<QL, G, FAST, SEG2, PL>(gb, kr, nch1, 1, sP + P_BUF, sQ + Q_BUF, tid);
+        store_chunk_slim<QL, G, PL>(ga, sP, sQ, tid);
+        store_chunk_slim<QL, G, PL>(gb, sP + P_BUF, sQ + Q_BUF, tid);
+    } else {
+        // ---- pipeline fill: chunks 0 .. PF-1
+#pragma unroll
+        for (int c = 0; c < PF; ++c)
+            if (c < nch && is_dma(c) && !BM_ABL(0))
+                dma_chunk<QL, G, SEG2, PL>(kr, pl1, pl2, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, w);
+        __builtin_amdgcn_sched_barrier(0);
+        side.fill();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)                      // register-path chunks among the first two: synchronously
+            if (c < nch && !is_dma(c) && !BM_ABL(0)) {
+                load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, c, tid);
+                store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, tid);
+            }
+        // chunks 0 and 1 complete (the DMA of chunk 2, if any, may stay in flight)
+        if (nch > 2 && is_dma(2) && !BM_ABL(0)) BM_WAIT_VM(NPW); else BM_WAIT_VM(0);
     }
     BM_MSTAMP(1);
-    __syncthreads();
+    if (!BM_ABL(5)) wg_barrier();
     read_frags<QL, G, ABL, PL>(fa, sP, sQ, wi, wj, lane);
     BM_MSTAMP(2);
-    int cc = 0, b1 = 1, b2 = 2;   // LDS slots of chunk cc+1 / cc+2
-    // Issue order of one step.  Instruction counts per wave and step:
-    //   NM MFMAs; NRG fused fragment-read groups of (1 + NJ) DS reads (hipcc pairs the reads of
-    //   two k-steps into ds_read2st64); NW DS writes; NL global loads.
-    // masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
+    // blocks of 16 k that the last chunk really holds
+    const int klast = (SEG2 && kr.K2 > 0) ? kr.K2 - (nch - nch1 - 1) * BK : kr.K1 - (nch1 - 1) * BK;
+    const int nq_last = (klast + 15) / 16;
+    // Issue order of a steady step: the DMA instructions behind the first MFMAs (longest latency), then one LDS
+    // read behind every further MFMA.   masks: 0x008 MFMA, 0x100 DS read, 0x020 VMEM read
     constexpr int NM = (BK / 4) * G::MI * G::NJ;
-    constexpr int NRG = BK / 8, RPG = (QL == KM && G::NJ == 2) ? 2 : 1 + G::NJ;
-    constexpr int NW = ((PL == XM) ? 2 * G::NVP : G::NVP) + ((QL == XM) ? 2 * G::NVQ : G::NVQ);
-    constexpr int NL = G::NVP + G::NVQ;
-    constexpr int MR = (NM >= 64) ? 2 : 1;            // MFMAs per read group
-    constexpr int MW = (NM >= 32) ? 2 : 1;            // MFMAs per DS write
-    constexpr int REST = NM - (NRG * MR + NW * MW + NL);
+    constexpr int NRP = (PL == XM) ? BK / 16 : BK / 4;
+    constexpr int NRQ = (QL == XM) ? (BK / 16) * G::NJ : BK / 4;
+    constexpr int NR = NRP + NRQ;
 #define BM_SG(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0);
 #ifndef BM_SCHED_VARIANT
 #define BM_SCHED_VARIANT 0
 #endif
 #if BM_SCHED_VARIANT == 0
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < NRG; ++s_) { BM_SG(0x008, MR) BM_SG(0x100, RPG) }    \
-    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, MW) BM_SG(0x200, 1) }        \
-    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }         \
-    if (REST > 0) { BM_SG(0x008, (REST > 0 ? REST : 1)) }
-#elif BM_SCHED_VARIANT == 1    /* every memory op behind its own MFMA: reads, writes, loads */
-#define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) }         \
-    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }         \
+    _Pragma("unroll") for (int s_ = 0; s_ < NPW; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NR; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) }         \
     BM_SG(0x008, NM)
-#elif BM_SCHED_VARIANT == 2    /* loads, writes, then reads, 1:1 */
+#elif BM_SCHED_VARIANT == 1    /* reads first, DMA behind them */
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }         \
-    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) }         \
-    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
+    _Pragma("unroll") for (int s_ = 0; s_ < NR; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) }         \
+    _Pragma("unroll") for (int s_ = 0; s_ < NPW; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }        \
     BM_SG(0x008, NM)
-#elif BM_SCHED_VARIANT == 3    /* writes and loads paired 1:1 first, then reads 1:1 */
-#define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) BM_SG(0x020, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
-    BM_SG(0x008, NM)
-#elif BM_SCHED_VARIANT == 4    /* reads 1 per 2 MFMAs with a write or load in the other slot */
-#define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < NW; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) BM_SG(0x008, 1) BM_SG(0x200, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < NL; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) BM_SG(0x008, 1) BM_SG(0x020, 1) } \
-    _Pragma("unroll") for (int s_ = 0; s_ < NRG * RPG; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) } \
-    BM_SG(0x008, NM)
-#elif BM_SCHED_VARIANT == 5    /* no pinning: leave the order to hipcc */
+#else                          /* no pinning: leave the order to hipcc */
 #define BM_SCHED_STEP
 #endif
-#define BM_STEP_TAIL                                                                              \
-        BM_SCHED_STEP                                                                             \
-        if (!BM_ABL(5)) __syncthreads();                                                          \
-        b1 = b2;                                                                                  \
-        b2 = (b2 == NBUF - 1) ? 0 : b2 + 1;                                                       \
-        ++cc;
-    // careful step: clamped loads, K-tail zero fill
-#define BM_STEP(FC, FN, G_)                                                                       \
-    {                                                                                             \
-        if (!BM_ABL(3)) read_frags<QL, G, ABL, PL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
-        if (!BM_ABL(2)) store_chunk<QL, G, FAST, SEG2, PL>(G_, kr, nch1, cc + 2, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid); \
-        if (!BM_ABL(0)) load_chunk<QL, G, FAST, SEG2, PL>(G_, kr, nch1, i0, j0, cc + 4, tid);         \
-        mfma_frags<G, ABL>(acc, FC);                                                              \
-        BM_STEP_TAIL                                                                              \
-    }
-    // slim step: chunks cc+2 (stored) and cc+4 (loaded) are full chunks
-#ifdef BM_PROBE
-    // ABL bit 7: phase-ordered step (reads | stores | loads | MFMAs | barrier) with a cycle stamp
-    // between the phases of step 4 -> where does one wave's issue time go?
-    long long pst[6] = {0, 0, 0, 0, 0, 0};
-#define BM_PSTAMP(k) if (BM_ABL(7)) { __builtin_amdgcn_sched_barrier(0); if (cc == 4) pst[k] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define BM_PSTAMP(k)
+    int cc = 0;
+    // PING-PONG (8-wave geometries: waves w and w+4 share a SIMD).  Lock-stepped waves all issue their memory
+    // instructions at the same time and their MFMAs at the same time, and the probe showed the three costs simply
+    // ADD (MFMA + LDS reads + global->LDS).  So a step is split into a memory phase (DMA issue + fragment reads)
+    // and a matrix phase (the chunk's MFMAs) with a barrier after each, and waves 4-7 run ONE PHASE BEHIND waves
+    // 0-3 (one extra barrier before the loop, one after it for waves 0-3): on every SIMD one wave is in its matrix
+    // phase while its partner is in its memory phase (MI355X_MICROARCH.md "Two waves per SIMD").  The ring
+    // hazards are unchanged: a chunk is read >= 2 phases after the barrier that follows its last DMA wait and
+    // overwritten >= 3 phases after its last fragment read.
+#ifndef BM_PINGPONG
+#define BM_PINGPONG 0      /* measured at 784x1024x512: 15.1 us per propagation kernel against 13.2 lock-stepped */
 #endif
-#define BM_STEP_SLIM(FC, FN, G_)                                                                  \
+    constexpr bool PP = BM_PINGPONG && (G::NW == 8) && !BM_ABL(7);
+    const bool late = PP && w >= 4;
+    if (PP && late && !BM_ABL(5)) wg_barrier();
+    // steady step: chunk cc+3 by DMA, no register-path chunk in sight
+#define BM_STEP_STEADY(FC, FN)                                                                    \
     {                                                                                             \
-        BM_PSTAMP(0)                                                                              \
-        if (!BM_ABL(3)) read_frags<QL, G, ABL, PL>(FN, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane); \
-        BM_PSTAMP(1)                                                                              \
-        if (!BM_ABL(2)) store_chunk_slim<QL, G, PL>(G_, sP + b2 * P_BUF, sQ + b2 * Q_BUF, tid);       \
-        BM_PSTAMP(2)                                                                              \
-        if (!BM_ABL(0)) load_chunk_slim<QL, G, SEG2, PL>(G_, kr, pl1, pl2, nch1, nch, cc + 4);        \
-        BM_PSTAMP(3)                                                                              \
-        mfma_frags<G, ABL>(acc, FC);                                                              \
-        BM_PSTAMP(4)                                                                              \
-        if (!BM_ABL(7)) { BM_SCHED_STEP }                                                         \
-        if (!BM_ABL(5)) __syncthreads();                                                          \
-        BM_PSTAMP(5)                                                                              \
-        b1 = b2;                                                                                  \
-        b2 = (b2 == NBUF - 1) ? 0 : b2 + 1;                                                       \
+        const int cd = cc + PF;                                                                   \
+        if (!BM_ABL(0)) dma_chunk<QL, G, SEG2, PL>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
+        read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
+        if (PP) {                                                                                 \
+            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM(NPW);                                   \
+            if (!BM_ABL(5)) wg_barrier();                                                         \
+            mfma_frags<G, ABL>(acc, FC);                                                          \
+        } else {                                                                                  \
+            mfma_frags<G, ABL>(acc, FC);                                                          \
+            BM_SCHED_STEP                                                                         \
+            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM(NPW);                                   \
+        }                                                                                         \
+        if (!BM_ABL(5)) wg_barrier();                                                             \
         ++cc;                                                                                     \
     }
-    // steady state: steps 0 .. nch-3 carry the full LDS / global traffic; the last two steps
-    // (pipeline drain) only have fragments to read and MFMAs to issue
-    const int full = (nch > 2) ? nch - 2 : 0;
-    const int npairs = full / 2;
-    // can the pair of steps starting at step c0 take the slim path?  chunks c0+2, c0+3 (stored)
-    // and c0+4, c0+5 (loaded; past nch: prefetch overrun) must all be full chunks
-    auto pair_is_slim = [&](int c0) -> bool {
-        if (!FAST || BM_ABL(6) || nfull1 == 0) return false;      // (overrun loads fall back on chunk 0)
-        bool ok = true;
-#pragma unroll
-        for (int d = 2; d < 6; ++d) {
-            const int c = c0 + d;
-            ok = ok && ((c < nfull1) | (SEG2 && c >= nch1 && c - nch1 < nfull2) | (d >= 4 && c >= nch));
-        }
-        return ok;
-    };
-    // Runs of slim / careful pairs as separate COUNTED loops (an if/else inside one loop, or a
-    // loop whose exit test depends on the chunk state, makes hipcc copy ~100 loop-carried
-    // registers - and wait for the loads in flight - on every back edge).
-    auto run_length = [&](int c0, int remaining, bool want_slim) -> int {
-        int n = 0;
-        while (n < remaining && pair_is_slim(c0 + 2 * n) == want_slim) ++n;
-        return n;
-    };
-    int left = npairs;
-#pragma unroll 1
-    for (int round = 0; round < 2 && left > 0; ++round) {       // segment 1, then segment 2
-        const int ns = run_length(cc, left, true);
-#pragma unroll 1
-        for (int q = 0; q < ns; ++q) {
-            BM_STEP_SLIM(fa, fb, g0)
-            BM_STEP_SLIM(fb, fa, g1)
-        }
-        left -= ns;
-        const int nc = (round == 1) ? left : run_length(cc, left, false);
-#pragma unroll 1
-        for (int q = 0; q < nc; ++q) {
-            BM_STEP(fa, fb, g0)
-            BM_STEP(fb, fa, g1)
-        }
-        left -= nc;
+    // general step: FC = fragments of chunk cc, FN <- fragments of chunk cc+1
+#define BM_STEP(FC, FN, LAST)                                                                     \
+    {                                                                                             \
+        const int cd = cc + PF, cr = cc + 2;                                                      \
+        const bool do_dma = cd < nch && is_dma(cd) && !BM_ABL(0);                                 \
+        const bool do_reg = cr < nch && !is_dma(cr) && !BM_ABL(0);                                \
+        if (do_reg) load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, cr, tid);             \
+        if (do_dma) dma_chunk<QL, G, SEG2, PL>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
+        if (!(LAST) && cc + 1 < nch) read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
+        if (!PP) { if (LAST) mfma_frags_head<G, ABL>(acc, FC, nq_last); else mfma_frags<G, ABL>(acc, FC); } \
+        if (do_reg) {                                                                             \
+            BM_WAIT_VM(0);                                                                        \
+            store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, cr, sP + (cr % NBUF) * P_BUF, sQ + (cr % NBUF) * Q_BUF, tid); \
+        } else if (do_dma) {                                                                      \
+            BM_WAIT_VM(NPW);                                                                      \
+        } else {                                                                                  \
+            BM_WAIT_VM(0);                                                                        \
+        }                                                                                         \
+        if (PP) {                                                                                 \
+            if (!BM_ABL(5)) wg_barrier();                                                         \
+            if (LAST) mfma_frags_head<G, ABL>(acc, FC, nq_last); else mfma_frags<G, ABL>(acc, FC); \
+            if (!BM_ABL(5) && (!(LAST) || !late || Side::kFinalSync)) wg_barrier();               \
+        } else {                                                                                  \
+            if (!BM_ABL(5) && (!(LAST) || Side::kFinalSync)) wg_barrier();                        \
+        }                                                                                         \
+        ++cc;                                                                                     \
     }
-    if (full & 1) {
-        BM_STEP(fa, fb, g0)
-        fa = fb;               // keep the current fragments in `fa` for the drain (once per kernel)
+    // REG steady step: chunk cc+2 (register set G_) -> its slot, chunk cc+4 -> the same set (RELOAD), fragments of
+    // chunk cc+1, MFMAs of chunk cc.   masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
+    constexpr int NWR = G::NVP + G::NVQ;              // DS writes / global loads per thread and chunk
+#ifndef BM_REG_SCHED_VARIANT
+#define BM_REG_SCHED_VARIANT 0
+#endif
+#if BM_REG_SCHED_VARIANT == 0      /* writes, loads, reads: each behind one MFMA */
+#define BM_REG_SCHED(RELOAD)                                                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < NWR; ++s_) { BM_SG(0x008, 1) BM_SG(0x200, 1) }    \
+        if (RELOAD) { _Pragma("unroll") for (int s_ = 0; s_ < NWR; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } } \
+        _Pragma("unroll") for (int s_ = 0; s_ < NR; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) }     \
+        BM_SG(0x008, NM)
+#elif BM_REG_SCHED_VARIANT == 1    /* round 1's order: reads (2 MFMAs apart when there are >= 64), writes, loads */
+#define BM_REG_SCHED(RELOAD)                                                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < NR; ++s_) { BM_SG(0x008, (NM >= 64 ? 2 : 1)) BM_SG(0x100, 2) } \
+        _Pragma("unroll") for (int s_ = 0; s_ < NWR; ++s_) { BM_SG(0x008, (NM >= 32 ? 2 : 1)) BM_SG(0x200, 1) } \
+        if (RELOAD) { _Pragma("unroll") for (int s_ = 0; s_ < NWR; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } } \
+        BM_SG(0x008, NM)
+#elif BM_REG_SCHED_VARIANT == 2    /* any memory instruction behind every MFMA */
+#define BM_REG_SCHED(RELOAD)                                                                      \
+        _Pragma("unroll") for (int s_ = 0; s_ < NR + 2 * NWR; ++s_) { BM_SG(0x008, 1) BM_SG(0x320, 1) } \
+        BM_SG(0x008, NM)
+#else                               /* no pinning */
+#define BM_REG_SCHED(RELOAD)
+#endif
+#define BM_STEP_REG(FC, FN, G_, RELOAD)                                                           \
+    {                                                                                             \
+        store_chunk_slim<QL, G, PL>(G_, sP + ((cc + 2) % NBUF) * P_BUF, sQ + ((cc + 2) % NBUF) * Q_BUF, tid); \
+        if (RELOAD) load_chunk_slim<QL, G, SEG2, PL>(G_, kr, rp1, rp2, nch1, cc + 4);             \
+        read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
+        mfma_frags<G, ABL>(acc, FC);                                                              \
+        BM_REG_SCHED(RELOAD)                                                                      \
+        if (!BM_ABL(5)) wg_barrier();                                                             \
+        ++cc;                                                                                     \
+    }
+    if (n_reg > 0) {
+#pragma unroll 1
+        for (int q = 0; q < n_reg / 2; ++q) {
+            BM_STEP_REG(fa, fb, g0, true)
+            BM_STEP_REG(fb, fa, g1, true)
+        }
+        BM_STEP_REG(fa, fb, g0, false)                // the two chunks still in registers
+        BM_STEP_REG(fb, fa, g1, false)
+    }
+    // leading run of DMA steady steps (in pairs: the two fragment sets alternate)
+    int n_steady = 0;
+    if (FAST && STG == STG_DMA && !BM_ABL(6))
+        while (n_steady + PF < nch && is_dma(n_steady + PF) && is_dma(n_steady + 2)) ++n_steady;
+    const int nsp = n_steady / 2;
+#pragma unroll 1
+    for (int q = 0; q < nsp; ++q) {
+        BM_STEP_STEADY(fa, fb)
+        BM_STEP_STEADY(fb, fa)
+    }
+    const int nrest = nch - 1 - cc;                   // general steps before the last one
+    const int npairs = nrest / 2;
+#pragma unroll 1
+    for (int q = 0; q < npairs; ++q) {
+        BM_STEP(fa, fb, false)
+        BM_STEP(fb, fa, false)
+    }
+    if (nrest & 1) {
+        BM_STEP(fa, fb, false)
+        fa = fb;                 // keep the current fragments in `fa` (once per kernel)
     }
     BM_MSTAMP(3);
-    // groups of 16 k that the last chunk really holds
-    const int klast = (SEG2 && kr.K2 > 0) ? kr.K2 - (nch - nch1 - 1) * BK : kr.K1 - (nch1 - 1) * BK;
-    const int nq_last = (klast + 15) / 16;
     side.drain();
-    if (nch >= 2) {
-        if (!BM_ABL(3)) read_frags<QL, G, ABL, PL>(fb, sP + b1 * P_BUF, sQ + b1 * Q_BUF, wi, wj, lane);
-        mfma_frags<G, ABL>(acc, fa);
-        mfma_frags_head<G, ABL>(acc, fb, nq_last);
-    } else {
-        mfma_frags_head<G, ABL>(acc, fa, nq_last);
-    }
-    if (Side::kFinalSync) __syncthreads();     // the LDS ring may be refilled by a following pipeline
+    BM_STEP(fa, fb, true)        // last chunk: only the k blocks it really holds
+    if (PP && !late && !BM_ABL(5) && Side::kFinalSync) wg_barrier();     // waves 0-3 catch up with the extra barrier of waves 4-7
     BM_MSTAMP(4);
-#ifdef BM_PROBE
-    if (BM_ABL(7) && stamps && lane == 0 && (w == 0 || w == 3)) {
-        long long *o = stamps + 2048 + (long long)blockIdx.x * 8 + (w ? 8 : 0);    // (stamps = dbg + 2048 + 8*block)
-        for (int k = 0; k < 6; ++k) o[k] = pst[k];
-    }
-#undef BM_PSTAMP
-#endif
 #undef BM_STEP
-#undef BM_STEP_SLIM
-#undef BM_STEP_TAIL
+#undef BM_STEP_REG
+#undef BM_REG_SCHED
+#undef BM_STEP_STEADY
 #undef BM_SCHED_STEP
 #undef BM_SG
 }

@@ -177,7 +177,7 @@ template <int E, class Rng> struct ActSide {
     __device__ __forceinline__ void drain() {}
 };
 
-template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM>
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
             }
     }
 #ifdef BM_PROBE
-    mainloop<XM, G, FAST, SEG2, ABL, PL>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+    mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
 #else
-    mainloop<XM, G, FAST, SEG2, ABL, PL>(acc, kr, i0, j0, smem, side);
+    mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
 #endif
     const float (&bs)[E] = side.bs;
     const float (&sg)[E] = side.sg;
@@ -666,7 +666,7 @@ template <int NJ> struct GradSide {
     }
 };
 
-template <class G, bool FAST, int ABL = 0>
+template <class G, bool FAST, int ABL = 0, int STG = STG_DMA>
 __global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
     constexpr int TI = G::TI, NJ = G::NJ;
     static_assert(G::MI == 2 && G::TI == 64 && G::TJ == 64, "grad_kernel: 64 x 64 tiles, 8 consecutive outputs per lane");
@@ -722,13 +722,13 @@ __global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
         // passes Pneg = -h_k (act_kernel's `negmeans` output), fma(-p, q, acc) == acc - p*q exactly
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
         kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = a.Kneg;
-        mainloop<KM, G, FAST, true, ABL>(pos, kr, i0, j0, smem, side);
+        mainloop<KM, G, FAST, true, ABL, KM, STG>(pos, kr, i0, j0, smem, side);
     } else {
         // DBM: pos/N - neg/M with N != M needs the two sums separately
         kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0;
-        mainloop<KM, G, FAST, false>(pos, kr, i0, j0, smem, side);
+        mainloop<KM, G, FAST, false, 0, KM, STG>(pos, kr, i0, j0, smem, side);
         kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
-        mainloop<KM, G, FAST, false>(neg, kr, i0, j0, smem, side);
+        mainloop<KM, G, FAST, false, 0, KM, STG>(neg, kr, i0, j0, smem, side);
     }
 
     BM_GSTAMP(1);
@@ -1333,26 +1333,27 @@ __global__ void maxabsdiff_kernel(const float *A, int lda, const float *B, int l
 // ------------------------------------------------------------- host launchers
 template <class G> static inline int tile_grid(int I, int J) { return ((I + G::TI - 1) / G::TI) * ((J + G::TJ - 1) / G::TJ); }
 
-template <class G, int MINB>
+template <class G, int MINB, int STG>
 static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
     const bool seg2 = a.K2 > 0;
     const int pl = a.p_xm ? XM : KM;
     const bool fast = operand_fast(a.P1, pl, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
                       (!seg2 || (operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2)));
     const dim3 grid(tile_grid<G>(a.I, a.J)), blk(G::NT);
+    // (shapes without 16-byte loads have ONE flavour: every chunk passes through registers)
     if constexpr (G::MI == 1) {
         if (a.p_xm) {                       // x-major P: single segment only (RBM prop-down from W)
-            if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, XM>), grid, blk, 0, st, a);
-            else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, XM>), grid, blk, 0, st, a);
+            if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, XM, STG>), grid, blk, 0, st, a);
+            else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, XM, STG_DMA>), grid, blk, 0, st, a);
             return;
         }
     }
     if (seg2) {
-        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true>), grid, blk, 0, st, a);
-        else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false>), grid, blk, 0, st, a);
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true, 0, KM, STG>), grid, blk, 0, st, a);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false, 0, KM, STG_DMA>), grid, blk, 0, st, a);
     } else {
-        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true>), grid, blk, 0, st, a);
-        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false>), grid, blk, 0, st, a);
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, KM, STG>), grid, blk, 0, st, a);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, KM, STG_DMA>), grid, blk, 0, st, a);
     }
 }
 
@@ -1375,17 +1376,27 @@ static inline int act_geo_override() {
     if (v < 0) { const char *e = getenv("BM355_ACT_GEO"); v = e ? atoi(e) : 0; }
     return v;
 }
+// geo: tile geometry 8 | 4 | 1 | 3, + 100 for register staging of the full chunks (default: LDS-DMA)
 static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
+    const bool reg = geo >= 100;
+    geo %= 100;
     if (a.p_xm && geo == 4) geo = 8;        // x-major P exists for the MI == 1 geometries only
-    if (geo == 8)      launch_act_geo<GeoAct8, 1>(a, st);
-    else if (geo == 1) launch_act_geo<GeoActS, 2>(a, st);
-    else if (geo == 3) launch_act_geo<GeoActS32, 4>(a, st);
-    else               launch_act_geo<GeoAct, 1>(a, st);
+    if (reg) {
+        if (geo == 8)      launch_act_geo<GeoAct8, 1, STG_REG>(a, st);
+        else if (geo == 1) launch_act_geo<GeoActS, 2, STG_REG>(a, st);
+        else if (geo == 3) launch_act_geo<GeoActS32, 4, STG_REG>(a, st);
+        else               launch_act_geo<GeoAct, 1, STG_REG>(a, st);
+    } else {
+        if (geo == 8)      launch_act_geo<GeoAct8, 1, STG_DMA>(a, st);
+        else if (geo == 1) launch_act_geo<GeoActS, 2, STG_DMA>(a, st);
+        else if (geo == 3) launch_act_geo<GeoActS32, 4, STG_DMA>(a, st);
+        else               launch_act_geo<GeoAct, 1, STG_DMA>(a, st);
+    }
 }
 struct ActTune {
-    static constexpr int NC = 4;
+    static constexpr int NC = 8;
     int best = 0;
-    float t_us[NC] = {0.f, 0.f, 0.f, 0.f};
+    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 // scratch pool of the tuning launches (per process and device; grown on demand, never on the hot path)
 struct TuneScratch {
@@ -1401,7 +1412,7 @@ struct TuneScratch {
     }
 };
 static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3};
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103};
     constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
     static TuneScratch pool;
     const size_t mat = ((size_t)a.J * (size_t)a.ldo + 3) & ~(size_t)3;
@@ -1424,10 +1435,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
-    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f};
+    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < TUNE_ROUNDS; ++round) {
         for (int c = 0; c < ActTune::NC; ++c) {
-            if (a.p_xm && cand_geo[c] == 4) continue;             // not instantiated for an x-major P
+            if (a.p_xm && cand_geo[c] % 100 == 4) continue;       // not instantiated for an x-major P
             launch_act_as(cand_geo[c], t, st);                    // warm (instruction cache, clocks)
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < TUNE_REP; ++r) launch_act_as(cand_geo[c], t, st);
@@ -1446,8 +1457,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     if (b >= 0) T.best = cand_geo[b];
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
-        fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f)\n",
-                a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0], T.t_us[1], T.t_us[2], T.t_us[3]);
+        fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us, dma: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; "
+                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f)\n",
+                a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0] > 1e29f ? -1.f : T.t_us[0], T.t_us[1] > 1e29f ? -1.f : T.t_us[1], T.t_us[2], T.t_us[3],
+                T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7]);
 }
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     const int ov = act_geo_override();
@@ -1473,17 +1486,20 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
 // ---- grad_kernel geometry choice: 4 waves of 32 x 32 or 8 waves of 32 x 16 (bit-identical results), measured
 // once per shape like the act geometries (tune_act_shape), on scratch copies of every buffer the kernel writes.
 // BM355_GRAD_GEO=4|8 forces one.
-template <class G>
+template <class G, int STG>
 static inline void launch_grad_geo(const GradArgs &g, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
     const dim3 grid(tile_grid<G>(g.I, g.J) + g.nbias), blk(G::NT);
-    if (fast) hipLaunchKernelGGL((grad_kernel<G, true>), grid, blk, 0, st, g);
-    else      hipLaunchKernelGGL((grad_kernel<G, false>), grid, blk, 0, st, g);
+    if (fast) hipLaunchKernelGGL((grad_kernel<G, true, 0, STG>), grid, blk, 0, st, g);
+    else      hipLaunchKernelGGL((grad_kernel<G, false, 0, STG_DMA>), grid, blk, 0, st, g);
 }
+// geo: 4 | 8 waves, + 100 for register staging of the full chunks
 static inline void launch_grad_as(int geo, const GradArgs &g, hipStream_t st) {
-    if (geo == 8) launch_grad_geo<GeoGrad8>(g, st);
-    else          launch_grad_geo<GeoGrad>(g, st);
+    if (geo == 108)      launch_grad_geo<GeoGrad8, STG_REG>(g, st);
+    else if (geo == 104) launch_grad_geo<GeoGrad, STG_REG>(g, st);
+    else if (geo == 8)   launch_grad_geo<GeoGrad8, STG_DMA>(g, st);
+    else                 launch_grad_geo<GeoGrad, STG_DMA>(g, st);
 }
 static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
     // the tile workgroups only: scratch W / dW / raw (the update is not idempotent), no bias groups
@@ -1500,10 +1516,10 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return 4; }
-    const int cand[2] = {4, 8};
-    float best_us[2] = {1e30f, 1e30f};
+    const int cand[4] = {4, 8, 104, 108};
+    float best_us[4] = {1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < 3; ++round)
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < 4; ++c) {
             launch_grad_as(cand[c], t, st);
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < 4; ++r) launch_grad_as(cand[c], t, st);
@@ -1513,11 +1529,13 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 250.f * ms < best_us[c]) best_us[c] = 250.f * ms;
         }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    const int best = (best_us[1] < best_us[0]) ? 8 : 4;
+    int b = 0;
+    for (int c = 1; c < 4; ++c) if (best_us[c] < best_us[b]) b = c;
+    const int best = cand[b];
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
-        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> %d waves (us: 4w %.1f, 8w %.1f)\n",
-                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1]);
+        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f)\n",
+                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3]);
     return best;
 }
 static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {

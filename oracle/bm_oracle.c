@@ -24,12 +24,17 @@
  * Every other value of the train step is "parity unpinned" by the reference
  * (it holds no fixture for them) and is pinned by this oracle only.
  *
- * "Canonical order": every dot product is the sequential chain
- *     acc = 0; for k ascending: acc = fmaf(a[k], b[k], acc)
- * and every column sum is the sequential fp32 sum over rows.  The HIP kernels
- * reproduce exactly this order (v_mfma_f32_16x16x4_f32 is a k-ordered fma
- * chain), so probabilities, sample bitmaps and parameter updates are
- * BIT-IDENTICAL between this file and the GPU.  Build with -ffp-contract=off.
+ * "Canonical order": every dot product of a matmul is ONE sequential fma chain
+ *     acc = 0; for k in ORDER: acc = fmaf(a[k], b[k], acc)
+ * whose ORDER visits every aligned block of 16 k as  k = 16m + 4g + j  for j = 0..3 (outer), g = 0..3 (inner)
+ * - i.e. 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15, then the next block (k >= K skipped; the second segment of
+ * a two-segment contraction starts its own blocks).  The order of a float32 matmul's accumulation is an
+ * implementation detail of the reference's backend (Eigen / cuBLAS inside TensorFlow 1.3: blocked, unknowable
+ * and certainly not sequential either); the engine and this file fix it, identically, to the order in which
+ * v_mfma_f32_16x16x4_f32 consumes 16-byte chunks of k-contiguous rows (csrc/bm_gemm.h), so that
+ * probabilities, sample bitmaps and parameter updates are BIT-IDENTICAL between this file and the GPU.
+ * tests/np_reference.py (float64, NumPy's own order) checks that nothing depends on the choice beyond
+ * float32 round-off.  Every column sum is the sequential fp32 sum over rows.  Build with -ffp-contract=off.
  */
 #include <math.h>
 #include <stdint.h>
@@ -138,11 +143,15 @@ static double softplus_d(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x)));
 /* out[j][i] = sum_k Q[j][k] * Pk[k][i]   (k ascending fmaf chain), optionally
  * continuing from a second segment.  Pk is k-major ([K][I], i contiguous). */
 static void chain_kmajor(float *acc, const float *Qrow, const float *Pk, int K, int I) {
-    for (int k = 0; k < K; ++k) {
-        const float q = Qrow[k];
-        const float *p = Pk + (size_t)k * I;
-        for (int i = 0; i < I; ++i) acc[i] = fmaf(p[i], q, acc[i]);
-    }
+    for (int kb = 0; kb < K; kb += 16)                      /* canonical order (file header) */
+        for (int j = 0; j < 4; ++j)
+            for (int g = 0; g < 4; ++g) {
+                const int k = kb + 4 * g + j;
+                if (k >= K) continue;
+                const float q = Qrow[k];
+                const float *p = Pk + (size_t)k * I;
+                for (int i = 0; i < I; ++i) acc[i] = fmaf(p[i], q, acc[i]);
+            }
 }
 
 static float *transpose(const float *A, int R, int C) {   /* A[R][C] -> T[C][R] */
@@ -268,11 +277,15 @@ static void outer_chain(float *out, const float *Qb, int J, const float *Pb, int
     for (int j = 0; j < J; ++j) {
         float *acc = out + (size_t)j * I;
         if (!accumulate) for (int i = 0; i < I; ++i) acc[i] = 0.0f;
-        for (int b = 0; b < B; ++b) {
-            const float q = sgn * Qb[(size_t)b * J + j];
-            const float *p = Pb + (size_t)b * I;
-            for (int i = 0; i < I; ++i) acc[i] = fmaf(p[i], q, acc[i]);
-        }
+        for (int bb = 0; bb < B; bb += 16)                  /* canonical order over the rows b (file header) */
+            for (int jj = 0; jj < 4; ++jj)
+                for (int g = 0; g < 4; ++g) {
+                    const int b = bb + 4 * g + jj;
+                    if (b >= B) continue;
+                    const float q = sgn * Qb[(size_t)b * J + j];
+                    const float *p = Pb + (size_t)b * I;
+                    for (int i = 0; i < I; ++i) acc[i] = fmaf(p[i], q, acc[i]);
+                }
     }
 }
 

@@ -71,6 +71,9 @@ int main(int argc, char **argv) {
     RUN(4, "mfma + reads + gloads + barrier")
     printf("---- 8-wave geometry (the one the tuner picks at this shape)\n");
     RUNG(GeoAct8, 1, 0, "8w full")
+    RUNG(GeoAct8, 1, 128, "8w lock-step (no ping-pong)")
+    RUNG(GeoAct8, 1, 129, "8w lock-step no-gload")
+    RUNG(GeoAct8, 1, 136, "8w lock-step no-ldsread")
     RUNG(GeoAct8, 1, 16, "8w no-epilogue")
     RUNG(GeoAct8, 1, 1, "8w no-gload")
     RUNG(GeoAct8, 1, 4, "8w no-ldswrite")
@@ -82,7 +85,7 @@ int main(int argc, char **argv) {
     RUNG(GeoAct8, 1, 2, "8w no-mfma")
     RUNG(GeoAct8, 1, 63, "8w nothing")
     {   // phase-ordered step with stamps (wave 0 and wave 3 of every workgroup, step 4)
-        RUN(128, "phase-ordered steps")
+        RUN(0, "(phase-ordered probe removed)")
         std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost));
         for (int wv = 0; wv < 2; ++wv) {
             double d[5] = {0, 0, 0, 0, 0};
@@ -164,6 +167,17 @@ int main(int argc, char **argv) {
         GRUN(8, "no-ldsread")
         GRUN(32, "no-barrier")
         GRUN(45, "only mfma")
+        {   const dim3 gg4(tile_grid<GeoGrad>(g.I, g.J));
+            printf("grad 4w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad, true, 0, STG_REG>), gg4, dim3(256), 0, st, g); }));
+            printf("grad 8w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 0, STG_REG>), gg4, dim3(512), 0, st, g); }));
+            printf("act  8w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0, KM, STG_REG>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a); }));
+        }
+        {   const dim3 gg(tile_grid<GeoGrad8>(g.I, g.J));
+            printf("grad 8w ping-pong                %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 0>), gg, dim3(512), 0, st, g); }));
+            printf("grad 8w lock-step                %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 128>), gg, dim3(512), 0, st, g); }));
+            printf("grad 8w ping-pong no-gload       %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 1>), gg, dim3(512), 0, st, g); }));
+            printf("grad 8w ping-pong only-mfma      %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 45>), gg, dim3(512), 0, st, g); }));
+        }
         for (int variant = 0; variant < 1; ++variant) {
             g.Wt = (variant == 2) ? nullptr : Wt.p;
             float us = time_it(st, e0, e1, [&] { launch_grad(g, st); });
