@@ -193,6 +193,22 @@ class DeviceArray(object):
         check(load().bm_h2d(d.ptr, a.ctypes.data_as(_vp), a.nbytes))
         return d
 
+    @classmethod
+    def from_numpy_reusing(cls, old, a, dtype=np.float32):
+        """like from_numpy, but into `old`'s allocation when it is large enough (repeated fit() calls re-upload the
+        training set: hipMalloc + hipFree of a few hundred MB cost tens of milliseconds per call)"""
+        a = np.ascontiguousarray(a, dtype=dtype)
+        if old is None or not old._own or not old.ptr or getattr(old, '_capacity', old.nbytes) < a.nbytes:
+            if old is not None:
+                old.free()
+            d = cls(a.shape, dtype)
+            d._capacity = d.nbytes
+        else:
+            d = old
+            d.shape, d.dtype, d.nbytes = tuple(int(x) for x in a.shape), np.dtype(dtype), a.nbytes
+        check(load().bm_h2d(d.ptr, a.ctypes.data_as(_vp), a.nbytes))
+        return d
+
     def numpy(self):
         out = np.empty(self.shape, dtype=self.dtype)
         check(load().bm_d2h(out.ctypes.data_as(_vp), self.ptr, self.nbytes))

@@ -117,7 +117,10 @@ def run_on_engine(check_initialized=True, update_seed=False):
             model._ensure_engine()
             if update_seed:
                 model._seed_engine(model._graph_seed)
-            return f(model, *args, **kwargs)
+            try:
+                return f(model, *args, **kwargs)
+            finally:
+                model._join_save()          # checkpoint files of this call are complete when it returns
         return wrapped_f
     return wrap
 
@@ -224,13 +227,30 @@ class EngineModel(BaseModel, DtypeMixin):
         params = self.get_params(deep=False)
         params = self._serialize(dict(params))
         params['__class_name__'] = self.__class__.__name__
-        with open(self._params_filepath, 'w') as params_file:
-            json.dump(params, params_file, **self.json_params)
-        if self.random_seed is not None:
-            with open(self._random_state_filepath, 'w') as random_state_file:
-                json.dump(self._rng.get_state(), random_state_file)
-        # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
-        np.savez(self._model_filepath + '.npz', **self._variables())
+        self._join_save()
+        params_json = json.dumps(params, **self.json_params)
+        rng_json = json.dumps(self._rng.get_state()) if self.random_seed is not None else None
+        variables = self._variables()            # device -> host snapshot, taken NOW (synchronises the stream)
+        paths = (self._params_filepath, self._random_state_filepath, self._model_filepath + '.npz')
+
+        def write():
+            with open(paths[0], 'w') as f:
+                f.write(params_json)
+            if rng_json is not None:
+                with open(paths[1], 'w') as f:
+                    f.write(rng_json)
+            # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
+            np.savez(paths[2], **variables)
+        # the files are written by a background thread while the next epoch trains (the snapshot above is what
+        # they contain); every public call joins it before it returns, so callers never see half-written files
+        import threading
+        self._save_thread = threading.Thread(target=write, daemon=False)
+        self._save_thread.start()
+
+    def _join_save(self):
+        t = self.__dict__.pop('_save_thread', None)
+        if t is not None:
+            t.join()
 
     @classmethod
     def load_model(cls, model_path):

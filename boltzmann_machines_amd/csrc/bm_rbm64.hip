@@ -1,12 +1,14 @@
 // bm_rbm64.hip — the RBM hot path in float64 (bm_rbm64_* entry points of include/bm355.h).
 //
 // The reference's dtype is a constructor argument (base/mixin.py:15) and its own tests train a
-// float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  This is the compatibility path for
-// that dtype: the same graph (base_rbm.py:415-531) and the same canonical summation order as the
-// float32 engine, every operation in IEEE double, bit-identical to the float64 functions of
-// oracle/bm_oracle.c.  It is NOT the tuned path: plain vector-FMA kernels (8 outputs per thread, each a
-// sequential fma chain over k, operands through L1/L2): a 784x1024x512 CD-1 update takes a few
-// hundred microseconds.  Bernoulli hidden units; Bernoulli or Gaussian visible units.
+// float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  This is the path for that dtype: the same graph
+// (base_rbm.py:415-531), every operation in IEEE double, every dot product the sequential ascending-k fma
+// chain of the float64 functions of oracle/bm_oracle.c (bit-identical).
+// The contractions run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: an exact fma chain over its four k,
+// continued through the accumulator): one 16 x 16 output tile per wave, operands straight from L1 / L2 (a W
+// panel is read coalesced in 128-byte rows, the 16 input rows of a tile are shared by the four waves of a
+// workgroup).  Round 1 used one thread per output and vector FMAs (0.62 ms per 784x1024x512 CD-1 update).
+// Bernoulli hidden units; Bernoulli or Gaussian visible units.
 #include "bm_common.h"
 #include "bm_rng.h"
 
@@ -78,43 +80,144 @@ struct ActArgs {
     double *means, *states;          // dense [J][I], may be null
     PhiloxKey key; long long row0;
 };
-constexpr int RB = 4;        // rows per thread (register blocking: every P element is loaded once per RB rows)
-__global__ __launch_bounds__(256) void act_kernel(ActArgs a) {
-    // (readfirstlane: the wave index is uniform, so the Q rows are read with scalar loads)
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RB;
-    if (j0 >= a.J) return;
-    const bool live = i < a.I;
-    if (!live) return;
-    const double *p = a.P + i;
-    const double *q[RB];
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ---- FP64-MFMA tile engine (float64 twin of csrc/bm_gemm.h, much simpler: the float64 path is a compatibility
+// path, it only has to stay within a small factor of the float32 one).
+// Workgroup = 4 waves = 64 (i) x 32 (j) outputs; wave (wi, wj) = 32 x 16 = two 16 x 16 tiles that share the B
+// fragment.  K streams in chunks of 32 through a double-buffered LDS tile pair filled through registers.
+//   v_mfma_f64_16x16x4_f64:  A (lane l: m = l & 15, k = l >> 4), B (lane l: n = l & 15, k = l >> 4),
+//   D (lane l, register r) = (m = 4 r + (l >> 4), n = l & 15)          [tools/mf64_probe.hip]
+// A <- P[k][i] (k-major), B <- Q: x-major rows [j][k] (propagations) or k-major [k][j] (outer products).
+// The four k of an instruction and the instructions of a dot product run in ascending k: the sequential
+// chain of the float64 oracle.
+constexpr int T64_TI = 64, T64_TJ = 32, T64_BK = 32;
+constexpr int T64_PLD = T64_TI + 16;        // k-major P rows: +128 B, rows k / k+1 hit different bank halves
+constexpr int T64_QLD_XM = T64_BK + 2;      // x-major Q rows: +16 B per row
+constexpr int T64_QLD_KM = T64_TJ + 16;     // k-major Q rows (32 j + pad)
+constexpr int T64_PBUF = T64_BK * T64_PLD;                                   // doubles
+constexpr int T64_QBUF = (T64_TJ * T64_QLD_XM > T64_BK * T64_QLD_KM) ? T64_TJ * T64_QLD_XM : T64_BK * T64_QLD_KM;
+
+// [rows][cols] window of a row-major matrix -> registers (pairs of doubles), zero outside [nrows][ncols]
+template <int ROWS, int COLS>
+__device__ __forceinline__ void t64_fetch(double2 (&r)[ROWS * COLS / 512], const double *p, int ld, int row0, int col0,
+                                          int nrows, int ncols, int tid) {
+    constexpr int NV = ROWS * COLS / 512, CP = COLS / 2;
+    // branch-free: clamped addresses, unconditional loads (all of a chunk's loads are in flight together),
+    // out-of-range elements selected to zero afterwards
+    const bool vec = ((ld & 1) == 0) && (((uintptr_t)p & 15u) == 0) && ncols >= 2;      // wave-uniform (col is even)
 #pragma unroll
-    for (int r = 0; r < RB; ++r) q[r] = a.Q + (size_t)min(j0 + r, a.J - 1) * a.ldq;     // wave-uniform rows
-    double z[RB];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) z[r] = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < a.K; ++k) {
-        const double pv = p[(size_t)k * a.ldp];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) z[r] = fma(pv, q[r][k], z[r]);
-    }
-    const double b = a.mult * a.bias[i];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int j = j0 + r;
-        if (j >= a.J) break;
-        const double x = a.mult * z[r];
-        const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (x * a.sigma[i] + b);
-        double s = m;
-        if (a.sample) {
-            const unsigned long long idx = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + (unsigned long long)i;
-            if (a.kind == BM_UNIT_BERNOULLI) s = (uniform_at(a.key, idx) < m) ? 1.0 : 0.0;
-            else s = normal_at(a.key, idx) * a.sigma[i] + m;
+    for (int n = 0; n < NV; ++n) {
+        const int f = tid + n * 256;
+        const int row = row0 + f / CP, col = col0 + 2 * (f % CP);
+        const int rc = min(row, nrows - 1);
+        double2 v;
+        if (vec) {
+            v = *reinterpret_cast<const double2 *>(p + (size_t)rc * ld + min(col, (ncols - 2) & ~1));
+        } else {
+            v.x = p[(size_t)rc * ld + min(col, ncols - 1)];
+            v.y = p[(size_t)rc * ld + min(col + 1, ncols - 1)];
         }
-        if (a.means) a.means[(size_t)j * a.I + i] = m;
-        if (a.states) a.states[(size_t)j * a.I + i] = s;
+        const bool rok = row < nrows;
+        r[n] = make_double2((rok && col < ncols) ? v.x : 0.0, (rok && col + 1 < ncols) ? v.y : 0.0);
     }
+}
+template <int ROWS, int COLS, int LD>
+__device__ __forceinline__ void t64_stash(const double2 (&r)[ROWS * COLS / 512], double *s, int tid, double sgn) {
+    constexpr int NV = ROWS * COLS / 512, CP = COLS / 2;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+        const int f = tid + n * 256;
+        double *d = s + (f / CP) * LD + 2 * (f % CP);
+        d[0] = sgn * r[n].x; d[1] = sgn * r[n].y;
+    }
+}
+
+struct T64Seg { const double *P; int ldp; const double *Q; int ldq; int K; double qsgn; };
+
+// acc[t] += sum_k P[k][i] * Q(j, k) for the wave's two tiles (t = 0, 1: i sub-tile), over `nseg` segments
+template <bool QKM>
+__device__ __forceinline__ void t64_mainloop(d4 (&acc)[2], const T64Seg *seg, int nseg, int I, int J, int i0, int j0,
+                                             double *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1, l15 = lane & 15, g = lane >> 4;
+    double *sP = smem, *sQ = smem + 2 * T64_PBUF;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        const T64Seg sg = seg[sgi];
+        const int nch = (sg.K + T64_BK - 1) / T64_BK;
+        double2 rp[T64_BK * T64_TI / 512], rq[T64_BK * T64_TJ / 512];
+        t64_fetch<T64_BK, T64_TI>(rp, sg.P, sg.ldp, 0, i0, sg.K, I, tid);
+        if (QKM) t64_fetch<T64_BK, T64_TJ>(rq, sg.Q, sg.ldq, 0, j0, sg.K, J, tid);
+        else     t64_fetch<T64_TJ, T64_BK>(rq, sg.Q, sg.ldq, j0, 0, J, sg.K, tid);
+        __syncthreads();                               // the previous segment's last chunk has been consumed
+        t64_stash<T64_BK, T64_TI, T64_PLD>(rp, sP, tid, 1.0);
+        if (QKM) t64_stash<T64_BK, T64_TJ, T64_QLD_KM>(rq, sQ, tid, sg.qsgn);
+        else     t64_stash<T64_TJ, T64_BK, T64_QLD_XM>(rq, sQ, tid, sg.qsgn);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            const int cur = c & 1;
+            if (c + 1 < nch) {                          // next chunk in flight under the MFMAs
+                t64_fetch<T64_BK, T64_TI>(rp, sg.P, sg.ldp, (c + 1) * T64_BK, i0, sg.K, I, tid);
+                if (QKM) t64_fetch<T64_BK, T64_TJ>(rq, sg.Q, sg.ldq, (c + 1) * T64_BK, j0, sg.K, J, tid);
+                else     t64_fetch<T64_TJ, T64_BK>(rq, sg.Q, sg.ldq, j0, (c + 1) * T64_BK, J, sg.K, tid);
+            }
+            const double *pP = sP + cur * T64_PBUF + wi * 32 + l15;
+            const double *pQ = QKM ? sQ + cur * T64_QBUF + wj * 16 + l15
+                                   : sQ + cur * T64_QBUF + (wj * 16 + l15) * T64_QLD_XM;
+            const int ksteps = ((sg.K - c * T64_BK < T64_BK) ? (sg.K - c * T64_BK + 3) / 4 : T64_BK / 4);
+            // all fragments of the chunk first (one LDS round trip per chunk, not one per k-step), then its MFMAs
+            double a0[T64_BK / 4], a1[T64_BK / 4], bq[T64_BK / 4];
+#pragma unroll
+            for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
+                const int k = 4 * s4 + g;
+                a0[s4] = pP[k * T64_PLD]; a1[s4] = pP[k * T64_PLD + 16];
+                bq[s4] = QKM ? pQ[k * T64_QLD_KM] : pQ[k];
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
+                if (s4 < ksteps) {                      // wave-uniform (the K tail is zero-filled in LDS)
+                    acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s4], bq[s4], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], bq[s4], acc[1], 0, 0, 0);
+                }
+            }
+            if (c + 1 < nch) {
+                t64_stash<T64_BK, T64_TI, T64_PLD>(rp, sP + (cur ^ 1) * T64_PBUF, tid, 1.0);
+                if (QKM) t64_stash<T64_BK, T64_TJ, T64_QLD_KM>(rq, sQ + (cur ^ 1) * T64_QBUF, tid, sg.qsgn);
+                else     t64_stash<T64_TJ, T64_BK, T64_QLD_XM>(rq, sQ + (cur ^ 1) * T64_QBUF, tid, sg.qsgn);
+                __syncthreads();
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void act_kernel(ActArgs a) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * (T64_PBUF + T64_QBUF)];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wi = w & 1, wj = w >> 1, l15 = lane & 15, g = lane >> 4;
+    const int i0 = blockIdx.x * T64_TI, j0 = blockIdx.y * T64_TJ;
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    T64Seg sg = {a.P, a.ldp, a.Q, a.ldq, a.K, 1.0};
+    t64_mainloop<false>(acc, &sg, 1, a.I, a.J, i0, j0, smem);
+    const int j = j0 + wj * 16 + l15;
+    if (j >= a.J) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wi * 32 + 16 * t + 4 * r + g;
+            if (i >= a.I) continue;
+            const double b = a.mult * a.bias[i];
+            const double x = a.mult * acc[t][r];
+            const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+            double s = m;
+            if (a.sample) {
+                const unsigned long long idx = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + (unsigned long long)i;
+                if (a.kind == BM_UNIT_BERNOULLI) s = (uniform_at(a.key, idx) < m) ? 1.0 : 0.0;
+                else s = normal_at(a.key, idx) * a.sigma[i] + m;
+            }
+            if (a.means) a.means[(size_t)j * a.I + i] = m;
+            if (a.states) a.states[(size_t)j * a.I + i] = s;
+        }
 }
 
 // raw CD gradient + update of W (and of the transpose Wt) in one pass: thread (j = visible, i = hidden)
@@ -127,44 +230,33 @@ struct GradArgs {
     double N, l2, lr, mom;
 };
 __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RB;
-    if (i >= a.H || j0 >= a.V) return;
-    int jj[RB];
+    // workgroup = 64 hidden (i) x 32 visible (j) of W; the chain runs over the rows b: positive phase, then the
+    // negative phase with the visible operand negated (fma(h, -v, acc), as the oracle)
+    __shared__ __attribute__((aligned(16))) double smem[2 * (T64_PBUF + T64_QBUF)];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wi = w & 1, wj = w >> 1, l15 = lane & 15, g = lane >> 4;
+    const int i0 = blockIdx.x * T64_TI, j0 = blockIdx.y * T64_TJ;
+    d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    T64Seg sg[2] = {{a.h0m, a.H, a.X, a.ldx, a.B, 1.0}, {a.hm, a.H, a.vs, a.V, a.B, -1.0}};
+    t64_mainloop<true>(acc, sg, 2, a.H, a.V, i0, j0, smem);
+    const int j = j0 + wj * 16 + l15;
+    if (j >= a.V) return;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) jj[r] = min(j0 + r, a.V - 1);
-    double acc[RB];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
-#pragma unroll 8
-    for (int b = 0; b < a.B; ++b) {
-        const double pv = a.h0m[(size_t)b * a.H + i];
-        const double *x = a.X + (size_t)b * a.ldx;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = fma(pv, x[jj[r]], acc[r]);
-    }
-#pragma unroll 8
-    for (int b = 0; b < a.B; ++b) {
-        const double pv = a.hm[(size_t)b * a.H + i];
-        const double *v = a.vs + (size_t)b * a.V;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) acc[r] = fma(pv, -v[jj[r]], acc[r]);
-    }
-    const double pen = a.pen[i];
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-        const int j = j0 + r;
-        if (j >= a.V) break;
-        const size_t e = (size_t)j * a.H + i;
-        double g = acc[r] / a.N;
-        g = g - a.l2 * a.W[e];
-        g = g - pen;
-        const double d = a.lr * (a.mom * a.dW[e] + g);
-        a.dW[e] = d;
-        const double w = a.W[e] + d;
-        a.W[e] = w;
-        a.Wt[(size_t)i * a.V + j] = w;
-    }
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + wi * 32 + 16 * t + 4 * r + g;
+            if (i >= a.H) continue;
+            const size_t e = (size_t)j * a.H + i;
+            double gr = acc[t][r] / a.N;
+            gr = gr - a.l2 * a.W[e];
+            gr = gr - a.pen[i];
+            const double d = a.lr * (a.mom * a.dW[e] + gr);
+            a.dW[e] = d;
+            const double wn = a.W[e] + d;
+            a.W[e] = wn;
+            a.Wt[(size_t)i * a.V + j] = wn;
+        }
 }
 
 // column sums (sequential over rows) + bias / q_means update (base_rbm.py:450-474)
@@ -174,10 +266,21 @@ struct BiasArgs {
     double N, lr, mom, damping, cost, target;
 };
 __global__ void bias_kernel(BiasArgs a) {
+    // one thread per column, rows in ascending order (the sequential sums of the oracle); the loads of 16 rows
+    // are issued together, only the additions are serial
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int UB = 16;
     if (c < a.V) {
         double s = 0.0;
-        for (int b = 0; b < a.B; ++b) s = s + (a.X[(size_t)b * a.ldx + c] - a.vs[(size_t)b * a.V + c]);
+        int b = 0;
+        for (; b + UB <= a.B; b += UB) {
+            double x[UB], v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { x[u] = a.X[(size_t)(b + u) * a.ldx + c]; v[u] = a.vs[(size_t)(b + u) * a.V + c]; }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) s = s + (x[u] - v[u]);
+        }
+        for (; b < a.B; ++b) s = s + (a.X[(size_t)b * a.ldx + c] - a.vs[(size_t)b * a.V + c]);
         const double g = s / a.N;
         const double d = a.lr * (a.mom * a.dvb[c] + g);
         a.dvb[c] = d;
@@ -185,7 +288,15 @@ __global__ void bias_kernel(BiasArgs a) {
     } else if (c < a.V + a.H) {
         const int h = c - a.V;
         double sh = 0.0, sq = 0.0;
-        for (int b = 0; b < a.B; ++b) {
+        int b = 0;
+        for (; b + UB <= a.B; b += UB) {
+            double p[UB], q[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { p[u] = a.h0m[(size_t)(b + u) * a.H + h]; q[u] = a.hm[(size_t)(b + u) * a.H + h]; }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { sh = sh + (p[u] - q[u]); sq = sq + q[u]; }
+        }
+        for (; b < a.B; ++b) {
             const double hm = a.hm[(size_t)b * a.H + h];
             sh = sh + (a.h0m[(size_t)b * a.H + h] - hm);
             sq = sq + hm;
@@ -313,7 +424,7 @@ static void launch_act(bm_rbm64 *h, bool up, const double *in, int ldin, int B, 
               a.mult = 1.0 + (h->cfg.dbm_last ? 1.0 : 0.0); }
     a.Q = in; a.ldq = ldin; a.J = B; a.sample = sample; a.means = means; a.states = states;
     a.key = make_key(h, site, t); a.row0 = h->row0;
-    hipLaunchKernelGGL(act_kernel, dim3((a.I + 63) / 64, (B + 4 * RB - 1) / (4 * RB)), dim3(256), 0, h->stream, a);
+    hipLaunchKernelGGL(act_kernel, dim3((a.I + T64_TI - 1) / T64_TI, (B + T64_TJ - 1) / T64_TJ), dim3(256), 0, h->stream, a);
 }
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426)
 static int run_chain(bm_rbm64 *h, const double *X_dev, int B, int k, double *hm_out) {
@@ -344,12 +455,12 @@ static void launch_update(bm_rbm64 *h, int B, double lr, double mom) {
     b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
     b.N = (double)B; b.lr = lr; b.mom = mom;
     b.damping = h->sp_damping; b.cost = h->sp_cost; b.target = h->sp_target;
-    hipLaunchKernelGGL(bias_kernel, dim3((h->V + h->H + 255) / 256), dim3(256), 0, h->stream, b);
+    hipLaunchKernelGGL(bias_kernel, dim3((h->V + h->H + 63) / 64), dim3(64), 0, h->stream, b);
     GradArgs g;
     g.h0m = h->h0m.p; g.hm = h->hm.p; g.X = h->Xin; g.vs = h->vs.p; g.ldx = h->Xin_ld; g.B = B; g.V = h->V; g.H = h->H;
     g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p; g.pen = h->pen.p;
     g.N = (double)B; g.l2 = h->l2; g.lr = lr; g.mom = mom;
-    hipLaunchKernelGGL(grad_kernel, dim3((h->H + 63) / 64, (h->V + 4 * RB - 1) / (4 * RB)), dim3(256), 0, h->stream, g);
+    hipLaunchKernelGGL(grad_kernel, dim3((h->H + T64_TI - 1) / T64_TI, (h->V + T64_TJ - 1) / T64_TJ), dim3(256), 0, h->stream, g);
 }
 static int metrics_from_chain(bm_rbm64 *h, int B, double *out4) {
     BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));

@@ -200,10 +200,15 @@ class BaseRBM(EngineModel):
             raise NotImplementedError("no device path for %s with dtype='%s'" % (self.__class__.__name__, self.dtype))
         return self._engine
 
-    def _to_device(self, X):
-        """host array -> DeviceArray in the engine's dtype"""
+    def _to_device(self, X, slot=None):
+        """host array -> DeviceArray in the engine's dtype; `slot` names a buffer of this model that is reused
+        across calls (the training / validation set of repeated fit() calls)"""
         dt = self._engine.dtype
-        return _ffi.DeviceArray.from_numpy(np.ascontiguousarray(X, dtype=dt), dt)
+        if slot is None:
+            return _ffi.DeviceArray.from_numpy(np.ascontiguousarray(X, dtype=dt), dt)
+        pool = self.__dict__.setdefault('_dev_pool', {})
+        pool[slot] = _ffi.DeviceArray.from_numpy_reusing(pool.get(slot), X, dt)
+        return pool[slot]
 
     def _upload_variables(self, d):
         for name, _ in self._VAR_SCOPES:
@@ -306,11 +311,11 @@ class BaseRBM(EngineModel):
 
     def _fit(self, X, X_val=None, *args, **kwargs):
         self._on_device()
-        Xd = self._to_device(X)
+        Xd = self._to_device(X, 'fit_X')
         N = len(X)
         Xvd, Nv = None, 0
         if X_val is not None:
-            Xvd, Nv = self._to_device(X_val), len(X_val)
+            Xvd, Nv = self._to_device(X_val, 'fit_X_val'), len(X_val)
         for self.epoch_ in epoch_iter(start_epoch=self.epoch_, max_epoch=self.max_epoch, verbose=self.verbose):
             val_results = {}
             feg = None

@@ -125,3 +125,38 @@ def test_no_cpu_fallback_without_gpu():
     from boltzmann_machines_amd import BernoulliRBM
     with pytest.raises(_ffi.Bm355Error):
         BernoulliRBM(n_visible=8, n_hidden=4, verbose=False, model_path='/tmp/bm355_nogpu/').fit(np.zeros((4, 8)))
+
+
+def test_dataset_readers(tmp_path):
+    """utils/dataset.py (reference utils/dataset.py:10-130): IDX / CIFAR-pickle readers on synthetic files in the
+    reference's directory layout, and the flatten round trips of its doctests."""
+    import pickle
+    import struct
+    from boltzmann_machines_amd.utils import dataset
+    rng = np.random.RandomState(0)
+    d = tmp_path / 'mnist'
+    d.mkdir()
+    pix = rng.randint(0, 256, size=(7, 28, 28)).astype(np.uint8)
+    lab = rng.randint(0, 10, size=7).astype(np.int8)
+    for stem in ('train', 't10k'):
+        (d / (stem + '-images-idx3-ubyte')).write_bytes(struct.pack('>IIII', 2051, 7, 28, 28) + pix.tobytes())
+        (d / (stem + '-labels-idx1-ubyte')).write_bytes(struct.pack('>II', 2049, 7) + lab.tobytes())
+    X, y = dataset.load_mnist('train', str(tmp_path))
+    assert X.shape == (7, 784) and X.dtype == np.float64 and np.array_equal(X, pix.reshape(7, -1)) and np.array_equal(y, lab)
+    assert dataset.load_mnist('test', str(tmp_path))[0].shape == (7, 784)
+    with pytest.raises(ValueError):
+        dataset.load_mnist('val', str(tmp_path))
+    c = tmp_path / 'cifar-10-batches-py'
+    c.mkdir()
+    for i, name in enumerate(['data_batch_%d' % k for k in range(1, 6)] + ['test_batch']):
+        with open(str(c / name), 'wb') as f:
+            pickle.dump({'data': np.full((3, 3072), i, dtype=np.uint8), 'labels': [i, i, i]}, f)
+    X, y = dataset.load_cifar10('train', str(tmp_path))
+    assert X.shape == (15, 3072) and y.tolist() == sum(([i] * 3 for i in range(5)), [])
+    assert dataset.load_cifar10('test', str(tmp_path))[1].tolist() == [5, 5, 5]
+    for shape in ((10, 3072), (3072,), (9, 8 * 8 * 3)):
+        A = rng.rand(*shape)
+        np.testing.assert_allclose(A, dataset.im_flatten(dataset.im_unflatten(A)))
+    for shape in ((7, 32, 32, 3), (32, 32, 3), (8, 8, 3)):
+        A = rng.rand(*shape)
+        np.testing.assert_allclose(A, dataset.im_unflatten(dataset.im_flatten(A)))
