@@ -791,13 +791,17 @@ __device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[G::MI][G::NJ], i
 // XCD-aware block -> tile map: blocks are dispatched round-robin over the 8 XCDs
 // (block b -> XCD b % 8, MI355X_MICROARCH.md), so consecutive logical tiles
 // t (which share the P panel = same i-tile) are placed on ONE XCD's L2.
-__device__ __forceinline__ void block_to_tile(int tiles_j, int &ti, int &tj, int skip = 0, int trail = 0) {
+// `q_major`: consecutive tiles share the Q panel (same j-tile) instead: for tall outputs (AIS: 20 000 chain rows
+// against a 784 x 512 weight matrix) the row operand is the big one - 41 MB that every i-tile would otherwise
+// stream from the Infinity Cache again (rocprofv3 FETCH_SIZE: 1.17 GB per launch) while the weights stay in L2.
+__device__ __forceinline__ void block_to_tile(int tiles_j, int &ti, int &tj, int skip = 0, int trail = 0,
+                                              int q_major = 0, int tiles_i = 1) {
     // `skip` leading / `trail` trailing non-tile workgroups in the launch
     const int nb = gridDim.x - skip - trail, b = blockIdx.x - skip;
     const int q = nb / 8, r = nb % 8, xcd = b % 8;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    ti = t / tiles_j;
-    tj = t % tiles_j;
+    if (q_major) { tj = t / tiles_i; ti = t % tiles_i; }
+    else         { ti = t / tiles_j; tj = t % tiles_j; }
 }
 
 }  // namespace bm

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
         if (blockIdx.x == 0 && threadIdx.x == 0 && !was_done) { a.chk_ctl->steps += 1; a.chk_ctl->done = done; }
         if (done) return;
     } else if (a.skip && *a.skip) return;          // wave-uniform: converged mean-field loop
-    block_to_tile(tiles_j, ti, tj);
+    // tile order: tiles that share the LARGER operand panel are neighbours (same XCD L2); see block_to_tile
+    block_to_tile(tiles_j, ti, tj, 0, 0, a.J > 2 * a.I, (a.I + G::TI - 1) / G::TI);
     const int i0 = ti * G::TI, j0 = tj * G::TJ;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;

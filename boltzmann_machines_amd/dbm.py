@@ -304,17 +304,11 @@ class DBM(EngineModel):
             self._log_scalars('train', self.iter_, dict(msre=train_msre, n_mf_updates=train_n_mf_updates, epoch=self.epoch_))
             if X_val is not None and self.epoch_ % self.val_metrics_every_epoch == 0:
                 self._log_scalars('val', self.iter_, dict(msre=val_msre, n_mf_updates=val_n_mf_updates))
-            if self.verbose:
-                s = "epoch: {0:{1}}/{2}".format(self.epoch_, len(str(self.max_epoch)), self.max_epoch)
-                if train_msre:
-                    s += "; msre: {0:.5f}".format(train_msre)
-                if train_n_mf_updates:
-                    s += "; n_mf_upds: {0:.1f}".format(train_n_mf_updates)
-                if val_msre:
-                    s += "; val.msre: {0:.5f}".format(val_msre)
-                if val_n_mf_updates:
-                    s += "; val.n_mf_upds: {0:.1f}".format(val_n_mf_updates)
-                write_during_training(s)
+            if self.verbose:        # the reference's progress line (dbm.py:843-854)
+                shown = (('msre', train_msre, '%.5f'), ('n_mf_upds', train_n_mf_updates, '%.1f'),
+                         ('val.msre', val_msre, '%.5f'), ('val.n_mf_upds', val_n_mf_updates, '%.1f'))
+                write_during_training('; '.join(['epoch: %*d/%d' % (len(str(self.max_epoch)), self.epoch_, self.max_epoch)] +
+                                                [('%s: ' + f) % (n, v) for n, v, f in shown if v]))
             if self.save_after_each_epoch:
                 self._save_model(global_step=self.epoch_)
         self._engine.sync()

@@ -328,36 +328,36 @@ class BaseRBM(EngineModel):
             self._log_scalars('train', self.iter_, dict(train_results, epoch=self.epoch_))
             self._log_scalars('val', self.iter_, dict(val_results, feg=feg))
             if self.verbose:
-                s = "epoch: {0:{1}}/{2}".format(self.epoch_, len(str(self.max_epoch)), self.max_epoch)
-                for m, v in sorted(train_results.items()):
-                    if v is not None:
-                        s += "; {0}: {1:{2}}".format(m, v, self.metrics_config['{0}_fmt'.format(m)])
-                for m, v in sorted(val_results.items()):
-                    if v is not None:
-                        s += "; val.{0}: {1:{2}}".format(m, v, self.metrics_config['{0}_fmt'.format(m)])
-                if feg is not None:
-                    s += " ; feg: {0:{1}}".format(feg, self.metrics_config['feg_fmt'])
-                write_during_training(s)
+                self._report_epoch(train_results, val_results, feg)
             if self.save_after_each_epoch:
                 self._save_model(global_step=self.epoch_)
         self._engine.sync()
 
+    def _report_epoch(self, train_results, val_results, feg):
+        """one progress line per epoch in the reference's wording (`epoch: 3/10; msre: ...; val.pll: ...; feg: ...`,
+        base_rbm.py:652-666), formats from metrics_config['<metric>_fmt']"""
+        fmt = lambda name, value: format(value, self.metrics_config[name + '_fmt'])
+        parts = ['epoch: %*d/%d' % (len(str(self.max_epoch)), self.epoch_, self.max_epoch)]
+        parts += ['%s: %s' % (m, fmt(m, v)) for m, v in sorted(train_results.items()) if v is not None]
+        parts += ['val.%s: %s' % (m, fmt(m, v)) for m, v in sorted(val_results.items()) if v is not None]
+        line = '; '.join(parts)
+        if feg is not None:
+            line += ' ; feg: ' + fmt('feg', feg)
+        write_during_training(line)
+
     def init_from(self, rbm):
-        """Start from another RBM's weights and momentum buffers (reference base_rbm.py:668-685)."""
+        """Warm start from another RBM of the same class: its weights become this model's initialisers, its
+        momentum buffers the initial accumulators, and its run-time attributes (epoch_, iter_, ...) carry over
+        (reference base_rbm.py:668-685)."""
         if type(self) != type(rbm):
-            raise ValueError('an attempt to initialize `{0}` from `{1}`'.
-                             format(self.__class__.__name__, rbm.__class__.__name__))
-        weights = rbm.get_tf_params(scope='weights')
-        self.W_init = weights['W']
-        self.vb_init = weights['vb']
-        self.hb_init = weights['hb']
-        grads_accumulators = rbm.get_tf_params(scope='grads_accumulators')
-        self._dW_init = grads_accumulators['dW']
-        self._dvb_init = grads_accumulators['dvb']
-        self._dhb_init = grads_accumulators['dhb']
-        for k, v in vars(rbm).items():
-            if is_attribute_name(k):
-                setattr(self, k, v)
+            raise ValueError('an attempt to initialize `{0}` from `{1}`'
+                             .format(type(self).__name__, type(rbm).__name__))
+        w, acc = rbm.get_tf_params(scope='weights'), rbm.get_tf_params(scope='grads_accumulators')
+        self.W_init, self.vb_init, self.hb_init = w['W'], w['vb'], w['hb']
+        self._dW_init, self._dvb_init, self._dhb_init = acc['dW'], acc['dvb'], acc['dhb']
+        for name, value in vars(rbm).items():
+            if is_attribute_name(name):
+                setattr(self, name, value)
 
     @run_on_engine(update_seed=True)
     def transform(self, X, np_dtype=None):
