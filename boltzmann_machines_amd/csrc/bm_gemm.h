@@ -76,15 +76,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 constexpr int NT = 256;        // threads per workgroup of the non-tile kernels (column sums, max-norm)
-constexpr int NBUF = 4;        // LDS ring depth
-constexpr int PF = NBUF - 1;   // DMA prefetch distance in chunks
 
 enum : int { KM = 0, XM = 1 };
 
 // Tile geometry (see the header comment).
-template <int WI_, int WJ_, int MI_, int NJ_, int BK_>
+template <int WI_, int WJ_, int MI_, int NJ_, int BK_, int NB_ = 4>
 struct Geo {
     static constexpr int WI = WI_, WJ = WJ_, MI = MI_, NJ = NJ_, BK = BK_;
+    static constexpr int NBUF = NB_;                     // LDS ring depth (chunks)
+    static constexpr int PF = NB_ - 1;                   // DMA prefetch distance in chunks
     static constexpr int NW = WI * WJ;                   // waves per workgroup
     static constexpr int NT = 64 * NW;                   // threads per workgroup
     static constexpr int TI = 16 * MI * WI;              // tile extent along i
@@ -102,12 +102,15 @@ struct Geo {
     static_assert(MI == 1 || MI == 2, "MI");
     static_assert(NJ == 1 || NJ == 2, "NJ");
     static_assert(BK == 32 || BK == 64, "BK");
+    static_assert(NB_ >= 4 && NB_ <= 8, "ring depth");
     static_assert(NPP >= 1 && NPP * 1024 * NW == P_BUF * 4, "P chunk must split into whole DMA pieces per wave");
     static_assert(NPQ >= 1 && NPQ * 1024 * NW == Q_BUF * 4, "Q chunk must split into whole DMA pieces per wave");
     static_assert(NVP >= 1 && NVP * 4 * NT == TI * BK && NVQ >= 1 && NVQ * 4 * NT == TJ * BK, "register path split");
     static_assert(SMEM_FLOATS * 4 <= 160 * 1024 - 1024, "LDS");
 };
 using GeoAct = Geo<2, 2, 2, 1, 64>;      // 64 x 32 tile, 4 waves of 32 x 16, 96 KiB LDS
+// (Geo<2, 4, 1, 1, 64, 6>, the 8-wave tile with a 6-deep ring = DMA five chunks ahead, measured 16.2 us against 14.7
+//  at 784x1024x512 and 295 against 259 us at 20000 rows: more loads in flight do not help, latency is not the bound)
 using GeoAct8 = Geo<2, 4, 1, 1, 64>;     // 32 x 64 tile, 8 waves of 16 x 16 (two per SIMD), 96 KiB LDS:
                                          // more LDS traffic per MFMA but half the per-wave fill and
                                          // epilogue; wins while the launch is about one tile per CU
@@ -352,8 +355,9 @@ __device__ __forceinline__ const float *sel_p(const float *a, const float *b, in
 // ---- LDS-DMA plan: per-lane byte offsets (relative to the chunk base of the operand) of the 16-byte
 // global chunk this lane moves in each of the wave's pieces; piece n of wave w is piece p = w + n*NW of the
 // tile image (1 KiB = 64 consecutive 16-byte slots: lane l fills slot l of the piece).
-template <class G> struct DmaPlan {
-    uint32_t p[G::NPP], q[G::NPQ];
+template <class G, int DW = G::NW> struct DmaPlan {
+    static constexpr int NPP = G::P_BUF / (256 * DW), NPQ = G::Q_BUF / (256 * DW);   // pieces per DMA wave and chunk
+    uint32_t p[NPP], q[NPQ];
 };
 
 template <int L, int TX, int BK, int NW, int NP, int S>
@@ -374,10 +378,10 @@ __device__ __forceinline__ void plan_offsets(uint32_t (&off)[NP], int ld, int nx
     }
 }
 
-template <int QL, class G, int PL = KM>
-__device__ __forceinline__ void make_plan(DmaPlan<G> &pl, const Operand &P, const Operand &Q, int i0, int j0, int wave, int lane) {
-    plan_offsets<PL, G::TI, G::BK, G::NW, G::NPP, G::SP>(pl.p, P.ld, P.nx, i0, wave, lane);
-    plan_offsets<QL, G::TJ, G::BK, G::NW, G::NPQ, G::SQ>(pl.q, Q.ld, Q.nx, j0, wave, lane);
+template <int QL, class G, int PL = KM, int DW = G::NW>
+__device__ __forceinline__ void make_plan(DmaPlan<G, DW> &pl, const Operand &P, const Operand &Q, int i0, int j0, int wave, int lane) {
+    plan_offsets<PL, G::TI, G::BK, DW, DmaPlan<G, DW>::NPP, G::SP>(pl.p, P.ld, P.nx, i0, wave, lane);
+    plan_offsets<QL, G::TJ, G::BK, DW, DmaPlan<G, DW>::NPQ, G::SQ>(pl.q, Q.ld, Q.nx, j0, wave, lane);
 }
 
 // One LDS-DMA wave instruction: 64 lanes x 16 bytes from each lane's `src` to lds_dst + 16 * lane.
@@ -394,8 +398,8 @@ __device__ __forceinline__ void dma16(const char *src, float *lds_dst) {
 }
 
 // chunk c (a FULL chunk of its segment) -> LDS slot images sP / sQ, all pieces of this wave
-template <int QL, class G, bool SEG2, int PL = KM>
-__device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G> &pl1, const DmaPlan<G> &pl2, int nch1, int c,
+template <int QL, class G, bool SEG2, int PL = KM, int DW = G::NW>
+__device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G, DW> &pl1, const DmaPlan<G, DW> &pl2, int nch1, int c,
                                           float *sP, float *sQ, int wave) {
     constexpr int BK = G::BK;
     const int m = SEG2 ? -(int)(c >= nch1) : 0;           // all-ones in segment 2 (wave-uniform)
@@ -407,16 +411,16 @@ __device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G> &pl
     const char *qb = (const char *)((SEG2 ? sel_p(kr.Q1.ptr, kr.Q2.ptr, m) : kr.Q1.ptr) +
                                     ((QL == KM) ? (size_t)kc * BK * ldq : (size_t)kc * BK));
 #pragma unroll
-    for (int n = 0; n < G::NPP; ++n) {
+    for (int n = 0; n < DmaPlan<G, DW>::NPP; ++n) {
         const uint32_t o1 = pl1.p[n], o2 = SEG2 ? pl2.p[n] : 0u;
         const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
-        dma16(pb + o, sP + (wave + n * G::NW) * 256);
+        dma16(pb + o, sP + (wave + n * DW) * 256);
     }
 #pragma unroll
-    for (int n = 0; n < G::NPQ; ++n) {
+    for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) {
         const uint32_t o1 = pl1.q[n], o2 = SEG2 ? pl2.q[n] : 0u;
         const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
-        dma16(qb + o, sQ + (wave + n * G::NW) * 256);
+        dma16(qb + o, sQ + (wave + n * DW) * 256);
     }
 }
 
@@ -504,10 +508,23 @@ __device__ __forceinline__ void store_chunk_slim(const ChunkRegs<G> &r, float *s
     r2s<QL, G::TJ, G::BK, G::NT, G::SQ, false>(r.q, sQ, tid, 0);
 }
 
-enum : int { STG_DMA = 0, STG_REG = 1 };
+// STG_DMAH ("half"): in the 8-wave geometries only waves 0 .. 3 - one per SIMD - issue the DMA instructions (twice
+// as many each); their SIMD partners 4 .. 7 go straight to the MFMAs, so the time a DMA instruction holds its
+// wave is covered by the partner's matrix work instead of stalling both waves of the SIMD at the same moment.
+enum : int { STG_DMA = 0, STG_REG = 1, STG_DMAH = 2 };
 
 // counted waits / raw barrier (a __syncthreads() would insert vmcnt(0) and drain the DMA queue)
 #define BM_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// wait until at most n (wave-uniform, 0 .. MAXC) chunks' worth of this wave's DMA instructions are in flight
+template <int NPW, int MAXC>
+__device__ __forceinline__ void wait_vm_chunks(int n) {
+    static_assert(MAXC * NPW <= 63, "vmcnt range");
+    if (MAXC >= 4 && n >= 4)      BM_WAIT_VM(4 * NPW <= 63 ? 4 * NPW : 0);
+    else if (MAXC >= 3 && n == 3) BM_WAIT_VM(3 * NPW <= 63 ? 3 * NPW : 0);
+    else if (MAXC >= 2 && n == 2) BM_WAIT_VM(2 * NPW <= 63 ? 2 * NPW : 0);
+    else if (n == 1)              BM_WAIT_VM(NPW);
+    else                          BM_WAIT_VM(0);
+}
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads / writes have completed
     __builtin_amdgcn_s_barrier();
@@ -534,8 +551,9 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #else
 #define BM_MSTAMP(n) do {} while (0)
 #endif
-    constexpr int BK = G::BK, P_BUF = G::P_BUF, Q_BUF = G::Q_BUF;
-    constexpr int NPW = G::NPP + G::NPQ;              // DMA instructions per wave and chunk
+    constexpr int BK = G::BK, P_BUF = G::P_BUF, Q_BUF = G::Q_BUF, NBUF = G::NBUF, PF = G::PF;
+    constexpr int DW = (STG == STG_DMAH && G::NW == 8) ? 4 : G::NW;       // waves that issue DMA instructions
+    constexpr int NPW = DmaPlan<G, DW>::NPP + DmaPlan<G, DW>::NPQ;         // DMA instructions per DMA wave and chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (SGPR): LDS piece bases stay scalar
     const int wi = w % G::WI, wj = w / G::WI;
@@ -548,17 +566,18 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         return (c < nfull1) | (SEG2 && c >= nch1 && c - nch1 < nfull2);
     };
     auto is_dma = [&](int c) -> bool {
-        if (!FAST || STG != STG_DMA || BM_ABL(6)) return false;
+        if (!FAST || STG == STG_REG || BM_ABL(6)) return false;
         return is_full(c);
     };
     ChunkRegs<G> gr;             // register-path staging (one chunk)
     Frags<G> fa, fb;
-    DmaPlan<G> pl1, pl2;
+    DmaPlan<G, DW> pl1, pl2;
     RegPlan<G> rp1, rp2;
+    const bool dmaw = (DW == G::NW) || w < DW;       // wave-uniform
     ChunkRegs<G> g0, g1;         // REG staging: the two register sets of the steady steps (named, never arrays)
-    if (FAST && STG == STG_DMA) {
-        make_plan<QL, G, PL>(pl1, kr.P1, kr.Q1, i0, j0, w, lane);
-        if (SEG2) make_plan<QL, G, PL>(pl2, kr.P2, kr.Q2, i0, j0, w, lane);
+    if (FAST && STG != STG_REG && dmaw) {
+        make_plan<QL, G, PL, DW>(pl1, kr.P1, kr.Q1, i0, j0, w, lane);
+        if (SEG2) make_plan<QL, G, PL, DW>(pl2, kr.P2, kr.Q2, i0, j0, w, lane);
     }
     // REG staging: leading run of steps c whose chunks c+2 (stored) and c+4 (loaded) are full chunks; chunks
     // 0 .. 3 are then full as well and go through the same slim path in the fill
@@ -590,8 +609,8 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         // ---- pipeline fill: chunks 0 .. PF-1
 #pragma unroll
         for (int c = 0; c < PF; ++c)
-            if (c < nch && is_dma(c) && !BM_ABL(0))
-                dma_chunk<QL, G, SEG2, PL>(kr, pl1, pl2, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, w);
+            if (c < nch && is_dma(c) && dmaw && !BM_ABL(0))
+                dma_chunk<QL, G, SEG2, PL, DW>(kr, pl1, pl2, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, w);
         __builtin_amdgcn_sched_barrier(0);
         side.fill();
         __builtin_amdgcn_sched_barrier(0);
@@ -601,8 +620,13 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
                 load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, c, tid);
                 store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, tid);
             }
-        // chunks 0 and 1 complete (the DMA of chunk 2, if any, may stay in flight)
-        if (nch > 2 && is_dma(2) && !BM_ABL(0)) BM_WAIT_VM(NPW); else BM_WAIT_VM(0);
+        // chunks 0 and 1 complete (the DMAs of chunks 2 .. PF-1, if any, may stay in flight)
+        {
+            int n_after = 0;
+#pragma unroll
+            for (int c = 2; c < PF; ++c) n_after += (c < nch && is_dma(c) && !BM_ABL(0)) ? 1 : 0;
+            wait_vm_chunks<NPW, PF - 2>(n_after);
+        }
     }
     BM_MSTAMP(1);
     if (!BM_ABL(5)) wg_barrier();
@@ -623,7 +647,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #endif
 #if BM_SCHED_VARIANT == 0
 #define BM_SCHED_STEP                                                                             \
-    _Pragma("unroll") for (int s_ = 0; s_ < NPW; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) }        \
+    if (DW == G::NW) { _Pragma("unroll") for (int s_ = 0; s_ < NPW; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } } \
     _Pragma("unroll") for (int s_ = 0; s_ < NR; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) }         \
     BM_SG(0x008, NM)
 #elif BM_SCHED_VARIANT == 1    /* reads first, DMA behind them */
@@ -653,16 +677,16 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #define BM_STEP_STEADY(FC, FN)                                                                    \
     {                                                                                             \
         const int cd = cc + PF;                                                                   \
-        if (!BM_ABL(0)) dma_chunk<QL, G, SEG2, PL>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
+        if (dmaw && !BM_ABL(0)) dma_chunk<QL, G, SEG2, PL, DW>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
         read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
         if (PP) {                                                                                 \
-            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM(NPW);                                   \
+            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM((PF - 2) * NPW);                        \
             if (!BM_ABL(5)) wg_barrier();                                                         \
             mfma_frags<G, ABL>(acc, FC);                                                          \
         } else {                                                                                  \
             mfma_frags<G, ABL>(acc, FC);                                                          \
             BM_SCHED_STEP                                                                         \
-            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM(NPW);                                   \
+            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM((PF - 2) * NPW);                        \
         }                                                                                         \
         if (!BM_ABL(5)) wg_barrier();                                                             \
         ++cc;                                                                                     \
@@ -674,16 +698,17 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         const bool do_dma = cd < nch && is_dma(cd) && !BM_ABL(0);                                 \
         const bool do_reg = cr < nch && !is_dma(cr) && !BM_ABL(0);                                \
         if (do_reg) load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, cr, tid);             \
-        if (do_dma) dma_chunk<QL, G, SEG2, PL>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
+        if (do_dma && dmaw) dma_chunk<QL, G, SEG2, PL, DW>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
         if (!(LAST) && cc + 1 < nch) read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
         if (!PP) { if (LAST) mfma_frags_head<G, ABL>(acc, FC, nq_last); else mfma_frags<G, ABL>(acc, FC); } \
         if (do_reg) {                                                                             \
             BM_WAIT_VM(0);                                                                        \
             store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, cr, sP + (cr % NBUF) * P_BUF, sQ + (cr % NBUF) * Q_BUF, tid); \
-        } else if (do_dma) {                                                                      \
-            BM_WAIT_VM(NPW);                                                                      \
         } else {                                                                                  \
-            BM_WAIT_VM(0);                                                                        \
+            /* chunk cc+2 must have landed: the DMAs of chunks cc+3 .. cc+PF may stay in flight */ \
+            int n_after = 0;                                                                      \
+            _Pragma("unroll") for (int c_ = 3; c_ <= PF; ++c_) n_after += (cc + c_ < nch && is_dma(cc + c_) && !BM_ABL(0)) ? 1 : 0; \
+            wait_vm_chunks<NPW, PF - 2>(n_after);                                                 \
         }                                                                                         \
         if (PP) {                                                                                 \
             if (!BM_ABL(5)) wg_barrier();                                                         \
@@ -740,8 +765,14 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     }
     // leading run of DMA steady steps (in pairs: the two fragment sets alternate)
     int n_steady = 0;
-    if (FAST && STG == STG_DMA && !BM_ABL(6))
-        while (n_steady + PF < nch && is_dma(n_steady + PF) && is_dma(n_steady + 2)) ++n_steady;
+    if (FAST && STG != STG_REG && !BM_ABL(6))
+        while (n_steady + PF < nch) {                  // every chunk the step's counted wait assumes in flight is a DMA chunk
+            bool all = true;
+#pragma unroll
+            for (int c_ = 2; c_ <= PF; ++c_) all = all && is_dma(n_steady + c_);
+            if (!all) break;
+            ++n_steady;
+        }
     const int nsp = n_steady / 2;
 #pragma unroll 1
     for (int q = 0; q < nsp; ++q) {

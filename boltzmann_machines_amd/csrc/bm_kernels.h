@@ -1379,6 +1379,8 @@ static inline int act_geo_override() {
 }
 // geo: tile geometry 8 | 4 | 1 | 3, + 100 for register staging of the full chunks (default: LDS-DMA)
 static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
+    // 208: 8 waves, DMA issued by waves 0-3 only (not a tuner candidate: within noise of 8 on every shape measured)
+    if (geo == 208) { launch_act_geo<GeoAct8, 1, STG_DMAH>(a, st); return; }
     const bool reg = geo >= 100;
     geo %= 100;
     if (a.p_xm && geo == 4) geo = 8;        // x-major P exists for the MI == 1 geometries only
@@ -1497,7 +1499,8 @@ static inline void launch_grad_geo(const GradArgs &g, hipStream_t st) {
 }
 // geo: 4 | 8 waves, + 100 for register staging of the full chunks
 static inline void launch_grad_as(int geo, const GradArgs &g, hipStream_t st) {
-    if (geo == 108)      launch_grad_geo<GeoGrad8, STG_REG>(g, st);
+    if (geo == 208)      launch_grad_geo<GeoGrad8, STG_DMAH>(g, st);
+    else if (geo == 108) launch_grad_geo<GeoGrad8, STG_REG>(g, st);
     else if (geo == 104) launch_grad_geo<GeoGrad, STG_REG>(g, st);
     else if (geo == 8)   launch_grad_geo<GeoGrad8, STG_DMA>(g, st);
     else                 launch_grad_geo<GeoGrad, STG_DMA>(g, st);
@@ -1517,10 +1520,11 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return 4; }
-    const int cand[4] = {4, 8, 104, 108};
-    float best_us[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+    constexpr int NC = 4;
+    const int cand[NC] = {4, 8, 104, 108};             // 208 (half-wave DMA) is forceable, never the fastest
+    float best_us[NC] = {1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < 3; ++round)
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NC; ++c) {
             launch_grad_as(cand[c], t, st);
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < 4; ++r) launch_grad_as(cand[c], t, st);
@@ -1531,7 +1535,7 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
         }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     int b = 0;
-    for (int c = 1; c < 4; ++c) if (best_us[c] < best_us[b]) b = c;
+    for (int c = 1; c < NC; ++c) if (best_us[c] < best_us[b]) b = c;
     const int best = cand[b];
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
