@@ -102,8 +102,10 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B,
                               float learning_rate, float momentum, int32_t n_gibbs_steps,
                               float *out4);
 /* The `for X_batch in batch_iter(X, batch_size)` loop of _train_epoch
- * (base_rbm.py:549-571) run device-side without host round trips:
- * N rows, consecutive batches of `batch` rows (last one may be short). */
+ * (base_rbm.py:549-571) behind ONE call: N rows, consecutive batches of `batch` rows (last one may be
+ * short).  The library enqueues every update's four launches from a native loop, asynchronously on the
+ * handle's stream (no synchronisation, no device-to-host traffic, one FFI crossing per run of batches);
+ * the stream stays GPU-bound, a HIP graph of the same launches measured 0.35 us per kernel less. */
 int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
                        float learning_rate, float momentum, int32_t n_gibbs_steps);
 

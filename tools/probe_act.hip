@@ -43,6 +43,28 @@ int main(int argc, char **argv) {
     printf("k_empty 256x256      %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, Hs.p); }));
     printf("k_lds 73KB 256x256   %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_lds, dim3(256), dim3(256), 0, st, Hs.p); }));
     printf("k_args 256x256       %.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL(k_args, dim3(256), dim3(256), 0, st, a); }));
+    {   // does a HIP graph shrink the kernel boundary?  200 kernels per replay, stream launches vs graph replay
+        auto graph_time = [&](auto enqueue, const char *name) {
+            hipGraph_t gr; hipGraphExec_t ge;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeGlobal) != hipSuccess) { printf("capture failed\n"); return; }
+            for (int i = 0; i < 200; ++i) enqueue();
+            if (hipStreamEndCapture(st, &gr) != hipSuccess) { printf("end capture failed\n"); return; }
+            if (hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0) != hipSuccess) { printf("instantiate failed\n"); return; }
+            for (int i = 0; i < 3; ++i) (void)hipGraphLaunch(ge, st);
+            (void)hipStreamSynchronize(st);
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < 5; ++i) (void)hipGraphLaunch(ge, st);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("%-34s %6.2f us per kernel in a 200-kernel graph\n", name, 1e3f * ms / 1000);
+            (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr);
+        };
+        graph_time([&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, Hs.p); }, "k_empty (graph)");
+        graph_time([&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a); }, "8w full (graph)");
+        printf("%-34s %6.2f us per kernel, stream launches\n", "8w full (stream)",
+               time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a); }));
+    }
     long long *dbg; CK(hipMalloc((void **)&dbg, 8192 * 8)); CK(hipMemset(dbg, 0, 8192 * 8));
     a.dbg = dbg;
 #define RUNG(GEO, MINB, MASK, NAME) { \
