@@ -25,6 +25,19 @@ struct bm_dbm {
     int n[MAXL + 1];                       // n[0] = V, n[i+1] = hidden layer i
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The fantasy-particle sweeps (PCD) read only the parameters and the particles, the mean-field only the
+    // parameters, X and mu: within one update they are independent, so the particle sweeps run on a second stream
+    // (fork at the start of the update, join before the gradients) and fill the launch / fill / tail gaps of the
+    // small mean-field kernels.  `cur` is the stream layer_update / gibbs_sweep enqueue on.
+    hipStream_t stream2 = nullptr, cur = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int updates_seen = 0;                          // the first updates run on one stream (launch tuning measures alone)
+    // mean-field loop control mirror: pinned host copies of `ctl`, one per enqueued group of sweeps, so that the next
+    // group is enqueued BEFORE the previous group's result is read (the GPU never waits for the host)
+    static constexpr int MF_RING = 4;
+    MfCtl *ctl_host = nullptr;
+    hipEvent_t ctl_ev[MF_RING] = {nullptr, nullptr, nullptr, nullptr};
+    int mf_pred = 0;                               // trip count of the previous mean-field call (size of the first group)
     // variables
     Mat W[MAXL], Wt[MAXL], dW[MAXL];       // W[i]: [n[i]][n[i+1]]
     DevBuf vb, dvb, sigma;
@@ -40,6 +53,7 @@ struct bm_dbm {
     bm_comm *comm = nullptr;                       // bm_dbm_set_comm: the residual is all-reduced (max) ON DEVICE, on the
                                                    // engine stream, by the library's own RCCL communicator
     DevBuf wnorm[MAXL];
+    DevBuf mn_fac[MAXL];                           // max-norm column factors [2][n_{i+1}]: min(norm, c) | max(norm, 1e-8)
     Mat logits[MAXL];                              // Multinomial layers: row store of the logits / means [rows][n_i], on demand
     int logit_rows[MAXL] = {0, 0, 0, 0};
     bool multinomial(int layer) const { return layer >= 0 && cfg.h_unit[layer] == BM_UNIT_MULTINOMIAL; }
@@ -116,17 +130,17 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
         }
         a.kind = 3; a.sample = 0; a.means = lg; a.ldo = ldl; a.states = nullptr; a.negmeans = nullptr;
         a.prev = nullptr; a.maxdiff = nullptr; a.maxdiff_blk = nullptr;
-        launch_act(a, h->stream);
+        launch_act(a, h->cur);
         SmArgs m;
         memset(&m, 0, sizeof(m));
         m.L = lg; m.ld = ldl; m.I = a.I; m.J = J; m.M = h->cfg.n_samples[layer]; m.sample = sample;
         m.states = (states && (sample || states != lg)) ? states : nullptr;
         m.key = key; m.row0 = row0;
         m.prev = prev; m.ld_prev = ldo; m.maxdiff = maxdiff; m.skip = a.skip;
-        hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(J), dim3(64), 2 * (size_t)a.I * sizeof(float), h->stream, m);
+        hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(J), dim3(64), 2 * (size_t)a.I * sizeof(float), h->cur, m);
         return;
     }
-    launch_act(a, h->stream);
+    launch_act(a, h->cur);
 }
 
 // `_make_gibbs_step` (dbm.py:385-427): bottom-up Gauss-Seidel sweep.
@@ -160,7 +174,7 @@ static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout
             e.mult = 1.f; e.bmult = 1.f; e.sample = 0;
             e.means = Hout[0].p; e.ldo = Hout[0].ld;
             e.prev = maxdiff ? Hin[0].p : nullptr; e.maxdiff = maxdiff;
-            launch_act(e, h->stream);
+            launch_act(e, h->cur);
             continue;
         }
         // without sampling the layer's value is its mean: write it as `means` only
@@ -213,7 +227,7 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
     // cond at step 0 compares the persistent mu with the init values (:449-452)
     BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
     for (int i = 0; i < L; ++i)
-        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(64), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
+        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 512 ? N : 512), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
                            (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
     int step = 0;
     Mat *cur = h->mu, *alt = h->mu_alt;
@@ -254,11 +268,17 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         const size_t set_sz = (size_t)MAXL * BM_MF_SLOTS;
         if (self_ctl) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * set_sz * sizeof(float), h->stream));
         BM_TRY(ctl_step(1));
-        int enq = 0;
+        // Groups of sweeps are enqueued without host round trips; the loop-control record is copied to a pinned
+        // mirror after each group and READ ONE GROUP LATE: group g+1 is already in the queue when the host looks at
+        // group g, so the GPU never idles waiting for the host (sweeps enqueued past the end of the loop return at
+        // once).  The first group is as long as the previous call's trip count - for a training run the count
+        // barely moves from one minibatch to the next - so a typical call costs one or two reads.
+        constexpr int R = bm_dbm::MF_RING;
+        int enq = 0, g_enq = 0, g_read = 0;
         MfCtl host;
         host.done = 0; host.steps = 0;
-        while (enq < h->cfg.max_mf_updates) {
-            const int g = (h->cfg.max_mf_updates - enq < MF_GROUP) ? h->cfg.max_mf_updates - enq : MF_GROUP;
+        const int max_it = h->cfg.max_mf_updates;
+        auto enqueue_group = [&](int g) -> int {
             for (int s = 0; s < g; ++s) {
                 // sweep number enq+s runs only if all before it ran, so its ping-pong parity is static
                 const int sw = enq + s;
@@ -277,14 +297,41 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
                 }
             }
             enq += g;
-            BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
+            BM_HIP(hipMemcpyAsync(&h->ctl_host[g_enq % R], h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
+            BM_HIP(hipEventRecord(h->ctl_ev[g_enq % R], h->stream));
+            ++g_enq;
+            return 0;
+        };
+        if (max_it <= 0) {                 // no sweeps: fetch the step-0 record
+            BM_HIP(hipMemcpyAsync(&h->ctl_host[0], h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
             BM_HIP(hipStreamSynchronize(h->stream));
-            if (host.done) break;
+            host = h->ctl_host[0];
         }
-        if (!host.done) {      // max_mf_updates reached (or zero): fetch the final counter
-            BM_HIP(hipMemcpyAsync(&host, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
-            BM_HIP(hipStreamSynchronize(h->stream));
+        auto read_oldest = [&]() -> int {
+            BM_HIP(hipEventSynchronize(h->ctl_ev[g_read % R]));
+            host = h->ctl_host[g_read % R];
+            ++g_read;
+            return 0;
+        };
+        if (max_it > 0) {
+            // first group: the previous trip count + 1 (a sweep too many costs two kernels that return at once,
+            // a sweep too few costs a host round trip), read before anything else is enqueued
+            int g0 = h->mf_pred > 0 ? h->mf_pred + 1 : MF_GROUP;
+            if (g0 > max_it) g0 = max_it;
+            BM_TRY(enqueue_group(g0));
+            BM_TRY(read_oldest());
+            // not converged yet: short groups, one of them always queued behind the one being read
+            while (!host.done && (enq < max_it || g_read < g_enq)) {
+                while (enq < max_it && g_enq - g_read < 2)
+                    BM_TRY(enqueue_group(max_it - enq < MF_GROUP / 2 ? max_it - enq : MF_GROUP / 2));
+                BM_TRY(read_oldest());
+            }
+            if (g_read < g_enq) {          // groups enqueued past the end of the loop do nothing; free their ring slots
+                BM_HIP(hipEventSynchronize(h->ctl_ev[(g_enq - 1) % R]));
+                g_read = g_enq;
+            }
         }
+        h->mf_pred = host.steps > 0 ? host.steps : 0;
         step = host.steps;
         if (step & 1) { cur = h->mu_alt; alt = h->mu; }
     }
@@ -302,6 +349,33 @@ static void particles_update(bm_dbm *h, int k, bool sample, bool update_only_v_a
         Mat tv = h->v; h->v = h->v_new; h->v_new = tv;                    // swap particles (:493)
         for (int i = 0; i < h->L; ++i) { Mat th = h->H[i]; h->H[i] = h->H_new[i]; h->H_new[i] = th; }
     }
+}
+
+// mean-field on the data rows and PCD sweeps on the particles of one update, concurrently (see bm_dbm::stream2).
+// The particle sweeps are enqueued FIRST (mean_field() blocks the host on its loop control), on the second stream,
+// between a fork event (everything enqueued so far, i.e. the previous parameter update) and a join event the main
+// stream waits for before anything reads the particles.  Same kernels, same RNG streams: results do not change.
+static bool pcd_overlap_ok(const bm_dbm *h) {
+    static const bool off = getenv("BM355_DBM_OVERLAP") && atoi(getenv("BM355_DBM_OVERLAP")) == 0;
+    if (off || h->updates_seen < 2) return false;          // the first updates tune their launches undisturbed
+    for (int i = 0; i < h->L; ++i) if (h->multinomial(i)) return false;     // one logits row store per layer
+    return true;
+}
+static int mean_field_and_particles(bm_dbm *h, const float *X_dev, int k, int *out_n) {
+    const bool ov = pcd_overlap_ok(h);
+    if (ov) {
+        BM_HIP(hipEventRecord(h->ev_fork, h->stream));
+        BM_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        h->cur = h->stream2;
+        particles_update(h, k, true);                             // :521
+        h->cur = h->stream;
+        BM_HIP(hipEventRecord(h->ev_join, h->stream2));
+    }
+    const int rc = mean_field(h, X_dev, out_n);                   // :517
+    if (ov) BM_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    else if (!rc) particles_update(h, k, true);
+    h->updates_seen++;
+    return rc;
 }
 
 static size_t sums_off(const bm_dbm *h, int which /* 0: X, 1: v, 2+2i: mu_i, 3+2i: H_i */) {
@@ -387,7 +461,9 @@ static void launch_dbm_maxnorm(bm_dbm *h, int i) {
     MaxNormArgs m;
     m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = h->n[i + 1]; m.J = h->n[i]; m.ldw = h->W[i].ld; m.ldwt = h->Wt[i].ld;
     m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
+    m.num = h->mn_fac[i].p; m.den = h->mn_fac[i].p + m.I;
     hipLaunchKernelGGL(maxnorm_kernel, dim3((m.I + 15) / 16), dim3(NT), 0, h->stream, m);
+    hipLaunchKernelGGL(maxnorm_scale_kernel, dim3(((m.I + 31) / 32) * ((m.J + 31) / 32)), dim3(256), 0, h->stream, m);
 }
 
 // gradients + sparsity + momentum + max-norm (dbm.py:550-621) from the current mu / particles
@@ -432,14 +508,20 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
         h->n[i + 1] = cfg->n_hiddens[i];
     }
     BM_HIP(hipStreamCreate(&h->stream));
+    BM_HIP(hipStreamCreate(&h->stream2));
+    h->cur = h->stream;
     BM_HIP(hipEventCreate(&h->ev0));
     BM_HIP(hipEventCreate(&h->ev1));
+    BM_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    BM_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    BM_HIP(hipHostMalloc((void **)&h->ctl_host, bm_dbm::MF_RING * sizeof(MfCtl)));
+    for (int i = 0; i < bm_dbm::MF_RING; ++i) BM_HIP(hipEventCreateWithFlags(&h->ctl_ev[i], hipEventDisableTiming));
     size_t nsums = 2 * (size_t)h->V;
     for (int i = 0; i < h->L; ++i) {
         const int a = h->n[i], b = h->n[i + 1];
         BM_TRY(h->W[i].alloc(a, b)); BM_TRY(h->Wt[i].alloc(b, a)); BM_TRY(h->dW[i].alloc(a, b));
         BM_TRY(h->hb[i].alloc(b)); BM_TRY(h->dhb[i].alloc(b)); BM_TRY(h->q[i].alloc(b)); BM_TRY(h->mm[i].alloc(b));
-        BM_TRY(h->pen[i].alloc(b)); BM_TRY(h->wnorm[i].alloc(b));
+        BM_TRY(h->pen[i].alloc(b)); BM_TRY(h->wnorm[i].alloc(b)); BM_TRY(h->mn_fac[i].alloc(2 * (size_t)b));
         BM_TRY(h->mu[i].alloc(h->N, b)); BM_TRY(h->mu_alt[i].alloc(h->N, b)); BM_TRY(h->mu_new[i].alloc(h->N, b));
         BM_TRY(h->H[i].alloc(h->M, b)); BM_TRY(h->H_new[i].alloc(h->M, b));
         nsums += 2 * (size_t)b;
@@ -474,7 +556,7 @@ int bm_dbm_destroy(bm_dbm *h) {
     for (int i = 0; i < h->L; ++i) {
         Mat *ms[] = {&h->W[i], &h->Wt[i], &h->dW[i], &h->mu[i], &h->mu_alt[i], &h->mu_new[i], &h->H[i], &h->H_new[i]};
         for (Mat *m : ms) m->release();
-        DevBuf *bs[] = {&h->hb[i], &h->dhb[i], &h->q[i], &h->mm[i], &h->pen[i], &h->wnorm[i]};
+        DevBuf *bs[] = {&h->hb[i], &h->dhb[i], &h->q[i], &h->mm[i], &h->pen[i], &h->wnorm[i], &h->mn_fac[i]};
         for (DevBuf *b : bs) b->release();
         h->logits[i].release();
     }
@@ -484,6 +566,11 @@ int bm_dbm_destroy(bm_dbm *h) {
     for (DevBuf *b : bs) b->release();
     if (h->alogw) (void)hipFree(h->alogw);
     if (h->ctl) (void)hipFree(h->ctl);
+    if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+    for (int i = 0; i < bm_dbm::MF_RING; ++i) if (h->ctl_ev[i]) (void)hipEventDestroy(h->ctl_ev[i]);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     h->mfblk.release();
     h->xw0.release();
     if (h->scal) (void)hipFree(h->scal);
@@ -587,8 +674,7 @@ int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float lr, float mom, int32_
                       int32_t *out_n_mf, float *out_msre) {
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
     int nmf = 0;
-    BM_TRY(mean_field(h, X_dev, &nmf));                       // :517
-    particles_update(h, k, true);                             // :521
+    BM_TRY(mean_field_and_particles(h, X_dev, k, &nmf));      // :517, :521
     if (out_msre) BM_TRY(recon_msre(h, X_dev, out_msre));     // :625-630 (W before the update)
     BM_TRY(apply_update(h, X_dev, lr, mom));
     if (out_n_mf) *out_n_mf = nmf;
@@ -615,8 +701,7 @@ static int recon_msre(bm_dbm *h, const float *X_dev, float *out_msre) {
 int bm_dbm_metrics(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf, float *out_msre) {
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
     int nmf = 0;
-    BM_TRY(mean_field(h, X_dev, &nmf));
-    particles_update(h, k, true);
+    BM_TRY(mean_field_and_particles(h, X_dev, k, &nmf));
     if (out_msre) BM_TRY(recon_msre(h, X_dev, out_msre));
     if (out_n_mf) *out_n_mf = nmf;
     h->call++;
@@ -640,8 +725,7 @@ int bm_dbm_set_mf_allreduce(bm_dbm *h, float (*fn)(float, void *), void *ctx) {
 int bm_dbm_grad_step(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf) {
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
     int nmf = 0;
-    BM_TRY(mean_field(h, X_dev, &nmf));
-    particles_update(h, k, true);
+    BM_TRY(mean_field_and_particles(h, X_dev, k, &nmf));
     launch_dbm_colsums(h, X_dev);
     for (int i = 0; i < h->L; ++i) launch_dbm_grad(h, X_dev, i, 0, 1.f, 1.f, 0.f, 0.f);
     if (out_n_mf) *out_n_mf = nmf;

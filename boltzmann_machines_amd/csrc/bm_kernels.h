@@ -1213,18 +1213,22 @@ __global__ void dbm_bias_kernel(DbmBiasArgs a) {
 }
 
 // Max-norm column rescale (dbm.py:511-513, :603-607):  W[:,c] *= min(||W[:,c]||, c_max) / max(||W[:,c]||, 1e-8)
-// One workgroup per 16 columns.  ||.||^2 is the canonical chain sum_j fma(w_j, w_j, acc): the
-// diagonal of the 16x16 Gram block the MFMA produces when both operands are the column block.
+// Two kernels.  maxnorm_kernel: one workgroup per 16 columns computes ||.||^2 as the canonical chain
+// sum_j fma(w_j, w_j, acc) - the diagonal of the 16x16 Gram block the MFMA produces when both operands are the
+// column block - and leaves min(norm, c_max) / max(norm, 1e-8) per column in `num` / `den`.
+// maxnorm_scale_kernel: 32 x 32 tiles over the whole matrix rescale W in place and rewrite the maintained
+// transpose through LDS, both with full-line accesses on every CU (the one-kernel form of round 1 wrote the
+// transpose 4 bytes at a time from 32 - 64 workgroups: 30 us per matrix).
 struct MaxNormArgs {
     float *W, *Wt;          // [J][I] pitch ldw, transpose [I][J] pitch ldwt
     int I, J, ldw, ldwt;
     float max_norm;
     float *norm_out;        // [I] column norms (W_norm metric) or null
+    float *num, *den;       // [I] each: the column factors
 };
 __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
     constexpr int MN_ROWS = 512;
     __shared__ __attribute__((aligned(16))) float sA[MN_ROWS * 16];
-    __shared__ float s_num[16], s_den[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int c0 = blockIdx.x * 16;
@@ -1248,21 +1252,37 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
         }
         __syncthreads();
     }
-    if (w == 0 && (l15 >> 2) == g) {                         // diagonal element i == j == l15
+    if (w == 0 && (l15 >> 2) == g && c0 + l15 < a.I) {       // diagonal element i == j == l15
         const float nrm = sqrtf(acc[l15 & 3]);
-        s_num[l15] = fminf(nrm, a.max_norm);                 // tf.minimum(T_norm, max_norm)
-        s_den[l15] = fmaxf(nrm, 1e-8f);                      // tf.maximum(T_norm, 1e-8)
-        if (a.norm_out && c0 + l15 < a.I) a.norm_out[c0 + l15] = nrm;
+        a.num[c0 + l15] = fminf(nrm, a.max_norm);            // tf.minimum(T_norm, max_norm)
+        a.den[c0 + l15] = fmaxf(nrm, 1e-8f);                 // tf.maximum(T_norm, 1e-8)
+        if (a.norm_out) a.norm_out[c0 + l15] = nrm;
     }
-    __syncthreads();
-    for (int e = tid; e < a.J * 16; e += NT) {
-        const int row = e >> 4, cc = e & 15, c = c0 + cc;
-        if (c < a.I) {
-            const size_t o = (size_t)row * a.ldw + c;
-            const float wn = (a.W[o] * s_num[cc]) / s_den[cc];     // T * min / max, left to right
+}
+__global__ __launch_bounds__(256) void maxnorm_scale_kernel(MaxNormArgs a) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles_c = (a.I + 31) / 32;
+    const int c0 = (blockIdx.x % tiles_c) * 32, j0 = (blockIdx.x / tiles_c) * 32;
+    const int c = c0 + tx;
+    const float num = c < a.I ? a.num[c] : 0.f, den = c < a.I ? a.den[c] : 1.f;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r;
+        float wn = 0.f;
+        if (j < a.J && c < a.I) {
+            const size_t o = (size_t)j * a.ldw + c;
+            wn = (a.W[o] * num) / den;                       // T * min / max, left to right
             a.W[o] = wn;
-            if (a.Wt) a.Wt[(size_t)c * a.ldwt + row] = wn;
         }
+        t[r][tx] = wn;
+    }
+    if (!a.Wt) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {                       // row r of the transposed tile = column c0 + r
+        const int cc = c0 + r, j = j0 + tx;
+        if (cc < a.I && j < a.J) a.Wt[(size_t)cc * a.ldwt + j] = t[tx][r];
     }
 }
 
@@ -1319,12 +1339,11 @@ __global__ void mf_latch_kernel(MfCtl *c, float tol, int init) {
 }
 
 // ||A - B||_inf over a [rows][cols] window -> atomicMax on float bits (mean-field cond, dbm.py:449-452)
-__global__ void maxabsdiff_kernel(const float *A, int lda, const float *B, int ldb, int rows, int cols, unsigned *out) {
-    const size_t n = (size_t)rows * cols;
+__global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda, const float *B, int ldb, int rows, int cols, unsigned *out) {
     float m = 0.f;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const size_t r = e / (size_t)cols, c = e % (size_t)cols;
-        m = fmaxf(m, fabsf(A[r * lda + c] - B[r * ldb + c]));
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float *pa = A + (size_t)r * lda, *pb = B + (size_t)r * ldb;
+        for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(pa[c] - pb[c]));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));

@@ -69,6 +69,31 @@ def test_train_steps_bit_exact(gpu_lib, V, nh, N, M, kw):
     eng.close()
 
 
+def test_overlapped_particles_and_predicted_mean_field_bit_exact(gpu_lib):
+    # from the third update on the PCD sweeps run on a second stream next to the mean-field, and the mean-field's
+    # first group of sweeps is sized from the previous trip count (too long / too short both occur here)
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 28, [20, 12], 12, 8
+    eng, twin = make_pair(V, nh, N, M, max_mf_updates=30, mf_tol=2e-4, l2=1e-3, max_norm=1.2)
+    eng.seed(11); twin.set_seed(11)
+    names = ['vb', 'dvb', 'v', 'W', 'dW', 'hb', 'dhb', 'mu', 'h', 'W_1', 'dW_1', 'hb_1', 'dhb_1', 'mu_1', 'h_1']
+    counts = []
+    for s in range(7):
+        X = data(N, V, 40 + s) if s != 3 else np.zeros((N, V), dtype=np.float32)
+        if s == 5:                              # the validation fetch in between (no update, particles advance)
+            n1, m1 = eng.metrics(as_device(X), 2)
+            n2, m2 = twin.metrics(X, 2)
+        else:
+            n1, m1 = eng.train_step(as_device(X), 0.1, 0.5, 2, want_msre=True)
+            n2, m2 = twin.train_step(X, 0.1, 0.5, 2, want_msre=True)
+        assert n1 == n2, (s, n1, n2)
+        np.testing.assert_allclose(m1, m2, rtol=1e-5)
+        assert_equal(eng, twin, names)
+        counts.append(n1)
+    assert len(set(counts)) > 1, counts         # the trip count did move, so the prediction was wrong at least once
+    eng.close()
+
+
 def test_mean_field_reconstruct_sample_v(gpu_lib):
     from boltzmann_machines_amd._ffi import DeviceArray
     from boltzmann_machines_amd.engine import as_device
