@@ -69,7 +69,6 @@ struct NoSide {
 // instantiates other values to price each pipeline stage)
 //   bit 0: no global -> LDS traffic   bit 1: VALU instead of MFMA   bit 3: no fragment reads
 //   bit 4: no epilogue (act_kernel)   bit 5: no barriers             bit 6: register path for every chunk
-//   bit 7: no ping-pong (8-wave geometries run lock-stepped like the 4-wave ones)
 #define BM_ABL(bit) ((ABL >> (bit)) & 1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -397,6 +396,26 @@ __device__ __forceinline__ void dma16(const char *src, float *lds_dst) {
                  : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
 }
 
+// The same with a SCALAR global base and a 32-bit per-lane byte offset (`global_load_lds_dwordx4 v, s[..]`), and
+// the LDS destination as a wave-uniform BYTE address: no vector ALU instruction per piece.  That matters more than
+// it looks: the MFMA stream of a wave is one dependent chain, and tools/ubench_step.hip measures ~13 cycles of
+// matrix-pipe time lost per VALU instruction slipped between two MFMAs (16 MFMAs + 12 LDS reads + barrier: 1055
+// cycles per step; one v_add_u32 behind every MFMA: 1470), while scalar instructions are nearly free (4 per MFMA:
+// 1098).  The steady steps below are therefore written so that hipcc needs no VALU for addresses at all.
+__device__ __forceinline__ void dma16s(const void *sbase, uint32_t voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                 :: "s"(sbase), "v"(voff), "s"(lds_byte) : "memory", "m0");
+}
+// chunk `kc` of ONE segment (full chunk): scalar chunk bases pb / qb, plan of that segment, LDS byte addresses of
+// this wave's first piece in the destination slot images
+template <class G, int DW>
+__device__ __forceinline__ void dma_chunk_s(const DmaPlan<G, DW> &pl, const char *pb, const char *qb, unsigned ldsP, unsigned ldsQ) {
+#pragma unroll
+    for (int n = 0; n < DmaPlan<G, DW>::NPP; ++n) dma16s(pb, pl.p[n], ldsP + (unsigned)(n * DW * 1024));
+#pragma unroll
+    for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) dma16s(qb, pl.q[n], ldsQ + (unsigned)(n * DW * 1024));
+}
+
 // chunk c (a FULL chunk of its segment) -> LDS slot images sP / sQ, all pieces of this wave
 template <int QL, class G, bool SEG2, int PL = KM, int DW = G::NW>
 __device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G, DW> &pl1, const DmaPlan<G, DW> &pl2, int nch1, int c,
@@ -658,67 +677,68 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #else                          /* no pinning: leave the order to hipcc */
 #define BM_SCHED_STEP
 #endif
+    static_assert(NBUF == 4, "the steps below are written for a 4-slot ring");
     int cc = 0;
-    // PING-PONG (8-wave geometries: waves w and w+4 share a SIMD).  Lock-stepped waves all issue their memory
-    // instructions at the same time and their MFMAs at the same time, and the probe showed the three costs simply
-    // ADD (MFMA + LDS reads + global->LDS).  So a step is split into a memory phase (DMA issue + fragment reads)
-    // and a matrix phase (the chunk's MFMAs) with a barrier after each, and waves 4-7 run ONE PHASE BEHIND waves
-    // 0-3 (one extra barrier before the loop, one after it for waves 0-3): on every SIMD one wave is in its matrix
-    // phase while its partner is in its memory phase (MI355X_MICROARCH.md "Two waves per SIMD").  The ring
-    // hazards are unchanged: a chunk is read >= 2 phases after the barrier that follows its last DMA wait and
-    // overwritten >= 3 phases after its last fragment read.
-#ifndef BM_PINGPONG
-#define BM_PINGPONG 0      /* measured at 784x1024x512: 15.1 us per propagation kernel against 13.2 lock-stepped */
-#endif
-    constexpr bool PP = BM_PINGPONG && (G::NW == 8) && !BM_ABL(7);
-    const bool late = PP && w >= 4;
-    if (PP && late && !BM_ABL(5)) wg_barrier();
-    // steady step: chunk cc+3 by DMA, no register-path chunk in sight
-#define BM_STEP_STEADY(FC, FN)                                                                    \
+    // EVERY step works on COMPILE-TIME ring slots: the loops are unrolled by four and step cc uses slot S = cc % 4,
+    // so each LDS address is a loop-invariant base plus an immediate (hipcc hoists them), and the DMA takes a
+    // scalar chunk base.  The steady steps contain no vector ALU instruction at all (see dma16s for why it matters).
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+    const unsigned ldsPw = lds0 + (unsigned)w * 1024u, ldsQw = lds0 + (unsigned)(NBUF * P_BUF * 4) + (unsigned)w * 1024u;
+    // scalar base of chunk c of its segment, and the plan of that segment (swapped in once, under a scalar branch)
+    bool in2 = false;                                 // pl1 holds the segment-2 plan from then on
+    auto chunk_bases = [&](int c, const char *&pb, const char *&qb) {
+        const bool s2 = SEG2 && c >= nch1;
+        const Operand &P = s2 ? kr.P2 : kr.P1, &Q = s2 ? kr.Q2 : kr.Q1;
+        const int kc = s2 ? c - nch1 : c;
+        pb = (const char *)P.ptr + (size_t)kc * ((PL == KM) ? (size_t)BK * P.ld * 4 : (size_t)BK * 4);
+        qb = (const char *)Q.ptr + (size_t)kc * ((QL == KM) ? (size_t)BK * Q.ld * 4 : (size_t)BK * 4);
+    };
+#define BM_DMA_AT(CD, SD)                                                                         \
     {                                                                                             \
-        const int cd = cc + PF;                                                                   \
-        if (dmaw && !BM_ABL(0)) dma_chunk<QL, G, SEG2, PL, DW>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
-        read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
-        if (PP) {                                                                                 \
-            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM((PF - 2) * NPW);                        \
-            if (!BM_ABL(5)) wg_barrier();                                                         \
-            mfma_frags<G, ABL>(acc, FC);                                                          \
-        } else {                                                                                  \
-            mfma_frags<G, ABL>(acc, FC);                                                          \
-            BM_SCHED_STEP                                                                         \
-            if (BM_ABL(0)) BM_WAIT_VM(0); else BM_WAIT_VM((PF - 2) * NPW);                        \
-        }                                                                                         \
+        if (SEG2 && !in2 && (CD) >= nch1) { in2 = true; pl1 = pl2; }                              \
+        const char *pb_, *qb_;                                                                    \
+        chunk_bases((CD), pb_, qb_);                                                              \
+        if (dmaw) dma_chunk_s<G, DW>(pl1, pb_, qb_, ldsPw + (unsigned)((SD) * P_BUF * 4),         \
+                                     ldsQw + (unsigned)((SD) * Q_BUF * 4));                       \
+    }
+    // steady step: chunk cc+3 by DMA, chunk cc+2 a DMA chunk as well (nothing passes through registers)
+#define BM_STEP_Q(FC, FN, S)                                                                      \
+    {                                                                                             \
+        BM_DMA_AT(cc + PF, ((S) + PF) % NBUF)                                                     \
+        read_frags<QL, G, ABL, PL>(FN, sP + (((S) + 1) % NBUF) * P_BUF, sQ + (((S) + 1) % NBUF) * Q_BUF, wi, wj, lane); \
+        mfma_frags<G, ABL>(acc, FC);                                                              \
+        BM_SCHED_STEP                                                                             \
+        BM_WAIT_VM((PF - 2) * NPW);                                                               \
         if (!BM_ABL(5)) wg_barrier();                                                             \
         ++cc;                                                                                     \
     }
-    // general step: FC = fragments of chunk cc, FN <- fragments of chunk cc+1
-#define BM_STEP(FC, FN, LAST)                                                                     \
+    // general step: FC = fragments of chunk cc, FN <- fragments of chunk cc+1; chunk cc+3 by DMA if it is a DMA
+    // chunk, chunk cc+2 through registers if it is not
+#define BM_STEP_T(FC, FN, S1, S2, S3)      /* S1 / S2 / S3: ring slots of chunks cc+1 / cc+2 / cc+3 */ \
     {                                                                                             \
         const int cd = cc + PF, cr = cc + 2;                                                      \
         const bool do_dma = cd < nch && is_dma(cd) && !BM_ABL(0);                                 \
         const bool do_reg = cr < nch && !is_dma(cr) && !BM_ABL(0);                                \
         if (do_reg) load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, cr, tid);             \
-        if (do_dma && dmaw) dma_chunk<QL, G, SEG2, PL, DW>(kr, pl1, pl2, nch1, cd, sP + (cd % NBUF) * P_BUF, sQ + (cd % NBUF) * Q_BUF, w); \
-        if (!(LAST) && cc + 1 < nch) read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
-        if (!PP) { if (LAST) mfma_frags_head<G, ABL>(acc, FC, nq_last); else mfma_frags<G, ABL>(acc, FC); } \
+        if (do_dma) BM_DMA_AT(cd, S3)                                                             \
+        read_frags<QL, G, ABL, PL>(FN, sP + (S1) * P_BUF, sQ + (S1) * Q_BUF, wi, wj, lane);       \
+        mfma_frags<G, ABL>(acc, FC);                                                              \
+        _Pragma("unroll") for (int s_ = 0; s_ < NR; ++s_) { BM_SG(0x008, 1) BM_SG(0x100, 1) }     \
+        BM_SG(0x008, NM)                                                                          \
         if (do_reg) {                                                                             \
             BM_WAIT_VM(0);                                                                        \
-            store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, cr, sP + (cr % NBUF) * P_BUF, sQ + (cr % NBUF) * Q_BUF, tid); \
+            store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, cr, sP + (S2) * P_BUF, sQ + (S2) * Q_BUF, tid); \
         } else {                                                                                  \
             /* chunk cc+2 must have landed: the DMAs of chunks cc+3 .. cc+PF may stay in flight */ \
             int n_after = 0;                                                                      \
             _Pragma("unroll") for (int c_ = 3; c_ <= PF; ++c_) n_after += (cc + c_ < nch && is_dma(cc + c_) && !BM_ABL(0)) ? 1 : 0; \
             wait_vm_chunks<NPW, PF - 2>(n_after);                                                 \
         }                                                                                         \
-        if (PP) {                                                                                 \
-            if (!BM_ABL(5)) wg_barrier();                                                         \
-            if (LAST) mfma_frags_head<G, ABL>(acc, FC, nq_last); else mfma_frags<G, ABL>(acc, FC); \
-            if (!BM_ABL(5) && (!(LAST) || !late || Side::kFinalSync)) wg_barrier();               \
-        } else {                                                                                  \
-            if (!BM_ABL(5) && (!(LAST) || Side::kFinalSync)) wg_barrier();                        \
-        }                                                                                         \
+        if (!BM_ABL(5)) wg_barrier();                                                             \
         ++cc;                                                                                     \
     }
+#define BM_STEP_TC(FC, FN, S) BM_STEP_T(FC, FN, ((S) + 1) % NBUF, ((S) + 2) % NBUF, ((S) + 3) % NBUF)
+#define BM_STEP_TR(FC, FN)    BM_STEP_T(FC, FN, (cc + 1) % NBUF, (cc + 2) % NBUF, (cc + 3) % NBUF)
     // REG steady step: chunk cc+2 (register set G_) -> its slot, chunk cc+4 -> the same set (RELOAD), fragments of
     // chunk cc+1, MFMAs of chunk cc.   masks: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x020 VMEM read
     constexpr int NWR = G::NVP + G::NVQ;              // DS writes / global loads per thread and chunk
@@ -737,35 +757,44 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         _Pragma("unroll") for (int s_ = 0; s_ < NWR; ++s_) { BM_SG(0x008, (NM >= 32 ? 2 : 1)) BM_SG(0x200, 1) } \
         if (RELOAD) { _Pragma("unroll") for (int s_ = 0; s_ < NWR; ++s_) { BM_SG(0x008, 1) BM_SG(0x020, 1) } } \
         BM_SG(0x008, NM)
-#elif BM_REG_SCHED_VARIANT == 2    /* any memory instruction behind every MFMA */
-#define BM_REG_SCHED(RELOAD)                                                                      \
-        _Pragma("unroll") for (int s_ = 0; s_ < NR + 2 * NWR; ++s_) { BM_SG(0x008, 1) BM_SG(0x320, 1) } \
-        BM_SG(0x008, NM)
 #else                               /* no pinning */
 #define BM_REG_SCHED(RELOAD)
 #endif
-#define BM_STEP_REG(FC, FN, G_, RELOAD)                                                           \
+#define BM_STEP_REG(FC, FN, G_, RELOAD, S)                                                        \
     {                                                                                             \
-        store_chunk_slim<QL, G, PL>(G_, sP + ((cc + 2) % NBUF) * P_BUF, sQ + ((cc + 2) % NBUF) * Q_BUF, tid); \
+        store_chunk_slim<QL, G, PL>(G_, sP + (((S) + 2) % NBUF) * P_BUF, sQ + (((S) + 2) % NBUF) * Q_BUF, tid); \
         if (RELOAD) load_chunk_slim<QL, G, SEG2, PL>(G_, kr, rp1, rp2, nch1, cc + 4);             \
-        read_frags<QL, G, ABL, PL>(FN, sP + ((cc + 1) % NBUF) * P_BUF, sQ + ((cc + 1) % NBUF) * Q_BUF, wi, wj, lane); \
+        read_frags<QL, G, ABL, PL>(FN, sP + (((S) + 1) % NBUF) * P_BUF, sQ + (((S) + 1) % NBUF) * Q_BUF, wi, wj, lane); \
         mfma_frags<G, ABL>(acc, FC);                                                              \
         BM_REG_SCHED(RELOAD)                                                                      \
         if (!BM_ABL(5)) wg_barrier();                                                             \
         ++cc;                                                                                     \
     }
     if (n_reg > 0) {
+        // n_reg is even; the two chunks still in registers after the reloading steps make n_reg + 2 steps, taken in
+        // quads (slots 0 .. 3) plus, when n_reg + 2 is not a multiple of four, one final pair on slots 0 / 1
+        int left = n_reg;
 #pragma unroll 1
-        for (int q = 0; q < n_reg / 2; ++q) {
-            BM_STEP_REG(fa, fb, g0, true)
-            BM_STEP_REG(fb, fa, g1, true)
+        while (left >= 4) {
+            BM_STEP_REG(fa, fb, g0, true, 0)
+            BM_STEP_REG(fb, fa, g1, true, 1)
+            BM_STEP_REG(fa, fb, g0, true, 2)
+            BM_STEP_REG(fb, fa, g1, true, 3)
+            left -= 4;
         }
-        BM_STEP_REG(fa, fb, g0, false)                // the two chunks still in registers
-        BM_STEP_REG(fb, fa, g1, false)
+        if (left == 2) {           // slots 0, 1 reload; 2, 3 drain
+            BM_STEP_REG(fa, fb, g0, true, 0)
+            BM_STEP_REG(fb, fa, g1, true, 1)
+            BM_STEP_REG(fa, fb, g0, false, 2)
+            BM_STEP_REG(fb, fa, g1, false, 3)
+        } else {                   // drain on slots 0, 1: the tail below continues at slot 2
+            BM_STEP_REG(fa, fb, g0, false, 0)
+            BM_STEP_REG(fb, fa, g1, false, 1)
+        }
     }
-    // leading run of DMA steady steps (in pairs: the two fragment sets alternate)
+    // leading run of DMA steady steps
     int n_steady = 0;
-    if (FAST && STG != STG_REG && !BM_ABL(6))
+    if (FAST && STG != STG_REG && !BM_ABL(6) && !BM_ABL(0))
         while (n_steady + PF < nch) {                  // every chunk the step's counted wait assumes in flight is a DMA chunk
             bool all = true;
 #pragma unroll
@@ -773,32 +802,58 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
             if (!all) break;
             ++n_steady;
         }
-    const int nsp = n_steady / 2;
 #pragma unroll 1
-    for (int q = 0; q < nsp; ++q) {
-        BM_STEP_STEADY(fa, fb)
-        BM_STEP_STEADY(fb, fa)
+    for (int q = 0; q < n_steady / 4; ++q) {
+        BM_STEP_Q(fa, fb, 0)
+        BM_STEP_Q(fb, fa, 1)
+        BM_STEP_Q(fa, fb, 2)
+        BM_STEP_Q(fb, fa, 3)
     }
-    const int nrest = nch - 1 - cc;                   // general steps before the last one
-    const int npairs = nrest / 2;
+    // the remaining steps before the last one.  Compile-time slots again (cc % 4 == 0 here, or == 2 after a REG run
+    // that ended on a pair: then the first pass enters the quad in the middle) - except for the 8-wave geometry with
+    // two accumulator tiles per wave, whose 256-VGPR budget the four unrolled copies overflow (spills in the hot
+    // loop: 32 us instead of 25 for the 784x1024 outer products); it takes these few steps on run-time slots.
+    constexpr bool CTS = !(G::NW == 8 && G::MI * G::NJ > 1);
+    const int last = nch - 1;
+    bool odd = false;                                 // true: the current fragments are in fb
+    if (CTS) {
+        if ((cc & 3) == 2 && cc < last) {
+            BM_STEP_TC(fa, fb, 2)
+            if (cc < last) { BM_STEP_TC(fb, fa, 3) } else odd = true;
+        }
 #pragma unroll 1
-    for (int q = 0; q < npairs; ++q) {
-        BM_STEP(fa, fb, false)
-        BM_STEP(fb, fa, false)
+        while (cc < last && !odd) {
+            BM_STEP_TC(fa, fb, 0)
+            if (cc >= last) { odd = true; break; }
+            BM_STEP_TC(fb, fa, 1)
+            if (cc >= last) break;
+            BM_STEP_TC(fa, fb, 2)
+            if (cc >= last) { odd = true; break; }
+            BM_STEP_TC(fb, fa, 3)
+        }
+    } else {
+#pragma unroll 1
+        while (cc < last) {
+            BM_STEP_TR(fa, fb)
+            if (cc >= last) { odd = true; break; }
+            BM_STEP_TR(fb, fa)
+        }
     }
-    if (nrest & 1) {
-        BM_STEP(fa, fb, false)
-        fa = fb;                 // keep the current fragments in `fa` (once per kernel)
-    }
+    if (odd) fa = fb;            // keep the current fragments in `fa` (once per kernel)
     BM_MSTAMP(3);
     side.drain();
-    BM_STEP(fa, fb, true)        // last chunk: only the k blocks it really holds
-    if (PP && !late && !BM_ABL(5) && Side::kFinalSync) wg_barrier();     // waves 0-3 catch up with the extra barrier of waves 4-7
+    // last chunk: only the k blocks it really holds; nothing left to load
+    mfma_frags_head<G, ABL>(acc, fa, nq_last);
+    BM_WAIT_VM(0);
+    if (!BM_ABL(5) && Side::kFinalSync) wg_barrier();
     BM_MSTAMP(4);
-#undef BM_STEP
+#undef BM_STEP_TC
+#undef BM_STEP_TR
+#undef BM_STEP_T
+#undef BM_STEP_Q
+#undef BM_DMA_AT
 #undef BM_STEP_REG
 #undef BM_REG_SCHED
-#undef BM_STEP_STEADY
 #undef BM_SCHED_STEP
 #undef BM_SG
 }
