@@ -69,6 +69,7 @@ struct NoSide {
 // instantiates other values to price each pipeline stage)
 //   bit 0: no global -> LDS traffic   bit 1: VALU instead of MFMA   bit 3: no fragment reads
 //   bit 4: no epilogue (act_kernel)   bit 5: no barriers             bit 6: register path for every chunk
+//   bit 8: no wait for the DMA in the steady steps (wrong results: prices the data-arrival stalls)
 #define BM_ABL(bit) ((ABL >> (bit)) & 1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -708,7 +709,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         read_frags<QL, G, ABL, PL>(FN, sP + (((S) + 1) % NBUF) * P_BUF, sQ + (((S) + 1) % NBUF) * Q_BUF, wi, wj, lane); \
         mfma_frags<G, ABL>(acc, FC);                                                              \
         BM_SCHED_STEP                                                                             \
-        BM_WAIT_VM((PF - 2) * NPW);                                                               \
+        if (!BM_ABL(8)) BM_WAIT_VM((PF - 2) * NPW);                                               \
         if (!BM_ABL(5)) wg_barrier();                                                             \
         ++cc;                                                                                     \
     }

@@ -173,11 +173,19 @@ __device__ __forceinline__ void t64_mainloop(d4 (&acc)[2], const T64Seg *seg, in
                 a0[s4] = pP[k * T64_PLD]; a1[s4] = pP[k * T64_PLD + 16];
                 bq[s4] = QKM ? pQ[k * T64_QLD_KM] : pQ[k];
             }
+            if (ksteps == T64_BK / 4) {                 // full chunk: one straight run of MFMAs (wave-uniform test)
 #pragma unroll
-            for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
-                if (s4 < ksteps) {                      // wave-uniform (the K tail is zero-filled in LDS)
+                for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
                     acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s4], bq[s4], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], bq[s4], acc[1], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
+                    if (s4 < ksteps) {                  // K tail (zero-filled in LDS past K)
+                        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s4], bq[s4], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], bq[s4], acc[1], 0, 0, 0);
+                    }
                 }
             }
             if (c + 1 < nch) {

@@ -93,7 +93,7 @@ int main(int argc, char **argv) {
     RUN(4, "mfma + reads + gloads + barrier")
     printf("---- 8-wave geometry (the one the tuner picks at this shape)\n");
     RUNG(GeoAct8, 1, 0, "8w full")
-    RUNG(GeoAct8, 1, 128, "8w lock-step (no ping-pong)")
+    RUNG(GeoAct8, 1, 256, "8w no wait for the DMA")
     RUNG(GeoAct8, 1, 129, "8w lock-step no-gload")
     RUNG(GeoAct8, 1, 136, "8w lock-step no-ldsread")
     RUNG(GeoAct8, 1, 16, "8w no-epilogue")
