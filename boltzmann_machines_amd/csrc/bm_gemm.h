@@ -720,6 +720,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         const int cd = cc + PF, cr = cc + 2;                                                      \
         const bool do_dma = cd < nch && is_dma(cd) && !BM_ABL(0);                                 \
         const bool do_reg = cr < nch && !is_dma(cr) && !BM_ABL(0);                                \
+        if (cc == last - 1) side.drain();      /* step nch-2: every operand load has landed (waited in step nch-3) */ \
         if (do_reg) load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, cr, tid);             \
         if (do_dma) BM_DMA_AT(cd, S3)                                                             \
         read_frags<QL, G, ABL, PL>(FN, sP + (S1) * P_BUF, sQ + (S1) * Q_BUF, wi, wj, lane);       \
@@ -729,7 +730,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         if (do_reg) {                                                                             \
             BM_WAIT_VM(0);                                                                        \
             store_chunk<QL, G, SEG2, PL>(gr, kr, nch1, cr, sP + (S2) * P_BUF, sQ + (S2) * Q_BUF, tid); \
-        } else {                                                                                  \
+        } else if (cr < nch) {                                                                    \
             /* chunk cc+2 must have landed: the DMAs of chunks cc+3 .. cc+PF may stay in flight */ \
             int n_after = 0;                                                                      \
             _Pragma("unroll") for (int c_ = 3; c_ <= PF; ++c_) n_after += (cc + c_ < nch && is_dma(cc + c_) && !BM_ABL(0)) ? 1 : 0; \
@@ -842,10 +843,10 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     }
     if (odd) fa = fb;            // keep the current fragments in `fa` (once per kernel)
     BM_MSTAMP(3);
-    side.drain();
-    // last chunk: only the k blocks it really holds; nothing left to load
+    if (last < 1) side.drain();  // (a one-chunk contraction: no step before the last)
+    // last chunk: only the k blocks it really holds.  No operand load is in flight any more (the last chunk was
+    // waited for two steps ago); the loads of side.drain() are hipcc's to wait for, where the epilogue uses them
     mfma_frags_head<G, ABL>(acc, fa, nq_last);
-    BM_WAIT_VM(0);
     if (!BM_ABL(5) && Side::kFinalSync) wg_barrier();
     BM_MSTAMP(4);
 #undef BM_STEP_TC
