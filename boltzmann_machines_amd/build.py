@@ -14,6 +14,9 @@ LIB = os.path.join(HERE, 'libbm355.so')
 SOURCES = ['bm355.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
          '-ffp-contract=off',          # every fma is an explicit fmaf (DESIGN.md "Numerics")
+         '-mllvm', '-amdgpu-mfma-vgpr-form',   # MFMA accumulators stay in VGPRs: without it hipcc parks the FP64
+                                               # accumulators in AGPRs and copies all 16 of them in and out around
+                                               # every K chunk (32 VALU instructions per 16 MFMAs)
          '-Wall', '-Wno-unused-function']
 
 

@@ -135,6 +135,96 @@ __device__ __forceinline__ void t64_stash(const double2 (&r)[ROWS * COLS / 512],
 
 struct T64Seg { const double *P; int ldp; const double *Q; int ldq; int K; double qsgn; };
 
+// ---- interior tiles of 16-byte-aligned operands: the full K chunks of a segment stream through a pipeline without
+// address arithmetic in the loop (the lesson of the float32 engine: vector ALU work between the MFMAs of a
+// dependent chain is paid for in matrix-pipe time).  Per-thread byte offsets are fixed, the chunk base is scalar,
+// two register sets keep two chunks in flight, the loop is unrolled by two so that the LDS buffer is a constant.
+struct T64Fast {
+    uint32_t op[4], oq[2];       // byte offsets of this thread's double2 loads relative to the chunk bases
+    int sp[4], sq[2];            // LDS double offsets of the same pieces inside a buffer
+};
+template <bool QKM>
+__device__ __forceinline__ void t64_fast_plan(T64Fast &f, int ldp, int ldq, int tid) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int row = tid / 32 + 8 * n, col = 2 * (tid % 32);
+        f.op[n] = (uint32_t)(row * ldp + col) * 8u;
+        f.sp[n] = row * T64_PLD + col;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = tid / 16 + 16 * n, col = 2 * (tid % 16);
+        f.oq[n] = (uint32_t)(row * ldq + col) * 8u;
+        f.sq[n] = row * (QKM ? T64_QLD_KM : T64_QLD_XM) + col;
+    }
+}
+typedef double dv2 __attribute__((ext_vector_type(2)));
+struct T64Regs { dv2 p0, p1, p2, p3, q0, q1; };     // named members, native vectors: stay in registers
+__device__ __forceinline__ void t64_fast_fetch(T64Regs &r, const T64Fast &f, const char *pb, const char *qb) {
+    r.p0 = *reinterpret_cast<const dv2 *>(pb + f.op[0]); r.p1 = *reinterpret_cast<const dv2 *>(pb + f.op[1]);
+    r.p2 = *reinterpret_cast<const dv2 *>(pb + f.op[2]); r.p3 = *reinterpret_cast<const dv2 *>(pb + f.op[3]);
+    r.q0 = *reinterpret_cast<const dv2 *>(qb + f.oq[0]); r.q1 = *reinterpret_cast<const dv2 *>(qb + f.oq[1]);
+}
+__device__ __forceinline__ void t64_fast_stash(const T64Regs &r, const T64Fast &f, double *sP, double *sQ, bool neg) {
+    *reinterpret_cast<dv2 *>(sP + f.sp[0]) = r.p0; *reinterpret_cast<dv2 *>(sP + f.sp[1]) = r.p1;
+    *reinterpret_cast<dv2 *>(sP + f.sp[2]) = r.p2; *reinterpret_cast<dv2 *>(sP + f.sp[3]) = r.p3;
+    // block-uniform: the negated operand of the second segment
+    *reinterpret_cast<dv2 *>(sQ + f.sq[0]) = neg ? -r.q0 : r.q0;
+    *reinterpret_cast<dv2 *>(sQ + f.sq[1]) = neg ? -r.q1 : r.q1;
+}
+template <bool QKM>
+__device__ __forceinline__ void t64_chunk_mfma(d4 (&acc)[2], const double *sP, const double *sQ, int wi, int wj, int l15, int g) {
+    const double *pP = sP + wi * 32 + l15;
+    const double *pQ = QKM ? sQ + wj * 16 + l15 : sQ + (wj * 16 + l15) * T64_QLD_XM;
+    double a0[T64_BK / 4], a1[T64_BK / 4], bq[T64_BK / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
+        const int k = 4 * s4 + g;
+        a0[s4] = pP[k * T64_PLD]; a1[s4] = pP[k * T64_PLD + 16];
+        bq[s4] = QKM ? pQ[k * T64_QLD_KM] : pQ[k];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < T64_BK / 4; ++s4) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[s4], bq[s4], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s4], bq[s4], acc[1], 0, 0, 0);
+    }
+}
+// the first `nfull` (>= 1) chunks of one segment; on return the LDS buffers are free again (trailing barrier)
+template <bool QKM>
+__device__ __forceinline__ void t64_fast_segment(d4 (&acc)[2], const T64Seg &sg, int nfull, int i0, int j0, double *smem, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1, l15 = lane & 15, g = lane >> 4;
+    double *sP0 = smem, *sP1 = smem + T64_PBUF, *sQ0 = smem + 2 * T64_PBUF, *sQ1 = smem + 2 * T64_PBUF + T64_QBUF;
+    T64Fast f;
+    t64_fast_plan<QKM>(f, sg.ldp, sg.ldq, tid);
+    const bool neg = sg.qsgn < 0.0;
+    const char *pb = (const char *)(sg.P + i0);
+    const char *qb = QKM ? (const char *)(sg.Q + j0) : (const char *)(sg.Q + (size_t)j0 * sg.ldq);
+    const size_t stp = (size_t)T64_BK * sg.ldp * 8, stq = QKM ? (size_t)T64_BK * sg.ldq * 8 : (size_t)T64_BK * 8;
+    T64Regs ra, rb;
+    t64_fast_fetch(ra, f, pb, qb); pb += stp; qb += stq;                       // chunk 0
+    if (nfull > 1) { t64_fast_fetch(rb, f, pb, qb); pb += stp; qb += stq; }    // chunk 1
+    __syncthreads();                                    // the previous user of the buffers is done
+    t64_fast_stash(ra, f, sP0, sQ0, neg);
+    __syncthreads();
+    int c = 0;
+    // pairs: chunk c in buffer 0 (loaded through ra), chunk c+1 through rb into buffer 1
+    for (; c + 1 < nfull; c += 2) {
+        if (c + 2 < nfull) { t64_fast_fetch(ra, f, pb, qb); pb += stp; qb += stq; }     // chunk c+2
+        t64_chunk_mfma<QKM>(acc, sP0, sQ0, wi, wj, l15, g);                               // chunk c
+        t64_fast_stash(rb, f, sP1, sQ1, neg);                                             // chunk c+1
+        __syncthreads();
+        if (c + 3 < nfull) { t64_fast_fetch(rb, f, pb, qb); pb += stp; qb += stq; }     // chunk c+3
+        t64_chunk_mfma<QKM>(acc, sP1, sQ1, wi, wj, l15, g);                               // chunk c+1
+        if (c + 2 < nfull) t64_fast_stash(ra, f, sP0, sQ0, neg);                          // chunk c+2
+        __syncthreads();
+    }
+    if (c < nfull) {                                    // odd count: the last chunk sits in buffer 0
+        t64_chunk_mfma<QKM>(acc, sP0, sQ0, wi, wj, l15, g);
+        __syncthreads();
+    }
+}
+
 // acc[t] += sum_k P[k][i] * Q(j, k) for the wave's two tiles (t = 0, 1: i sub-tile), over `nseg` segments
 template <bool QKM>
 __device__ __forceinline__ void t64_mainloop(d4 (&acc)[2], const T64Seg *seg, int nseg, int I, int J, int i0, int j0,
@@ -145,17 +235,27 @@ __device__ __forceinline__ void t64_mainloop(d4 (&acc)[2], const T64Seg *seg, in
     for (int sgi = 0; sgi < nseg; ++sgi) {
         const T64Seg sg = seg[sgi];
         const int nch = (sg.K + T64_BK - 1) / T64_BK;
+        // interior tile, 16-byte-legal operands (block-uniform): the full chunks take the pipelined path, the
+        // generic loop below starts at the K tail (same k order, same zero fill: bit-identical)
+        int c0 = 0;
+        const bool fast = i0 + T64_TI <= I && j0 + T64_TJ <= J && ((sg.ldp | sg.ldq) & 1) == 0 &&
+                          ((((uintptr_t)sg.P | (uintptr_t)sg.Q) & 15u) == 0) && ((i0 | j0) & 1) == 0;
+        if (fast && sg.K >= T64_BK) {
+            c0 = sg.K / T64_BK;
+            t64_fast_segment<QKM>(acc, sg, c0, i0, j0, smem, tid);
+            if (c0 == nch) continue;
+        }
         double2 rp[T64_BK * T64_TI / 512], rq[T64_BK * T64_TJ / 512];
-        t64_fetch<T64_BK, T64_TI>(rp, sg.P, sg.ldp, 0, i0, sg.K, I, tid);
-        if (QKM) t64_fetch<T64_BK, T64_TJ>(rq, sg.Q, sg.ldq, 0, j0, sg.K, J, tid);
-        else     t64_fetch<T64_TJ, T64_BK>(rq, sg.Q, sg.ldq, j0, 0, J, sg.K, tid);
+        t64_fetch<T64_BK, T64_TI>(rp, sg.P, sg.ldp, c0 * T64_BK, i0, sg.K, I, tid);
+        if (QKM) t64_fetch<T64_BK, T64_TJ>(rq, sg.Q, sg.ldq, c0 * T64_BK, j0, sg.K, J, tid);
+        else     t64_fetch<T64_TJ, T64_BK>(rq, sg.Q, sg.ldq, j0, c0 * T64_BK, J, sg.K, tid);
         __syncthreads();                               // the previous segment's last chunk has been consumed
         t64_stash<T64_BK, T64_TI, T64_PLD>(rp, sP, tid, 1.0);
         if (QKM) t64_stash<T64_BK, T64_TJ, T64_QLD_KM>(rq, sQ, tid, sg.qsgn);
         else     t64_stash<T64_TJ, T64_BK, T64_QLD_XM>(rq, sQ, tid, sg.qsgn);
         __syncthreads();
-        for (int c = 0; c < nch; ++c) {
-            const int cur = c & 1;
+        for (int c = c0; c < nch; ++c) {
+            const int cur = (c - c0) & 1;
             if (c + 1 < nch) {                          // next chunk in flight under the MFMAs
                 t64_fetch<T64_BK, T64_TI>(rp, sg.P, sg.ldp, (c + 1) * T64_BK, i0, sg.K, I, tid);
                 if (QKM) t64_fetch<T64_BK, T64_TJ>(rq, sg.Q, sg.ldq, (c + 1) * T64_BK, j0, sg.K, J, tid);
@@ -198,7 +298,7 @@ __device__ __forceinline__ void t64_mainloop(d4 (&acc)[2], const T64Seg *seg, in
     }
 }
 
-__global__ __launch_bounds__(256) void act_kernel(ActArgs a) {
+__global__ __launch_bounds__(256, 1) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) double smem[2 * (T64_PBUF + T64_QBUF)];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wi = w & 1, wj = w >> 1, l15 = lane & 15, g = lane >> 4;
@@ -228,6 +328,76 @@ __global__ __launch_bounds__(256) void act_kernel(ActArgs a) {
         }
 }
 
+// column sums (sequential over rows) + bias / q_means update (base_rbm.py:450-474)
+struct BiasArgs {
+    const double *X, *vs, *h0m, *hm; int ldx, B, V, H;
+    double *vb, *dvb, *hb, *dhb, *q, *pen;
+    double N, lr, mom, damping, cost, target;
+};
+__device__ __forceinline__ void bias_wave(const BiasArgs &a, int blk, int lane) {
+    // One wave per 16 columns.  The column sums are the sequential row-ascending chains of the oracle, computed on
+    // the FP64 matrix core against a matrix of ones: D[c][*] = sum_b A[c][b] * 1, i.e. acc = fma(a_b, 1, acc) =
+    // acc + a_b rounded once, rows in ascending order (the four k of an instruction run in order, as in the GEMMs).
+    // A(c, b) = X[b][c] - v[b][c] for the visible columns (the difference is rounded first, as in the oracle's
+    // s + (x - v)); for the hidden columns two chains: sum (h0 - h) and sum h.
+    const int l15 = lane & 15, g = lane >> 4;
+    const int c0 = blk * 16;
+    const bool vis = c0 < a.V;                                   // blocks never straddle: the hidden blocks start at
+    const int nvb = (a.V + 15) / 16;                             // block nvb (wave-uniform)
+    const int hc0 = (blk - nvb) * 16;
+    const int c = vis ? c0 + l15 : hc0 + l15;                    // this lane's A row = column
+    const int ncol = vis ? a.V : a.H;
+    const bool ok = c < ncol;
+    const double *pa = vis ? a.X : a.h0m, *pb = vis ? a.vs : a.hm;
+    const int lda = vis ? a.ldx : a.H, ldb = vis ? a.V : a.H;
+    d4 s1 = {0.0, 0.0, 0.0, 0.0}, s2 = {0.0, 0.0, 0.0, 0.0};
+    constexpr int UB = 8;                                        // MFMA steps (4 rows each) whose loads go out together
+    const int cc = ok ? c : 0;
+    for (int b0 = 0; b0 < a.B; b0 += 4 * UB) {
+        double x[UB], y[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int b = b0 + 4 * u + g;
+            const int bc = b < a.B ? b : a.B - 1;
+            const double xa = pa[(size_t)bc * lda + cc], xb = pb[(size_t)bc * ldb + cc];
+            const bool live = ok && b < a.B;
+            x[u] = live ? xa - xb : 0.0;                         // padding rows / columns add fma(0, 1, acc) = acc
+            y[u] = live ? xb : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            if (b0 + 4 * u < a.B) {                              // wave-uniform
+                s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u], 1.0, s1, 0, 0, 0);
+                if (!vis) s2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y[u], 1.0, s2, 0, 0, 0);
+            }
+        }
+    }
+    if (l15 != 0) return;                                        // D(m = 4 r + g, n = l15): lanes 0, 16, 32, 48 hold n = 0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = (vis ? c0 : hc0) + 4 * r + g;
+        if (col >= ncol) continue;
+        if (vis) {
+            const double gr = s1[r] / a.N;
+            const double d = a.lr * (a.mom * a.dvb[col] + gr);
+            a.dvb[col] = d;
+            a.vb[col] = a.vb[col] + d;
+        } else {
+            const double qn = a.damping * a.q[col] + (1.0 - a.damping) * s2[r];
+            a.q[col] = qn;
+            const double pen = a.cost * (qn - a.target);
+            a.pen[col] = pen;
+            double gr = s1[r] / a.N;
+            gr = gr - pen;
+            const double d = a.lr * (a.mom * a.dhb[col] + gr);
+            a.dhb[col] = d;
+            a.hb[col] = a.hb[col] + d;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bias_kernel(BiasArgs a) { bias_wave(a, blockIdx.x, threadIdx.x); }
+
 // raw CD gradient + update of W (and of the transpose Wt) in one pass: thread (j = visible, i = hidden)
 //   acc = sum_b h0m[b][i] X[b][j]  then  acc = fma(hm[b][i], -vs[b][j], acc)   (one chain)
 struct GradArgs {
@@ -236,8 +406,17 @@ struct GradArgs {
     double *W, *dW, *Wt;
     const double *pen;
     double N, l2, lr, mom;
+    // sparsity_cost == 0 (the penalty the tiles read is zero whatever the bias update does): the bias / q_means
+    // update rides in extra grid rows of the same launch, one wave per 16 columns, in the shadow of the tiles
+    int ny, nbias;               // tile rows of the grid; 16-column bias jobs (0: separate bias_kernel launch)
+    BiasArgs bias;
 };
-__global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
+__global__ __launch_bounds__(256, 1) void grad_kernel(GradArgs a) {
+    if ((int)blockIdx.y >= a.ny) {                       // block-uniform
+        const int job = (((int)blockIdx.y - a.ny) * (int)gridDim.x + (int)blockIdx.x) * 4 + (int)(threadIdx.x >> 6);
+        if (job < a.nbias) bias_wave(a.bias, job, threadIdx.x & 63);
+        return;
+    }
     // workgroup = 64 hidden (i) x 32 visible (j) of W; the chain runs over the rows b: positive phase, then the
     // negative phase with the visible operand negated (fma(h, -v, acc), as the oracle)
     __shared__ __attribute__((aligned(16))) double smem[2 * (T64_PBUF + T64_QBUF)];
@@ -265,60 +444,6 @@ __global__ __launch_bounds__(256) void grad_kernel(GradArgs a) {
             a.W[e] = wn;
             a.Wt[(size_t)i * a.V + j] = wn;
         }
-}
-
-// column sums (sequential over rows) + bias / q_means update (base_rbm.py:450-474)
-struct BiasArgs {
-    const double *X, *vs, *h0m, *hm; int ldx, B, V, H;
-    double *vb, *dvb, *hb, *dhb, *q, *pen;
-    double N, lr, mom, damping, cost, target;
-};
-__global__ void bias_kernel(BiasArgs a) {
-    // one thread per column, rows in ascending order (the sequential sums of the oracle); the loads of 16 rows
-    // are issued together, only the additions are serial
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    constexpr int UB = 16;
-    if (c < a.V) {
-        double s = 0.0;
-        int b = 0;
-        for (; b + UB <= a.B; b += UB) {
-            double x[UB], v[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) { x[u] = a.X[(size_t)(b + u) * a.ldx + c]; v[u] = a.vs[(size_t)(b + u) * a.V + c]; }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) s = s + (x[u] - v[u]);
-        }
-        for (; b < a.B; ++b) s = s + (a.X[(size_t)b * a.ldx + c] - a.vs[(size_t)b * a.V + c]);
-        const double g = s / a.N;
-        const double d = a.lr * (a.mom * a.dvb[c] + g);
-        a.dvb[c] = d;
-        a.vb[c] = a.vb[c] + d;
-    } else if (c < a.V + a.H) {
-        const int h = c - a.V;
-        double sh = 0.0, sq = 0.0;
-        int b = 0;
-        for (; b + UB <= a.B; b += UB) {
-            double p[UB], q[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) { p[u] = a.h0m[(size_t)(b + u) * a.H + h]; q[u] = a.hm[(size_t)(b + u) * a.H + h]; }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) { sh = sh + (p[u] - q[u]); sq = sq + q[u]; }
-        }
-        for (; b < a.B; ++b) {
-            const double hm = a.hm[(size_t)b * a.H + h];
-            sh = sh + (a.h0m[(size_t)b * a.H + h] - hm);
-            sq = sq + hm;
-        }
-        const double qn = a.damping * a.q[h] + (1.0 - a.damping) * sq;
-        a.q[h] = qn;
-        const double pen = a.cost * (qn - a.target);
-        a.pen[h] = pen;
-        double g = sh / a.N;
-        g = g - pen;
-        const double d = a.lr * (a.mom * a.dhb[h] + g);
-        a.dhb[h] = d;
-        a.hb[h] = a.hb[h] + d;
-    }
 }
 
 __global__ void prep_kernel(const double *X, double *Y, const double *sigma, int rows, int cols, double keep,
@@ -463,12 +588,17 @@ static void launch_update(bm_rbm64 *h, int B, double lr, double mom) {
     b.vb = h->vb.p; b.dvb = h->dvb.p; b.hb = h->hb.p; b.dhb = h->dhb.p; b.q = h->q.p; b.pen = h->pen.p;
     b.N = (double)B; b.lr = lr; b.mom = mom;
     b.damping = h->sp_damping; b.cost = h->sp_cost; b.target = h->sp_target;
-    hipLaunchKernelGGL(bias_kernel, dim3((h->V + h->H + 63) / 64), dim3(64), 0, h->stream, b);
+    const int nbias = (h->V + 15) / 16 + (h->H + 15) / 16;
+    const bool fused = h->sp_cost == 0.0;
+    if (!fused) hipLaunchKernelGGL(bias_kernel, dim3(nbias), dim3(64), 0, h->stream, b);
     GradArgs g;
     g.h0m = h->h0m.p; g.hm = h->hm.p; g.X = h->Xin; g.vs = h->vs.p; g.ldx = h->Xin_ld; g.B = B; g.V = h->V; g.H = h->H;
     g.W = h->W.p; g.dW = h->dW.p; g.Wt = h->Wt.p; g.pen = h->pen.p;
     g.N = (double)B; g.l2 = h->l2; g.lr = lr; g.mom = mom;
-    hipLaunchKernelGGL(grad_kernel, dim3((h->H + T64_TI - 1) / T64_TI, (h->V + T64_TJ - 1) / T64_TJ), dim3(256), 0, h->stream, g);
+    const int nx = (h->H + T64_TI - 1) / T64_TI, ny = (h->V + T64_TJ - 1) / T64_TJ;
+    g.ny = ny; g.nbias = fused ? nbias : 0; g.bias = b;
+    const int extra = fused ? (nbias + 4 * nx - 1) / (4 * nx) : 0;
+    hipLaunchKernelGGL(grad_kernel, dim3(nx, ny + extra), dim3(256), 0, h->stream, g);
 }
 static int metrics_from_chain(bm_rbm64 *h, int B, double *out4) {
     BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
