@@ -195,11 +195,15 @@ class RbmCD(Workload):
         if self.use_dp:
             from boltzmann_machines_amd import parallel
             dev = torch.device('cuda', local_rank)
+            if args.delayed_grads:      # NON-parity mode: the reduction of step t runs under step t+1
+                self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+                self.dp = parallel.DelayedDataParallelRBM(eng, rank, world, B, comm=self.comm)
+                return
             if args.native_comm:
                 self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
                 ar = parallel.native_allreduce_on_engine_stream(eng, self.comm)
-            else:
-                ar = parallel.torch_allreduce_on_engine_stream(eng, dev)
+            else:           # --torch-comm: RCCL through torch.distributed (a nccl group next to the gloo default group)
+                ar = parallel.torch_allreduce_on_engine_stream(eng, dev, group=dist.new_group(backend='nccl'))
             self.dp = parallel.DataParallelRBM(eng, rank, world, B, ar)
 
     def step(self, i):
@@ -212,6 +216,8 @@ class RbmCD(Workload):
         return int(seconds * 12500)
 
     def reset(self):
+        if self.use_dp and hasattr(self.dp, 'flush'):
+            self.dp.flush()                      # delayed-gradient mode: nothing in flight across the reset
         for name in ('vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means'):
             self.eng.set(name, 0.0)
         self.eng.set('W', self.W)
@@ -259,7 +265,8 @@ class RbmCD(Workload):
                        'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
                        'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
                        'parallelism': 'dp%d' % world, 'dp_path': bool(self.use_dp),
-                       'collective': ('bm_comm (in-library RCCL)' if self.native else 'torch.distributed nccl') if self.use_dp else None},
+                       'collective': ('bm_comm (in-library RCCL)' if self.native else 'torch.distributed nccl') if self.use_dp else None,
+                       'gradient_delay_steps': 1 if (self.use_dp and getattr(args, 'delayed_grads', False)) else 0},
             'flops_per_step': flops,
             'roofline_extra': {
                 'traffic': pmc_traffic('rbm') if k == 1 else None,
@@ -498,9 +505,14 @@ def main():
                          'tuning, instruction caches, clock ramp of an idle GPU); parameters and RNG are reset afterwards, '
                          'so the warm-up and the timed steps start from the documented initial state.  0 disables')
     ap.add_argument('--native-comm', action='store_true',
-                    help='rbm: data-parallel all-reduce through the library\'s own RCCL communicator (bm_comm_*) instead of '
-                         'torch.distributed; torch (gloo) then only carries the 128-byte id and the timing barrier '
-                         '(dbm / grbm / ais always use bm_comm)')
+                    help='(default) the data-parallel all-reduce goes through the library\'s own RCCL communicator '
+                         '(bm_comm_*); torch.distributed (gloo) only carries the 128-byte id and the timing barrier')
+    ap.add_argument('--torch-comm', action='store_true',
+                    help='rbm: all-reduce the gradient buffer with torch.distributed (nccl = RCCL) on the engine stream '
+                         'instead (8.5 us per update slower at N = 1: host-side work of the process group per call)')
+    ap.add_argument('--delayed-grads', action='store_true',
+                    help='rbm, NON-parity: delayed-gradient data parallelism (the update of step t is the reduced '
+                         'gradient of step t-1; the all-reduce runs under the next step).  Implies --native-comm')
     ap.add_argument('--force-dp', action='store_true',
                     help='take the data-parallel code path (grad_step -> all-reduce -> apply_step) even at N=1')
     args = ap.parse_args()
@@ -524,15 +536,12 @@ def main():
     torch.cuda.set_device(local_rank)
     _ffi.check(lib.bm_set_device(local_rank))
     dist = None
-    native = args.native_comm or args.config not in ('rbm', 'gibbs')
+    native = not args.torch_comm or args.delayed_grads or args.config not in ('rbm', 'gibbs')
     if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        if native:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        dist.init_process_group('gloo', rank=rank, world_size=world)     # rendezvous + timing barrier only
     args.native_comm = native
 
     wl = WORKLOADS[args.config](args, rank, world, local_rank, dist)
@@ -565,7 +574,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device='cpu' if native else 'cuda')
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -60,6 +60,9 @@ SIGNATURES = {
     'bm_comm_allreduce_max': [_vp, _vp, _sz, _vp],
     'bm_comm_rank': [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     'bm_rbm_allreduce_grads': [_vp, _vp],
+    'bm_rbm_set_grad_slot': [_vp, _i32],
+    'bm_rbm_allreduce_grads_async': [_vp, _vp],
+    'bm_rbm_wait_grads': [_vp, _i32],
     'bm_dbm_allreduce_grads': [_vp, _vp],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],

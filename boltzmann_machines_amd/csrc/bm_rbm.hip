@@ -39,7 +39,13 @@ struct bm_rbm {
     // chain workspaces
     Mat h0m, h0s, hm, hs, hneg;        // [maxB][H]; hneg = -hm (negative-phase operand of the outer products)
     Mat vm, vs, Xs, Xd;                // [maxB][V]
-    DevBuf grad;      // [V*ldH | V | H | H] raw sums (the data-parallel all-reduce buffer)
+    DevBuf grad;      // [V*ldH | V | H | H] raw sums (the data-parallel all-reduce buffer): the ACTIVE one of two
+    // delayed-gradient data parallelism (bm_rbm_set_grad_slot / _allreduce_grads_async / _wait_grads): the buffer of
+    // the other slot, the stream the reductions run on and their events; allocated at the first use of slot 1
+    DevBuf grad_alt;
+    int grad_slot = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_reduced[2] = {nullptr, nullptr};
     DevBuf pen;       // [H]
     DevBuf rowacc;    // [3*maxB]
     DevBuf hhat;      // [3*H] MultinomialRBM free-energy h_hat vectors (rbm.py:58)
@@ -366,7 +372,12 @@ int bm_rbm_destroy(bm_rbm *h) {
     (void)hipStreamSynchronize(h->stream);
     Mat *mats[] = {&h->W, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
-    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->pen, &h->rowacc, &h->hhat};
+    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->grad_alt, &h->pen, &h->rowacc, &h->hhat};
+    for (int i = 0; i < 2; ++i) {
+        if (h->ev_ready[i]) (void)hipEventDestroy(h->ev_ready[i]);
+        if (h->ev_reduced[i]) (void)hipEventDestroy(h->ev_reduced[i]);
+    }
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (DevBuf *b : all) b->release();
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
@@ -464,6 +475,43 @@ int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
     rbm_grad(h, B, 0, (float)B, 0.f, 0.f, true);     // raw outer products + raw column sums, one launch
     h->call++;
     BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- delayed-gradient data parallelism (a documented NON-parity mode, SURVEY 8e / DESIGN 6): two gradient slots.
+// Step t: grad_step into slot t % 2, its all-reduce goes out on the communication stream and runs under step t+1's
+// Gibbs chain; the update applied at the end of step t is the (already reduced) one of step t-1.
+static int ensure_delayed(bm_rbm *h) {
+    if (h->comm_stream) return 0;
+    BM_TRY(h->grad_alt.alloc(h->grad.n));
+    BM_HIP(hipStreamCreate(&h->comm_stream));
+    for (int i = 0; i < 2; ++i) {
+        BM_HIP(hipEventCreateWithFlags(&h->ev_ready[i], hipEventDisableTiming));
+        BM_HIP(hipEventCreateWithFlags(&h->ev_reduced[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+int bm_rbm_set_grad_slot(bm_rbm *h, int32_t slot) {
+    BM_CHECK(h && (slot == 0 || slot == 1), "slot must be 0 or 1");
+    if (slot == h->grad_slot) return 0;
+    BM_TRY(ensure_delayed(h));
+    DevBuf t = h->grad; h->grad = h->grad_alt; h->grad_alt = t;
+    h->grad_slot = slot;
+    return 0;
+}
+int bm_rbm_allreduce_grads_async(bm_rbm *h, bm_comm *c) {
+    BM_CHECK(h && c, "null argument");
+    BM_TRY(ensure_delayed(h));
+    const int s = h->grad_slot;
+    BM_HIP(hipEventRecord(h->ev_ready[s], h->stream));
+    BM_HIP(hipStreamWaitEvent(h->comm_stream, h->ev_ready[s], 0));
+    BM_TRY(bm_comm_allreduce_sum(c, h->grad.p, h->grad.n, (void *)h->comm_stream));
+    BM_HIP(hipEventRecord(h->ev_reduced[s], h->comm_stream));
+    return 0;
+}
+int bm_rbm_wait_grads(bm_rbm *h, int32_t slot) {
+    BM_CHECK(h && (slot == 0 || slot == 1) && h->comm_stream, "no reduction was started on slot %d", slot);
+    BM_HIP(hipStreamWaitEvent(h->stream, h->ev_reduced[slot], 0));
     return 0;
 }
 

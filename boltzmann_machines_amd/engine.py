@@ -103,6 +103,16 @@ class RbmEngine(object):
     def apply_step(self, B_global, lr, momentum):
         check(self.lib.bm_rbm_apply_step(self._h, B_global, lr, momentum))
 
+    # delayed-gradient data parallelism (bm355.h: bm_rbm_set_grad_slot / _allreduce_grads_async / _wait_grads)
+    def set_grad_slot(self, slot):
+        check(self.lib.bm_rbm_set_grad_slot(self._h, slot))
+
+    def allreduce_grads_async(self, comm):
+        check(self.lib.bm_rbm_allreduce_grads_async(self._h, comm._c))
+
+    def wait_grads(self, slot):
+        check(self.lib.bm_rbm_wait_grads(self._h, slot))
+
     def transform(self, Xd, B, k, Hd, row=0, out_row=0):
         check(self.lib.bm_rbm_transform(self._h, Xd.offset_ptr(row * self.V), B, k, Hd.offset_ptr(out_row * self.H)))
 

@@ -55,9 +55,52 @@ class DataParallelRBM(object):
         self.engine.apply_step(self.local_batch * self.world, lr, momentum)
 
 
-def torch_allreduce_on_engine_stream(engine, device):
-    """all-reduce of the engine's "grad" buffer by RCCL, enqueued on the engine's HIP stream
-    (zero-copy: the buffer is wrapped through __cuda_array_interface__)."""
+class DelayedDataParallelRBM(object):
+    """Data-parallel CD-k with the all-reduce OFF the critical path - a documented NON-parity mode: the parameter
+    update applied at the end of step t is the reduced gradient of step t-1 (the reference, and DataParallelRBM, are
+    synchronous).  The reduction of step t's gradient runs on the engine's communication stream under step t+1's
+    Gibbs chain; the engine keeps two gradient slots.  `flush()` applies the gradient still in flight (call it at
+    the end of a run).  With `start_reduce(slot)` / `finish_reduce(slot)` injected the same schedule runs over any
+    collective (the gloo tests); by default they are the library's own communicator."""
+
+    def __init__(self, engine, rank, world, local_batch, comm=None, start_reduce=None, finish_reduce=None):
+        self.engine, self.rank, self.world, self.local_batch = engine, rank, world, local_batch
+        self.t, self.pending = 0, None           # pending = (slot, lr, momentum) of the gradient in flight
+        engine.set_row_offset(rank * local_batch)
+        if start_reduce is None:
+            start_reduce = lambda slot: engine.allreduce_grads_async(comm)
+            finish_reduce = lambda slot: engine.wait_grads(slot)
+        self.start_reduce, self.finish_reduce = start_reduce, finish_reduce
+
+    def _apply_pending(self):
+        if self.pending is not None:
+            slot, lr, momentum = self.pending
+            self.finish_reduce(slot)
+            self.engine.set_grad_slot(slot)
+            self.engine.apply_step(self.local_batch * self.world, lr, momentum)
+            self.pending = None
+
+    def train_step(self, X_local, lr, momentum, k, **kw):
+        slot = self.t & 1
+        self.engine.set_grad_slot(slot)
+        self.engine.grad_step(X_local, self.local_batch, k, **kw)     # on the parameters BEFORE the pending update
+        prev = self.pending
+        self.pending = None
+        self.start_reduce(slot)
+        if prev is not None:
+            self.pending = prev
+            self._apply_pending()
+        self.pending = (slot, lr, momentum)
+        self.t += 1
+
+    def flush(self):
+        self._apply_pending()
+
+
+def torch_allreduce_on_engine_stream(engine, device, group=None):
+    """all-reduce of the engine's "grad" buffer by RCCL through torch.distributed (`group`: a nccl process group,
+    default: the default group), enqueued on the engine's HIP stream (zero-copy: the buffer is wrapped through
+    __cuda_array_interface__)."""
     import torch
     import torch.distributed as dist
     stream = torch.cuda.ExternalStream(engine.stream(), device=device)
@@ -65,7 +108,7 @@ def torch_allreduce_on_engine_stream(engine, device):
 
     def allreduce_():
         with torch.cuda.stream(stream):
-            dist.all_reduce(buf)
+            dist.all_reduce(buf, group=group)
     return allreduce_
 
 

@@ -299,6 +299,16 @@ int bm_dbm_ais_sharded(bm_dbm *h, bm_comm *c, int32_t n_betas, int32_t n_runs_to
 /* the exchange step of data-parallel training: all-reduce of the handle's fused "grad" buffer on the
  * handle's stream, between bm_*_grad_step and bm_*_apply_step (no host synchronisation) */
 int bm_rbm_allreduce_grads(bm_rbm *h, bm_comm *c);
+/* Delayed-gradient data parallelism - a NON-parity mode (the reference is synchronous; here the update of step t is
+ * the reduced gradient of step t-1), for when the all-reduce must leave the critical path.  The handle has two
+ * gradient slots: bm_rbm_set_grad_slot picks the one bm_rbm_grad_step writes and bm_rbm_apply_step reads;
+ * bm_rbm_allreduce_grads_async reduces the current slot on the handle's communication stream, ordered after
+ * everything enqueued so far on the compute stream, and returns at once; bm_rbm_wait_grads makes the compute stream
+ * wait for the reduction of a slot.  Per step t: set_grad_slot(t % 2), grad_step, allreduce_grads_async; then, for
+ * t > 0: wait_grads((t-1) % 2), set_grad_slot((t-1) % 2), apply_step. */
+int bm_rbm_set_grad_slot(bm_rbm *h, int32_t slot);
+int bm_rbm_allreduce_grads_async(bm_rbm *h, bm_comm *c);
+int bm_rbm_wait_grads(bm_rbm *h, int32_t slot);
 int bm_dbm_allreduce_grads(bm_dbm *h, bm_comm *c);
 
 #ifdef __cplusplus

@@ -104,6 +104,96 @@ def test_dp_and_ais_sharding_world2(tmp_path):
     assert np.array_equal(got['ais'], dbm.ais(12, 7, 1, 777))
 
 
+class DelayedTwinAsEngine(TwinAsEngine):
+    """OracleRBM behind the two-slot interface of DelayedDataParallelRBM"""
+
+    def __init__(self, twin):
+        TwinAsEngine.__init__(self, twin)
+        self.slots, self.slot = [None, None], 0
+
+    def set_grad_slot(self, slot):
+        self.slot = slot
+
+    def grad_step(self, X, B, k):
+        self.slots[self.slot] = self.twin.raw_grads(X, k)
+
+    def apply_step(self, B_global, lr, mom):
+        self.twin.apply(self.slots[self.slot], float(B_global), lr, mom)
+
+
+def _delayed_reference(V, H, W, Xg, kw, steps, k, lr, mom):
+    """single process, global batch: the same delayed schedule (update t = gradient t-1), then the flush"""
+    from oracle import oracle as orc
+    ref = orc.OracleRBM(V, H, **kw)
+    ref.p['W'][...] = W
+    ref.set_seed(99)
+    pending = None
+    for step in range(steps):
+        raw = ref.raw_grads(Xg[step], k)
+        if pending is not None:
+            ref.apply(pending, float(len(Xg[step])), lr, mom)
+        pending = raw
+    ref.apply(pending, float(len(Xg[0])), lr, mom)
+    return ref
+
+
+def _delayed_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from boltzmann_machines_amd import parallel
+    from oracle import oracle as orc
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    V, H, Bl, k, steps = 24, 16, 6, 1, 4
+    kw = dict(sample_v_states=True, l2=1e-3)
+    W = (orc.normal(1, 2, 0, V * H) * np.float32(0.1)).reshape(V, H)
+    twin = orc.OracleRBM(V, H, **kw)
+    twin.p['W'][...] = W
+    twin.set_seed(99)
+    eng = DelayedTwinAsEngine(twin)
+    works = [None, None]
+
+    def start_reduce(slot):                      # asynchronous all-reduce of the slot's buffer
+        works[slot] = dist.all_reduce(torch.from_numpy(eng.slots[slot]), async_op=True)
+
+    def finish_reduce(slot):
+        works[slot].wait()
+    dp = parallel.DelayedDataParallelRBM(eng, rank, world, Bl, start_reduce=start_reduce, finish_reduce=finish_reduce)
+    for step in range(steps):
+        Xg = (orc.uniform(1, 30 + step, 0, world * Bl * V) < 0.3).astype(np.float32).reshape(world * Bl, V)
+        dp.train_step(Xg[rank * Bl:(rank + 1) * Bl], 0.05, 0.5, k)
+    dp.flush()
+    np.savez(out + ('.r%d' % rank), W=twin.p['W'], vb=twin.p['vb'], hb=twin.p['hb'])
+    dist.destroy_process_group()
+
+
+def test_delayed_gradient_dp_world2(tmp_path):
+    # the NON-parity mode of DESIGN 6: two ranks running the delayed schedule == one process running the same
+    # delayed schedule on the global batch (to the blocking of the sums), and the replicas stay identical
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    out = str(tmp_path / 'delayed')
+    mp.spawn(_delayed_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g0, g1 = np.load(out + '.r0.npz'), np.load(out + '.r1.npz')
+    for n in ('W', 'vb', 'hb'):
+        assert np.array_equal(g0[n], g1[n])
+    V, H, Bl, k, steps, world = 24, 16, 6, 1, 4, 2
+    kw = dict(sample_v_states=True, l2=1e-3)
+    W = (orc.normal(1, 2, 0, V * H) * np.float32(0.1)).reshape(V, H)
+    Xg = [(orc.uniform(1, 30 + s, 0, world * Bl * V) < 0.3).astype(np.float32).reshape(world * Bl, V) for s in range(steps)]
+    ref = _delayed_reference(V, H, W, Xg, kw, steps, k, 0.05, 0.5)
+    for n in ('W', 'vb', 'hb'):
+        np.testing.assert_allclose(g0[n], ref.p[n], rtol=2e-5, atol=2e-7)
+    # and it is NOT the synchronous trajectory
+    sync = orc.OracleRBM(V, H, **kw)
+    sync.p['W'][...] = W
+    sync.set_seed(99)
+    for s in range(steps):
+        sync.train_step(Xg[s], 0.05, 0.5, k)
+    assert not np.allclose(g0['W'], sync.p['W'], rtol=1e-6, atol=1e-9)
+
+
 def test_shard():
     from boltzmann_machines_amd.parallel import shard
     assert [shard(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]

@@ -182,3 +182,45 @@ def test_native_comm_dbm_and_ais_world1(gpu_lib):
     r = subprocess.run([sys.executable, '-c', NATIVE_DBM_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and 'NATIVE_DBM_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+DELAYED_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+assert 'torch' not in sys.modules
+from boltzmann_machines_amd import parallel
+from boltzmann_machines_amd.engine import RbmEngine, as_device
+from oracle import oracle as orc
+V, H, B, k, steps = 48, 40, 24, 1, 5
+kw = dict(l2=1e-3, sample_v_states=True, sample_h_states=True)
+W = (orc.normal(1, 2, 0, V * H) * np.float32(0.1)).reshape(V, H)
+eng = RbmEngine(V, H, max_batch=B, **kw)
+twin = orc.OracleRBM(V, H, **kw)
+eng.set('W', W); twin.p['W'][...] = W
+eng.seed(5); twin.set_seed(5)
+comm = parallel.NativeComm(0, 1, parallel.NativeComm.unique_id())
+dp = parallel.DelayedDataParallelRBM(eng, 0, 1, B, comm=comm)
+pending = None
+for s in range(steps):
+    X = (orc.uniform(1, 50 + s, 0, B * V) < 0.3).astype(np.float32).reshape(B, V)
+    dp.train_step(as_device(X), 0.05, 0.5, k)
+    raw = twin.raw_grads(X, k)                 # the oracle on the same delayed schedule
+    if pending is not None:
+        twin.apply(pending, float(B), 0.05, 0.5)
+    pending = raw
+dp.flush(); twin.apply(pending, float(B), 0.05, 0.5)
+for nm in ('W', 'dW', 'vb', 'hb', 'dvb', 'dhb', 'q_means'):
+    assert np.array_equal(eng.get(nm).view(np.uint32), twin.p[nm].view(np.uint32)), nm
+comm.close(); eng.close()
+print('DELAYED_OK')
+"""
+
+
+def test_delayed_gradient_dp_world1(gpu_lib):
+    """the NON-parity delayed-gradient mode through the library (two gradient slots, the reduction on the
+    communication stream, bm_rbm_wait_grads): bit-identical to the oracle driven on the same delayed schedule"""
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', DELAYED_SCRIPT % dict(root=ROOT)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and 'DELAYED_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
