@@ -598,7 +598,15 @@ def main():
         }
         if not args.no_cpu and world == 1 and args.config == 'rbm':
             out['cpu_baseline'] = cpu_baseline(args.k)
+        # the ONE line of the contract is the last thing on stdout: flush what C libraries (the RCCL banner under
+        # NCCL_DEBUG=VERSION) still hold in their stdio buffers first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 
