@@ -227,7 +227,7 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
     // cond at step 0 compares the persistent mu with the init values (:449-452)
     BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
     for (int i = 0; i < L; ++i)
-        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 512 ? N : 512), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
+        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 128 ? N : 128), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
                            (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
     int step = 0;
     Mat *cur = h->mu, *alt = h->mu_alt;

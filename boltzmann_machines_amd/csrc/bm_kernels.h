@@ -1235,9 +1235,20 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int r0 = 0; r0 < a.J; r0 += MN_ROWS) {
         const int nr = (a.J - r0 < MN_ROWS) ? a.J - r0 : MN_ROWS;
-        for (int e = tid; e < MN_ROWS * 16; e += NT) {
-            const int row = e >> 4, c = c0 + (e & 15);
-            sA[e] = (row < nr && c < a.I) ? a.W[(size_t)(r0 + row) * a.ldw + c] : 0.f;
+        // 16 columns x 512 rows per pass; 16-byte loads (eight in flight per thread) when the strip is whole
+        if (c0 + 16 <= a.I && (a.ldw & 3) == 0 && (((uintptr_t)a.W) & 15u) == 0) {
+#pragma unroll
+            for (int n = 0; n < MN_ROWS * 4 / NT; ++n) {
+                const int f = tid + n * NT, row = f >> 2, c4 = f & 3;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < nr) v = *reinterpret_cast<const float4 *>(a.W + (size_t)(r0 + row) * a.ldw + c0 + 4 * c4);
+                *reinterpret_cast<float4 *>(sA + row * 16 + 4 * c4) = v;
+            }
+        } else {
+            for (int e = tid; e < MN_ROWS * 16; e += NT) {
+                const int row = e >> 4, c = c0 + (e & 15);
+                sA[e] = (row < nr && c < a.I) ? a.W[(size_t)(r0 + row) * a.ldw + c] : 0.f;
+            }
         }
         __syncthreads();
         if (w == 0) {
@@ -1338,8 +1349,11 @@ __global__ void mf_latch_kernel(MfCtl *c, float tol, int init) {
     }
 }
 
-// ||A - B||_inf over a [rows][cols] window -> atomicMax on float bits (mean-field cond, dbm.py:449-452)
+// ||A - B||_inf over a [rows][cols] window -> atomicMax on float bits (mean-field cond, dbm.py:449-452).
+// Rows over workgroups, columns over threads (coalesced), ONE atomic per workgroup: same-address atomics serialise
+// in the L2 at ~12 ns each (2048 of them made this kernel take 25 us).
 __global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda, const float *B, int ldb, int rows, int cols, unsigned *out) {
+    __shared__ float s_m[4];
     float m = 0.f;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const float *pa = A + (size_t)r * lda, *pb = B + (size_t)r * ldb;
@@ -1347,7 +1361,12 @@ __global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
 }
 
 // ------------------------------------------------------------- host launchers
