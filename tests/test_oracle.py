@@ -332,3 +332,74 @@ def test_blas_restatement_matches_oracle():
         assert_allclose(t.work['hm'], r['hm'], rtol=2e-6, atol=1e-7)
         for a, b in ((t.p['W'], m.W), (t.p['vb'], m.vb), (t.p['hb'], m.hb), (t.p['q_means'], m.q)):
             assert_allclose(a, b, rtol=2e-5, atol=2e-7)
+
+
+def test_free_energy_and_pll_against_scikit_learn():
+    """A third-party pin: scikit-learn's BernoulliRBM holds the same free energy (rbm.py:17-22) as a formula of
+    its own, and the pseudo-log-likelihood of base_rbm.py:482-517 (flip one visible unit per row, n_visible *
+    log_sigmoid(F(x~) - F(x))) is built from it.  With the oracle's weights and the oracle's flip indices both must
+    agree with the oracle to fp32 accuracy."""
+    sk = pytest.importorskip('sklearn.neural_network')
+    V, H, B = 30, 17, 12
+    twin = orc.OracleRBM(V, H, sample_v_states=True, sample_h_states=True)
+    twin.p['W'][...] = (orc.normal(3, 1, 0, V * H) * np.float32(0.3)).reshape(V, H)
+    twin.p['vb'][...] = (orc.uniform(3, 2, 0, V) - np.float32(0.5))
+    twin.p['hb'][...] = (orc.uniform(3, 3, 0, H) - np.float32(0.5))
+    twin.set_seed(11)
+    X = (orc.uniform(3, 4, 0, B * V) < 0.4).astype(np.float32).reshape(B, V)
+    fe_oracle = twin.free_energy(X)
+    out, flip = twin.metrics(X, 1)
+    rbm = sk.BernoulliRBM(n_components=H)
+    rbm.components_ = twin.p['W'].T.astype(np.float64)
+    rbm.intercept_hidden_ = twin.p['hb'].astype(np.float64)
+    rbm.intercept_visible_ = twin.p['vb'].astype(np.float64)
+    X64 = X.astype(np.float64)
+    fe = rbm._free_energy(X64)
+    Xf = X64.copy()
+    Xf[np.arange(B), flip] = 1.0 - Xf[np.arange(B), flip]
+    # the reference's free energy op is the BATCH MEAN (rbm.py:21-22), so its PLL is n_visible * log_sigmoid of a
+    # difference of means (base_rbm.py:510-511) - scikit-learn averages per-row terms instead; its per-row free
+    # energies are what is borrowed here
+    pll = -V * np.logaddexp(0, -(rbm._free_energy(Xf).mean() - fe.mean()))
+    np.testing.assert_allclose(fe_oracle, fe.mean(), rtol=2e-6)
+    np.testing.assert_allclose(out[3], fe.mean(), rtol=2e-6)
+    np.testing.assert_allclose(out[1], pll, rtol=2e-5)
+    assert flip.min() >= 0 and flip.max() < V and len(set(flip.tolist())) > 1
+
+
+def test_cd1_update_against_scikit_learn_inner_fit():
+    """A third-party pin of the TRAIN STEP: scikit-learn's `BernoulliRBM._fit` is one (P)CD-1 update - positive phase
+    from the hidden MEANS of the data, negative phase from visible SAMPLES drawn from given hidden states and the
+    hidden means of those samples, `W += lr/B (v+' h+ - v-' h-)`, bias steps from the column sums - i.e. exactly the
+    reference's CD-1 train op (base_rbm.py:415-479) with momentum = l2 = sparsity = dropout = 0 and both layers
+    sampled.  Given the oracle's own random draws (its chain is started from the oracle's h0 states, its generator
+    returns numbers that reproduce the oracle's visible samples), sklearn's code must land on the oracle's new
+    parameters: the assembly of the update is checked by code that is neither the reference's nor ours."""
+    sk = pytest.importorskip('sklearn.neural_network')
+    V, H, B, lr = 28, 19, 16, 0.05
+    twin = orc.OracleRBM(V, H, sample_v_states=True, sample_h_states=True)
+    twin.p['W'][...] = (orc.normal(7, 1, 0, V * H) * np.float32(0.2)).reshape(V, H)
+    twin.p['vb'][...] = (orc.uniform(7, 2, 0, V) - np.float32(0.5)) * np.float32(0.3)
+    twin.p['hb'][...] = (orc.uniform(7, 3, 0, H) - np.float32(0.5)) * np.float32(0.3)
+    twin.set_seed(21)
+    X = (orc.uniform(7, 4, 0, B * V) < 0.35).astype(np.float32).reshape(B, V)
+    rbm = sk.BernoulliRBM(n_components=H, learning_rate=lr)
+    rbm.components_ = twin.p['W'].T.astype(np.float64).copy()
+    rbm.intercept_hidden_ = twin.p['hb'].astype(np.float64).copy()
+    rbm.intercept_visible_ = twin.p['vb'].astype(np.float64).copy()
+    twin.train_step(X, lr, 0.0, 1)
+    h0s, vs = twin.work['h0s'][:B].astype(np.float64), twin.work['vs'][:B].astype(np.float64)
+    assert 0.05 < vs.mean() < 0.95 and 0.05 < h0s.mean() < 0.95
+
+    class Replay(object):          # uniform() < p  <=>  the oracle's sample (p is never 0 or 1 here)
+        def __init__(self):
+            self.calls = 0
+
+        def uniform(self, size):
+            self.calls += 1
+            return np.where(vs > 0.5, 0.0, 1.0) if tuple(size) == vs.shape and self.calls == 1 else np.full(size, 0.5)
+    rbm.h_samples_ = h0s.copy()
+    rbm._fit(X.astype(np.float64), Replay())
+    np.testing.assert_allclose(twin.p['W'], rbm.components_.T, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(twin.p['hb'], rbm.intercept_hidden_, rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(twin.p['vb'], rbm.intercept_visible_, rtol=2e-5, atol=2e-7)
