@@ -548,8 +548,7 @@ def main():
     eng = wl.eng
 
     def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()         # device-wide: covers the engine's streams
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
@@ -570,9 +569,10 @@ def main():
     eng.timer_start()
     for i in range(args.steps):
         wl.step(i)
-    ev_ms = eng.timer_stop()
+    eng.timer_mark()                     # HIP event behind the last step (read after the clock has been stopped)
     barrier()
     dt = time.perf_counter() - t0
+    ev_ms = eng.timer_elapsed()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -98,6 +98,8 @@ SIGNATURES = {
     'bm_rbm_kernel_times': [_vp, _fp, _ip],
     'bm_rbm_timer_start': [_vp],
     'bm_rbm_timer_stop': [_vp, _fp],
+    'bm_rbm_timer_mark': [_vp],
+    'bm_rbm_timer_elapsed': [_vp, _fp],
     'bm_dbm_create': [C.POINTER(DbmConfig), C.POINTER(_vp)],
     'bm_dbm_destroy': [_vp],
     'bm_dbm_sync': [_vp],
@@ -121,6 +123,8 @@ SIGNATURES = {
     'bm_dbm_log_proba': [_vp, _vp, _vp],
     'bm_dbm_timer_start': [_vp],
     'bm_dbm_timer_stop': [_vp, _fp],
+    'bm_dbm_timer_mark': [_vp],
+    'bm_dbm_timer_elapsed': [_vp, _fp],
 }
 _RESTYPE = {'bm_last_error': C.c_char_p, 'bm_version': C.c_char_p}
 MF_REDUCE_FN = C.CFUNCTYPE(C.c_float, C.c_float, C.c_void_p)

@@ -1058,6 +1058,13 @@ int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host) {
 }
 
 int bm_dbm_timer_start(bm_dbm *h) { BM_HIP(hipEventRecord(h->ev0, h->stream)); return 0; }
+// the two halves of timer_stop: the mark is enqueued inside a timed region, the read (a host wait) after it
+int bm_dbm_timer_mark(bm_dbm *h) { BM_HIP(hipEventRecord(h->ev1, h->stream)); return 0; }
+int bm_dbm_timer_elapsed(bm_dbm *h, float *out_ms) {
+    BM_HIP(hipEventSynchronize(h->ev1));
+    BM_HIP(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+    return 0;
+}
 int bm_dbm_timer_stop(bm_dbm *h, float *out_ms) {
     BM_HIP(hipEventRecord(h->ev1, h->stream));
     BM_HIP(hipEventSynchronize(h->ev1));

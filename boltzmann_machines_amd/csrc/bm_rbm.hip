@@ -622,6 +622,13 @@ int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6) {
 }
 
 int bm_rbm_timer_start(bm_rbm *h) { BM_HIP(hipEventRecord(h->ev0, h->stream)); return 0; }
+// the two halves of timer_stop: the mark is enqueued inside a timed region, the read (a host wait) after it
+int bm_rbm_timer_mark(bm_rbm *h) { BM_HIP(hipEventRecord(h->ev1, h->stream)); return 0; }
+int bm_rbm_timer_elapsed(bm_rbm *h, float *out_ms) {
+    BM_HIP(hipEventSynchronize(h->ev1));
+    BM_HIP(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+    return 0;
+}
 int bm_rbm_timer_stop(bm_rbm *h, float *out_ms) {
     BM_HIP(hipEventRecord(h->ev1, h->stream));
     BM_HIP(hipEventSynchronize(h->ev1));

@@ -151,6 +151,14 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_timer_stop(self._h, C.byref(ms)))
         return float(ms.value)
 
+    def timer_mark(self):
+        check(self.lib.bm_rbm_timer_mark(self._h))
+
+    def timer_elapsed(self):
+        ms = C.c_float()
+        check(self.lib.bm_rbm_timer_elapsed(self._h, C.byref(ms)))
+        return float(ms.value)
+
 
 class RbmEngine64(object):
     """float64 RBM handle (bm_rbm64_*, include/bm355.h): same method names as RbmEngine, float64
@@ -388,4 +396,12 @@ class DbmEngine(object):
     def timer_stop(self):
         ms = C.c_float()
         check(self.lib.bm_dbm_timer_stop(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def timer_mark(self):
+        check(self.lib.bm_dbm_timer_mark(self._h))
+
+    def timer_elapsed(self):
+        ms = C.c_float()
+        check(self.lib.bm_dbm_timer_elapsed(self._h, C.byref(ms)))
         return float(ms.value)

@@ -152,6 +152,8 @@ int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6);
 /* HIP-event timer on the handle's stream (bench.py roofline leg). */
 int bm_rbm_timer_start(bm_rbm *h);
 int bm_rbm_timer_stop(bm_rbm *h, float *out_ms);
+int bm_rbm_timer_mark(bm_rbm *h);                       /* record the end event only (no host wait) ... */
+int bm_rbm_timer_elapsed(bm_rbm *h, float *out_ms);     /* ... wait for it and read start -> mark */
 
 /* ---- float64 RBM path ---------------------------------------------------------------------
  * The reference's dtype is a constructor argument (base/mixin.py:15, DtypeMixin) and its own
@@ -270,6 +272,8 @@ int bm_dbm_log_proba(bm_dbm *h, const float *X_dev, float *out_host);
 
 int bm_dbm_timer_start(bm_dbm *h);
 int bm_dbm_timer_stop(bm_dbm *h, float *out_ms);
+int bm_dbm_timer_mark(bm_dbm *h);
+int bm_dbm_timer_elapsed(bm_dbm *h, float *out_ms);
 
 
 /* ---- RCCL inside the library (bm_comm_init / bm_allreduce_grads; §8e: one exchange step
