@@ -38,6 +38,12 @@
 // those cycles come out of the same pipe the fragment reads use.  DMA runs three chunks ahead
 // (counted s_waitcnt vmcnt + raw s_barrier: a __syncthreads() would drain the DMA queue).
 //
+// Issue discipline: a wave's MFMAs form one dependent chain, and a vector-ALU instruction between two of them costs
+// ~13 cycles of matrix-pipe time (tools/ubench_step.hip; scalar instructions and the DMA issue are nearly free).
+// Every loop is therefore unrolled by the ring depth so that the ring slot is a compile-time constant - all LDS
+// addresses become loop-invariant bases + immediates - and the DMA addresses a scalar chunk base plus a fixed
+// per-lane offset: the steady steps contain no VALU instruction at all.
+//
 // LDS images (no padding: a DMA piece is 1 KiB of consecutive LDS; bank conflicts are avoided
 // by XOR-swizzling WHICH global 16-byte chunk a lane fetches — tools/bank_check.py proves every
 // fragment read conflict free under the bank model of MI355X_MICROARCH.md):
@@ -57,7 +63,7 @@
 namespace bm {
 
 // Side work hooks of the main loop: fill() runs in the shadow of the pipeline fill (the first
-// global round trip), drain() is issued before the MFMAs of the last chunk (loads the
+// global round trip), drain() is issued at the start of the last step but one (loads the
 // epilogue needs).  Default: none.
 struct NoSide {
     static constexpr bool kFinalSync = true;     // a following pipeline may refill the LDS ring
