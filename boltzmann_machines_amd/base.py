@@ -15,10 +15,9 @@ Differences that are deliberate (DESIGN.md "boundary"):
     object; they are written to `<model_filepath>.npz` where the reference runs
     the TF Saver, and re-read from there only by `load_model`.
   - dtype: the tuned device path is fp32 (the reference default).  'float64'
-    Bernoulli / Gaussian RBMs run on the device through `bm_rbm64_*`
-    (rbm.py -> RbmEngine64).  A float64 MultinomialRBM or DBM can be
-    constructed/initialised (the W-init known answer of
-    rbm/tests/test_rbm.py:67 holds) but `fit`/`transform` raise.
+    RBMs (Bernoulli, Gaussian, Multinomial) run on the device through
+    `bm_rbm64_*` (rbm.py -> RbmEngine64).  A float64 DBM can be
+    constructed/initialised but `fit`/`transform` raise.
 """
 import json
 import os
@@ -190,8 +189,8 @@ class EngineModel(BaseModel, DtypeMixin):
     def _ensure_engine(self):
         if self._engine is None:
             if np.dtype(self.dtype) != np.float32 and self._needs_device():
-                raise NotImplementedError("%s has no device path for dtype='%s': float64 runs for Bernoulli/Gaussian "
-                                          "RBMs (bm_rbm64_*), everything else computes in float32"
+                raise NotImplementedError("%s has no device path for dtype='%s': float64 runs for the RBMs "
+                                          "(bm_rbm64_*), the DBM computes in float32"
                                           % (self.__class__.__name__, self.dtype))
             # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher): bind this process to its GPU
             # and join the job's communicator before the handle is created (boltzmann_machines_amd/parallel.py)

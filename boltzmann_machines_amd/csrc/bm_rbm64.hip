@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void act_kernel(ActArgs a) {
             if (i >= a.I) continue;
             const double b = a.mult * a.bias[i];
             const double x = a.mult * acc[t][r];
-            const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (x * a.sigma[i] + b);
+            const double m = (a.kind == BM_UNIT_BERNOULLI) ? sigmoid(x + b) : (a.kind == 3 ? x + b : (x * a.sigma[i] + b));
             double s = m;
             if (a.sample) {
                 const unsigned long long idx = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + (unsigned long long)i;
@@ -483,6 +483,92 @@ __global__ void pll_index_kernel(int *out, int B, int V, PhiloxKey key, unsigned
     bm::philox_block(key, idx >> 2, w);
     out[b] = (int)(w[idx & 3] % (uint32_t)V);
 }
+// MultinomialLayer in double (layers.py:54-70), the twin of bm::softmax_multinomial_kernel and of the oracle's
+// softmax_multinomial_row_d: one wave per row of logits L[row][0..I) (written by act_kernel kind 3), in place:
+//   mx = max l;  e[i] = exp_neg(min(mx - l[i], 700));  c[i] = c[i-1] + e[i] SEQUENTIALLY;  S = c[I-1];
+//   means[i] = M * (e[i] / S);  draw d: t = u(row*M + d) * S, category = first c[i] > t.   LDS: c[I] | e[I] doubles
+__global__ __launch_bounds__(64) void softmax_multinomial_kernel(double *L, int I, int M, int sample, double *states,
+                                                                 PhiloxKey key, long long row0) {
+    extern __shared__ double sm64[];
+    double *c = sm64, *e = sm64 + I;
+    const int row = blockIdx.x, lane = threadIdx.x;
+    double *l = L + (size_t)row * I;
+    double mx = -1.7976931348623157e308;
+    for (int i = lane; i < I; i += 64) mx = fmax(mx, l[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+    for (int i = lane; i < I; i += 64) {
+        double d = mx - l[i];
+        if (d > 700.0) d = 700.0;
+        e[i] = exp_neg(d);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double run = 0.0;
+        for (int i = 0; i < I; ++i) { run = run + e[i]; c[i] = run; }
+    }
+    __syncthreads();
+    const double S = c[I - 1], Mf = (double)M;
+    for (int i = lane; i < I; i += 64) {
+        const double m = Mf * (e[i] / S);
+        l[i] = m;
+        if (states && !sample) states[(size_t)row * I + i] = m;
+    }
+    if (!states || !sample) return;
+    __syncthreads();
+    int *cnt = reinterpret_cast<int *>(e);
+    for (int i = lane; i < I; i += 64) cnt[i] = 0;
+    __syncthreads();
+    for (int d = lane; d < M; d += 64) {
+        const double u = uniform_at(key, (unsigned long long)(row0 + row) * (unsigned long long)M + (unsigned long long)d);
+        const double t = u * S;
+        int lo = 0, hi = I - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        atomicAdd(cnt + lo, 1);
+    }
+    __syncthreads();
+    for (int i = lane; i < I; i += 64) states[(size_t)row * I + i] = (double)cnt[i];
+}
+// h_hat ~ Multinomial(M, uniform over K) (rbm.py:58): counts of floor(u * K); three vectors (streams t = 0, 1, 2:
+// free_energy_op, F(x) and F(x~) of the PLL); hhat [3][K] zeroed by the caller
+__global__ void mn_hhat_kernel(double *hhat, int K, int M, PhiloxKey k0, PhiloxKey k1, PhiloxKey k2) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= M) return;
+    const PhiloxKey keys[3] = {k0, k1, k2};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        int idx = (int)(uniform_at(keys[t], (unsigned long long)d) * (double)K);
+        if (idx > K - 1) idx = K - 1;
+        atomicAdd(hhat + (size_t)t * K + idx, 1.0);
+    }
+}
+// MultinomialRBM free energy (rbm.py:52-62, without the lgamma constant): out[0] += F_hhat0(x), out[1] += F_hhat2(x~),
+// out[2] += F_hhat1(x);  F_hhat(v) = -v.vb - sum_h (v W)_h * hhat_h
+__global__ __launch_bounds__(256) void free_energy_mn_kernel(const double *X, int ldx, int B, int V, int H,
+                                                             const double *W, const double *vb, const double *hhat,
+                                                             const int *flip, double *out) {
+    const int b = blockIdx.x;
+    const double *x = X + (size_t)b * ldx;
+    const int fc = flip ? flip[b] : -1;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const double xv = x[v], xf = (v == fc) ? 1.0 - xv : xv;
+        t0 -= xv * vb[v]; t1 -= xv * vb[v]; t2 -= xf * vb[v];
+    }
+    const double delta = (fc >= 0) ? 1.0 - 2.0 * x[fc] : 0.0;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        double z = 0.0;
+        for (int v = 0; v < V; ++v) z = fma(x[v], W[(size_t)v * H + h], z);
+        t0 -= z * hhat[h];
+        t1 -= z * hhat[(size_t)H + h];
+        if (fc >= 0) t2 -= (z + delta * W[(size_t)fc * H + h]) * hhat[2 * (size_t)H + h];
+    }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 0, t0); atomicAdd(out + 2, t1); if (flip) atomicAdd(out + 1, t2); }
+}
 // free energy of rows (rbm.py:17-22 / :109-116), optionally of the row with column flip[b] flipped:
 // out[0] += F(x_b), out[1] += F(x~_b).  One workgroup per row; hidden units strided over the threads.
 __global__ __launch_bounds__(256) void free_energy_kernel(const double *X, int ldx, int B, int V, int H,
@@ -523,7 +609,7 @@ struct DBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; }
 };
-enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5 };
+enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PLL = 5, SITE_FE = 6 };
 }  // namespace bm64
 
 struct bm_rbm64 {
@@ -533,7 +619,9 @@ struct bm_rbm64 {
     bm64::DBuf W, Wt, dW, vb, hb, dvb, dhb, q, sigma, pen;
     bm64::DBuf h0m, h0s, hm, hs, vm, vs, Xp;
     int *flip = nullptr;
-    double *scal = nullptr;      // [4] msre, l2, F(x), F(x~)
+    double *scal = nullptr;      // [6] msre, l2, F(x), F(x~), F'(x) (multinomial: the PLL's own h_hat), spare
+    bm64::DBuf hhat;             // [3*H] MultinomialRBM free-energy h_hat vectors (rbm.py:58)
+    bool multinomial() const { return cfg.h_unit == BM_UNIT_MULTINOMIAL; }
     uint64_t seed = 0; uint32_t call = 0; int64_t row0 = 0;
     const double *Xin = nullptr; int Xin_ld = 0;
     // hyper-parameters as doubles (a Python float is a double; the float fields of cfg would round them)
@@ -557,7 +645,37 @@ static void launch_act(bm_rbm64 *h, bool up, const double *in, int ldin, int B, 
               a.mult = 1.0 + (h->cfg.dbm_last ? 1.0 : 0.0); }
     a.Q = in; a.ldq = ldin; a.J = B; a.sample = sample; a.means = means; a.states = states;
     a.key = make_key(h, site, t); a.row0 = h->row0;
+    if (up && h->multinomial()) {
+        // MultinomialLayer (layers.py:54-70): logits from the GEMM, then one wave per row for the softmax
+        // (activation) and the multinomial counts (sample)
+        a.kind = 3; a.sample = 0; a.states = nullptr;
+        hipLaunchKernelGGL(act_kernel, dim3((a.I + T64_TI - 1) / T64_TI, (B + T64_TJ - 1) / T64_TJ), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(B), dim3(64), 2 * (size_t)h->H * sizeof(double), h->stream,
+                           means, h->H, h->cfg.n_samples, sample, states, a.key, (long long)h->row0);
+        return;
+    }
     hipLaunchKernelGGL(act_kernel, dim3((a.I + T64_TI - 1) / T64_TI, (B + T64_TJ - 1) / T64_TJ), dim3(256), 0, h->stream, a);
+}
+// -lgamma(M + K) + lgamma(M + 1) + lgamma(K)  (rbm.py:61); 0 for the other RBMs
+static double mn_fe_const(const bm_rbm64 *h) {
+    if (!h->multinomial()) return 0.0;
+    const double M = h->cfg.n_samples, K = h->H;
+    return -lgamma(M + K) + lgamma(M + 1.0) + lgamma(K);
+}
+// free energies of the rows of Xin into scal[2] (F(x)), scal[3] (F(x~), with flip) and, MultinomialRBM, scal[4]
+static void launch_fe(bm_rbm64 *h, const double *Xin, int ldx, int B, const int *flip) {
+    if (h->multinomial()) {                    // rbm.py:52-62: fresh h_hat draws, streams t = 0, 1, 2
+        (void)hipMemsetAsync(h->hhat.p, 0, 3 * (size_t)h->H * sizeof(double), h->stream);
+        const int M = h->cfg.n_samples;
+        hipLaunchKernelGGL(mn_hhat_kernel, dim3((M + 255) / 256), dim3(256), 0, h->stream, h->hhat.p, h->H, M,
+                           make_key(h, SITE_FE, 0), make_key(h, SITE_FE, 1), make_key(h, SITE_FE, 2));
+        hipLaunchKernelGGL(free_energy_mn_kernel, dim3(B), dim3(256), 0, h->stream, Xin, ldx, B, h->V, h->H,
+                           (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hhat.p, flip, h->scal + 2);
+        return;
+    }
+    hipLaunchKernelGGL(free_energy_kernel, dim3(B), dim3(256), 0, h->stream, Xin, ldx, B, h->V, h->H,
+                       (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hb.p,
+                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), flip, h->scal + 2);
 }
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426)
 static int run_chain(bm_rbm64 *h, const double *X_dev, int B, int k, double *hm_out) {
@@ -601,18 +719,19 @@ static void launch_update(bm_rbm64 *h, int B, double lr, double mom) {
     hipLaunchKernelGGL(grad_kernel, dim3(nx, ny + extra), dim3(256), 0, h->stream, g);
 }
 static int metrics_from_chain(bm_rbm64 *h, int B, double *out4) {
-    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
+    BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
     hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, (const double *)h->vm.p, (size_t)B * h->V, h->scal + 0);
     hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, (const double *)h->W.p, (const double *)nullptr, (size_t)h->V * h->H, h->scal + 1);
     hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
                        make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
-    hipLaunchKernelGGL(free_energy_kernel, dim3(B), dim3(256), 0, h->stream, h->Xin, h->Xin_ld, B, h->V, h->H,
-                       (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hb.p,
-                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), (const int *)h->flip, h->scal + 2);
-    double host[4];
+    launch_fe(h, h->Xin, h->Xin_ld, B, (const int *)h->flip);
+    double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    const double fe = host[2] / B, fe2 = host[3] / B, d = fe2 - fe;
+    // MultinomialRBM: every _free_energy() call draws its own h_hat (host[4] = F(x) of the PLL pair) and carries the
+    // constant of rbm.py:61 (it cancels in the PLL difference)
+    const double fe = host[2] / B + mn_fe_const(h), fe1 = h->multinomial() ? host[4] / B + mn_fe_const(h) : fe;
+    const double fe2 = host[3] / B + mn_fe_const(h), d = fe2 - fe1;
     out4[0] = host[0] / ((double)B * h->V);
     out4[1] = (double)h->V * -(fmax(-d, 0.0) + log1p(exp(-fabs(d))));
     out4[2] = h->l2 * (0.5 * host[1]);
@@ -636,7 +755,9 @@ int bm_rbm64_create(const bm_rbm_config *cfg, const double *hyper5, bm_rbm64 **o
     BM_CHECK(cfg->n_visible >= 1 && cfg->n_hidden >= 1, "bad layer sizes %d x %d", cfg->n_visible, cfg->n_hidden);
     BM_CHECK(cfg->max_batch >= 1, "max_batch must be >= 1");
     BM_CHECK(cfg->v_unit == BM_UNIT_BERNOULLI || cfg->v_unit == BM_UNIT_GAUSSIAN, "unknown visible unit %d", cfg->v_unit);
-    BM_CHECK(cfg->h_unit == BM_UNIT_BERNOULLI, "the float64 path has Bernoulli hidden units only (h_unit %d)", cfg->h_unit);
+    BM_CHECK(cfg->h_unit == BM_UNIT_BERNOULLI || cfg->h_unit == BM_UNIT_MULTINOMIAL, "unknown hidden unit %d", cfg->h_unit);
+    BM_CHECK(cfg->h_unit != BM_UNIT_MULTINOMIAL || (cfg->n_samples >= 1 && cfg->n_hidden <= 8192),
+             "MultinomialRBM needs n_samples >= 1 and n_hidden <= 8192 (got %d, %d)", cfg->n_samples, cfg->n_hidden);
     BM_CHECK(bm_device_count() > 0, "no HIP device visible: libbm355 has no CPU fallback");
     bm_rbm64 *h = new bm_rbm64();
     h->cfg = *cfg;
@@ -654,7 +775,8 @@ int bm_rbm64_create(const bm_rbm_config *cfg, const double *hyper5, bm_rbm64 **o
     BM_TRY(h->h0m.alloc(B * H)); BM_TRY(h->h0s.alloc(B * H)); BM_TRY(h->hm.alloc(B * H)); BM_TRY(h->hs.alloc(B * H));
     BM_TRY(h->vm.alloc(B * V)); BM_TRY(h->vs.alloc(B * V)); BM_TRY(h->Xp.alloc(B * V));
     BM_HIP(hipMalloc((void **)&h->flip, B * sizeof(int)));
-    BM_HIP(hipMalloc((void **)&h->scal, 4 * sizeof(double)));
+    BM_HIP(hipMalloc((void **)&h->scal, 6 * sizeof(double)));
+    BM_TRY(h->hhat.alloc(3 * H));
     std::vector<double> ones(V, 1.0);
     BM_HIP(hipMemcpy(h->sigma.p, ones.data(), V * sizeof(double), hipMemcpyHostToDevice));
     *out = h;
@@ -669,6 +791,7 @@ int bm_rbm64_destroy(bm_rbm64 *h) {
     for (DBuf *b : all) b->release();
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
+    h->hhat.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -738,15 +861,13 @@ int bm_rbm64_free_energy(bm_rbm64 *h, const double *X_dev, int32_t B, double *ou
                            (unsigned long long)h->row0 * (unsigned long long)h->V);
         Xin = h->Xp.p;
     }
-    BM_HIP(hipMemsetAsync(h->scal, 0, 4 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(free_energy_kernel, dim3(B), dim3(256), 0, h->stream, Xin, h->V, B, h->V, h->H,
-                       (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hb.p,
-                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), (const int *)nullptr, h->scal + 2);
-    double host[4];
+    BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
+    launch_fe(h, Xin, h->V, B, (const int *)nullptr);
+    double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
-    *out1 = host[2] / B;
-    if (dropped) h->call++;                      // the dropout mask consumed one call of the stream
+    *out1 = host[2] / B + mn_fe_const(h);
+    if (dropped || h->multinomial()) h->call++;  // the dropout mask / the random h_hat consumed one call of the stream
     return 0;
 }
 

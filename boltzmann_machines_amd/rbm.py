@@ -32,7 +32,8 @@ def assert_len(obj, name, desired_len):
 
 
 class _HostVars(object):
-    """models without a device path for their dtype (float64 MultinomialRBM): variables on the host only."""
+    """models without a device path for their dtype (none of the RBMs any more; kept for dtypes other than
+    float32 / float64): variables on the host only."""
 
     def __init__(self, variables):
         self.vars = variables
@@ -170,7 +171,7 @@ class BaseRBM(EngineModel):
 
     def _make_engine(self):
         variables = self._initial_variables()
-        f64 = np.dtype(self.dtype) == np.float64 and self._H_UNIT == _ffi.UNIT_BERNOULLI
+        f64 = np.dtype(self.dtype) == np.float64
         if np.dtype(self.dtype) == np.float32 or f64:
             self._engine = (RbmEngine64 if f64 else RbmEngine)(
                                      self.n_visible, self.n_hidden, v_unit=self._V_UNIT,

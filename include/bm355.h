@@ -158,8 +158,8 @@ int bm_rbm_timer_elapsed(bm_rbm *h, float *out_ms);     /* ... wait for it and r
 /* ---- float64 RBM path ---------------------------------------------------------------------
  * The reference's dtype is a constructor argument (base/mixin.py:15, DtypeMixin) and its own
  * tests train a float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  Same fetch sites as
- * the float32 entry points above, every buffer and scalar in double; Bernoulli hidden units,
- * Bernoulli or Gaussian visible units (cfg->h_unit must be BM_UNIT_BERNOULLI).  Variables as in
+ * the float32 entry points above, every buffer and scalar in double; Bernoulli or Gaussian visible units,
+ * Bernoulli or Multinomial hidden units.  Variables as in
  * bm_rbm_set_param.  Compatibility path on the FP64 matrix cores, ~3x the float32 update. */
 typedef struct bm_rbm64 bm_rbm64;
 /* hyper5 = {l2, sparsity_target, sparsity_cost, sparsity_damping, dropout (<0: off)} as doubles (a Python

@@ -885,7 +885,43 @@ double orc_sigmoid_d(double x) {
 typedef struct { double *W, *vb, *hb, *dW, *dvb, *dhb, *q, *sigma; } orc_rbm_state_d;
 typedef struct { double *Xin, *h0m, *h0s, *vm, *vs, *hm, *hs; } orc_rbm_work_d;
 
-/* z[j][i] = sum_k Q[j][k] * Pk[k][i], then the layer activation / draw (layers.py:34-36,47-51,84-89) */
+/* MultinomialLayer in double (the float64 twin of softmax_multinomial_row): same operation sequence with
+ * exp_neg_d (argument clamped at 700), sequential prefix sums, uniforms from uniform_at_d */
+static double exp_neg_d(double a);
+static void softmax_multinomial_row_d(const double *l, int I, int M, int sample, double *means, double *states,
+                                      orc_key key, uint64_t row, double *e, double *c) {
+    double mx = l[0];
+    for (int i = 1; i < I; ++i) mx = fmax(mx, l[i]);
+    double run = 0.0;
+    for (int i = 0; i < I; ++i) {
+        double a = mx - l[i];
+        if (a > 700.0) a = 700.0;
+        e[i] = exp_neg_d(a);
+        run = run + e[i];
+        c[i] = run;
+    }
+    const double S = c[I - 1];
+    for (int i = 0; i < I; ++i) {
+        const double m = (double)M * (e[i] / S);
+        if (means) means[i] = m;
+        if (states) states[i] = sample ? 0.0 : m;
+    }
+    if (sample && states) {
+        for (int d = 0; d < M; ++d) {
+            const double u = uniform_at_d(key, row * (uint64_t)M + (uint64_t)d);
+            const double t = u * S;
+            int lo = 0, hi = I - 1;                 /* smallest i with c[i] > t */
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (c[mid] > t) hi = mid; else lo = mid + 1;
+            }
+            states[lo] = states[lo] + 1.0;
+        }
+    }
+}
+
+/* z[j][i] = sum_k Q[j][k] * Pk[k][i], then the layer activation / draw (layers.py:34-36,47-51,84-89);
+ * kind >= 16: MultinomialLayer with kind - 16 samples (layers.py:54-70) */
 static void act_d(const double *Q, int K, const double *Pk, int I, int J, const double *bias, const double *sigma,
                   double mult, int kind, int sample, double *means, double *states,
                   uint64_t seed, uint32_t site, uint32_t call, int64_t row0) {
@@ -900,6 +936,14 @@ static void act_d(const double *Q, int K, const double *Pk, int I, int J, const 
                 const double q = Q[(size_t)j * K + k];
                 const double *p = Pk + (size_t)k * I;
                 for (int i = 0; i < I; ++i) acc[i] = fma(p[i], q, acc[i]);
+            }
+            if (kind >= 16) {
+                double *e = (double *)malloc(2 * (size_t)I * sizeof(double));
+                for (int i = 0; i < I; ++i) acc[i] = mult * acc[i] + mult * bias[i];
+                softmax_multinomial_row_d(acc, I, kind - 16, sample, means ? means + (size_t)j * I : NULL,
+                                          states ? states + (size_t)j * I : NULL, key, (uint64_t)(row0 + j), e, e + I);
+                free(e);
+                continue;
             }
             for (int i = 0; i < I; ++i) {
                 const double x = mult * acc[i];
@@ -940,12 +984,13 @@ void orc_rbm_chain_d(const orc_rbm_cfg *c, const double *hy, const orc_rbm_state
     const double up = 1.0 + (c->dbm_first ? 1.0 : 0.0), down = 1.0 + (c->dbm_last ? 1.0 : 0.0);
     double *Wt = (double *)malloc((size_t)V * H * sizeof(double));
     for (int v = 0; v < V; ++v) for (int h = 0; h < H; ++h) Wt[(size_t)h * V + v] = s->W[(size_t)v * H + h];
-    act_d(w->Xin, V, s->W, H, B, s->hb, NULL, up, UNIT_BERNOULLI, 1, w->h0m, w->h0s, seed, SITE_H0, call, row0);
+    const int hkind = (c->h_unit == UNIT_MULTINOMIAL) ? 16 + c->n_samples : UNIT_BERNOULLI;
+    act_d(w->Xin, V, s->W, H, B, s->hb, NULL, up, hkind, 1, w->h0m, w->h0s, seed, SITE_H0, call, row0);
     const double *hstate = c->sample_h ? w->h0s : w->h0m;
     for (int t = 0; t < k; ++t) {
         act_d(hstate, H, Wt, V, B, s->vb, s->sigma, down, c->v_unit, c->sample_v, w->vm, w->vs,
               seed, SITE_V + 16u * (uint32_t)t, call, row0);
-        act_d(w->vs, V, s->W, H, B, s->hb, NULL, up, UNIT_BERNOULLI, c->sample_h, w->hm, w->hs,
+        act_d(w->vs, V, s->W, H, B, s->hb, NULL, up, hkind, c->sample_h, w->hm, w->hs,
               seed, SITE_H + 16u * (uint32_t)t, call, row0);
         hstate = w->hs;
     }
@@ -1003,10 +1048,26 @@ void orc_rbm_train_step_d(const orc_rbm_cfg *c, const double *hy, orc_rbm_state_
     free(pen); free(sv);
 }
 
-double orc_rbm_free_energy_d(const orc_rbm_cfg *c, const orc_rbm_state_d *s, const double *Xin, int B,
-                             const int32_t *flip) {
+/* h_hat of the MultinomialRBM free energy in double: counts of M uniform category draws floor(u * K) */
+static void multinomial_uniform_counts_d(int K, int M, uint64_t seed, uint32_t call, uint32_t t, double *hhat) {
+    const orc_key key = make_key(seed, SITE_FE + 16u * t, call);
+    for (int k = 0; k < K; ++k) hhat[k] = 0.0;
+    for (int d = 0; d < M; ++d) {
+        int idx = (int)(uniform_at_d(key, (uint64_t)d) * (double)K);
+        if (idx > K - 1) idx = K - 1;
+        hhat[idx] += 1.0;
+    }
+}
+
+double orc_rbm_free_energy_d_ex(const orc_rbm_cfg *c, const orc_rbm_state_d *s, const double *Xin, int B,
+                                const int32_t *flip, uint64_t seed, uint32_t call, uint32_t t_stream) {
     const int V = c->V, H = c->H;
     double total = 0.0;
+    double *hhat = NULL;
+    if (c->h_unit == UNIT_MULTINOMIAL) {
+        hhat = (double *)malloc((size_t)H * sizeof(double));
+        multinomial_uniform_counts_d(H, c->n_samples, seed, call, t_stream, hhat);
+    }
     for (int b = 0; b < B; ++b) {
         const double *x = Xin + (size_t)b * V;
         double t = 0.0;
@@ -1017,17 +1078,27 @@ double orc_rbm_free_energy_d(const orc_rbm_cfg *c, const orc_rbm_state_d *s, con
             else t -= xv * s->vb[v];
         }
         for (int h = 0; h < H; ++h) {
-            double z = s->hb[h];
+            double z = hhat ? 0.0 : s->hb[h];
             for (int v = 0; v < V; ++v) {
                 double xv = x[v];
                 if (flip && flip[b] == v) xv = 1.0 - xv;
                 z += xv * s->W[(size_t)v * H + h];
             }
-            t -= softplus_d(z);
+            t -= hhat ? z * hhat[h] : softplus_d(z);                      /* rbm.py:57-60 */
         }
         total += t;
     }
-    return total / B;
+    double fe = total / B;
+    if (hhat) {
+        const double M = c->n_samples, K = H;
+        fe += -lgamma(M + K) + lgamma(M + 1.0) + lgamma(K);                /* rbm.py:61 */
+        free(hhat);
+    }
+    return fe;
+}
+double orc_rbm_free_energy_d(const orc_rbm_cfg *c, const orc_rbm_state_d *s, const double *Xin, int B,
+                             const int32_t *flip) {
+    return orc_rbm_free_energy_d_ex(c, s, Xin, B, flip, 0, 0, 0);
 }
 
 /* out = [msre, pll, l2_loss, free_energy] from a finished chain (base_rbm.py:482-517) */
@@ -1047,9 +1118,11 @@ void orc_rbm_metrics_d(const orc_rbm_cfg *c, const double *hy, const orc_rbm_sta
         philox_block(key, idx >> 2, wd);
         flip[b] = (int32_t)(wd[idx & 3] % (uint32_t)V);
     }
-    const double fe = orc_rbm_free_energy_d(c, s, w->Xin, B, NULL);
-    const double fe2 = orc_rbm_free_energy_d(c, s, w->Xin, B, flip);
-    out4[1] = (double)V * -softplus_d(-(fe2 - fe));
+    const int mn = c->h_unit == UNIT_MULTINOMIAL;     /* a fresh h_hat per _free_energy() call: streams t = 0, 1, 2 */
+    const double fe = orc_rbm_free_energy_d_ex(c, s, w->Xin, B, NULL, seed, call, 0);
+    const double fe1 = mn ? orc_rbm_free_energy_d_ex(c, s, w->Xin, B, NULL, seed, call, 1) : fe;
+    const double fe2 = orc_rbm_free_energy_d_ex(c, s, w->Xin, B, flip, seed, call, 2);
+    out4[1] = (double)V * -softplus_d(-(fe2 - fe1));
     out4[3] = fe;
     free(flip);
 }

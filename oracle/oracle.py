@@ -208,11 +208,11 @@ class OracleRBM64(object):
 
     def __init__(self, n_visible, n_hidden, v_unit=0, sample_v_states=False, sample_h_states=True,
                  dbm_first=False, dbm_last=False, l2=1e-4, sparsity_target=0.1, sparsity_cost=0.,
-                 sparsity_damping=0.9, dropout=None):
+                 sparsity_damping=0.9, dropout=None, h_unit=0, n_samples=0):
         self.V, self.H = int(n_visible), int(n_hidden)
         self.cfg = RbmCfg(self.V, self.H, int(v_unit), int(bool(sample_v_states)), int(bool(sample_h_states)),
                           int(bool(dbm_first)), int(bool(dbm_last)), l2, sparsity_target, sparsity_cost,
-                          sparsity_damping, -1.0 if dropout is None else float(dropout), 0, 0)
+                          sparsity_damping, -1.0 if dropout is None else float(dropout), int(h_unit), int(n_samples))
         self.hy = np.array([l2, sparsity_target, sparsity_cost, sparsity_damping,
                             -1.0 if dropout is None else float(dropout)], dtype=np.float64)
         V, H = self.V, self.H
@@ -225,8 +225,9 @@ class OracleRBM64(object):
                                       C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(RbmWork)]
         L.orc_rbm_train_step_d.argtypes = [C.POINTER(RbmCfg), f64p, C.POINTER(RbmState), f64p, C.c_int, C.c_double,
                                            C.c_double, C.c_int, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(RbmWork)]
-        L.orc_rbm_free_energy_d.restype = C.c_double
-        L.orc_rbm_free_energy_d.argtypes = [C.POINTER(RbmCfg), C.POINTER(RbmState), f64p, C.c_int, C.c_void_p]
+        L.orc_rbm_free_energy_d_ex.restype = C.c_double
+        L.orc_rbm_free_energy_d_ex.argtypes = [C.POINTER(RbmCfg), C.POINTER(RbmState), f64p, C.c_int, C.c_void_p,
+                                               C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_rbm_metrics_d.argtypes = [C.POINTER(RbmCfg), f64p, C.POINTER(RbmState), C.POINTER(RbmWork), C.c_int,
                                         C.c_uint64, C.c_uint32, C.c_int64, f64p]
         L.orc_sigmoid_d.restype = C.c_double
@@ -281,8 +282,9 @@ class OracleRBM64(object):
             keep = self.hy[4]
             u = uniform_d(self.seed, 1, self.call, X.size, idx0=self.row0 * self.V).reshape(X.shape)
             X = np.ascontiguousarray((X / keep) * np.floor(keep + u))
-        fe = lib().orc_rbm_free_energy_d(C.byref(self.cfg), C.byref(self._state()), X, len(X), None)
-        if dropped:
+        fe = lib().orc_rbm_free_energy_d_ex(C.byref(self.cfg), C.byref(self._state()), X, len(X), None,
+                                            self.seed, self.call, 0)
+        if dropped or self.cfg.h_unit == 2:   # the dropout mask / the random h_hat consumed one call of the stream
             self.call += 1
         return fe
 

@@ -403,3 +403,28 @@ def test_cd1_update_against_scikit_learn_inner_fit():
     np.testing.assert_allclose(twin.p['W'], rbm.components_.T, rtol=2e-5, atol=2e-7)
     np.testing.assert_allclose(twin.p['hb'], rbm.intercept_hidden_, rtol=2e-5, atol=2e-7)
     np.testing.assert_allclose(twin.p['vb'], rbm.intercept_visible_, rtol=2e-5, atol=2e-7)
+
+
+def test_float64_multinomial_oracle_invariants_and_float32_agreement():
+    """the float64 MultinomialLayer restatement: means = M * softmax (rows sum to M), states are counts of M draws,
+    and the float32 oracle - an independent implementation of the same layer with its own exp - agrees to fp32"""
+    V, H, B, M = 21, 13, 7, 9
+    W = (orc.normal(9, 1, 0, V * H) * np.float32(0.4)).reshape(V, H)
+    hb = (orc.uniform(9, 2, 0, H) - np.float32(0.5))
+    X = (orc.uniform(9, 3, 0, B * V) < 0.4).astype(np.float32).reshape(B, V)
+    t64 = orc.OracleRBM64(V, H, sample_v_states=True, sample_h_states=True, h_unit=2, n_samples=M)
+    t32 = orc.OracleRBM(V, H, sample_v_states=True, sample_h_states=True, h_unit=2, n_samples=M)
+    for t in (t64, t32):
+        t.p['W'][...] = W
+        t.p['hb'][...] = hb
+        t.set_seed(5)
+        t.chain(X, 1)
+    for t in (t64, t32):
+        np.testing.assert_allclose(t.work['h0m'].sum(axis=1), M, rtol=1e-5)
+        hs = t.work['h0s']
+        assert np.array_equal(hs, np.round(hs)) and np.all(hs >= 0)
+        np.testing.assert_allclose(hs.sum(axis=1), M)
+    np.testing.assert_allclose(t64.work['h0m'], t32.work['h0m'], rtol=2e-5, atol=1e-6)
+    z = X.astype(np.float64) @ W.astype(np.float64) + hb.astype(np.float64)
+    sm = np.exp(z - z.max(axis=1, keepdims=True))
+    np.testing.assert_allclose(t64.work['h0m'], M * sm / sm.sum(axis=1, keepdims=True), rtol=1e-12)

@@ -90,8 +90,42 @@ def test_gaussian_visible_f64(gpu_lib):
     eng.close()
 
 
-def test_rejects_multinomial_f64(gpu_lib):
+MN_CASES = [
+    (12, 8, 16, 1, 10, dict(sample_v_states=True, sample_h_states=True)),
+    (40, 33, 9, 2, 25, dict(sample_v_states=True, l2=1e-3, sparsity_cost=1e-3)),
+    (96, 70, 37, 1, 7, dict(sample_h_states=False, dropout=0.8)),
+    (200, 130, 64, 2, 100, dict(sample_v_states=True, dbm_first=True)),     # interior tiles + K tails of the fast path
+]
+
+
+@pytest.mark.parametrize('V,H,B,k,M,kw', MN_CASES)
+def test_multinomial_hidden_f64_bit_exact(gpu_lib, V, H, B, k, M, kw):
+    """MultinomialRBM in float64 (MultinomialLayer of layers.py:54-70 as the hidden layer): parameters, softmax
+    means and multinomial counts bit-identical to the float64 oracle; metrics (three independent h_hat draws per
+    fetch, rbm.py:52-62) to 1e-10"""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    eng, twin = make_pair(V, H, B, h_unit=2, n_samples=M, **kw)
+    eng.seed(77); twin.set_seed(77)
+    for s in range(2):
+        X = data(B, V, s)
+        eng.train_step(dev(X), B, 0.05, 0.9, k)
+        twin.train_step(X, 0.05, 0.9, k)
+        assert_state_equal(eng, twin)
+    X = data(B, V, 9)
+    Hd = DeviceArray((B, H), np.float64)
+    eng.transform(dev(X), B, k, Hd)
+    eng.sync()
+    g, c = Hd.numpy(), twin.transform(X, k)
+    assert np.array_equal(g.view(np.uint64), c.view(np.uint64))
+    np.testing.assert_allclose(g.sum(axis=1), M, rtol=1e-12)            # means = M * softmax
+    np.testing.assert_allclose(eng.metrics(dev(X), B, k), twin.metrics(X, k), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(eng.free_energy(dev(X), B), twin.free_energy(X), rtol=1e-12)
+    np.testing.assert_allclose(eng.free_energy(dev(X), B), twin.free_energy(X), rtol=1e-12)   # the stream advanced alike
+    eng.close()
+
+
+def test_rejects_bad_multinomial_f64(gpu_lib):
     from boltzmann_machines_amd._ffi import Bm355Error
     from boltzmann_machines_amd.engine import RbmEngine64
     with pytest.raises(Bm355Error):
-        RbmEngine64(8, 8, max_batch=4, h_unit=2, n_samples=5)
+        RbmEngine64(8, 8, max_batch=4, h_unit=2, n_samples=0)

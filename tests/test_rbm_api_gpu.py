@@ -42,7 +42,7 @@ def compare_transforms(rbm1, rbm2):
 
 
 @pytest.mark.parametrize('C,dtype', [(BernoulliRBM, 'float32'), (BernoulliRBM, 'float64'), (MultinomialRBM, 'float32'),
-                                     (GaussianRBM, 'float32')])
+                                     (GaussianRBM, 'float32'), (MultinomialRBM, 'float64'), (GaussianRBM, 'float64')])
 def test_initialization(gpu_lib, dirs, C, dtype):
     """reference test_rbm.py:52-67 — the W-init known answer after init()."""
     rbm = C(max_epoch=2, model_path=dirs[0], dtype=dtype, **CONFIG)
@@ -52,7 +52,7 @@ def test_initialization(gpu_lib, dirs, C, dtype):
 
 
 @pytest.mark.parametrize('C,dtype', [(BernoulliRBM, 'float32'), (BernoulliRBM, 'float64'), (MultinomialRBM, 'float32'),
-                                     (GaussianRBM, 'float32')])
+                                     (GaussianRBM, 'float32'), (MultinomialRBM, 'float64'), (GaussianRBM, 'float64')])
 def test_consistency(gpu_lib, dirs, C, dtype):
     """reference test_rbm.py:69-114 — twin models stay identical through fit, +1 epoch,
     load_model from disk, +1 epoch (same class / dtype list as the reference)."""
@@ -120,9 +120,6 @@ def test_errors(gpu_lib, dirs):
         rbm.set_params(nope=1)
     with pytest.raises(RuntimeError):
         GaussianRBM.load_model(dirs[0])                      # class mismatch (tf_model.py:149-150)
-    m64 = MultinomialRBM(n_visible=4, n_hidden=3, dtype='float64', model_path=dirs[1], verbose=False).init()
-    with pytest.raises(NotImplementedError):             # float64 device path: Bernoulli hidden units only
-        m64.fit(np.zeros((4, 4)))
 
 
 def test_scalar_logs_and_checkpoint_files(gpu_lib, dirs):
