@@ -1419,6 +1419,10 @@ static inline int act_geo_override() {
 static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     // 208: 8 waves, DMA issued by waves 0-3 only (not a tuner candidate: within noise of 8 on every shape measured)
     if (geo == 208) { launch_act_geo<GeoAct8, 1, STG_DMAH>(a, st); return; }
+    // 6: 64 x 64 tile, 8 waves of 32 x 16 (the outer-product geometry): half the operand traffic per flop of the
+    // 32 x 64 tile, for outputs large enough to fill the chip with tiles of that size
+    if (geo == 6 && !a.p_xm) { launch_act_geo<GeoGrad8, 1, STG_DMA>(a, st); return; }
+    if (geo == 6) geo = 8;
     const bool reg = geo >= 100;
     geo %= 100;
     if (a.p_xm && geo == 4) geo = 8;        // x-major P exists for the MI == 1 geometries only
@@ -1435,9 +1439,9 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     }
 }
 struct ActTune {
-    static constexpr int NC = 8;
+    static constexpr int NC = 9;
     int best = 0;
-    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 // scratch pool of the tuning launches (per process and device; grown on demand, never on the hot path)
 struct TuneScratch {
@@ -1453,7 +1457,7 @@ struct TuneScratch {
     }
 };
 static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103};
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6};
     constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
     static TuneScratch pool;
     const size_t mat = ((size_t)a.J * (size_t)a.ldo + 3) & ~(size_t)3;
@@ -1476,10 +1480,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
-    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < TUNE_ROUNDS; ++round) {
         for (int c = 0; c < ActTune::NC; ++c) {
-            if (a.p_xm && cand_geo[c] % 100 == 4) continue;       // not instantiated for an x-major P
+            if (a.p_xm && (cand_geo[c] % 100 == 4 || cand_geo[c] == 6)) continue;   // not instantiated for an x-major P
             launch_act_as(cand_geo[c], t, st);                    // warm (instruction cache, clocks)
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < TUNE_REP; ++r) launch_act_as(cand_geo[c], t, st);
@@ -1499,9 +1503,9 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us, dma: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; "
-                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f)\n",
+                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0] > 1e29f ? -1.f : T.t_us[0], T.t_us[1] > 1e29f ? -1.f : T.t_us[1], T.t_us[2], T.t_us[3],
-                T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7]);
+                T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7], T.t_us[8] > 1e29f ? -1.f : T.t_us[8]);
 }
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     const int ov = act_geo_override();
