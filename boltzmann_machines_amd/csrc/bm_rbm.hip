@@ -327,7 +327,23 @@ int bm_device_count(void) {
 int bm_set_device(int device) { BM_HIP(hipSetDevice(device)); return 0; }
 int bm_dev_alloc(size_t bytes, void **out_dev) { BM_HIP(hipMalloc(out_dev, bytes ? bytes : 1)); return 0; }
 int bm_dev_free(void *dev) { BM_HIP(hipFree(dev)); return 0; }
-int bm_h2d(void *dst, const void *src, size_t bytes) { BM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+// Host -> device.  Large pageable sources (a training set) are pinned in place for the duration of the copy: the
+// runtime otherwise stages them through its own bounce buffers at a fraction of the link rate.  BM355_H2D_PIN=0
+// keeps the plain copy; any failure of the registration falls back to it.
+int bm_h2d(void *dst, const void *src, size_t bytes) {
+    static const bool pin = !(getenv("BM355_H2D_PIN") && atoi(getenv("BM355_H2D_PIN")) == 0);
+    if (pin && bytes >= ((size_t)32 << 20)) {
+        if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+            const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+            (void)hipHostUnregister(const_cast<void *>(src));
+            BM_HIP(e);
+            return 0;
+        }
+        (void)hipGetLastError();
+    }
+    BM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
 int bm_d2h(void *dst, const void *src, size_t bytes) { BM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
 int bm_dev_memset(void *dst, int value, size_t bytes) { BM_HIP(hipMemset(dst, value, bytes)); return 0; }
 
