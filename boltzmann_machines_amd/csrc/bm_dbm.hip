@@ -201,10 +201,12 @@ static int read_flag(bm_dbm *h, float *out) {
 }
 
 // `_make_mf` (dbm.py:429-478).  Leaves the result in h->mu; returns executed sweeps.
-// The loop trip count is data dependent (residual > tol).  Single GPU: the sweeps are enqueued in
-// groups of MF_GROUP without host round trips — a device-side control word (MfCtl) latches `done`
-// and every later launch of the group returns at once — and the host reads the control word once
-// per group.  Data parallel (all-reduce(max) hook installed): one host round trip per sweep.
+// The loop trip count is data dependent (residual > tol).  The sweeps are enqueued in groups without host
+// round trips — a device-side control word (MfCtl) latches `done` and every later launch returns at once.
+// The first group is as long as the previous call's trip count + 1, the host reads the control word of a
+// group from a pinned mirror while the next group is already queued.  With the library's communicator
+// installed (bm_dbm_set_comm) the residual is all-reduced (max) on the device, in stream order, per sweep;
+// only the host-callback hook (bm_dbm_set_mf_allreduce) costs a host round trip per sweep.
 static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
     const int L = h->L, N = h->N;
     constexpr int MF_GROUP = 8;
