@@ -14,8 +14,8 @@ import numpy as np
 
 from . import _ffi
 from .base import EngineModel, is_attribute_name, run_on_engine
-from .engine import RbmEngine, RbmEngine64, as_device
-from .utils import batch_iter, epoch_iter, make_list_from, write_during_training
+from .engine import RbmEngine, RbmEngine64
+from .utils import epoch_iter, make_list_from, write_during_training
 from .utils import philox
 
 
