@@ -410,8 +410,12 @@ __device__ __forceinline__ void dma16(const char *src, float *lds_dst) {
 // cycles per step; one v_add_u32 behind every MFMA: 1470), while scalar instructions are nearly free (4 per MFMA:
 // 1098).  The steady steps below are therefore written so that hipcc needs no VALU for addresses at all.
 __device__ __forceinline__ void dma16s(const void *sbase, uint32_t voff, unsigned lds_byte) {
+    // M0 is written and NOT restored (two scalar moves per DMA cost 0.6 us per update): nothing else in these kernels
+    // reads it - gfx9+ DS instructions do not, and hipcc emits no LDS-direct / movrel / GWS / sendmsg here (the
+    // generated ISA is checked for stray M0 uses by tests/test_host_logic.py).  hipcc refuses M0 in a clobber list
+    // (reserved register), so it is not declared.
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
-                 :: "s"(sbase), "v"(voff), "s"(lds_byte) : "memory", "m0");
+                 :: "s"(sbase), "v"(voff), "s"(lds_byte) : "memory");
 }
 // chunk `kc` of ONE segment (full chunk): scalar chunk bases pb / qb, plan of that segment, LDS byte addresses of
 // this wave's first piece in the destination slot images

@@ -160,3 +160,24 @@ def test_dataset_readers(tmp_path):
     for shape in ((7, 32, 32, 3), (32, 32, 3), (8, 8, 3)):
         A = rng.rand(*shape)
         np.testing.assert_allclose(A, dataset.im_unflatten(dataset.im_flatten(A)))
+
+
+def test_generated_isa_has_no_implicit_m0_reader(tmp_path):
+    """csrc/bm_gemm.h dma16s writes M0 (the LDS-DMA base) without restoring it - legal only while nothing hipcc
+    generates reads M0 implicitly.  Compile the device code to assembly and look."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    from boltzmann_machines_amd import build as b
+    flags = [f for f in b.FLAGS if f not in ('-shared', '-fPIC')]
+    out = str(tmp_path / 'bm355.s')
+    r = subprocess.run([hipcc] + flags + ['--cuda-device-only', '-S', os.path.join(b.CSRC, 'bm355.hip'), '-o', out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'bm_' not in r.stderr, r.stderr[-2000:]               # no diagnostics from the sources themselves
+    asm = open(out).read()
+    assert 'global_load_lds_dwordx4' in asm                      # the DMA path is really there
+    for op in ('s_movrel', 'v_movrel', 's_sendmsg', 'ds_gws', 'v_interp', 'lds_direct', '_addtid'):
+        assert op not in asm, 'hipcc emitted %s: it reads M0, which dma16s leaves modified' % op
