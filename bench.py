@@ -159,7 +159,8 @@ def pmc_traffic(config):
     if not files:
         return None
     try:
-        return float(json.load(open(files[-1]))['traffic_bytes_per_update'])
+        return (float(json.load(open(files[-1]))['traffic_bytes_per_update']),
+                'profiles/' + os.path.basename(files[-1]) + ' (rocprofv3 --pmc passes of this command; not measured in this run)')
     except Exception:
         return None
 
@@ -191,19 +192,26 @@ class RbmCD(Workload):
         eng.set_row_offset(rank * B)
         self.Xd = as_device(self.X)
         self.use_dp = world > 1 or args.force_dp
-        self.native = args.native_comm
+        self.collective, self.collective_note = None, None
         if self.use_dp:
             from boltzmann_machines_amd import parallel
-            dev = torch.device('cuda', local_rank)
             if args.delayed_grads:      # NON-parity mode: the reduction of step t runs under step t+1
                 self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
                 self.dp = parallel.DelayedDataParallelRBM(eng, rank, world, B, comm=self.comm)
+                self.collective = 'rccl (bm_comm), delayed'
                 return
-            if args.native_comm:
+            mode, note = choose_collective(args, eng, rank, world, dist)
+            self.collective, self.collective_note = mode, note
+            if mode == 'direct':
+                ar = parallel.direct_allreduce_on_engine_stream(eng, args._xchg[id(eng)])
+            elif mode == 'rccl':
                 self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
                 ar = parallel.native_allreduce_on_engine_stream(eng, self.comm)
-            else:           # --torch-comm: RCCL through torch.distributed (a nccl group next to the gloo default group)
+            elif mode == 'torch':   # RCCL through torch.distributed (a nccl group next to the gloo default group)
+                dev = torch.device('cuda', local_rank)
                 ar = parallel.torch_allreduce_on_engine_stream(eng, dev, group=dist.new_group(backend='nccl'))
+            else:                   # 'gloo': staged through the host (no device collective usable)
+                ar = gloo_staged_allreduce(eng, dist)
             self.dp = parallel.DataParallelRBM(eng, rank, world, B, ar)
 
     def step(self, i):
@@ -265,7 +273,8 @@ class RbmCD(Workload):
                        'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'global_batch': B * world,
                        'n_gibbs_steps': k, 'sample_v_states': True, 'sample_h_states': True,
                        'parallelism': 'dp%d' % world, 'dp_path': bool(self.use_dp),
-                       'collective': ('bm_comm (in-library RCCL)' if self.native else 'torch.distributed nccl') if self.use_dp else None,
+                       'collective': COLLECTIVE_NAMES.get(self.collective, self.collective) if self.use_dp else None,
+                       'collective_note': self.collective_note,
                        'gradient_delay_steps': 1 if (self.use_dp and getattr(args, 'delayed_grads', False)) else 0},
             'flops_per_step': flops,
             'roofline_extra': {
@@ -323,18 +332,36 @@ class RbmGibbs(Workload):
                          'number north_star asks for' % (k, 2 * F / 1e9),
                 'hbm': {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': PEAK_HBM, 'unit': 'GB/s',
                         'frac': round(gbps / PEAK_HBM, 4),
-                        'algorithmic_bytes_per_sweep': bytes_sweep, 'traffic': pmc_traffic('gibbs')}},
+                        'algorithmic_bytes_per_sweep': bytes_sweep, 'traffic': (pmc_traffic('gibbs') or (None,))[0]}},
         }
 
 
 class _DbmBase(Workload):
     def _dp_setup(self, args, rank, world, dist):
-        self.comm = None
+        self.comm, self.collective, self.collective_note = None, None, None
         if world > 1 or args.force_dp:
             from boltzmann_machines_amd import parallel
-            self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
-            self.dp = parallel.DataParallelDBM(self.eng, rank, world,
-                                               parallel.native_allreduce_on_engine_stream(self.eng, self.comm), comm=self.comm)
+            mode, note = choose_collective(args, self.eng, rank, world, dist)
+            self.collective, self.collective_note = mode, note
+            if mode == 'direct':
+                x = args._xchg[id(self.eng)]
+                self.comm = x
+                self.dp = parallel.DataParallelDBM(self.eng, rank, world,
+                                                   parallel.direct_allreduce_on_engine_stream(self.eng, x), xchg=x)
+            elif mode == 'gloo':
+                self.comm = 'gloo'
+                import torch
+
+                def amax(v):
+                    t = torch.tensor([v], dtype=torch.float32)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return float(t.item())
+                self.dp = parallel.DataParallelDBM(self.eng, rank, world, gloo_staged_allreduce(self.eng, dist),
+                                                   allreduce_max=amax)
+            else:
+                self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+                self.dp = parallel.DataParallelDBM(self.eng, rank, world,
+                                                   parallel.native_allreduce_on_engine_stream(self.eng, self.comm), comm=self.comm)
 
 
 class Grbm(_DbmBase):
@@ -381,7 +408,8 @@ class Grbm(_DbmBase):
             'unit': 'Gibbs-steps/s (256-particle block sweeps incl. the PCD-5 update)',
             'config': {'workload': 'Gaussian-Bernoulli RBM 3072x5000 PCD-5 batch=256 fp32 (BASELINE configs[2])',
                        'n_visible': self.GV, 'n_hidden': self.GH, 'batch_per_gpu': self.GN, 'n_particles_per_gpu': self.GN,
-                       'n_gibbs_steps': self.GK, 'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world},
+                       'n_gibbs_steps': self.GK, 'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world,
+                       'collective': COLLECTIVE_NAMES.get(self.collective, self.collective)},
             'flops_per_step': flops,
             'roofline_extra': {'scope': 'whole PCD-5 update = (2*5+3)*2*B*V*H = %.1f GFLOP (SURVEY 8d)' % (flops / 1e9),
                                'traffic': pmc_traffic('grbm')},
@@ -435,8 +463,9 @@ class Dbm(_DbmBase):
             'config': {'workload': '2-layer DBM 784-512-1024 mean-field (<=50 sweeps, tol 1e-7) + PCD-5 fp32 (BASELINE configs[3])',
                        'layers': [V_, H1, H2], 'batch_per_gpu': N_, 'particles_per_gpu': N_, 'n_gibbs_steps': k,
                        'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world,
-                       'collective': 'bm_comm (in-library RCCL): all-reduce(max) of the mean-field residual per sweep + '
-                                     'one all-reduce(sum) of the fused gradient buffer' if self.comm is not None else None},
+                       'collective': ('%s: all-reduce(max) of the mean-field residual per sweep + one all-reduce(sum) of '
+                                      'the fused gradient buffer' % COLLECTIVE_NAMES.get(self.collective, self.collective))
+                       if self.comm is not None else None, 'collective_note': self.collective_note},
             'flops_per_step': flops,
             'roofline_extra': {'scope': 'whole update, SURVEY 8d formula with T = %.1f executed mean-field sweeps = %.2f GFLOP'
                                         % (T, flops / 1e9), 'traffic': pmc_traffic('dbm')},
@@ -488,6 +517,169 @@ class Ais(_DbmBase):
 
 WORKLOADS = {w.name: w for w in (RbmCD, RbmGibbs, Grbm, Dbm, Ais)}
 DEFAULTS = {'rbm': (2000, 100), 'gibbs': (300, 30), 'grbm': (30, 5), 'dbm': (40, 5), 'ais': (2, 1)}
+# the short passes the default run adds behind the headline: (steps, warm-up, untimed precondition seconds)
+OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 20, 5, 0.2), ('ais', 1, 1, 0.0))
+COLLECTIVE_NAMES = {
+    'direct': 'bm_xchg (in-library one-shot reduce-scatter + all-gather over peer-mapped memory / xGMI)',
+    'rccl': 'bm_comm (in-library RCCL all-reduce)',
+    'torch': 'torch.distributed nccl (RCCL) on the engine stream',
+    'gloo': 'gloo, staged through the host (no device collective usable: ranks share a device and the direct path is off)',
+}
+
+
+def gloo_staged_allreduce(eng, dist):
+    """all-reduce of the engine's grad buffer through the host over gloo (a dry-run path for boxes where neither
+    device collective can run; it synchronises the stream)"""
+    import ctypes as C
+    import torch
+    from boltzmann_machines_amd import _ffi
+    grad = eng.device_view('grad')
+
+    def allreduce_():
+        eng.sync()
+        host = grad.numpy()
+        dist.all_reduce(torch.from_numpy(host))
+        _ffi.check(_ffi.load().bm_h2d(grad.ptr, host.ctypes.data_as(C.c_void_p), host.nbytes))
+    return allreduce_
+
+
+def choose_collective(args, eng, rank, world, dist):
+    """Which exchange the data-parallel step uses: --collective direct|rccl|torch|gloo, default `direct` (the one-shot
+    peer-memory exchange) after a SELF-CHECK at start-up: the direct all-reduce of a rank-dependent test pattern in
+    the engine's own grad buffer must equal the gloo (host) all-reduce of the same pattern to fp32 round-off and
+    report no timed-out wait on any rank; otherwise the run falls back to the library's RCCL all-reduce (or to the
+    host-staged gloo reducer when the ranks share a device, which RCCL refuses) and says so in `collective_note`."""
+    import torch
+    from boltzmann_machines_amd import parallel
+    want = args.collective
+    if args.torch_comm:
+        want = 'torch'
+    if not hasattr(args, '_xchg'):
+        args._xchg = {}
+    fallback = 'gloo' if args._shared_devices else 'rccl'
+    if want != 'direct':
+        if want in ('rccl', 'torch') and args._shared_devices:
+            return 'gloo', 'RCCL refuses two ranks on one device (dry run on a box with fewer GPUs than ranks)'
+        return want, None
+    note = None
+    try:
+        x = parallel.DirectExchange(eng, rank, world)
+        grad = eng.device_view('grad')
+        n = grad.shape[0]
+        ok_local = True
+        for trial in range(2):          # twice: the second pass runs on warm flags / staging
+            rs = np.random.RandomState(1000 * trial + rank)
+            pat = rs.standard_normal(n).astype(np.float32)
+            _h2d(grad, pat)
+            eng.sync()
+            x.allreduce_grads()
+            eng.sync()
+            got = grad.numpy()
+            ref = torch.from_numpy(pat.copy())
+            if world > 1:
+                dist.all_reduce(ref)
+            ok_local = ok_local and x.status() == 0 and np.allclose(got, ref.numpy(), rtol=1e-5, atol=1e-5)
+        flag = torch.tensor([0 if ok_local else 1], dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(flag)
+        _h2d(grad, np.zeros(n, dtype=np.float32))
+        if int(flag.item()) == 0:
+            args._xchg[id(eng)] = x
+            return 'direct', 'start-up self-check against the gloo all-reduce passed on every rank'
+        note = 'direct exchange failed its start-up self-check on %d rank(s): fell back' % int(flag.item())
+        x.close()
+    except Exception as e:      # every rank takes the same branch only if the failure is symmetric: confirm it
+        note = 'direct exchange could not be set up (%s): fell back' % (str(e)[:200],)
+        flag = torch.tensor([1], dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(flag)
+    return fallback, note
+
+
+def _h2d(darr, host):
+    import ctypes as C
+    from boltzmann_machines_amd import _ffi
+    host = np.ascontiguousarray(host)
+    _ffi.check(_ffi.load().bm_h2d(darr.ptr, host.ctypes.data_as(C.c_void_p), host.nbytes))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks ourselves (one process per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, a free port on 127.0.0.1); rank 0's stdout is
+    ours, so the ONE JSON line comes out unchanged."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p_ in procs:
+        rc = p_.wait() or rc
+    sys.exit(rc)
+
+
+def measure(wl, steps, warmup, precondition_s, barrier, dist):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between two barriers (+ device synchronisation); returns
+    (wall seconds, max over ranks; HIP-event milliseconds on the engine stream of this rank)."""
+    import torch
+    eng = wl.eng
+    # Precondition the device: a GPU box that has been idle needs a few hundred ms of work before its clocks and
+    # caches are in the state a training job runs in (a 25-step run from cold measured 74 us/update against 66.7
+    # steady).  A FIXED number of steps (every rank of a data-parallel run must issue the same number of
+    # collectives); untimed; the model is then put back to its initial state.
+    if precondition_s > 0:
+        for i in range(wl.precondition_steps(precondition_s)):
+            wl.step(i)
+        eng.sync()
+        wl.reset()
+    for i in range(warmup):
+        wl.step(i)
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for i in range(steps):
+        wl.step(i)
+    eng.timer_mark()                     # HIP event behind the last step (read after the clock has been stopped)
+    barrier()
+    dt = time.perf_counter() - t0
+    ev_ms = eng.timer_elapsed()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, ev_ms
+
+
+def make_record(wl, rep, world, steps, warmup, precondition_s, dt, ev_ms):
+    flops = rep.pop('flops_per_step')
+    extra = rep.pop('roofline_extra')
+    achieved = flops / (ev_ms / steps * 1e-3) / 1e12
+    achieved_wall = flops / (dt / steps) / 1e12
+    traffic = extra.pop('traffic', None)
+    src = None
+    if isinstance(traffic, tuple):
+        traffic, src = traffic
+    roof = dict({'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s',
+                 'frac': round(achieved / PEAK_FP32_MFMA, 4),
+                 # the same flops over the WALL clock of the timed region (ms_per_step): what the driver's own clock sees
+                 'frac_wall': round(achieved_wall / PEAK_FP32_MFMA, 4),
+                 'timebase': 'frac: HIP events on the engine stream around the timed steps; frac_wall: ms_per_step',
+                 'traffic': traffic,
+                 # HBM-side bytes come from a committed rocprofv3 PMC pass of this same command, not from this run
+                 'traffic_source': src}, **extra)
+    return {'metric': rep['metric'], 'value': rep['value'], 'unit': rep['unit'],
+            'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': round(1e3 * dt / steps, 5), 'higher_is_better': True, 'scaling': wl.scaling,
+            'precondition_s': precondition_s,
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': rep['config'], 'roofline': roof}
 
 
 def main():
@@ -500,52 +692,61 @@ def main():
     ap.add_argument('--ais-runs', type=int, default=20000)
     ap.add_argument('--ais-betas', type=int, default=1000)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-others', action='store_true',
+                    help='rbm: do not add the short passes of the other BASELINE configurations (`other_configs`)')
+    ap.add_argument('--others-budget-s', type=float, default=150.0,
+                    help='wall-clock budget of the `other_configs` passes; a pass still running when it expires is '
+                         'abandoned (the headline line is printed with what finished)')
     ap.add_argument('--precondition-s', type=float, default=0.4,
                     help='seconds (approximate: a fixed step count) of untimed steps BEFORE the W warm-up steps (launch '
                          'tuning, instruction caches, clock ramp of an idle GPU); parameters and RNG are reset afterwards, '
                          'so the warm-up and the timed steps start from the documented initial state.  0 disables')
-    ap.add_argument('--native-comm', action='store_true',
-                    help='(default) the data-parallel all-reduce goes through the library\'s own RCCL communicator '
-                         '(bm_comm_*); torch.distributed (gloo) only carries the 128-byte id and the timing barrier')
-    ap.add_argument('--torch-comm', action='store_true',
-                    help='rbm: all-reduce the gradient buffer with torch.distributed (nccl = RCCL) on the engine stream '
-                         'instead (8.5 us per update slower at N = 1: host-side work of the process group per call)')
+    ap.add_argument('--collective', choices=('direct', 'rccl', 'torch', 'gloo'), default='direct',
+                    help='exchange step of the data-parallel configurations at N > 1: the library\'s one-shot peer-memory '
+                         'exchange (bm_xchg_*, default, behind a start-up self-check with a fallback to rccl), the '
+                         'library\'s RCCL all-reduce (bm_comm_*), torch.distributed nccl, or gloo staged through the host')
+    ap.add_argument('--native-comm', action='store_true', help='(kept for old command lines) same as --collective rccl')
+    ap.add_argument('--torch-comm', action='store_true', help='same as --collective torch')
     ap.add_argument('--delayed-grads', action='store_true',
                     help='rbm, NON-parity: delayed-gradient data parallelism (the update of step t is the reduced '
-                         'gradient of step t-1; the all-reduce runs under the next step).  Implies --native-comm')
+                         'gradient of step t-1; the all-reduce runs under the next step) over bm_comm')
     ap.add_argument('--force-dp', action='store_true',
                     help='take the data-parallel code path (grad_step -> all-reduce -> apply_step) even at N=1')
     args = ap.parse_args()
+    if args.native_comm:
+        args.collective = 'rccl'
+    explicit_steps = args.steps is not None
     if args.steps is None:
         args.steps = DEFAULTS[args.config][0]
     if args.warmup is None:
         args.warmup = DEFAULTS[args.config][1]
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)                # does not return
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)'
-                         % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
     import torch
     from boltzmann_machines_amd import _ffi
     lib = _ffi.load()
-    if lib.bm_device_count() < 1 or not torch.cuda.is_available():
+    ndev = lib.bm_device_count()
+    if ndev < 1 or not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    _ffi.check(lib.bm_set_device(local_rank))
+    # fewer devices than ranks (a dry run of the N > 1 path on a 1-GPU box): ranks share devices.  RCCL refuses that;
+    # the direct exchange and the gloo-staged reducer do not care
+    args._shared_devices = ndev < world
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    _ffi.check(lib.bm_set_device(device))
     dist = None
-    native = not args.torch_comm or args.delayed_grads or args.config not in ('rbm', 'gibbs')
     if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('gloo', rank=rank, world_size=world)     # rendezvous + timing barrier only
-    args.native_comm = native
-
-    wl = WORKLOADS[args.config](args, rank, world, local_rank, dist)
-    eng = wl.eng
 
     def barrier():
         torch.cuda.synchronize()         # device-wide: covers the engine's streams
@@ -553,51 +754,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Precondition the device: a GPU box that has been idle needs a few hundred ms of work before its clocks and
-    # caches are in the state a training job runs in (a 25-step run from cold measured 74 us/update against 66.7
-    # steady).  A FIXED number of steps (every rank of a data-parallel run must issue the same number of
-    # collectives); untimed; the model is then put back to its initial state.
-    if args.precondition_s > 0:
-        for i in range(wl.precondition_steps(args.precondition_s)):
-            wl.step(i)
-        eng.sync()
-        wl.reset()
-    for i in range(args.warmup):
-        wl.step(i)
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    for i in range(args.steps):
-        wl.step(i)
-    eng.timer_mark()                     # HIP event behind the last step (read after the clock has been stopped)
-    barrier()
-    dt = time.perf_counter() - t0
-    ev_ms = eng.timer_elapsed()
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
+    wl = WORKLOADS[args.config](args, rank, world, device, dist)
+    dt, ev_ms = measure(wl, args.steps, args.warmup, args.precondition_s, barrier, dist)
     rep = wl.report(args, world, dt, ev_ms) if rank == 0 else None
     barrier()
+    out = make_record(wl, rep, world, args.steps, args.warmup, args.precondition_s, dt, ev_ms) if rank == 0 else None
+    if rank == 0 and args.config == 'rbm':
+        out['unit'] += '; steady state: %.1f s of untimed updates precede the warm-up steps' % args.precondition_s \
+            if args.precondition_s > 0 else ''
+    if rank == 0 and args.config == 'rbm' and args._shared_devices:
+        out['config']['devices_shared'] = 'DRY RUN: %d ranks on %d device(s); not a scaling figure' % (world, ndev)
 
-    if rank == 0:
-        flops = rep.pop('flops_per_step')
-        extra = rep.pop('roofline_extra')
-        achieved = flops / (ev_ms / args.steps * 1e-3) / 1e12
-        out = {
-            'metric': rep['metric'], 'value': rep['value'], 'unit': rep['unit'],
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * dt / args.steps, 5), 'higher_is_better': True, 'scaling': wl.scaling,
-            'precondition_s': args.precondition_s,
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': rep['config'],
-            'roofline': dict({'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA,
-                              'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MFMA, 4), 'traffic': extra.pop('traffic', None)},
-                             **extra),
-        }
-        if not args.no_cpu and world == 1 and args.config == 'rbm':
-            out['cpu_baseline'] = cpu_baseline(args.k)
+    def emit():
+        if rank != 0:
+            return
         # the ONE line of the contract is the last thing on stdout: flush what C libraries (the RCCL banner under
         # NCCL_DEBUG=VERSION) still hold in their stdio buffers first
         try:
@@ -607,8 +777,59 @@ def main():
             pass
         print(json.dumps(out))
         sys.stdout.flush()
+
+    # ---- the other BASELINE configurations, short passes, embedded in the same line (rbm default run only).
+    # Every rank runs the same sequence.  A watchdog bounds the whole block: if a pass hangs (a collective that
+    # never completes on some rank), rank 0 prints the headline line with what finished and all ranks leave.
+    if args.config == 'rbm' and not args.no_others and not args.delayed_grads:
+        import threading
+        others = {}
+        if rank == 0:
+            out['other_configs'] = others
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.others_budget_s):
+                if rank == 0:
+                    others['_aborted'] = 'other_configs exceeded --others-budget-s=%.0f s; abandoned' % args.others_budget_s
+                    emit()
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        wl.eng.close()
+        del wl
+        for name, st, wu, pre in OTHERS:
+            t_begin = time.time()
+            try:
+                a2 = argparse.Namespace(**vars(args))
+                a2.k = 1
+                a2._xchg = {}
+                if name == 'ais' and args._shared_devices:
+                    raise RuntimeError('skipped in a shared-device dry run (the chain all-gather is RCCL)')
+                w2 = WORKLOADS[name](a2, rank, world, device, dist)
+                dt2, ev2 = measure(w2, st, wu, pre, barrier, dist)
+                if rank == 0:
+                    rec = make_record(w2, w2.report(argparse.Namespace(**dict(vars(a2), steps=st)), world, dt2, ev2),
+                                      world, st, wu, pre, dt2, ev2)
+                    for k_ in ('higher_is_better', 'vs_baseline', 'data', 'n_gpus'):
+                        rec.pop(k_, None)
+                    rec['pass_seconds'] = round(time.time() - t_begin, 1)
+                    others[name] = rec
+                barrier()
+                w2.eng.close()
+                del w2
+            except Exception as e:       # noqa: BLE001 - recorded in the line; the headline stands
+                if rank == 0:
+                    others[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+        done.set()
+
+    if rank == 0 and not args.no_cpu and world == 1 and args.config == 'rbm':
+        out['cpu_baseline'] = cpu_baseline(args.k)
+    emit()
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == '__main__':

@@ -64,6 +64,20 @@ SIGNATURES = {
     'bm_rbm_allreduce_grads_async': [_vp, _vp],
     'bm_rbm_wait_grads': [_vp, _i32],
     'bm_dbm_allreduce_grads': [_vp, _vp],
+    'bm_xchg_create': [C.c_int32, C.c_int32, _vp, _sz, C.POINTER(_vp)],
+    'bm_xchg_blob_bytes': [],
+    'bm_xchg_export': [_vp, _vp],
+    'bm_xchg_attach': [_vp, _vp],
+    'bm_xchg_destroy': [_vp],
+    'bm_xchg_allreduce_sum': [_vp, _vp],
+    'bm_xchg_allreduce_max1': [_vp, _vp, _vp],
+    'bm_xchg_status': [_vp, C.POINTER(C.c_int32)],
+    'bm_xchg_info': [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(_sz)],
+    'bm_rbm_xchg_create': [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
+    'bm_dbm_xchg_create': [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
+    'bm_rbm_allreduce_grads_direct': [_vp, _vp],
+    'bm_dbm_allreduce_grads_direct': [_vp, _vp],
+    'bm_dbm_set_xchg': [_vp, _vp],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],
     'bm_rbm64_sync': [_vp],

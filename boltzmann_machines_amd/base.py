@@ -192,10 +192,18 @@ class EngineModel(BaseModel, DtypeMixin):
                 raise NotImplementedError("%s has no device path for dtype='%s': float64 runs for the RBMs "
                                           "(bm_rbm64_*), the DBM computes in float32"
                                           % (self.__class__.__name__, self.dtype))
-            # one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE from the launcher): bind this process to its GPU
-            # and join the job's communicator before the handle is created (boltzmann_machines_amd/parallel.py)
+            # Data parallelism is OPT-IN: BM355_DATA_PARALLEL=1 in the environment of a one-process-per-GPU job
+            # (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  Then this process binds to its GPU and joins the
+            # job's communicator before the handle is created (boltzmann_machines_amd/parallel.py), and the semantics
+            # of fit() change: a global minibatch is world x batch_size rows (N must be a multiple of it), every rank
+            # holds n_particles particles (world x n_particles in total), rank 0 alone writes checkpoints and logs,
+            # and EVERY RANK MUST MAKE THE SAME PUBLIC CALLS IN THE SAME ORDER (checked at every fit(): a diverging
+            # rank raises instead of dead-locking in a collective).  Without the opt-in a launcher's RANK / WORLD_SIZE
+            # are ignored: independent per-rank work (hyper-parameter sweeps, pytest under torchrun) stays independent.
             from . import parallel
-            self._rank, local_rank, self._world = parallel.dist_env()
+            self._rank, local_rank, self._world = 0, 0, 1
+            if os.environ.get('BM355_DATA_PARALLEL', '0') == '1':
+                self._rank, local_rank, self._world = parallel.dist_env()
             self._comm = None
             if self._world > 1:
                 from . import _ffi
@@ -233,13 +241,25 @@ class EngineModel(BaseModel, DtypeMixin):
         paths = (self._params_filepath, self._random_state_filepath, self._model_filepath + '.npz')
 
         def write():
-            with open(paths[0], 'w') as f:
-                f.write(params_json)
-            if rng_json is not None:
-                with open(paths[1], 'w') as f:
-                    f.write(rng_json)
-            # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
-            np.savez(paths[2], **variables)
+            # every file goes to a temporary name first and is renamed into place: a failed write (disk full,
+            # directory removed) never leaves a half-written checkpoint behind, and its exception is kept for
+            # _join_save() to re-raise in the calling thread (the reference's synchronous save raises there)
+            try:
+                tmp = paths[0] + '.tmp'
+                with open(tmp, 'w') as f:
+                    f.write(params_json)
+                os.replace(tmp, paths[0])
+                if rng_json is not None:
+                    tmp = paths[1] + '.tmp'
+                    with open(tmp, 'w') as f:
+                        f.write(rng_json)
+                    os.replace(tmp, paths[1])
+                # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
+                tmp = paths[2] + '.tmp.npz'
+                np.savez(tmp, **variables)
+                os.replace(tmp, paths[2])
+            except BaseException as e:      # noqa: BLE001 - handed to the caller by _join_save
+                self._save_exc = e
         # the files are written by a background thread while the next epoch trains (the snapshot above is what
         # they contain); every public call joins it before it returns, so callers never see half-written files
         import threading
@@ -250,6 +270,32 @@ class EngineModel(BaseModel, DtypeMixin):
         t = self.__dict__.pop('_save_thread', None)
         if t is not None:
             t.join()
+        e = self.__dict__.pop('_save_exc', None)
+        if e is not None:
+            raise e
+
+    def _check_lockstep(self, tag):
+        """data-parallel mode: every rank must be making the same public call on the same model (a fingerprint of
+        class, layer sizes, call counter and `tag` is max- and min-reduced over the ranks); raises on divergence
+        instead of letting the collectives of the training loop dead-lock."""
+        comm = getattr(self, '_comm', None)
+        if comm is None:
+            return
+        import zlib
+        from ._ffi import DeviceArray
+        self._dp_calls = getattr(self, '_dp_calls', 0) + 1
+        sig = '%s|%s|%d|%s' % (self.__class__.__name__, self._lockstep_signature(), self._dp_calls, tag)
+        f = float(zlib.crc32(sig.encode()) & 0xFFFFFF)          # exact in float32
+        d = DeviceArray.from_numpy(np.array([f, -f], dtype=np.float32))
+        comm.allreduce_max(d, 2)
+        hi, lo = d.numpy()
+        if hi != f or -lo != f:
+            raise RuntimeError('data-parallel ranks diverged at %s (rank %d): every rank must make the same public '
+                               'calls on identically configured models' % (sig, self._rank))
+
+    def _lockstep_signature(self):
+        return '%s|%s|%s' % (getattr(self, 'n_visible', ''), getattr(self, 'n_hidden', getattr(self, 'n_hiddens', '')),
+                             getattr(self, 'batch_size', ''))
 
     @classmethod
     def load_model(cls, model_path):
@@ -283,6 +329,22 @@ class EngineModel(BaseModel, DtypeMixin):
         with open(os.path.join(d, 'scalars.jsonl'), 'a') as f:
             f.write(json.dumps(values, sort_keys=True) + '\n')
 
+    # ---- array dumps: the TensorBoard-free stand-in for tf.summary.image (base_rbm.py:300-306, :429-435,
+    # dbm.py:312-322, :531-547): one .npy per quantity and epoch under logs/train, in the layout the reference
+    # hands to tf.summary.image ([n, height, width, channels] for filters / particles) ----------------------------
+    def _dump_array(self, name, array):
+        if getattr(self, '_world', 1) > 1 and getattr(self, '_rank', 0) != 0:
+            return
+        d = self._train_summary_dirpath
+        if not os.path.exists(d):
+            os.makedirs(d)
+        np.save(os.path.join(d, '%s_epoch%04d.npy' % (name, int(self.epoch_))), np.asarray(array, dtype=np.float32))
+
+    def _as_images(self, rows):
+        """[n, V] -> [n, v_shape[0], v_shape[1], v_shape[2]] exactly as the reference reshapes before tf.summary.image"""
+        rows = np.asarray(rows)
+        return rows.reshape(len(rows), self.v_shape[2], self.v_shape[0], self.v_shape[1]).transpose(0, 2, 3, 1)
+
     # ---- public API (reference tf_model.py:164-202) ------------------------------
     def _fit(self, X, X_val=None, *args, **kwargs):
         raise NotImplementedError('`fit` is not implemented')
@@ -297,6 +359,7 @@ class EngineModel(BaseModel, DtypeMixin):
     @run_on_engine(check_initialized=False, update_seed=True)
     def fit(self, X, X_val=None, *args, **kwargs):
         self.initialized_ = True
+        self._check_lockstep('fit')
         self._fit(X, X_val=X_val, *args, **kwargs)
         self._save_model()
         return self

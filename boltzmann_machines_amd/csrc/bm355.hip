@@ -5,3 +5,4 @@
 #include "bm_dbm.hip"
 #include "bm_rbm64.hip"
 #include "bm_comm.hip"
+#include "bm_xchg.hip"

@@ -41,7 +41,8 @@ struct DevBuf {
     size_t n = 0;
     int alloc(size_t count) {
         n = count;
-        if (count == 0) count = 1;
+        count = (count + 3) & ~(size_t)3;      // whole 16-byte groups: vector kernels (bm_xchg) may touch the round-up
+        if (count == 0) count = 4;
         BM_HIP(hipMalloc((void **)&p, count * sizeof(float)));
         BM_HIP(hipMemset(p, 0, count * sizeof(float)));
         return 0;

@@ -52,10 +52,12 @@ struct bm_dbm {
     void *mf_ctx = nullptr;                        // (bm_dbm_set_mf_allreduce: collectives the library does not own)
     bm_comm *comm = nullptr;                       // bm_dbm_set_comm: the residual is all-reduced (max) ON DEVICE, on the
                                                    // engine stream, by the library's own RCCL communicator
+    bm_xchg *xchg = nullptr;                       // bm_dbm_set_xchg: the same through the direct peer-memory exchange
     DevBuf wnorm[MAXL];
     DevBuf mn_fac[MAXL];                           // max-norm column factors [2][n_{i+1}]: min(norm, c) | max(norm, 1e-8)
     Mat logits[MAXL];                              // Multinomial layers: row store of the logits / means [rows][n_i], on demand
     int logit_rows[MAXL] = {0, 0, 0, 0};
+    bool failed = false;                           // a launch helper could not allocate (sticky; reported by the entry points)
     bool multinomial(int layer) const { return layer >= 0 && cfg.h_unit[layer] == BM_UNIT_MULTINOMIAL; }
     unsigned *flag = nullptr;                      // mean-field residual cell (= &ctl->maxdiff)
     MfCtl *ctl = nullptr;                          // device-side loop control
@@ -68,6 +70,7 @@ struct bm_dbm {
     Mat ax, ax2, av, ah2;
     DevBuf apart_v, apart_h, apart_x[2], rowtmp;   // per-16-column slot partial sums (ActArgs::rowacc / rowdot_out)
     double *alogw = nullptr;                       // [ais_rows] log-weights, accumulated in double in a fixed order
+    DevBuf ais_send, ais_recv;                     // bm_dbm_ais_sharded: this rank's values / the all-gathered values
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0, prow0 = 0;
@@ -122,8 +125,9 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
         float *lg = means; int ldl = ldo;
         if (!lg) {                                 // sampled sweep: the means are not kept, they pass through a row store
             if (h->logit_rows[layer] < J) {
+                // (bm_dbm_create preallocates max(N, M) rows: this only grows the store for an unusual row count)
                 h->logits[layer].release();
-                if (h->logits[layer].alloc(J, a.I)) return;
+                if (h->logits[layer].alloc(J, a.I)) { h->failed = true; h->logit_rows[layer] = 0; return; }
                 h->logit_rows[layer] = J;
             }
             lg = h->logits[layer].p; ldl = h->logits[layer].ld;
@@ -133,7 +137,7 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
         launch_act(a, h->cur);
         SmArgs m;
         memset(&m, 0, sizeof(m));
-        m.L = lg; m.ld = ldl; m.I = a.I; m.J = J; m.M = h->cfg.n_samples[layer]; m.sample = sample;
+        m.L = lg; m.ld = ldl; m.ld_states = ldo; m.I = a.I; m.J = J; m.M = h->cfg.n_samples[layer]; m.sample = sample;
         m.states = (states && (sample || states != lg)) ? states : nullptr;
         m.key = key; m.row0 = row0;
         m.prev = prev; m.ld_prev = ldo; m.maxdiff = maxdiff; m.skip = a.skip;
@@ -250,13 +254,14 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         // order: every rank enqueues the same sequence and latches the same `done`, so no host round trip is
         // needed and the ranks stay in lockstep)
         auto ctl_step = [&](int init) -> int {
-            if (!h->comm) {
+            if (!h->comm && !h->xchg) {
                 hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, init,
                                    h->mfblk.p, h->L * BM_MF_SLOTS);
                 return 0;
             }
             hipLaunchKernelGGL(mf_resid_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->mfblk.p, h->L * BM_MF_SLOTS);
-            BM_TRY(bm_comm_allreduce_max(h->comm, &h->ctl->resid, 1, (void *)h->stream));
+            if (h->xchg) BM_TRY(bm_xchg_allreduce_max1(h->xchg, &h->ctl->resid, (void *)h->stream));
+            else         BM_TRY(bm_comm_allreduce_max(h->comm, &h->ctl->resid, 1, (void *)h->stream));
             hipLaunchKernelGGL(mf_latch_kernel, dim3(1), dim3(64), 0, h->stream, h->ctl, h->cfg.mf_tol, init);
             return 0;
         };
@@ -264,7 +269,7 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         // update of sweep s-1 is evaluated by the first kernel of sweep s (ActArgs::chk_ctl) from the slot set of
         // the other parity; only the LAST sweep of a group needs the one-workgroup control kernel.  Otherwise
         // (communicator installed, Multinomial layers, > BM_MF_SLOTS workgroups possible) one control step per sweep.
-        bool self_ctl = !h->comm;
+        bool self_ctl = !h->comm && !h->xchg;
         for (int i = 0; i < L; ++i)
             self_ctl = self_ctl && !h->multinomial(i) && ((h->n[i + 1] + 31) / 32) * ((N + 31) / 32) <= BM_MF_SLOTS;
         const size_t set_sz = (size_t)MAXL * BM_MF_SLOTS;
@@ -374,7 +379,9 @@ static int mean_field_and_particles(bm_dbm *h, const float *X_dev, int k, int *o
         BM_HIP(hipEventRecord(h->ev_join, h->stream2));
     }
     const int rc = mean_field(h, X_dev, out_n);                   // :517
-    if (ov) BM_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    // (the join is enqueued even when the mean-field failed: later calls on the main stream must not race the
+    //  particle sweeps still running on the second one)
+    if (ov) { if (hipStreamWaitEvent(h->stream, h->ev_join, 0) != hipSuccess && !rc) { set_error("hipStreamWaitEvent(join) failed"); return 1; } }
     else if (!rc) particles_update(h, k, true);
     h->updates_seen++;
     return rc;
@@ -477,6 +484,7 @@ static int apply_update(bm_dbm *h, const float *X_dev, float lr, float mom) {
         launch_dbm_grad(h, X_dev, i, 1, N, M, lr, mom);
         launch_dbm_maxnorm(h, i);
     }
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -526,6 +534,11 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
         BM_TRY(h->pen[i].alloc(b)); BM_TRY(h->wnorm[i].alloc(b)); BM_TRY(h->mn_fac[i].alloc(2 * (size_t)b));
         BM_TRY(h->mu[i].alloc(h->N, b)); BM_TRY(h->mu_alt[i].alloc(h->N, b)); BM_TRY(h->mu_new[i].alloc(h->N, b));
         BM_TRY(h->H[i].alloc(h->M, b)); BM_TRY(h->H_new[i].alloc(h->M, b));
+        if (h->multinomial(i)) {                   // row store of the logits: the sweeps cannot fail on an allocation
+            const int rows = h->N > h->M ? h->N : h->M;
+            BM_TRY(h->logits[i].alloc(rows, b));
+            h->logit_rows[i] = rows;
+        }
         nsums += 2 * (size_t)b;
     }
     BM_TRY(h->vb.alloc(h->V)); BM_TRY(h->dvb.alloc(h->V)); BM_TRY(h->sigma.alloc(h->V));
@@ -564,7 +577,8 @@ int bm_dbm_destroy(bm_dbm *h) {
     }
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
-    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp};
+    DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp,
+                     &h->ais_send, &h->ais_recv};
     for (DevBuf *b : bs) b->release();
     if (h->alogw) (void)hipFree(h->alogw);
     if (h->ctl) (void)hipFree(h->ctl);
@@ -707,6 +721,7 @@ int bm_dbm_metrics(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf, 
     if (out_msre) BM_TRY(recon_msre(h, X_dev, out_msre));
     if (out_n_mf) *out_n_mf = nmf;
     h->call++;
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -714,6 +729,12 @@ int bm_dbm_metrics(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf, 
 int bm_dbm_set_comm(bm_dbm *h, bm_comm *c) {
     BM_CHECK(h, "null argument");
     h->comm = c;
+    return 0;
+}
+
+int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x) {
+    BM_CHECK(h, "null argument");
+    h->xchg = x;
     return 0;
 }
 
@@ -732,6 +753,7 @@ int bm_dbm_grad_step(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf
     for (int i = 0; i < h->L; ++i) launch_dbm_grad(h, X_dev, i, 0, 1.f, 1.f, 0.f, 0.f);
     if (out_n_mf) *out_n_mf = nmf;
     h->call++;
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -749,6 +771,7 @@ int bm_dbm_apply_step(bm_dbm *h, int32_t N_global, int32_t M_global, float lr, f
         launch_apply_w(a, nullptr, h->stream);
         launch_dbm_maxnorm(h, i);
     }
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -765,6 +788,7 @@ int bm_dbm_mean_field(bm_dbm *h, const float *X_dev, float *MU_top_dev, int32_t 
     }
     if (out_n_mf) *out_n_mf = nmf;
     h->call++;
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -774,6 +798,7 @@ int bm_dbm_reconstruct(bm_dbm *h, const float *X_dev, float *R_dev) {
     BM_TRY(mean_field(h, X_dev, nullptr));
     reconstruct_from_mu(h, R_dev, h->V);
     h->call++;
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -932,6 +957,7 @@ static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint6
         beta = beta + db;
     }
     BM_TRY(visit(true, prev, 1.0f, false, 0.f, step++));                     // +log p_1(x_M) - log p_prev(x_M)  (:728)
+    BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
     return 0;
 }
@@ -976,26 +1002,41 @@ int bm_dbm_ais_sharded(bm_dbm *h, bm_comm *c, int32_t n_betas, int32_t n_runs_to
     int a = 0, b = 0;
     shard(rank, a, b);
     const int n = b - a, npad = (n_runs_total + world - 1) / world;
-    float *send = nullptr, *recv = nullptr;
-    BM_HIP(hipMalloc((void **)&send, (size_t)npad * sizeof(float)));
-    BM_HIP(hipMalloc((void **)&recv, (size_t)npad * world * sizeof(float)));
+    // send / receive buffers live in the handle (grown on demand, never on the steady path)
+    if (h->ais_send.n < (size_t)npad) { h->ais_send.release(); BM_TRY(h->ais_send.alloc((size_t)npad)); }
+    if (h->ais_recv.n < (size_t)npad * world) { h->ais_recv.release(); BM_TRY(h->ais_recv.alloc((size_t)npad * world)); }
+    float *send = h->ais_send.p, *recv = h->ais_recv.p;
+    // A rank whose sweep fails must still enter the collective - the other ranks would block in it forever - so the
+    // failure is made collective: the failing rank contributes NaNs and every rank reports the error.
+    std::string first_err;
     int rc = 0;
     if (n > 0) rc = ais_core(h, n_betas, n, k, seed, a);
-    if (!rc) {
+    if (rc) {
+        first_err = bm_last_error();
+        (void)hipGetLastError();
+        std::vector<float> nan((size_t)npad, __builtin_nanf(""));
+        (void)hipMemcpyAsync(send, nan.data(), nan.size() * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+    } else {
         hipLaunchKernelGGL(ais_finish_kernel, dim3((npad + 255) / 256), dim3(256), 0, h->stream, (const double *)h->alogw, send,
                            n, npad, ais_log_Z0(h));
-        rc = bm_comm_allgather(c, send, recv, (size_t)npad, (void *)h->stream);
     }
+    const int rc_c = bm_comm_allgather(c, send, recv, (size_t)npad, (void *)h->stream);
+    if (rc_c && first_err.empty()) first_err = bm_last_error();
     std::vector<float> all((size_t)npad * world);
-    if (!rc && hipMemcpyAsync(all.data(), recv, all.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc = 1;
-    if (hipStreamSynchronize(h->stream) != hipSuccess && !rc) rc = 1;
-    (void)hipFree(send); (void)hipFree(recv);
-    if (rc) { if (rc == 1) bm::set_error("bm_dbm_ais_sharded: device copy / synchronisation failed"); return rc; }
+    int rc_m = 0;
+    if (!rc_c && hipMemcpyAsync(all.data(), recv, all.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc_m = 1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc_m = 1;
+    if (rc || rc_c) { bm::set_error("bm_dbm_ais_sharded (rank %d): %s", rank, first_err.c_str()); return rc ? rc : rc_c; }
+    if (rc_m) { bm::set_error("bm_dbm_ais_sharded: device copy / synchronisation failed"); return 1; }
+    bool peer_failed = false;
     for (int r = 0; r < world; ++r) {
         int ra, rb;
         shard(r, ra, rb);
         memcpy(values_host + ra, all.data() + (size_t)r * npad, (size_t)(rb - ra) * sizeof(float));
+        for (int e = ra; e < rb; ++e) if (values_host[e] != values_host[e]) { peer_failed = true; break; }
     }
+    BM_CHECK(!peer_failed, "bm_dbm_ais_sharded: another rank's AIS sweep failed (its slice arrived as NaN)");
     return 0;
 }
 

@@ -930,7 +930,8 @@ static inline void launch_apply_w(const ApplyWArgs &a, const RbmBiasArgs *bias, 
 // LDS: c[I] | e[I] (e is reused for the integer counts); I <= 8192.
 struct SmArgs {
     float *L; int ld, I, J, M, sample;
-    float *states, *negmeans;        // may be null
+    float *states, *negmeans;        // may be null; pitch ld_states (0: the pitch of L)
+    int ld_states;
     PhiloxKey key; long long row0;
     // DBM sweeps (a Multinomial layer inside the stack): mean-field residual max|means - prev| -> atomicMax on
     // float bits, and the device-side "loop finished" flag of the mean-field loop (launch becomes a no-op)
@@ -943,6 +944,7 @@ __global__ __launch_bounds__(64) void softmax_multinomial_kernel(SmArgs a) {
     const int row = blockIdx.x, lane = threadIdx.x;
     if (a.skip && *a.skip) return;
     float *l = a.L + (size_t)row * a.ld;
+    const int lds = a.ld_states ? a.ld_states : a.ld;
     float mx = -3.402823466e38f;
     for (int i = lane; i < a.I; i += 64) mx = fmaxf(mx, l[i]);
 #pragma unroll
@@ -972,8 +974,8 @@ __global__ __launch_bounds__(64) void softmax_multinomial_kernel(SmArgs a) {
         const float m = Mf * (e[i] / S);
         if (a.prev) dmax = fmaxf(dmax, fabsf(m - a.prev[(size_t)row * a.ld_prev + i]));
         l[i] = m;
-        if (a.negmeans) a.negmeans[(size_t)row * a.ld + i] = -m;
-        if (a.states && !a.sample) a.states[(size_t)row * a.ld + i] = m;
+        if (a.negmeans) a.negmeans[(size_t)row * lds + i] = -m;
+        if (a.states && !a.sample) a.states[(size_t)row * lds + i] = m;
     }
     if (a.maxdiff) {            // wave-uniform
 #pragma unroll
@@ -996,7 +998,7 @@ __global__ __launch_bounds__(64) void softmax_multinomial_kernel(SmArgs a) {
         atomicAdd(cnt + lo, 1);
     }
     __syncthreads();
-    for (int i = lane; i < a.I; i += 64) a.states[(size_t)row * a.ld + i] = (float)cnt[i];
+    for (int i = lane; i < a.I; i += 64) a.states[(size_t)row * lds + i] = (float)cnt[i];
 }
 
 // h_hat ~ Multinomial(M, uniform over K) (rbm.py:58): counts of floor(u * K); three independent

@@ -466,14 +466,38 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
-__global__ void sqdiff_kernel(const double *A, const double *B, size_t n, double *out) {
+// Reductions of the metrics are DETERMINISTIC (the fp32 path's row sums are): no atomics.  Every
+// workgroup (256 threads) combines its four wave sums in wave order and stores ONE partial; reduce_fixed_kernel adds
+// the partials of each quantity in a fixed order (strided per thread, xor tree, waves in order).
+__device__ __forceinline__ void block_store(double v, double *dst, double (*s_w)[4], int slot) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_w[slot][threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) *dst = ((s_w[slot][0] + s_w[slot][1]) + s_w[slot][2]) + s_w[slot][3];
+}
+constexpr int SQ_BLOCKS = 128;
+__global__ __launch_bounds__(256) void sqdiff_kernel(const double *A, const double *B, size_t n, double *part) {
+    __shared__ double s_w[1][4];
     double s = 0.0;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const double d = B ? A[e] - B[e] : A[e];
         s += d * d;
     }
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    block_store(s, part + blockIdx.x, s_w, 0);
+}
+// out[j] = sum of part[off[j] .. off[j] + cnt[j]) for up to 5 quantities, fixed order; cnt 0: out[j] = 0
+struct ReduceJobs { int off[5], cnt[5]; };
+__global__ __launch_bounds__(256) void reduce_fixed_kernel(const double *part, ReduceJobs jb, double *out) {
+    __shared__ double s_w[5][4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        double s = 0.0;
+        for (int e = threadIdx.x; e < jb.cnt[j]; e += 256) s += part[jb.off[j] + e];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) s_w[j][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) out[threadIdx.x] = ((s_w[threadIdx.x][0] + s_w[threadIdx.x][1]) + s_w[threadIdx.x][2]) + s_w[threadIdx.x][3];
 }
 __global__ void pll_index_kernel(int *out, int B, int V, PhiloxKey key, unsigned long long row0) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -549,7 +573,8 @@ __global__ void mn_hhat_kernel(double *hhat, int K, int M, PhiloxKey k0, PhiloxK
 // out[2] += F_hhat1(x);  F_hhat(v) = -v.vb - sum_h (v W)_h * hhat_h
 __global__ __launch_bounds__(256) void free_energy_mn_kernel(const double *X, int ldx, int B, int V, int H,
                                                              const double *W, const double *vb, const double *hhat,
-                                                             const int *flip, double *out) {
+                                                             const int *flip, double *rows /* [3][ldr] */, int ldr) {
+    __shared__ double s_w[3][4];
     const int b = blockIdx.x;
     const double *x = X + (size_t)b * ldx;
     const int fc = flip ? flip[b] : -1;
@@ -566,14 +591,17 @@ __global__ __launch_bounds__(256) void free_energy_mn_kernel(const double *X, in
         t1 -= z * hhat[(size_t)H + h];
         if (fc >= 0) t2 -= (z + delta * W[(size_t)fc * H + h]) * hhat[2 * (size_t)H + h];
     }
-    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 0, t0); atomicAdd(out + 2, t1); if (flip) atomicAdd(out + 1, t2); }
+    // rows[0]: F(x), rows[1]: F(x~), rows[2]: the PLL's own F(x)
+    block_store(t0, rows + b, s_w, 0);
+    block_store(t2, rows + ldr + b, s_w, 1);
+    block_store(t1, rows + 2 * (size_t)ldr + b, s_w, 2);
 }
 // free energy of rows (rbm.py:17-22 / :109-116), optionally of the row with column flip[b] flipped:
 // out[0] += F(x_b), out[1] += F(x~_b).  One workgroup per row; hidden units strided over the threads.
 __global__ __launch_bounds__(256) void free_energy_kernel(const double *X, int ldx, int B, int V, int H,
                                                           const double *W, const double *vb, const double *hb,
-                                                          const double *sigma, const int *flip, double *out) {
+                                                          const double *sigma, const int *flip, double *rows /* [2][ldr] */, int ldr) {
+    __shared__ double s_w[2][4];
     const int b = blockIdx.x;
     const double *x = X + (size_t)b * ldx;
     const int fc = flip ? flip[b] : -1;
@@ -596,8 +624,8 @@ __global__ __launch_bounds__(256) void free_energy_kernel(const double *X, int l
         t -= softplus(z);
         if (fc >= 0) t2 -= softplus(z + delta * W[(size_t)fc * H + h]);
     }
-    t = wave_sum(t); t2 = wave_sum(t2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(out + 0, t); if (flip) atomicAdd(out + 1, t2); }
+    block_store(t, rows + b, s_w, 0);
+    block_store(t2, rows + ldr + b, s_w, 1);
 }
 
 struct DBuf {
@@ -621,6 +649,7 @@ struct bm_rbm64 {
     int *flip = nullptr;
     double *scal = nullptr;      // [6] msre, l2, F(x), F(x~), F'(x) (multinomial: the PLL's own h_hat), spare
     bm64::DBuf hhat;             // [3*H] MultinomialRBM free-energy h_hat vectors (rbm.py:58)
+    bm64::DBuf part;             // partial sums of the metric reductions: [2][SQ_BLOCKS] msre / l2 | [3][maxB] free-energy rows
     bool multinomial() const { return cfg.h_unit == BM_UNIT_MULTINOMIAL; }
     uint64_t seed = 0; uint32_t call = 0; int64_t row0 = 0;
     const double *Xin = nullptr; int Xin_ld = 0;
@@ -670,12 +699,25 @@ static void launch_fe(bm_rbm64 *h, const double *Xin, int ldx, int B, const int 
         hipLaunchKernelGGL(mn_hhat_kernel, dim3((M + 255) / 256), dim3(256), 0, h->stream, h->hhat.p, h->H, M,
                            make_key(h, SITE_FE, 0), make_key(h, SITE_FE, 1), make_key(h, SITE_FE, 2));
         hipLaunchKernelGGL(free_energy_mn_kernel, dim3(B), dim3(256), 0, h->stream, Xin, ldx, B, h->V, h->H,
-                           (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hhat.p, flip, h->scal + 2);
+                           (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hhat.p, flip,
+                           h->part.p + 2 * SQ_BLOCKS, h->maxB);
         return;
     }
     hipLaunchKernelGGL(free_energy_kernel, dim3(B), dim3(256), 0, h->stream, Xin, ldx, B, h->V, h->H,
                        (const double *)h->W.p, (const double *)h->vb.p, (const double *)h->hb.p,
-                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), flip, h->scal + 2);
+                       (const double *)(h->cfg.v_unit == BM_UNIT_GAUSSIAN ? h->sigma.p : nullptr), flip,
+                       h->part.p + 2 * SQ_BLOCKS, h->maxB);
+}
+// scal[0..4] = msre sum, l2 sum, sum F(x), sum F(x~), sum F'(x) from the partials, in a fixed order
+static void launch_reduce(bm_rbm64 *h, int B, bool with_sq, bool with_flip) {
+    ReduceJobs jb;
+    const int fe0 = 2 * SQ_BLOCKS;
+    jb.off[0] = 0;          jb.cnt[0] = with_sq ? SQ_BLOCKS : 0;
+    jb.off[1] = SQ_BLOCKS;  jb.cnt[1] = with_sq ? SQ_BLOCKS : 0;
+    jb.off[2] = fe0;                 jb.cnt[2] = B;
+    jb.off[3] = fe0 + h->maxB;       jb.cnt[3] = with_flip ? B : 0;
+    jb.off[4] = fe0 + 2 * h->maxB;   jb.cnt[4] = h->multinomial() ? B : 0;
+    hipLaunchKernelGGL(reduce_fixed_kernel, dim3(1), dim3(256), 0, h->stream, (const double *)h->part.p, jb, h->scal);
 }
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426)
 static int run_chain(bm_rbm64 *h, const double *X_dev, int B, int k, double *hm_out) {
@@ -720,11 +762,12 @@ static void launch_update(bm_rbm64 *h, int B, double lr, double mom) {
 }
 static int metrics_from_chain(bm_rbm64 *h, int B, double *out4) {
     BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, (const double *)h->vm.p, (size_t)B * h->V, h->scal + 0);
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, (const double *)h->W.p, (const double *)nullptr, (size_t)h->V * h->H, h->scal + 1);
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(SQ_BLOCKS), dim3(256), 0, h->stream, h->Xin, (const double *)h->vm.p, (size_t)B * h->V, h->part.p);
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(SQ_BLOCKS), dim3(256), 0, h->stream, (const double *)h->W.p, (const double *)nullptr, (size_t)h->V * h->H, h->part.p + SQ_BLOCKS);
     hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
                        make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
     launch_fe(h, h->Xin, h->Xin_ld, B, (const int *)h->flip);
+    launch_reduce(h, B, true, true);
     double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
@@ -777,6 +820,7 @@ int bm_rbm64_create(const bm_rbm_config *cfg, const double *hyper5, bm_rbm64 **o
     BM_HIP(hipMalloc((void **)&h->flip, B * sizeof(int)));
     BM_HIP(hipMalloc((void **)&h->scal, 6 * sizeof(double)));
     BM_TRY(h->hhat.alloc(3 * H));
+    BM_TRY(h->part.alloc(2 * (size_t)bm64::SQ_BLOCKS + 3 * (size_t)h->maxB));
     std::vector<double> ones(V, 1.0);
     BM_HIP(hipMemcpy(h->sigma.p, ones.data(), V * sizeof(double), hipMemcpyHostToDevice));
     *out = h;
@@ -792,6 +836,7 @@ int bm_rbm64_destroy(bm_rbm64 *h) {
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
     h->hhat.release();
+    h->part.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -863,6 +908,7 @@ int bm_rbm64_free_energy(bm_rbm64 *h, const double *X_dev, int32_t B, double *ou
     }
     BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
     launch_fe(h, Xin, h->V, B, (const int *)nullptr);
+    bm64::launch_reduce(h, B, false, false);
     double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));

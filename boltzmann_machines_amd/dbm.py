@@ -309,9 +309,30 @@ class DBM(EngineModel):
                          ('val.msre', val_msre, '%.5f'), ('val.n_mf_upds', val_n_mf_updates, '%.1f'))
                 write_during_training('; '.join(['epoch: %*d/%d' % (len(str(self.max_epoch)), self.epoch_, self.max_epoch)] +
                                                 [('%s: ' + f) % (n, v) for n, v, f in shown if v]))
+            self._display_dumps()
             if self.save_after_each_epoch:
                 self._save_model(global_step=self.epoch_)
         self._engine.sync()
+
+    def _display_dumps(self):
+        """`display_filters` / `display_particles` (dbm.py:312-322, :531-547) as .npy files per epoch under logs/train:
+        `W_filters_<i>` [n, h, w, c]: the first n columns of W_0 W_1 ... W_i as images (the reference's product and
+        transposes); `particles_v` [n, h, w, c] and `particles_h_<i>` [n_particles, n]: the first n fantasy particles
+        as they stand after the epoch (the reference shows the means of one more, unsampled, particle sweep)."""
+        if self.display_filters:
+            W = None
+            for i in range(self.n_layers_):
+                Wi = np.asarray(self._engine.get('W' + self._sfx(i)), dtype=np.float64)
+                W = Wi if W is None else W.dot(Wi)
+                if W.shape[0] == int(np.prod(self.v_shape)):
+                    self._dump_array('W_filters_%d' % i, self._as_images(W.T[:self.display_filters]))
+        if self.display_particles:
+            n = self.display_particles
+            v = self._engine.get('v')
+            if v.shape[1] == int(np.prod(self.v_shape)):
+                self._dump_array('particles_v', self._as_images(v[:n]))
+            for i in range(self.n_layers_):
+                self._dump_array('particles_h_%d' % i, self._engine.get('h' + self._sfx(i))[:, :n])
 
     # ---- public inference API ---------------------------------------------------------------
     # The reference re-loads the variables from disk at the start of every public call

@@ -346,6 +346,11 @@ class DbmEngine(object):
         self._comm = comm
         check(self.lib.bm_dbm_set_comm(self._h, comm._c if comm is not None else None))
 
+    def set_xchg(self, xchg):
+        """like set_comm, with the per-sweep residual max over the direct peer-memory exchange (bm_dbm_set_xchg)"""
+        self._xchg = xchg
+        check(self.lib.bm_dbm_set_xchg(self._h, xchg._c if xchg is not None else None))
+
     def ais_sharded(self, comm, n_betas, n_runs_total, k, seed):
         """this rank's slice of the chains + ONE all-gather (bm_dbm_ais_sharded); returns all n_runs_total values"""
         out = np.empty(n_runs_total, dtype=np.float32)

@@ -144,11 +144,14 @@ class DataParallelDBM(object):
     `grad_step` (mean-field with an all-reduce(max) of the residual per sweep, PCD, raw sums) ->
     ONE all-reduce(sum) of the fused buffer -> `apply_step` with the global N and M."""
 
-    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None, comm=None):
+    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None, comm=None, xchg=None):
         self.engine, self.rank, self.world = engine, rank, world
         self.allreduce_ = allreduce_
         engine.set_row_offset(rank * engine.N, rank * engine.M)
-        if comm is not None:
+        if xchg is not None:
+            # the direct peer-memory exchange: one 8-byte store per peer and sweep, on the device, in stream order
+            engine.set_xchg(xchg)
+        elif comm is not None:
             # the library's own communicator: residual all-reduce(max) on the device, in stream order
             engine.set_comm(comm)
         elif allreduce_max is not None and world > 1:
@@ -223,6 +226,12 @@ class NativeComm(object):
             dist.broadcast_object_list(box, src=0)
         return cls(rank, world, box[0])
 
+    def allreduce_max(self, darr, count):
+        """in-place all-reduce(max) of `count` floats of a DeviceArray (default stream; synchronises)"""
+        lib = self._ffi.load()
+        self._ffi.check(lib.bm_comm_allreduce_max(self._c, darr.ptr, count, None))    # null stream; a later blocking
+                                                                                      # copy (darr.numpy()) orders behind it
+
     def allreduce_grads(self, engine):
         """in-place all-reduce(sum) of the engine's fused grad buffer on the engine's stream"""
         from .engine import DbmEngine
@@ -240,6 +249,129 @@ class NativeComm(object):
             self.close()
         except Exception:
             pass
+
+
+class DirectExchange(object):
+    """One-shot all-reduce over peer-mapped device memory (`bm_xchg_*`, include/bm355.h): every rank maps every
+    peer's `grad` buffer through hipIpc handles and ONE kernel per rank does reduce-scatter + all-gather straight
+    over the xGMI links (sums in rank order 0..N-1: all replicas receive the same bits).  The host only gathers the
+    256-byte blobs once, at construction: over torch.distributed when a process group exists, else over TCP
+    (`socket_allgather`).  One process per rank; several ranks may share one device (tests on a 1-GPU box)."""
+
+    def __init__(self, engine, rank, world, gather=None):
+        import ctypes as C
+        from . import _ffi
+        from .engine import DbmEngine
+        self._ffi, self.engine, self.rank, self.world = _ffi, engine, rank, world
+        lib = _ffi.load()
+        self._dbm = isinstance(engine, DbmEngine)
+        self._c = C.c_void_p()
+        create = lib.bm_dbm_xchg_create if self._dbm else lib.bm_rbm_xchg_create
+        _ffi.check(create(engine._h, rank, world, C.byref(self._c)))
+        if world > 1:
+            blob = (C.c_char * 256)()
+            _ffi.check(lib.bm_xchg_export(self._c, blob))
+            blobs = (gather or default_gather(rank, world))(bytes(blob))
+            assert len(blobs) == world and all(len(b) == 256 for b in blobs)
+            allb = (C.c_char * (256 * world)).from_buffer_copy(b''.join(blobs))
+            _ffi.check(lib.bm_xchg_attach(self._c, allb))
+
+    def allreduce_grads(self, engine=None):
+        """in-place all-reduce(sum) of the engine's fused grad buffer, one kernel on the engine's stream"""
+        lib = self._ffi.load()
+        f = lib.bm_dbm_allreduce_grads_direct if self._dbm else lib.bm_rbm_allreduce_grads_direct
+        self._ffi.check(f(self.engine._h, self._c))
+
+    def status(self):
+        """0 when no in-kernel wait has timed out (synchronises the device)"""
+        import ctypes as C
+        st = C.c_int32()
+        self._ffi.check(self._ffi.load().bm_xchg_status(self._c, C.byref(st)))
+        return int(st.value)
+
+    def close(self):
+        if getattr(self, '_c', None) is not None and self._c:
+            self._ffi.load().bm_xchg_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def default_gather(rank, world):
+    """bytes -> list of every rank's bytes: torch.distributed when initialised, else TCP through rank 0"""
+    import sys
+    dist = sys.modules.get('torch.distributed')
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        def gather(b):
+            out = [None] * world
+            dist.all_gather_object(out, b)
+            return out
+        return gather
+    return lambda b: socket_allgather(b, rank, world)
+
+
+def direct_allreduce_on_engine_stream(engine, xchg):
+    """`allreduce_` for DataParallelRBM / DataParallelDBM over the direct peer-memory exchange"""
+    def allreduce_():
+        xchg.allreduce_grads()
+    return allreduce_
+
+
+def socket_allgather(payload, rank, world, addr=None, port=None, timeout=120.0):
+    """every rank sends `payload` (bytes) to rank 0 over TCP and receives the list of all payloads (rank order)"""
+    import pickle
+    import socket
+    import time
+    addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(port or int(os.environ.get('MASTER_PORT', '29533')) + 2)
+
+    def recv_msg(c):
+        buf = b''
+        while len(buf) < 4 or len(buf) < 4 + int.from_bytes(buf[:4], 'little'):
+            chunk = c.recv(65536)
+            if not chunk:
+                break
+            buf += chunk
+        return buf[4:4 + int.from_bytes(buf[:4], 'little')]
+
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        parts, conns = {0: payload}, []
+        for _ in range(world - 1):
+            c, _a = srv.accept()
+            r, b = pickle.loads(recv_msg(c))
+            parts[r] = b
+            conns.append(c)
+        out = [parts[r] for r in range(world)]
+        msg = pickle.dumps(out)
+        for c in conns:
+            c.sendall(len(msg).to_bytes(4, 'little') + msg)
+            c.close()
+        srv.close()
+        return out
+    t0 = time.time()
+    while True:
+        try:
+            c = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() - t0 > timeout:
+                raise
+            time.sleep(0.05)
+    c.settimeout(timeout)
+    msg = pickle.dumps((rank, payload))
+    c.sendall(len(msg).to_bytes(4, 'little') + msg)
+    out = pickle.loads(recv_msg(c))
+    c.close()
+    return out
 
 
 def socket_broadcast(payload, rank, world, addr=None, port=None, timeout=120.0):

@@ -330,9 +330,36 @@ class BaseRBM(EngineModel):
             self._log_scalars('val', self.iter_, dict(val_results, feg=feg))
             if self.verbose:
                 self._report_epoch(train_results, val_results, feg)
+            self._display_dumps(X)
             if self.save_after_each_epoch:
                 self._save_model(global_step=self.epoch_)
         self._engine.sync()
+
+    def _display_dumps(self, X):
+        """`display_filters` / `display_hidden_activations` (base_rbm.py:300-306, :429-435): where the reference adds
+        image summaries to the train summary, one .npy per epoch goes to logs/train: `W_filters` [n, h, w, c] (the
+        first n columns of W as images, the reference's transposes) and `hidden_activation_means` [batch, n] (means
+        of the first n hidden units for the first minibatch, computed on the host from the fetched parameters so that
+        the device RNG stream of the run does not depend on the display options; the reference shows the last Gibbs
+        step's means instead)."""
+        if not (self.display_filters or self.display_hidden_activations):
+            return
+        W = np.asarray(self._engine.get('W'), dtype=np.float64)
+        if self.display_filters and self.n_visible == int(np.prod(self.v_shape)):
+            self._dump_array('W_filters', self._as_images(W.T[:self.display_filters]))
+        if self.display_hidden_activations:
+            n = self.display_hidden_activations
+            Xb = np.asarray(X[:self.batch_size], dtype=np.float64)
+            if self._V_UNIT == _ffi.UNIT_GAUSSIAN:
+                Xb = Xb / np.asarray(self._sigma_vector(), dtype=np.float64)
+            z = (1.0 + float(bool(self.dbm_first))) * (Xb.dot(W[:, :n]) + np.asarray(self._engine.get('hb'), dtype=np.float64)[:n])
+            if self._H_UNIT == _ffi.UNIT_MULTINOMIAL:      # means of the whole layer are needed for the softmax
+                zz = (1.0 + float(bool(self.dbm_first))) * (Xb.dot(W) + np.asarray(self._engine.get('hb'), dtype=np.float64))
+                e = np.exp(zz - zz.max(axis=1, keepdims=True))
+                hm = (self.n_samples if hasattr(self, 'n_samples') else 1) * (e / e.sum(axis=1, keepdims=True))[:, :n]
+            else:
+                hm = 1.0 / (1.0 + np.exp(-z))
+            self._dump_array('hidden_activation_means', hm)
 
     def _report_epoch(self, train_results, val_results, feg):
         """one progress line per epoch in the reference's wording (`epoch: 3/10; msre: ...; val.pll: ...; feg: ...`,

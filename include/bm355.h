@@ -315,6 +315,36 @@ int bm_rbm_allreduce_grads_async(bm_rbm *h, bm_comm *c);
 int bm_rbm_wait_grads(bm_rbm *h, int32_t slot);
 int bm_dbm_allreduce_grads(bm_dbm *h, bm_comm *c);
 
+/* ---- one-shot exchange over peer-mapped device memory (SURVEY §5 "Distributed communication backend": a direct
+ * reduce-scatter + all-gather over the 7 xGMI links instead of a ring; §8e: the ONE exchange step of a data-parallel
+ * update).  One process per GPU.  Every rank: bm_xchg_create on the buffer it wants summed -> bm_xchg_export (a
+ * 256-byte blob: hipIpc handles of the buffer, a staging slice and the flag words) -> the host gathers the blobs
+ * of all ranks in rank order (any channel) -> bm_xchg_attach.  bm_xchg_allreduce_sum then runs ONE kernel per rank
+ * on `stream`: rank r adds slice r of every rank's buffer in rank order 0..N-1 (16-byte cache-bypassing loads over
+ * all links at once), publishes it, and pulls the other slices from their owners; every rank ends with the same
+ * bits.  Every wait inside the kernel is bounded (BM_XCHG_TIMEOUT_S, default 20 s); bm_xchg_status reports a
+ * timed-out wait instead of a hung device.  The RCCL path (bm_comm_*) computes the same sums in ring order. */
+typedef struct bm_xchg bm_xchg;
+int bm_xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t count, bm_xchg **out);
+int bm_xchg_blob_bytes(void);                                            /* 256 */
+int bm_xchg_export(bm_xchg *x, void *out_blob256);
+int bm_xchg_attach(bm_xchg *x, const void *all_blobs /* nranks x 256 bytes, ordered by rank */);
+int bm_xchg_destroy(bm_xchg *x);
+int bm_xchg_allreduce_sum(bm_xchg *x, void *stream);
+/* all-reduce(max) of ONE non-negative float in this rank's device memory: one 8-byte {value, epoch} store into
+ * every peer's slot, one fabric hop (the mean-field residual of a data-parallel DBM, dbm.py:449-452) */
+int bm_xchg_allreduce_max1(bm_xchg *x, float *val_dev, void *stream);
+int bm_xchg_status(bm_xchg *x, int32_t *out_status);                     /* synchronises; 0 = no wait timed out */
+int bm_xchg_info(bm_xchg *x, int32_t *out_rank, int32_t *out_nranks, size_t *out_count);
+/* the handle's fused "grad" buffer as the exchanged buffer; bm_*_allreduce_grads_direct is the drop-in for
+ * bm_*_allreduce_grads between bm_*_grad_step and bm_*_apply_step */
+int bm_rbm_xchg_create(bm_rbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
+int bm_dbm_xchg_create(bm_dbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
+int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x);
+int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
+/* like bm_dbm_set_comm, with the per-sweep residual max going through bm_xchg_allreduce_max1; NULL removes it */
+int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x);
+
 #ifdef __cplusplus
 }
 #endif

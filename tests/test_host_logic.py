@@ -181,3 +181,85 @@ def test_generated_isa_has_no_implicit_m0_reader(tmp_path):
     assert 'global_load_lds_dwordx4' in asm                      # the DMA path is really there
     for op in ('s_movrel', 'v_movrel', 's_sendmsg', 'ds_gws', 'v_interp', 'lds_direct', '_addtid'):
         assert op not in asm, 'hipcc emitted %s: it reads M0, which dma16s leaves modified' % op
+
+
+class _StubModel(object):
+    """smallest EngineModel that can save: the variables are host arrays (no device needed)"""
+
+    @staticmethod
+    def make(tmp_path):
+        from boltzmann_machines_amd.base import EngineModel
+
+        class Stub(EngineModel):
+            def _variables(self):
+                return {'W': np.arange(6, dtype=np.float32).reshape(2, 3)}
+        return Stub(model_path=str(tmp_path / 'm') + '/', random_seed=5)
+
+
+def test_checkpoint_write_is_atomic_and_errors_reach_the_caller(tmp_path):
+    """round-2 advisor: the background checkpoint writer must not lose its exception (the reference's synchronous
+    save raises), and a failed write must not leave a half-written file behind."""
+    m = _StubModel.make(tmp_path)
+    m._save_model()
+    m._join_save()
+    d = str(tmp_path / 'm')
+    assert sorted(f for f in os.listdir(d) if not f.startswith('logs')) == ['model.npz', 'params.json', 'random_state.json']
+    with np.load(os.path.join(d, 'model.npz')) as z:
+        assert np.array_equal(z['W'], np.arange(6, dtype=np.float32).reshape(2, 3))
+    before = open(os.path.join(d, 'params.json')).read()
+    # make the write fail inside the writer thread
+
+    class Bad(object):                               # a mapping whose expansion (`np.savez(path, **variables)`) fails
+        def keys(self):
+            raise IOError('disk full')
+
+        def __getitem__(self, k):
+            raise KeyError(k)
+    m._variables = lambda: Bad()
+    m._save_model()
+    with pytest.raises(IOError, match='disk full'):
+        m._join_save()
+    m._join_save()                                   # the error is reported once
+    assert not [f for f in os.listdir(d) if f.endswith('.tmp')]
+    with np.load(os.path.join(d, 'model.npz')) as z:     # the previous checkpoint is intact
+        assert np.array_equal(z['W'], np.arange(6, dtype=np.float32).reshape(2, 3))
+    assert json.loads(open(os.path.join(d, 'params.json')).read()).keys() == json.loads(before).keys()
+
+
+def test_data_parallel_is_opt_in(monkeypatch):
+    """round-2 advisor: RANK / WORLD_SIZE set by a launcher must not switch a model into data-parallel mode
+    (collectives, rank-0-only checkpoints) unless BM355_DATA_PARALLEL=1 asks for it."""
+    src = open(os.path.join(ROOT, 'boltzmann_machines_amd', 'base.py')).read()
+    assert "BM355_DATA_PARALLEL" in src
+    from boltzmann_machines_amd import parallel
+    monkeypatch.setenv('RANK', '1'); monkeypatch.setenv('WORLD_SIZE', '4'); monkeypatch.setenv('LOCAL_RANK', '1')
+    assert parallel.dist_env() == (1, 1, 4)
+    from boltzmann_machines_amd import BernoulliRBM
+    from boltzmann_machines_amd import _ffi
+    rbm = BernoulliRBM(n_visible=4, n_hidden=3, model_path='/tmp/bm355_optin/')
+    monkeypatch.delenv('BM355_DATA_PARALLEL', raising=False)
+    if _ffi.load().bm_device_count() == 0:
+        with pytest.raises(_ffi.Bm355Error):         # reaches engine creation (no GPU here) ...
+            rbm._ensure_engine()
+    else:
+        rbm._ensure_engine()
+    assert rbm._world == 1 and rbm._rank == 0 and rbm._comm is None     # ... as an independent, single-process model
+
+
+def test_socket_allgather_world3():
+    """the torch-free rendezvous of the direct exchange's 256-byte blobs"""
+    import multiprocessing as mp
+    import socket
+    from boltzmann_machines_amd import parallel
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('fork')
+    q = ctx.Queue()
+
+    def run(r):
+        q.put((r, parallel.socket_allgather(bytes([r]) * 256, r, 3, addr='127.0.0.1', port=port)))
+    ps = [ctx.Process(target=run, args=(r,)) for r in range(3)]
+    [p.start() for p in ps]
+    got = dict(q.get(timeout=60) for _ in ps)
+    [p.join() for p in ps]
+    for r in range(3):
+        assert got[r] == [bytes([0]) * 256, bytes([1]) * 256, bytes([2]) * 256]

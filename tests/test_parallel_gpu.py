@@ -1,8 +1,10 @@
-"""-m gpu: the data-parallel split of the HIP engine with world_size 2 — two processes, each with its
-own bm_rbm handle (both on the one GPU of the test box), gloo all-reduce of the fused `grad` buffer
-staged through the host (RCCL refuses two ranks on one device; the driver's multi-GPU bench runs the
-RCCL path).  Checked: replicas stay identical, the update equals the oracle's two-shard algebra BIT
-FOR BIT, and the sample bitmaps (functions of the GLOBAL row) equal a single-process full-batch run."""
+"""-m gpu: data-parallel training with world_size 2 and 3 ON THE GPU — one process per rank, each with its own
+bm_rbm / bm_dbm handle (all on the one GPU of the test box: hipIpc maps another process's allocation whether or
+not it lives on another device), the exchange step through the library's direct peer-memory all-reduce
+(`bm_xchg_*`: reduce-scatter + all-gather in one kernel per rank, sums in rank order).  RCCL refuses two ranks on
+one device; its path is covered at world 1 below and by the driver's multi-GPU bench.  Checked: replicas stay
+identical, the update equals the oracle's shard algebra BIT FOR BIT, and the sample bitmaps (functions of the GLOBAL
+row) equal a single-process full-batch run."""
 import ctypes as C
 import os
 import socket
@@ -13,43 +15,36 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-V, H, BL, K, WORLD = 100, 52, 24, 2, 2
+V, H, BL, K = 100, 52, 24, 2
 KW = dict(sample_v_states=True, l2=1e-3, sparsity_cost=1e-2)
 
 
-def _inputs():
+def _inputs(world=2):
     from oracle import oracle as orc
     W = (orc.normal(1, 2, 0, V * H) * np.float32(0.1)).reshape(V, H)
-    Xg = (orc.uniform(1, 3, 0, WORLD * BL * V) < 0.3).astype(np.float32).reshape(WORLD * BL, V)
+    Xg = (orc.uniform(1, 3, 0, world * BL * V) < 0.3).astype(np.float32).reshape(world * BL, V)
     return W, Xg
 
 
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch
-    import torch.distributed as dist
-    from boltzmann_machines_amd import _ffi, parallel
+    from boltzmann_machines_amd import parallel
     from boltzmann_machines_amd.engine import RbmEngine, as_device
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    W, Xg = _inputs()
+    W, Xg = _inputs(world)
     eng = RbmEngine(V, H, max_batch=BL, **KW)
     eng.set('W', W)
     eng.seed(99)
-    grad = eng.device_view('grad')
-
-    def allreduce_():
-        eng.sync()
-        host = grad.numpy()
-        dist.all_reduce(torch.from_numpy(host))
-        _ffi.check(_ffi.load().bm_h2d(grad.ptr, host.ctypes.data_as(C.c_void_p), host.nbytes))
-    dp = parallel.DataParallelRBM(eng, rank, world, BL, allreduce_)
+    # the blobs travel over a plain TCP socket (no process group): the library's exchange needs nothing else
+    xchg = parallel.DirectExchange(eng, rank, world, gather=lambda b: parallel.socket_allgather(b, rank, world))
+    dp = parallel.DataParallelRBM(eng, rank, world, BL, parallel.direct_allreduce_on_engine_stream(eng, xchg))
     Xd = as_device(Xg[rank * BL:(rank + 1) * BL])
     for step in range(3):
         dp.train_step(Xd, 0.05, 0.5, K)
     eng.sync()
+    assert xchg.status() == 0
     np.savez(out + '.r%d' % rank, **{n: eng.get(n) for n in ('W', 'vb', 'hb', 'dW', 'q_means')})
-    dist.destroy_process_group()
+    xchg.close()
 
 
 def _free_port():
@@ -60,18 +55,20 @@ def _free_port():
     return p
 
 
-def test_dp_world2_on_gpu(gpu_lib, tmp_path):
+@pytest.mark.parametrize('world', [2, 3])
+def test_dp_direct_exchange_on_gpu(gpu_lib, tmp_path, world):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
     out = str(tmp_path / 'dp')
-    mp.spawn(_worker, args=(WORLD, _free_port(), out), nprocs=WORLD, join=True)
-    r0, r1 = np.load(out + '.r0.npz'), np.load(out + '.r1.npz')
-    for n in r0.files:                                         # replicas identical
-        assert np.array_equal(r0[n].view(np.uint32), r1[n].view(np.uint32)), n
-    # the oracle's two-shard algebra: raw sums per shard (global row offsets), summed, applied with N = 2*BL
-    W, Xg = _inputs()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    rs = [np.load(out + '.r%d.npz' % r) for r in range(world)]
+    for r in rs[1:]:
+        for n in rs[0].files:                                  # replicas identical
+            assert np.array_equal(rs[0][n].view(np.uint32), r[n].view(np.uint32)), n
+    # the oracle's shard algebra: raw sums per shard (global row offsets), added in RANK ORDER, applied with N = world*BL
+    W, Xg = _inputs(world)
     twins = []
-    for r in range(WORLD):
+    for r in range(world):
         t = orc.OracleRBM(V, H, **KW)
         t.p['W'][...] = W
         t.set_seed(99)
@@ -79,11 +76,13 @@ def test_dp_world2_on_gpu(gpu_lib, tmp_path):
         twins.append(t)
     for step in range(3):
         raws = [t.raw_grads(Xg[r * BL:(r + 1) * BL], K) for r, t in enumerate(twins)]
-        total = raws[0] + raws[1]
+        total = raws[0]
+        for r in range(1, world):
+            total = total + raws[r]
         for t in twins:
-            t.apply(total, float(WORLD * BL), 0.05, 0.5)
+            t.apply(total, float(world * BL), 0.05, 0.5)
     for n in ('W', 'vb', 'hb', 'dW', 'q_means'):
-        assert np.array_equal(r0[n].view(np.uint32), twins[0].p[n].view(np.uint32)), n
+        assert np.array_equal(rs[0][n].view(np.uint32), twins[0].p[n].view(np.uint32)), n
     # and the same model trained on the full batch by one engine agrees to fp32 round-off
     # (the per-rank sums are blocked differently), i.e. the rank count only changes the rounding
     ref = orc.OracleRBM(V, H, **KW)
@@ -91,7 +90,78 @@ def test_dp_world2_on_gpu(gpu_lib, tmp_path):
     ref.set_seed(99)
     for step in range(3):
         ref.train_step(Xg, 0.05, 0.5, K)
-    np.testing.assert_allclose(r0['W'], ref.p['W'], rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(rs[0]['W'], ref.p['W'], rtol=2e-5, atol=2e-7)
+
+
+DV, DNH, DN, DM = 36, [24, 16], 12, 8
+DKW = dict(max_mf_updates=6, mf_tol=1e-4, l2=1e-3, max_norm=1.5, sparsity_target=[0.2, 0.1], sparsity_cost=[1e-2, 5e-3])
+
+
+def _dbm_setup(rows, prow, N, M):
+    """DbmEngine with pinned parameters; the particles of global indices [prow]"""
+    from boltzmann_machines_amd.engine import DbmEngine
+    from oracle import oracle as orc
+    n = [DV] + DNH
+    eng = DbmEngine(DV, DNH, n_particles=M, batch_size=N, **DKW)
+    Mg = 2 * DM
+    for i in range(2):
+        sfx = '' if i == 0 else '_1'
+        eng.set('W' + sfx, (orc.normal(5, 1 + i, 0, n[i] * n[i + 1]) * np.float32(0.2)).reshape(n[i], n[i + 1]))
+        eng.set('hb' + sfx, (orc.uniform(5, 5 + i, 0, n[i + 1]) - np.float32(0.5)) * np.float32(0.4))
+        eng.set('h' + sfx, (orc.uniform(5, 10 + i, 0, Mg * n[i + 1]) < 0.5).astype(np.float32).reshape(Mg, n[i + 1])[prow])
+    eng.set('v', (orc.uniform(5, 21, 0, Mg * DV) < 0.3).astype(np.float32).reshape(Mg, DV)[prow])
+    X = (orc.uniform(5, 30, 0, 3 * 2 * DN * DV) < 0.25).astype(np.float32).reshape(3, 2 * DN, DV)
+    eng.seed(77)
+    return eng, X[:, rows]
+
+
+def _dbm_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from boltzmann_machines_amd import parallel
+    from boltzmann_machines_amd.engine import as_device
+    eng, X = _dbm_setup(slice(rank * DN, (rank + 1) * DN), slice(rank * DM, (rank + 1) * DM), DN, DM)
+    xchg = parallel.DirectExchange(eng, rank, world, gather=lambda b: parallel.socket_allgather(b, rank, world))
+    dp = parallel.DataParallelDBM(eng, rank, world, parallel.direct_allreduce_on_engine_stream(eng, xchg), xchg=xchg)
+    nmf, first = [], None
+    for s in range(3):
+        nmf.append(dp.train_step(as_device(X[s]), 0.05, 0.5, 2))
+        if s == 0:
+            first = {k_: eng.get(k_) for k_ in ('v', 'h', 'h_1')}
+    eng.sync()
+    assert xchg.status() == 0
+    names = ('W', 'W_1', 'hb', 'hb_1', 'vb', 'dW', 'q_means', 'mu_means_1')
+    np.savez(out + '.r%d' % rank, nmf=nmf, **{k_: eng.get(k_) for k_ in names}, **{'first_' + k_: a for k_, a in first.items()})
+    eng.set_xchg(None)
+    xchg.close()
+
+
+def test_dp_dbm_direct_exchange_on_gpu(gpu_lib, tmp_path):
+    """DataParallelDBM, world 2, both exchange steps over the direct path: the mean-field residual max per sweep
+    (bm_xchg_allreduce_max1, device side, in stream order) and the all-reduce(sum) of the fused gradient buffer.
+    Replicas identical; the executed sweep counts are the global ones (= a single engine on the concatenated
+    minibatch); the particles after the first update are the slices of that engine's particles bit for bit;
+    parameters agree with it to fp32 round-off (the shard sums are blocked differently)."""
+    import torch.multiprocessing as mp
+    from boltzmann_machines_amd.engine import as_device
+    out = str(tmp_path / 'dpdbm')
+    mp.spawn(_dbm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = np.load(out + '.r0.npz'), np.load(out + '.r1.npz')
+    names = ('W', 'W_1', 'hb', 'hb_1', 'vb', 'dW', 'q_means', 'mu_means_1')
+    for k_ in names:
+        assert np.array_equal(r0[k_].view(np.uint32), r1[k_].view(np.uint32)), k_
+    ref, X = _dbm_setup(slice(0, 2 * DN), slice(0, 2 * DM), 2 * DN, 2 * DM)
+    nmf = []
+    for s in range(3):
+        nmf.append(ref.train_step(as_device(X[s]), 0.05, 0.5, 2)[0])
+        if s == 0:
+            for k_ in ('v', 'h', 'h_1'):
+                both = np.concatenate([r0['first_' + k_], r1['first_' + k_]])
+                assert np.array_equal(both.view(np.uint32), ref.get(k_).view(np.uint32)), k_
+    assert list(r0['nmf']) == list(r1['nmf']) == nmf, (list(r0['nmf']), list(r1['nmf']), nmf)
+    for k_ in names:
+        np.testing.assert_allclose(r0[k_], ref.get(k_), rtol=5e-5, atol=1e-6, err_msg=k_)
+    ref.close()
 
 
 NATIVE_SCRIPT = r"""

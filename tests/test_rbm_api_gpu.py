@@ -139,3 +139,21 @@ def test_scalar_logs_and_checkpoint_files(gpu_lib, dirs):
     va = [json.loads(l) for l in open(os.path.join(d, 'logs/val/scalars.jsonl'))]
     assert len(tr) == 2 and len(va) == 2 and {'msre', 'pll', 'l2_loss', 'epoch', 'step'} <= set(tr[0])
     assert tr[-1]['step'] == rbm.iter_ and np.isfinite(tr[-1]['pll']) and tr[-1]['msre'] > 0
+
+
+def test_display_dumps_do_not_change_the_run(gpu_lib, dirs):
+    """`display_filters` / `display_hidden_activations` (base_rbm.py:300-306, :429-435): one .npy per epoch under
+    logs/train in the reference's image layout, and the trained weights do not depend on the display options."""
+    cfg = dict(CONFIG, v_shape=(4, 3))
+    a = BernoulliRBM(max_epoch=2, model_path=dirs[0], **dict(cfg, display_filters=3, display_hidden_activations=5))
+    b = BernoulliRBM(max_epoch=2, model_path=dirs[1], **cfg)
+    a.fit(X); b.fit(X)
+    compare_weights(a, b)
+    d = os.path.join(dirs[0], 'logs/train')
+    for ep in (1, 2):
+        f = np.load(os.path.join(d, 'W_filters_epoch%04d.npy' % ep))
+        h = np.load(os.path.join(d, 'hidden_activation_means_epoch%04d.npy' % ep))
+        assert f.shape == (3, 4, 3, 1) and h.shape == (10, 5) and np.all((h > 0) & (h < 1))
+    W = a.get_tf_params(scope='weights')['W']
+    assert_allclose(f[:, :, :, 0].reshape(3, 12), W.T[:3], rtol=1e-6)
+    assert not os.path.exists(os.path.join(dirs[1], 'logs/train', 'W_filters_epoch0001.npy'))
