@@ -191,12 +191,18 @@ class RbmCD(Workload):
         eng.seed(1337)
         eng.set_row_offset(rank * B)
         self.Xd = as_device(self.X)
+        # the initial state, resident: reset() restores it with device-to-device copies in stream order, so the GPU does
+        # not idle (and clock down) between the untimed precondition steps and the warm-up steps
+        self.init = {'W': as_device(self.W)}
+        for name, n in (('vb', V), ('hb', H), ('dvb', V), ('dhb', H), ('q_means', H)):
+            self.init[name] = as_device(np.zeros(n, dtype=np.float32))
+        self.init['dW'] = as_device(np.zeros((V, H), dtype=np.float32))
         self.use_dp = world > 1 or args.force_dp
         self.collective, self.collective_note = None, None
         if self.use_dp:
             from boltzmann_machines_amd import parallel
             if args.delayed_grads:      # NON-parity mode: the reduction of step t runs under step t+1
-                self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+                self.comm = get_comm(rank, world)
                 self.dp = parallel.DelayedDataParallelRBM(eng, rank, world, B, comm=self.comm)
                 self.collective = 'rccl (bm_comm), delayed'
                 return
@@ -205,7 +211,7 @@ class RbmCD(Workload):
             if mode == 'direct':
                 ar = parallel.direct_allreduce_on_engine_stream(eng, args._xchg[id(eng)])
             elif mode == 'rccl':
-                self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+                self.comm = get_comm(rank, world)
                 ar = parallel.native_allreduce_on_engine_stream(eng, self.comm)
             elif mode == 'torch':   # RCCL through torch.distributed (a nccl group next to the gloo default group)
                 dev = torch.device('cuda', local_rank)
@@ -226,9 +232,8 @@ class RbmCD(Workload):
     def reset(self):
         if self.use_dp and hasattr(self.dp, 'flush'):
             self.dp.flush()                      # delayed-gradient mode: nothing in flight across the reset
-        for name in ('vb', 'hb', 'dW', 'dvb', 'dhb', 'q_means'):
-            self.eng.set(name, 0.0)
-        self.eng.set('W', self.W)
+        for name, d in self.init.items():
+            self.eng.set_from_device(name, d)
         self.eng.seed(1337)
 
     def kernel_pass(self, steps, ev_ms):
@@ -301,6 +306,8 @@ class RbmGibbs(Workload):
         eng.set('W', W)
         eng.seed(1337)
         eng.set_row_offset(rank * B)
+        self.fast = bool(getattr(args, 'fast_binary', False))
+        eng.set_fast_binary(self.fast)
         h0 = (philox.uniform(87654321, 7 + rank, 0, B * H) < 0.5).astype(np.float32).reshape(B, H)
         self.Hd = DeviceArray.from_numpy(h0)
         self.Vd = DeviceArray((B, V))
@@ -324,7 +331,7 @@ class RbmGibbs(Workload):
             'unit': 'Gibbs-steps/s (512-row block sweeps h->v->h, sampling both ways, no update)',
             'config': {'workload': 'BernoulliRBM 784x1024 sampling sweep batch=512 fp32 (SURVEY 8d-ii, bm_rbm_gibbs)',
                        'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'sweeps_per_call': k,
-                       'parallelism': 'replicas%d' % world},
+                       'parallelism': 'replicas%d' % world, 'fast_binary': FAST_NOTE if self.fast else False},
             'flops_per_step': flops,
             'roofline_extra': {
                 'scope': '%d sweeps per call, 2*2*B*V*H = %.3f GFLOP per sweep; the sweep is MFMA-bound (the 6.4 MB of W '
@@ -359,7 +366,7 @@ class _DbmBase(Workload):
                 self.dp = parallel.DataParallelDBM(self.eng, rank, world, gloo_staged_allreduce(self.eng, dist),
                                                    allreduce_max=amax)
             else:
-                self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world)
+                self.comm = get_comm(rank, world)
                 self.dp = parallel.DataParallelDBM(self.eng, rank, world,
                                                    parallel.native_allreduce_on_engine_stream(self.eng, self.comm), comm=self.comm)
 
@@ -487,7 +494,9 @@ class Ais(_DbmBase):
         self.eng = eng = DbmEngine(self.DV, [self.H1, self.H2], n_particles=8, batch_size=8)
         eng.set('W', philox.tf_random_normal((self.DV, self.H1), 0.01, 1337))
         eng.set('W_1', philox.tf_random_normal((self.H1, self.H2), 0.01, 1111))
-        self.comm = parallel.NativeComm.from_torch_rendezvous(rank, world) if (world > 1 or args.force_dp) else None
+        self.fast = bool(getattr(args, 'fast_binary', False))
+        eng.set_fast_binary(self.fast)
+        self.comm = get_comm(rank, world) if (world > 1 or args.force_dp) else None
         self.start, self.stop = parallel.shard(self.R, rank, world)
         self.last = None
 
@@ -507,6 +516,7 @@ class Ais(_DbmBase):
             'config': {'workload': 'AIS log Z, %d chains x %d betas, k=%d, DBM 784-512-1024 fp32 (BASELINE configs[4])'
                                    % (self.R, self.nb, self.k),
                        'chains_per_gpu': self.stop - self.start, 'parallelism': 'chains/%d' % world,
+                       'fast_binary': FAST_NOTE if self.fast else False,
                        'collective': 'bm_comm all-gather of the per-chain log-weights (once per run)' if self.comm else None,
                        'log_Z_estimate': float(log_mean_exp(self.last.astype(np.float64))) if self.last is not None else None},
             'flops_per_step': flops,
@@ -518,13 +528,28 @@ class Ais(_DbmBase):
 WORKLOADS = {w.name: w for w in (RbmCD, RbmGibbs, Grbm, Dbm, Ais)}
 DEFAULTS = {'rbm': (2000, 100), 'gibbs': (300, 30), 'grbm': (30, 5), 'dbm': (40, 5), 'ais': (2, 1)}
 # the short passes the default run adds behind the headline: (steps, warm-up, untimed precondition seconds)
-OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 20, 5, 0.2), ('ais', 1, 1, 0.0))
+OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 20, 5, 0.2), ('ais', 1, 1, 0.0),
+          ('gibbs+fast_binary', 100, 10, 0.2), ('ais+fast_binary', 1, 1, 0.0))
+FAST_NOTE = ('NON-DEFAULT opt-in mode: exact-product bf16 x 3 on the bf16 matrix cores (csrc/bm_bf3.h); results agree with '
+             'the f32 chain to fp32 round-off, not bit for bit; the roofline block still prices the algorithmic flops '
+             'against the fp32-MFMA peak, so frac may exceed what an f32 kernel can reach')
 COLLECTIVE_NAMES = {
     'direct': 'bm_xchg (in-library one-shot reduce-scatter + all-gather over peer-mapped memory / xGMI)',
     'rccl': 'bm_comm (in-library RCCL all-reduce)',
     'torch': 'torch.distributed nccl (RCCL) on the engine stream',
     'gloo': 'gloo, staged through the host (no device collective usable: ranks share a device and the direct path is off)',
 }
+
+
+_COMM = [None]
+
+
+def get_comm(rank, world):
+    """the process-wide RCCL communicator of the library (created once: communicator set-up takes seconds)"""
+    if _COMM[0] is None:
+        from boltzmann_machines_amd import parallel
+        _COMM[0] = parallel.NativeComm.from_torch_rendezvous(rank, world)
+    return _COMM[0]
 
 
 def gloo_staged_allreduce(eng, dist):
@@ -585,7 +610,32 @@ def choose_collective(args, eng, rank, world, dist):
         _h2d(grad, np.zeros(n, dtype=np.float32))
         if int(flag.item()) == 0:
             args._xchg[id(eng)] = x
-            return 'direct', 'start-up self-check against the gloo all-reduce passed on every rank'
+            note = 'start-up self-check against the gloo all-reduce passed on every rank'
+            if world > 1 and not args._shared_devices and not args.no_collective_race:
+                # ... and the faster of the two device collectives is used, by measurement on this very buffer
+                try:
+                    comm = get_comm(rank, world)
+
+                    def timed(fn, iters=30):
+                        for _ in range(3):
+                            fn()
+                        eng.sync(); dist.barrier()
+                        t0 = time.perf_counter()
+                        for _ in range(iters):
+                            fn()
+                        eng.sync()
+                        t = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                        return float(t.item())
+                    t_direct = timed(x.allreduce_grads)
+                    t_rccl = timed(lambda: comm.allreduce_grads(eng))
+                    _h2d(grad, np.zeros(n, dtype=np.float32))
+                    note += '; all-reduce of the %.1f MB buffer: direct %.1f us, rccl %.1f us' % (4e-6 * n, 1e6 * t_direct, 1e6 * t_rccl)
+                    if t_rccl < t_direct:
+                        return 'rccl', note + ' -> rccl'
+                except Exception as e:       # noqa: BLE001 - RCCL unusable: the direct path stands
+                    note += '; rccl could not be timed (%s)' % (str(e)[:120],)
+            return 'direct', note
         note = 'direct exchange failed its start-up self-check on %d rank(s): fell back' % int(flag.item())
         x.close()
     except Exception as e:      # every rank takes the same branch only if the failure is symmetric: confirm it
@@ -637,8 +687,7 @@ def measure(wl, steps, warmup, precondition_s, barrier, dist):
     if precondition_s > 0:
         for i in range(wl.precondition_steps(precondition_s)):
             wl.step(i)
-        eng.sync()
-        wl.reset()
+        wl.reset()              # (in stream order where the workload can: no idle gap before the warm-up steps)
     for i in range(warmup):
         wl.step(i)
     barrier()
@@ -678,8 +727,8 @@ def make_record(wl, rep, world, steps, warmup, precondition_s, dt, ev_ms):
             'n_gpus': world, 'steps': steps, 'warmup': warmup,
             'ms_per_step': round(1e3 * dt / steps, 5), 'higher_is_better': True, 'scaling': wl.scaling,
             'precondition_s': precondition_s,
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': rep['config'], 'roofline': roof}
+            'vs_baseline': None, 'dtype': 'bf16x3 products, f32 accumulate' if rep['config'].get('fast_binary') else 'f32',
+            'data': 'synthetic', 'config': rep['config'], 'roofline': roof}
 
 
 def main():
@@ -692,6 +741,9 @@ def main():
     ap.add_argument('--ais-runs', type=int, default=20000)
     ap.add_argument('--ais-betas', type=int, default=1000)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--fast-binary', action='store_true',
+                    help='gibbs / ais: the opt-in exact-product bf16 x 3 mode (bm_*_set_fast_binary); a NON-default, '
+                         'tolerance-parity mode, reported separately from the f32 figures')
     ap.add_argument('--no-others', action='store_true',
                     help='rbm: do not add the short passes of the other BASELINE configurations (`other_configs`)')
     ap.add_argument('--others-budget-s', type=float, default=150.0,
@@ -705,6 +757,8 @@ def main():
                     help='exchange step of the data-parallel configurations at N > 1: the library\'s one-shot peer-memory '
                          'exchange (bm_xchg_*, default, behind a start-up self-check with a fallback to rccl), the '
                          'library\'s RCCL all-reduce (bm_comm_*), torch.distributed nccl, or gloo staged through the host')
+    ap.add_argument('--no-collective-race', action='store_true',
+                    help='--collective direct: do not time the direct exchange against RCCL at start-up (use direct)')
     ap.add_argument('--native-comm', action='store_true', help='(kept for old command lines) same as --collective rccl')
     ap.add_argument('--torch-comm', action='store_true', help='same as --collective torch')
     ap.add_argument('--delayed-grads', action='store_true',
@@ -739,8 +793,8 @@ def main():
     # the direct exchange and the gloo-staged reducer do not care
     args._shared_devices = ndev < world
     device = local_rank % ndev
+    _ffi.check(lib.bm_set_device(device))      # first: the library's host-wait policy (spin) applies to a fresh context
     torch.cuda.set_device(device)
-    _ffi.check(lib.bm_set_device(device))
     dist = None
     if world > 1 or args.force_dp:
         import torch.distributed as dist
@@ -803,9 +857,11 @@ def main():
                 a2 = argparse.Namespace(**vars(args))
                 a2.k = 1
                 a2._xchg = {}
-                if name == 'ais' and args._shared_devices:
+                a2.fast_binary = name.endswith('+fast_binary')
+                name_wl = name.split('+')[0]
+                if name_wl == 'ais' and args._shared_devices:
                     raise RuntimeError('skipped in a shared-device dry run (the chain all-gather is RCCL)')
-                w2 = WORKLOADS[name](a2, rank, world, device, dist)
+                w2 = WORKLOADS[name_wl](a2, rank, world, device, dist)
                 dt2, ev2 = measure(w2, st, wu, pre, barrier, dist)
                 if rank == 0:
                     rec = make_record(w2, w2.report(argparse.Namespace(**dict(vars(a2), steps=st)), world, dt2, ev2),

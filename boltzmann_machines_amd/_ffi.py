@@ -52,6 +52,7 @@ SIGNATURES = {
     'bm_h2d': [_vp, _vp, _sz],
     'bm_d2h': [_vp, _vp, _sz],
     'bm_dev_memset': [_vp, C.c_int, _sz],
+    'bm_debug_tile_map': [_i32, _i32, C.c_double, C.c_double, _ip, _ip, _ip],
     'bm_comm_unique_id': [_vp],
     'bm_comm_init': [C.c_int32, C.c_int32, _vp, C.POINTER(_vp)],
     'bm_comm_destroy': [_vp],
@@ -78,6 +79,8 @@ SIGNATURES = {
     'bm_rbm_allreduce_grads_direct': [_vp, _vp],
     'bm_dbm_allreduce_grads_direct': [_vp, _vp],
     'bm_dbm_set_xchg': [_vp, _vp],
+    'bm_dbm_set_fast_binary': [_vp, _i32],
+    'bm_rbm_set_fast_binary': [_vp, _i32],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],
     'bm_rbm64_sync': [_vp],
@@ -95,6 +98,7 @@ SIGNATURES = {
     'bm_rbm_sync': [_vp],
     'bm_rbm_set_param': [_vp, C.c_char_p, _vp, _sz],
     'bm_rbm_get_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_rbm_set_param_dev': [_vp, C.c_char_p, _vp, _sz],
     'bm_rbm_dev_ptr': [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)],
     'bm_rbm_seed': [_vp, _u64],
     'bm_rbm_set_row_offset': [_vp, _i64],

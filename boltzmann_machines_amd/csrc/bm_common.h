@@ -91,4 +91,24 @@ struct Mat {
     }
 };
 
+// bf16 matrix [planes][rows][ld] (bm_bf3.h): weight planes or the shadow of a {0,1} state matrix; ld % 64 == 0,
+// zero initialised (the padding must stay zero: the bf16 contraction has no K tail handling)
+struct Mat16 {
+    uint16_t *p = nullptr;
+    int planes = 0, rows = 0, cols = 0, ld = 0;
+    long long plane_stride() const { return (long long)rows * ld; }
+    int alloc(int np, int r, int c) {
+        release();
+        planes = np; rows = r; cols = c; ld = (c + 63) & ~63;
+        const size_t bytes = (size_t)np * r * ld * sizeof(uint16_t);
+        BM_HIP(hipMalloc((void **)&p, bytes ? bytes : 2));
+        BM_HIP(hipMemset(p, 0, bytes ? bytes : 2));
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; planes = rows = cols = ld = 0;
+    }
+};
+
 }  // namespace bm

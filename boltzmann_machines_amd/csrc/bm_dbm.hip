@@ -71,6 +71,12 @@ struct bm_dbm {
     DevBuf apart_v, apart_h, apart_x[2], rowtmp;   // per-16-column slot partial sums (ActArgs::rowacc / rowdot_out)
     double *alogw = nullptr;                       // [ais_rows] log-weights, accumulated in double in a fixed order
     DevBuf ais_send, ais_recv;                     // bm_dbm_ais_sharded: this rank's values / the all-gathered values
+    // fast-binary mode (bm_bf3.h, bm_dbm_set_fast_binary): bf16 planes of W_l (x = below unit, k = above unit) and of
+    // W_l^T, bf16 shadows of the AIS state matrices; `fast_now` is set while a sweep with all-binary states runs
+    int fast = 0;
+    bool fast_now = false;
+    Mat16 W3[MAXL], W3t[MAXL];
+    Mat16 ax16, ax2_16, av16, ah2_16;
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0, prow0 = 0;
@@ -82,6 +88,29 @@ static PhiloxKey dkey(const bm_dbm *h, uint32_t site, int t, uint64_t seed, uint
     k.site = site + 16u * (uint32_t)t;
     k.call = call;
     return k;
+}
+
+// the bf16 shadow of a state matrix of the running fast-binary sweep (null: none)
+static const Mat16 *fast_shadow(const bm_dbm *h, const float *p) {
+    if (p == h->ax.p) return &h->ax16;
+    if (p == h->ax2.p) return &h->ax2_16;
+    if (p == h->av.p) return &h->av16;
+    if (p == h->ah2.p) return &h->ah2_16;
+    return nullptr;
+}
+
+// (re)build the bf16 weight planes from the current parameters (fast-binary mode; cheap next to any sweep)
+static int fast_build_planes(bm_dbm *h) {
+    for (int l = 0; l < h->L; ++l) {
+        const int a = h->n[l], b = h->n[l + 1];
+        if (h->W3[l].rows != a || h->W3[l].cols != b) { BM_TRY(h->W3[l].alloc(3, a, b)); BM_TRY(h->W3t[l].alloc(3, b, a)); }
+        hipLaunchKernelGGL(split3_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)h->W[l].p, h->W[l].ld, a, b,
+                           h->W3[l].p, h->W3[l].plane_stride(), h->W3[l].ld, 0);
+        hipLaunchKernelGGL(split3_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)h->W[l].p, h->W[l].ld, a, b,
+                           h->W3t[l].p, h->W3t[l].plane_stride(), h->W3t[l].ld, 1);
+    }
+    BM_HIP(hipGetLastError());
+    return 0;
 }
 
 // one layer update: out = act(mult * (below.W_lo [+ above.W_hi^T]) + bmult * bias)
@@ -118,6 +147,28 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
     a.means = means; a.states = states; a.ldo = ldo;
     a.key = key; a.row0 = row0;
     a.prev = prev; a.maxdiff = maxdiff;
+    if (h->fast_now && !h->multinomial(layer) && a.kind != 2) {
+        // fast-binary: the same contraction from the bf16 weight planes and the bf16 shadows of the {0,1} inputs
+        // (every state matrix of the running sweep has a shadow; a missing one keeps the fp32 path)
+        const Mat16 *sb = below.p ? fast_shadow(h, below.p) : nullptr, *sa = above.p ? fast_shadow(h, above.p) : nullptr;
+        auto opnd = [](const Mat16 &m, int nx) { Bf3Operand o; o.p = m.p; o.plane_stride = m.plane_stride(); o.ld = m.ld; o.nx = nx; return o; };
+        bool ok = false;
+        Bf3Range r;
+        memset(&r, 0, sizeof(r));
+        if (layer >= 0 && sb && (!above.p || sa)) {
+            r.P1 = opnd(h->W3t[layer], a.I); r.Q1 = opnd(*sb, J); r.K1 = sb->ld;          // W_layer^T: [i][k = below]
+            if (above.p) { r.P2 = opnd(h->W3[layer + 1], a.I); r.Q2 = opnd(*sa, J); r.K2 = sa->ld; }   // W_{layer+1}: [i][k = above]
+            ok = true;
+        } else if (layer < 0 && sa) {
+            r.P1 = opnd(h->W3[0], a.I); r.Q1 = opnd(*sa, J); r.K1 = sa->ld;               // W_0: [i = v][k = h0]
+            ok = true;
+        }
+        if (ok) {
+            a.b3 = r;
+            const Mat16 *so = states ? fast_shadow(h, states) : nullptr;
+            if (so) { a.states16 = so->p; a.ld16 = so->ld; }
+        }
+    }
     if (h->multinomial(layer) && a.kind != 2) {
         // MultinomialLayer inside the stack (layers.py:54-70): the GEMM writes the logits mult*z + bmult*b, then one
         // wave per row does the softmax (activation = n_samples * softmax) and, when sampling, the n_samples
@@ -574,7 +625,9 @@ int bm_dbm_destroy(bm_dbm *h) {
         DevBuf *bs[] = {&h->hb[i], &h->dhb[i], &h->q[i], &h->mm[i], &h->pen[i], &h->wnorm[i], &h->mn_fac[i]};
         for (DevBuf *b : bs) b->release();
         h->logits[i].release();
+        h->W3[i].release(); h->W3t[i].release();
     }
+    h->ax16.release(); h->ax2_16.release(); h->av16.release(); h->ah2_16.release();
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
     DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp,
@@ -732,6 +785,15 @@ int bm_dbm_set_comm(bm_dbm *h, bm_comm *c) {
     return 0;
 }
 
+// Opt-in fast-binary mode (bm_bf3.h): contractions whose input states are {0,1} bitmaps run as exact-product
+// bf16 x 3 on the bf16 matrix cores (AIS with all layers sampled).  Results then agree with the default fp32 chain to
+// fp32 round-off, not bit for bit.  0 restores the default.
+int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on) {
+    BM_CHECK(h, "null argument");
+    h->fast = on ? 1 : 0;
+    return 0;
+}
+
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x) {
     BM_CHECK(h, "null argument");
     h->xchg = x;
@@ -852,6 +914,7 @@ static int ensure_ais(bm_dbm *h, int rows) {
     BM_TRY(h->apart_x[0].alloc((size_t)nslots(h->n[1]) * rows)); BM_TRY(h->apart_x[1].alloc((size_t)nslots(h->n[1]) * rows));
     BM_TRY(h->rowtmp.alloc(rows));
     BM_HIP(hipMalloc((void **)&h->alogw, (size_t)rows * sizeof(double)));
+    h->ax16.release(); h->ax2_16.release(); h->av16.release(); h->ah2_16.release();     // (re)allocated by the fast path
     h->ais_rows = rows;
     return 0;
 }
@@ -906,6 +969,17 @@ static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint6
     Mat *x = &h->ax, *xn = &h->ax2;
     hipLaunchKernelGGL(ais_init_kernel, dim3(512), dim3(256), 0, h->stream, x->p, x->ld, R, H1,
                        dkey(h, SITE_AIS_X0, 0, seed, 0), (unsigned long long)chain0);
+    // fast-binary mode: every state of the run is a {0,1} bitmap when all three layers are sampled (the default)
+    struct FastScope { bm_dbm *h; ~FastScope() { h->fast_now = false; } } fast_scope{h};
+    if (h->fast && h->cfg.sample_v_states && h->cfg.sample_h_states[0] && h->cfg.sample_h_states[1]) {
+        BM_TRY(fast_build_planes(h));
+        if (h->ax16.rows != h->ais_rows) {
+            BM_TRY(h->ax16.alloc(1, h->ais_rows, H1)); BM_TRY(h->ax2_16.alloc(1, h->ais_rows, H1));
+            BM_TRY(h->av16.alloc(1, h->ais_rows, V)); BM_TRY(h->ah2_16.alloc(1, h->ais_rows, H2));
+        }
+        hipLaunchKernelGGL(shadow16_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)x->p, x->ld, R, H1, h->ax16.p, h->ax16.ld);
+        h->fast_now = true;
+    }
     hipLaunchKernelGGL(rowdot_kernel, dim3((R + 3) / 4), dim3(256), 0, h->stream, (const float *)x->p, x->ld, R, H1,
                        (const float *)h->hb[0].p, rdot_cur);
 

@@ -59,6 +59,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace bm {
 
@@ -886,12 +888,104 @@ __device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[G::MI][G::NJ], i
         for (int t = 0; t < G::MI; ++t) v[G::MI * r + t] = acc[t][n][r];
 }
 
-// XCD-aware block -> tile map: blocks are dispatched round-robin over the 8 XCDs
-// (block b -> XCD b % 8, MI355X_MICROARCH.md), so consecutive logical tiles
-// t (which share the P panel = same i-tile) are placed on ONE XCD's L2.
-// `q_major`: consecutive tiles share the Q panel (same j-tile) instead: for tall outputs (AIS: 20 000 chain rows
-// against a 784 x 512 weight matrix) the row operand is the big one - 41 MB that every i-tile would otherwise
-// stream from the Infinity Cache again (rocprofv3 FETCH_SIZE: 1.17 GB per launch) while the weights stay in L2.
+// XCD-aware block -> tile map.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8,
+// MI355X_MICROARCH.md; a speed assumption only - any placement computes the same tiles), every XCD has its own
+// 4 MiB L2, and the L2s are refilled from the Infinity Cache after every kernel boundary.  What a launch pulls
+// through the fabric is therefore sum over XCDs of (the i-operand panels + the j-operand panels its tiles touch):
+//   * the 8 XCDs form an xi x xj grid over the tile matrix; XCD (a, b) owns the rectangle of tiles
+//     i in [a tiles_i / xi, (a+1) tiles_i / xi) x j in [b tiles_j / xj, ...) - a 1-D slab (round 2: xi = 8 or xj = 8)
+//     makes every L2 read ALL of the other operand (prop-up at 784 x 1024 x 512: 16.3 MB for 4.8 MB of operands);
+//   * inside its rectangle an XCD walks j-GROUPS of gj tile columns, all tile rows of a group before the next group,
+//     so that the gj j-panels of a group stay L2 resident while the i-panels stream past them (the 3072 x 5000 outer
+//     products: 6.3 MB of X / v column panels per slab did not fit the L2 and were re-streamed once per tile row,
+//     683 MB per launch for 124 MB of operands).
+// xi, xj, gj are chosen on the host by make_tile_map (modelled fill traffic; BM355_XCD_MAP=xi:gj overrides).
+// Rectangle sizes and the number of blocks an XCD receives differ by a few tiles: tiles beyond an XCD's block count
+// are handed, in a fixed order, to the XCDs with spare blocks.
+struct TileMap {
+    int tiles_i, tiles_j, xi, xj, gj;
+    // per XCD (host-computed: no divisions on the device beyond the two of the in-rectangle walk): the rectangle,
+    // the number of spare blocks in the XCDs before this one, and the number of tiles its own blocks do not reach
+    short i0[8], hi[8], j0[8], wj[8], spare_before[8], left[8];
+};
+
+// force_xi: 0 = the traffic model's choice (or BM355_XCD_MAP=xi[:gj]); 8 / 4 / 2 / 1 = that grid (the launch tuner
+// measures them per shape)
+static inline TileMap make_tile_map(int tiles_i, int tiles_j, double bytes_i, double bytes_j, int force_xi = 0) {
+    // bytes_i / bytes_j: operand bytes one tile row / column pulls in (K * tile extent * 4)
+    static int env_xi = -1, env_gj = 0;
+    if (env_xi < 0) {
+        const char *e = getenv("BM355_XCD_MAP");
+        env_xi = 0;
+        if (e) { env_xi = atoi(e); const char *c = strchr(e, ':'); env_gj = c ? atoi(c + 1) : 0; }
+    }
+    if (env_xi > 0) force_xi = env_xi;
+    const double l2_budget = 2.5 * 1024 * 1024;          // of 4 MiB: the rest holds the streaming panels and outputs
+    TileMap best;
+    memset(&best, 0, sizeof(best));
+    best.tiles_i = tiles_i; best.tiles_j = tiles_j; best.xi = 8; best.xj = 1; best.gj = tiles_j;
+    double best_cost = -1.0;
+    for (int xi = 8; xi >= 1; xi >>= 1) {
+        const int xj = 8 / xi;
+        if (force_xi > 0 && xi != force_xi) continue;
+        const double hi = (double)tiles_i / xi, wj = (double)tiles_j / xj;
+        // widest j-group whose panels fit the budget next to ~4 streaming i-panels
+        int gj = (int)((l2_budget - 4.0 * bytes_i) / (bytes_j > 1.0 ? bytes_j : 1.0));
+        if (gj < 1) gj = 1;
+        if (gj > (int)(wj + 0.999)) gj = (int)(wj + 0.999);
+        if (env_gj > 0) gj = env_gj;
+        const double groups = (double)(((int)(wj + 0.999) + gj - 1) / gj);
+        const double cost = 8.0 * (hi * bytes_i * groups + wj * bytes_j);
+        if (best_cost < 0.0 || cost < best_cost * 0.999) { best_cost = cost; best.xi = xi; best.xj = xj; best.gj = gj; }
+    }
+    const int nb = tiles_i * tiles_j, q = nb / 8, r = nb % 8;
+    int spare = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int a = x % best.xi, c = x / best.xi;
+        const int i0 = a * tiles_i / best.xi, hi = (a + 1) * tiles_i / best.xi - i0;
+        const int j0 = c * tiles_j / best.xj, wj = (c + 1) * tiles_j / best.xj - j0;
+        best.i0[x] = (short)i0; best.hi[x] = (short)hi; best.j0[x] = (short)j0; best.wj[x] = (short)wj;
+        const int cap = q + (x < r ? 1 : 0), sz = hi * wj;
+        best.spare_before[x] = (short)spare;
+        if (cap > sz) spare += cap - sz;
+        best.left[x] = (short)(sz > cap ? sz - cap : 0);
+    }
+    return best;
+}
+
+__host__ __device__ __forceinline__ void tile_of_block(const TileMap &m, int b, int nb, int &ti, int &tj) {
+    const int q = nb >> 3, r = nb & 7;
+    int x = b & 7, l = b >> 3;
+    int i0 = m.i0[x], hi = m.hi[x], j0 = m.j0[x], wj = m.wj[x];
+    if (l >= hi * wj) {
+        // a spare block of this XCD: its rank among all spare blocks (XCD order, then local order) takes the tile of
+        // the same rank among the tiles no block of their own XCD reaches
+        int k = l - hi * wj + m.spare_before[x];
+#pragma unroll
+        for (int xc = 0; xc < 8; ++xc) {
+            const int lf = m.left[xc];
+            if (k >= 0 && k < lf) {
+                x = xc; l = q + (xc < r ? 1 : 0) + k;
+                i0 = m.i0[xc]; hi = m.hi[xc]; j0 = m.j0[xc]; wj = m.wj[xc];
+                k = -1;
+            } else if (k >= 0) {
+                k -= lf;
+            }
+        }
+    }
+    // l-th tile of the rectangle: j-groups of gj columns, inside a group row by row
+    const int gj = m.gj < 1 ? 1 : m.gj;
+    const int nfull = wj / gj, per = hi * gj;
+    if (l < nfull * per) {
+        const int g = l / per, rem = l - g * per, row = rem / gj;
+        ti = i0 + row; tj = j0 + g * gj + (rem - row * gj);
+    } else {
+        const int wl = wj - nfull * gj > 0 ? wj - nfull * gj : 1, rem = l - nfull * per, row = rem / wl;
+        ti = i0 + row; tj = j0 + nfull * gj + (rem - row * wl);
+    }
+}
+
+// round-2 form (1-D slabs), still used by the kernels without a TileMap argument (free-energy GEMM)
 __device__ __forceinline__ void block_to_tile(int tiles_j, int &ti, int &tj, int skip = 0, int trail = 0,
                                               int q_major = 0, int tiles_i = 1) {
     // `skip` leading / `trail` trailing non-tile workgroups in the launch

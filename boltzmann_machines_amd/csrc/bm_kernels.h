@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include "bm_gemm.h"
+#include "bm_bf3.h"
 #include "bm_numerics.h"
 #include "bm_rng.h"
 
@@ -75,6 +76,12 @@ struct ActArgs {
     // boundary less per sweep (~3.5 us of ~25 at the 784-512-1024 shape).  Null: plain `skip` behaviour.
     MfCtl *chk_ctl;
     const float *chk_slots; int chk_n; float chk_tol;
+    // fast-binary mode (bm_bf3.h): the contraction from bf16 weight planes and bf16 state shadows (b3.K1 > 0), and
+    // the bf16 shadow of the states this launch writes (null: none)
+    Bf3Range b3;
+    uint16_t *states16; int ld16;
+    TileMap tmap;                // block -> tile map of this launch (set by launch_act_geo for its geometry)
+    int map_xi;                  // XCD grid of the map: 0 = the traffic model's choice, 8 / 4 / 2 / 1 forced (launch tuner)
 #ifdef BM_PROBE
     long long *dbg;              // [grid][4] s_memtime stamps (tools/probe_act.hip only)
 #endif
@@ -177,75 +184,21 @@ template <int E, class Rng> struct ActSide {
     __device__ __forceinline__ void drain() {}
 };
 
-template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
-__global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
-    constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
-    BM_STAMP(0);
-    // All hot kernel arguments in SGPRs after ONE scalar-memory round trip (hipcc otherwise
-    // loads them lazily: five serialized kernarg waits before the first operand load goes out).
-    asm volatile("" :: "s"(a.P1.ptr), "s"(a.Q1.ptr), "s"(a.P1.ld), "s"(a.Q1.ld), "s"(a.P1.nx), "s"(a.Q1.nx),
-                       "s"(a.K1), "s"(a.K2), "s"(a.bias), "s"(a.sigma), "s"(a.means), "s"(a.states), "s"(a.ldo),
-                       "s"(a.sample), "s"(a.kind), "s"(a.row0), "s"(a.I), "s"(a.J), "s"(a.skip));
-    const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
-    int ti, tj;
-    if (a.chk_ctl) {                               // wave-uniform: Check(s-1), see ActArgs::chk_ctl
-        __shared__ float s_chk[G::NT / 64];
-        float m = 0.f;
-        for (int e = threadIdx.x; e < a.chk_n; e += G::NT) m = fmaxf(m, a.chk_slots[e]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if ((threadIdx.x & 63) == 0) s_chk[threadIdx.x >> 6] = m;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_chk[q]);
-        const int was_done = a.chk_ctl->done;
-        const int done = was_done || !(m > a.chk_tol);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && !was_done) { a.chk_ctl->steps += 1; a.chk_ctl->done = done; }
-        if (done) return;
-    } else if (a.skip && *a.skip) return;          // wave-uniform: converged mean-field loop
-    // tile order: tiles that share the LARGER operand panel are neighbours (same XCD L2); see block_to_tile
-    block_to_tile(tiles_j, ti, tj, 0, 0, a.J > 2 * a.I, (a.I + G::TI - 1) / G::TI);
-    const int i0 = ti * G::TI, j0 = tj * G::TJ;
+// act_kernel's epilogue for the lane's outputs of ONE output tile (i0, j0): activation, draw, stores, the per-row
+// partial sums.  Returns the lane's mean-field residual max|m - prev| (0 without a.prev).  A function so that the
+// persistent fast-binary kernel (act_bf3_kernel) can call it once per tile of its strip.
+template <class G, int ABL, class SideT>
+__device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&acc)[G::MI][1], const SideT &side, int i0, int j0) {
+    constexpr int E = G::E, NH = G::MI;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
     const int g = lane >> 4, l15 = lane & 15;
-    const int ib0 = i0 + wi * (16 * G::MI) + g * E;     // E consecutive outputs i = ib0 + e
-
-    const bool rng_fast = ((a.I & 3) == 0);
-    KRange kr;
-    kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
-    kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2;
-    static_assert(G::NJ == 1, "act_kernel: one j sub-tile per wave");
+    const int ib0 = i0 + wi * (16 * G::MI) + g * E;
     const int j = j0 + wj * 16 + l15;
-    // Side work for the pipeline fill (runs while the first operand loads are in flight):
-    // the epilogue inputs (bias, sigma) and, when a draw follows, the lane's Philox block(s).
-    ActSide<E, typename PhiloxFor<G::MI>::type> side;
-    side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
-    side.prev_row = (a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
-    side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
-
-    f32x4 acc[G::MI][1];
-#pragma unroll
-    for (int t = 0; t < G::MI; ++t) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.acc_init && j < a.J) {                   // start the chain from a stored partial sum
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < G::MI; ++t) {
-                const int i = ib0 + G::MI * r + t;
-                if (i < a.I) acc[t][0][r] = a.acc_init[(size_t)j * a.ld_init + i];
-            }
-    }
-#ifdef BM_PROBE
-    mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
-#else
-    mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
-#endif
+    const bool rng_fast = ((a.I & 3) == 0);
     const float (&bs)[E] = side.bs;
     const float (&sg)[E] = side.sg;
     const typename PhiloxFor<G::MI>::type &rng = side.rng;
-    BM_STAMP(1);
 
     float z[E];
     lane_outputs<G>(acc, 0, z);
@@ -303,21 +256,18 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
                 store4(a.negmeans, o, nm, nvalid, v4 && (((uintptr_t)a.negmeans & 15u) == 0));
             }
             if (a.states) store4(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
-        }
-    }
-    if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
-                               // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
-        __shared__ float s_wavemax[G::NT / 64];
+            if (a.states16) {                  // bf16 shadow of the {0,1} states (exact), pitch ld16 % 64 == 0
+                uint16_t *d = a.states16 + (size_t)j * a.ld16 + ib;
+                if (nvalid == 4 && (ib & 3) == 0) {
+                    uint2 pk;
+                    pk.x = (__float_as_uint(s[0]) >> 16) | (__float_as_uint(s[1]) & 0xffff0000u);
+                    pk.y = (__float_as_uint(s[2]) >> 16) | (__float_as_uint(s[3]) & 0xffff0000u);
+                    *reinterpret_cast<uint2 *>(d) = pk;
+                } else {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
-        if (lane == 0) s_wavemax[w] = dmax;
-        __syncthreads();
-        if (tid == 0) {
-            float m = 0.f;
-#pragma unroll
-            for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_wavemax[q]);
-            if (a.maxdiff_blk && gridDim.x <= BM_MF_SLOTS) a.maxdiff_blk[blockIdx.x] = m;
-            else if (m > 0.f) atomicMax(a.maxdiff, __float_as_uint(m));
+                    for (int r = 0; r < 4; ++r) if (r < nvalid) d[r] = (uint16_t)(__float_as_uint(s[r]) >> 16);
+                }
+            }
         }
     }
     if (a.rowacc || a.rowdot_out) {           // wave-uniform
@@ -358,7 +308,135 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
             if (a.rowdot_out) a.rowdot_out[(size_t)slot * a.ld_part + j] = rdot;
         }
     }
+    return dmax;
+}
+
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
+__global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
+    constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
+    BM_STAMP(0);
+    // All hot kernel arguments in SGPRs after ONE scalar-memory round trip (hipcc otherwise
+    // loads them lazily: five serialized kernarg waits before the first operand load goes out).
+    asm volatile("" :: "s"(a.P1.ptr), "s"(a.Q1.ptr), "s"(a.P1.ld), "s"(a.Q1.ld), "s"(a.P1.nx), "s"(a.Q1.nx),
+                       "s"(a.K1), "s"(a.K2), "s"(a.bias), "s"(a.sigma), "s"(a.means), "s"(a.states), "s"(a.ldo),
+                       "s"(a.sample), "s"(a.kind), "s"(a.row0), "s"(a.I), "s"(a.J), "s"(a.skip));
+    const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
+    int ti, tj;
+    if (a.chk_ctl) {                               // wave-uniform: Check(s-1), see ActArgs::chk_ctl
+        __shared__ float s_chk[G::NT / 64];
+        float m = 0.f;
+        for (int e = threadIdx.x; e < a.chk_n; e += G::NT) m = fmaxf(m, a.chk_slots[e]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if ((threadIdx.x & 63) == 0) s_chk[threadIdx.x >> 6] = m;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_chk[q]);
+        const int was_done = a.chk_ctl->done;
+        const int done = was_done || !(m > a.chk_tol);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !was_done) { a.chk_ctl->steps += 1; a.chk_ctl->done = done; }
+        if (done) return;
+    } else if (a.skip && *a.skip) return;          // wave-uniform: converged mean-field loop
+    // tile order: 2-D XCD rectangles, L2-sized column groups (tile_of_block)
+    (void)tiles_j;
+    tile_of_block(a.tmap, (int)blockIdx.x, (int)gridDim.x, ti, tj);
+    const int i0 = ti * G::TI, j0 = tj * G::TJ;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w % G::WI, wj = w / G::WI;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int ib0 = i0 + wi * (16 * G::MI) + g * E;     // E consecutive outputs i = ib0 + e
+
+    const bool rng_fast = ((a.I & 3) == 0);
+    KRange kr;
+    kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
+    kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2;
+    static_assert(G::NJ == 1, "act_kernel: one j sub-tile per wave");
+    const int j = j0 + wj * 16 + l15;
+    // Side work for the pipeline fill (runs while the first operand loads are in flight):
+    // the epilogue inputs (bias, sigma) and, when a draw follows, the lane's Philox block(s).
+    ActSide<E, typename PhiloxFor<G::MI>::type> side;
+    side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
+    side.prev_row = (a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
+    side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
+
+    f32x4 acc[G::MI][1];
+#pragma unroll
+    for (int t = 0; t < G::MI; ++t) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.acc_init && j < a.J) {                   // start the chain from a stored partial sum
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < G::MI; ++t) {
+                const int i = ib0 + G::MI * r + t;
+                if (i < a.I) acc[t][0][r] = a.acc_init[(size_t)j * a.ld_init + i];
+            }
+    }
+#ifdef BM_PROBE
+    mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
+#else
+    mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
+#endif
+    BM_STAMP(1);
+    float dmax = act_epilogue<G, ABL>(a, acc, side, i0, j0);
+    if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
+                               // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
+        __shared__ float s_wavemax[G::NT / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
+        if (lane == 0) s_wavemax[w] = dmax;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_wavemax[q]);
+            if (a.maxdiff_blk && gridDim.x <= BM_MF_SLOTS) a.maxdiff_blk[blockIdx.x] = m;
+            else if (m > 0.f) atomicMax(a.maxdiff, __float_as_uint(m));
+        }
+    }
     BM_STAMP(2);
+}
+
+// ----------------------------------------------------------- act_bf3_kernel (fast-binary mode, bm_bf3.h)
+// The same propagation + activation + draw from bf16 weight planes and bf16 state shadows, as a PERSISTENT strip
+// kernel: the bf16 matrix cores run a 64-k chunk in ~0.1 us, far below a memory round trip, so a tile-per-workgroup
+// launch spends its time in the pipeline fill and the epilogue of every tile (measured: 11.7 us per 64 x 64 tile of
+// the AIS visible update, 1.3 us of it matrix time).  Here a workgroup owns tile row ti and a strip of tile columns
+// [tj0, tj1): the first chunks of tile tj+1 are requested BEFORE the epilogue of tile tj runs, the bias / sigma
+// loads and the DMA plan of the weight planes are done once per strip.
+struct Bf3Strip { int tiles_i, tiles_j, strips; };      // grid = tiles_i * strips; strip s of row ti: blocks ti * strips + s
+
+template <class G, bool SEG2>
+__global__ __launch_bounds__(G::NT, 1) void act_bf3_kernel(ActArgs a, Bf3Strip sp) {
+    __shared__ __attribute__((aligned(16))) float smem[Bf3Geo<G>::SMEM_FLOATS];
+    constexpr int E = G::E;
+    const int ti = (int)blockIdx.x / sp.strips, st = (int)blockIdx.x % sp.strips;
+    const int per = sp.tiles_j / sp.strips, rem = sp.tiles_j % sp.strips;
+    const int tj0 = st * per + (st < rem ? st : rem), tj1 = tj0 + per + (st < rem ? 1 : 0);
+    const int i0 = ti * G::TI;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w % G::WI, wj = w / G::WI;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int ib0 = i0 + wi * (16 * G::MI) + g * E;
+    ActSide<E, typename PhiloxFor<G::MI>::type> side;
+    side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = 0;
+    side.prev_row = nullptr;
+    side.fill();                                   // bias / sigma of the lane's outputs: once per strip
+    side.with_rng = a.sample;
+    Bf3Pipe<G, SEG2> pipe;
+    pipe.setup(a.b3, i0, smem);
+    if (tj0 < tj1) { pipe.set_tile(a.b3, tj0 * G::TJ); pipe.prefetch(); }
+    for (int tj = tj0; tj < tj1; ++tj) {
+        const int j0 = tj * G::TJ, j = j0 + wj * 16 + l15;
+        f32x4 acc[G::MI][1];
+#pragma unroll
+        for (int t = 0; t < G::MI; ++t) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
+        if (a.sample) side.rng.fill();             // the lane's Philox blocks, while the tile's first chunks arrive
+        pipe.run(acc);
+        if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * G::TJ); pipe.prefetch(); }     // next tile's pipeline fill ...
+        (void)act_epilogue<G, 0>(a, acc, side, i0, j0);                                    // ... under this tile's epilogue
+    }
 }
 
 // -------------------------------------------------------------- colstat_kernel
@@ -611,6 +689,8 @@ struct GradArgs {
     int nbias;
     RbmBiasFusedArgs bias;
     int fetch_at_fill;                // 1: read W/dW of the lane's outputs during the pipeline fill (set by launch_grad)
+    TileMap tmap;                     // block -> tile map (set by launch_grad_geo)
+    int map_xi;                       // see ActArgs::map_xi
 #ifdef BM_PROBE
     long long *dbg;
 #endif
@@ -687,9 +767,8 @@ __global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
                        "s"(a.Pneg.ptr), "s"(a.Qneg.ptr), "s"(a.Pneg.ld), "s"(a.Qneg.ld), "s"(a.Kpos), "s"(a.Kneg),
                        "s"(a.I), "s"(a.J), "s"(a.W), "s"(a.dW), "s"(a.ldw), "s"(a.form), "s"(a.fused));
     constexpr int TJ2 = G::TJ;                    // NJ = 2: 64 x 64 tiles
-    const int tiles_j = (a.J + TJ2 - 1) / TJ2;
     int ti, tj;
-    block_to_tile(tiles_j, ti, tj, 0, a.nbias);
+    tile_of_block(a.tmap, (int)blockIdx.x, ntile_blocks, ti, tj);
     const int i0 = ti * TI, j0 = tj * TJ2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
@@ -1375,7 +1454,12 @@ __global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda
 template <class G> static inline int tile_grid(int I, int J) { return ((I + G::TI - 1) / G::TI) * ((J + G::TJ - 1) / G::TJ); }
 
 template <class G, int MINB, int STG>
-static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
+static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
+    ActArgs a = a_in;
+    {   // operand bytes one tile row (TI outputs along i) / one tile column (TJ rows) pulls through the L2
+        const double kt = (double)a.K1 + (double)a.K2;
+        a.tmap = make_tile_map((a.I + G::TI - 1) / G::TI, (a.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, a.map_xi);
+    }
     const bool seg2 = a.K2 > 0;
     const int pl = a.p_xm ? XM : KM;
     const bool fast = operand_fast(a.P1, pl, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
@@ -1396,6 +1480,29 @@ static inline void launch_act_geo(const ActArgs &a, hipStream_t st) {
         if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, KM, STG>), grid, blk, 0, st, a);
         else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, KM, STG_DMA>), grid, blk, 0, st, a);
     }
+}
+
+// fast-binary launch (a.b3 filled): 64 x 64 tiles (8 waves) when they fill the chip, else 64 x 32 (4 waves); one
+// workgroup per CU (the ring takes most of the LDS), every workgroup a strip of tile columns
+template <class G>
+static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
+    static int ncu = 0;
+    if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    Bf3Strip sp;
+    sp.tiles_i = (a.I + G::TI - 1) / G::TI; sp.tiles_j = (a.J + G::TJ - 1) / G::TJ;
+    sp.strips = ncu / sp.tiles_i;
+    if (sp.strips < 1) sp.strips = 1;
+    if (sp.strips > sp.tiles_j) sp.strips = sp.tiles_j;
+    const dim3 grid(sp.tiles_i * sp.strips), blk(G::NT);
+    if (a.b3.K2 > 0) hipLaunchKernelGGL((act_bf3_kernel<G, true>), grid, blk, 0, st, a, sp);
+    else             hipLaunchKernelGGL((act_bf3_kernel<G, false>), grid, blk, 0, st, a, sp);
+}
+static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
+    static int geo_env = -1;
+    if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
+    const bool big = geo_env ? geo_env == 8 : tile_grid<GeoGrad8>(a.I, a.J) >= 256;
+    if (big) launch_act_bf3_geo<GeoGrad8>(a, st);
+    else     launch_act_bf3_geo<GeoAct>(a, st);
 }
 
 // ---- act_kernel geometry choice ---------------------------------------------------------
@@ -1443,6 +1550,7 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
 struct ActTune {
     static constexpr int NC = 9;
     int best = 0;
+    int xi = 0;                  // XCD grid of the block -> tile map (TileMap), measured with the chosen geometry
     float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 // scratch pool of the tuning launches (per process and device; grown on demand, never on the hot path)
@@ -1495,21 +1603,46 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 1e3f * ms / TUNE_REP < best_us[c]) best_us[c] = 1e3f * ms / TUNE_REP;
         }
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     int b = -1;
     for (int c = 0; c < ActTune::NC; ++c) {
         T.t_us[c] = best_us[c];
         if (best_us[c] < 1e29f && (b < 0 || best_us[c] < best_us[b])) b = c;
     }
     if (b >= 0) T.best = cand_geo[b];
+    // second dimension: the XCD grid of the block -> tile map, with the chosen geometry (the traffic model's choice is
+    // one of the four; which one is fastest also depends on how the panels fall onto the memory channels)
+    float xi_us[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+    static const int cand_xi[4] = {8, 4, 2, 1};
+    static const bool tune_xi = !(getenv("BM355_XCD_MAP") || (getenv("BM355_TUNE_XCD") && atoi(getenv("BM355_TUNE_XCD")) == 0));
+    if (tune_xi) {
+        for (int round = 0; round < TUNE_ROUNDS; ++round)
+            for (int c = 0; c < 4; ++c) {
+                t.map_xi = cand_xi[c];
+                launch_act_as(T.best, t, st);
+                (void)hipEventRecord(e0, st);
+                for (int r = 0; r < TUNE_REP; ++r) launch_act_as(T.best, t, st);
+                (void)hipEventRecord(e1, st);
+                if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 1e3f * ms / TUNE_REP < xi_us[c]) xi_us[c] = 1e3f * ms / TUNE_REP;
+            }
+        int bx = 0;
+        for (int c = 1; c < 4; ++c) if (xi_us[c] < xi_us[bx]) bx = c;
+        if (xi_us[bx] < 1e29f) T.xi = cand_xi[bx];
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us, dma: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; "
                         "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0] > 1e29f ? -1.f : T.t_us[0], T.t_us[1] > 1e29f ? -1.f : T.t_us[1], T.t_us[2], T.t_us[3],
                 T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7], T.t_us[8] > 1e29f ? -1.f : T.t_us[8]);
+    if (log && tune_xi)
+        fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> XCD grid %d x %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
+                a.I, a.J, a.K1, a.K2, flags, T.xi, T.xi ? 8 / T.xi : 0, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
 }
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
+    if (a.b3.K1 > 0) { launch_act_bf3(a, st); return; }
     const int ov = act_geo_override();
     if (ov) { launch_act_as(ov, a, st); return; }
     static std::mutex mu;
@@ -1520,12 +1653,18 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
                                         (a.acc_init ? 64 : 0) | (a.p_xm ? 128 : 0) | (a.rowdot_out ? 256 : 0) |
                                         (a.dot_mat ? 512 : 0) | (a.negmeans ? 1024 : 0));
     const std::array<long long, 6> key = {a.I, a.J, a.K1, a.K2, flags, (long long)dev};
-    int geo;
+    int geo, xi;
     {
         std::lock_guard<std::mutex> lk(mu);
         ActTune &T = table[key];
         if (!T.best) tune_act_shape(a, st, T, flags);
-        geo = T.best;
+        geo = T.best; xi = T.xi;
+    }
+    if (xi && !a.map_xi) {
+        ActArgs a2 = a;
+        a2.map_xi = xi;
+        launch_act_as(geo, a2, st);
+        return;
     }
     launch_act_as(geo, a, st);
 }
@@ -1534,7 +1673,12 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
 // once per shape like the act geometries (tune_act_shape), on scratch copies of every buffer the kernel writes.
 // BM355_GRAD_GEO=4|8 forces one.
 template <class G, int STG>
-static inline void launch_grad_geo(const GradArgs &g, hipStream_t st) {
+static inline void launch_grad_geo(const GradArgs &g_in, hipStream_t st) {
+    GradArgs g = g_in;
+    {
+        const double kt = (double)g.Kpos + (double)g.Kneg;
+        g.tmap = make_tile_map((g.I + G::TI - 1) / G::TI, (g.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, g.map_xi);
+    }
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
     const dim3 grid(tile_grid<G>(g.I, g.J) + g.nbias), blk(G::NT);
@@ -1577,15 +1721,37 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 250.f * ms < best_us[c]) best_us[c] = 250.f * ms;
         }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     int b = 0;
     for (int c = 1; c < NC; ++c) if (best_us[c] < best_us[b]) b = c;
     const int best = cand[b];
+    // the XCD grid of the block -> tile map with that geometry (see tune_act_shape)
+    float xi_us[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+    static const int cand_xi[4] = {8, 4, 2, 1};
+    static const bool tune_xi = !(getenv("BM355_XCD_MAP") || (getenv("BM355_TUNE_XCD") && atoi(getenv("BM355_TUNE_XCD")) == 0));
+    int xi = 0;
+    if (tune_xi) {
+        for (int round = 0; round < 3; ++round)
+            for (int c = 0; c < 4; ++c) {
+                t.map_xi = cand_xi[c];
+                launch_grad_as(best, t, st);
+                (void)hipEventRecord(e0, st);
+                for (int r = 0; r < 4; ++r) launch_grad_as(best, t, st);
+                (void)hipEventRecord(e1, st);
+                if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 250.f * ms < xi_us[c]) xi_us[c] = 250.f * ms;
+            }
+        int bx = 0;
+        for (int c = 1; c < 4; ++c) if (xi_us[c] < xi_us[bx]) bx = c;
+        if (xi_us[bx] < 1e29f) xi = cand_xi[bx];
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
-        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f)\n",
-                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3]);
-    return best;
+        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f), "
+                        "XCD grid %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
+                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3], xi, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
+    return best + 1000 * xi;
 }
 static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
     static int fetch_env = -1, geo_env = -1;          // BM355_GRAD_FETCH=0|1, BM355_GRAD_GEO=4|8 override (experiments)
@@ -1605,6 +1771,7 @@ static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
         if (!b) b = tune_grad_shape(g, st);
         geo = b;
     }
+    if (geo >= 1000) { if (!g.map_xi) g.map_xi = geo / 1000; geo %= 1000; }
     launch_grad_as(geo, g, st);
 }
 

@@ -59,6 +59,13 @@ struct bm_rbm {
     const float *Xin = nullptr;
     int Xin_ld = 0;
     bool hm_is_neg = false;    // the last run_chain() wrote -h_k (hneg) instead of h_k (hm)
+    // fast-binary mode (bm_bf3.h, bm_rbm_set_fast_binary): bf16 planes of W ([V][H]: the prop-down operand) and of
+    // W^T ([H][V]: the prop-up operand), bf16 shadows of the state workspaces hs / vs; `fast_now` while a sweep with
+    // {0,1} states on both sides runs (bm_rbm_gibbs)
+    int fast = 0;
+    bool fast_now = false;
+    Mat16 W3, W3t, hs16, vs16;
+    int *nonbinary = nullptr;  // device flag: a state handed to the fast path was not a {0,1} bitmap
     // optional per-kernel-class event timing
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; };
@@ -107,6 +114,12 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
+    if (h->fast_now && v == h->vs.p) {           // fast-binary: W^T planes x the bf16 shadow of the visible bitmap
+        a.b3.P1 = Bf3Operand{h->W3t.p, h->W3t.plane_stride(), h->W3t.ld, h->H};
+        a.b3.Q1 = Bf3Operand{h->vs16.p, 0, h->vs16.ld, B};
+        a.b3.K1 = h->vs16.ld;
+        if (states == h->hs.p) { a.states16 = h->hs16.p; a.ld16 = h->hs16.ld; }
+    }
     if (h->multinomial()) {
         // MultinomialLayer (layers.py:54-70): logits from the GEMM, then one wave per row for the
         // softmax (activation) and the multinomial counts (sample)
@@ -142,6 +155,12 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
     a.means = means; a.states = states; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
+    if (h->fast_now && hs == h->hs.p) {          // fast-binary: W planes x the bf16 shadow of the hidden bitmap
+        a.b3.P1 = Bf3Operand{h->W3.p, h->W3.plane_stride(), h->W3.ld, h->V};
+        a.b3.Q1 = Bf3Operand{h->hs16.p, 0, h->hs16.ld, B};
+        a.b3.K1 = h->hs16.ld;
+        if (states == h->vs.p) { a.states16 = h->vs16.p; a.ld16 = h->vs16.ld; }
+    }
     launch_act(a, h->stream);
 }
 
@@ -324,7 +343,20 @@ int bm_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-int bm_set_device(int device) { BM_HIP(hipSetDevice(device)); return 0; }
+// Host waits (bm_*_sync, the blocking reads of metrics) SPIN instead of sleeping on an interrupt: a training loop waits
+// for the device every few hundred microseconds (metric fetches, the mean-field loop control), and the wake-up of a
+// blocked host thread costs tens of microseconds per wait.  BM355_HOST_WAIT=yield|block selects the other policies.
+// The flag can only be set before the device's context exists: when the host framework created it first (torch), the
+// call fails harmlessly and the framework's policy stays.
+int bm_set_device(int device) {
+    BM_HIP(hipSetDevice(device));
+    const char *w = getenv("BM355_HOST_WAIT");
+    unsigned flags = hipDeviceScheduleSpin;
+    if (w && !strcmp(w, "yield")) flags = hipDeviceScheduleYield;
+    if (w && !strcmp(w, "block")) flags = hipDeviceScheduleBlockingSync;
+    if (hipSetDeviceFlags(flags) != hipSuccess) (void)hipGetLastError();
+    return 0;
+}
 int bm_dev_alloc(size_t bytes, void **out_dev) { BM_HIP(hipMalloc(out_dev, bytes ? bytes : 1)); return 0; }
 int bm_dev_free(void *dev) { BM_HIP(hipFree(dev)); return 0; }
 // Host -> device.  Large pageable sources (a training set) are pinned in place for the duration of the copy: the
@@ -395,6 +427,8 @@ int bm_rbm_destroy(bm_rbm *h) {
     }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     for (DevBuf *b : all) b->release();
+    h->W3.release(); h->W3t.release(); h->hs16.release(); h->vs16.release();
+    if (h->nonbinary) (void)hipFree(h->nonbinary);
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -405,7 +439,27 @@ int bm_rbm_destroy(bm_rbm *h) {
     return 0;
 }
 
-int bm_rbm_sync(bm_rbm *h) { BM_HIP(hipStreamSynchronize(h->stream)); return 0; }
+int bm_rbm_sync(bm_rbm *h) {
+    BM_HIP(hipStreamSynchronize(h->stream));
+    if (h->nonbinary) {
+        int bad = 0;
+        BM_HIP(hipMemcpy(&bad, h->nonbinary, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad) {
+            BM_HIP(hipMemset(h->nonbinary, 0, sizeof(int)));
+            BM_CHECK(false, "fast-binary mode: bm_rbm_gibbs was given hidden states that are not a {0,1} bitmap");
+        }
+    }
+    return 0;
+}
+
+// Opt-in fast-binary mode (bm_bf3.h): the sampling sweep (bm_rbm_gibbs) of a Bernoulli-Bernoulli RBM with both layers
+// sampled runs its contractions as exact-product bf16 x 3 on the bf16 matrix cores; agreement with the default path
+// is to fp32 round-off, not bit for bit.  0 restores the default.
+int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on) {
+    BM_CHECK(h, "null argument");
+    h->fast = on ? 1 : 0;
+    return 0;
+}
 
 // name -> vector variable
 static DevBuf *find_vec(bm_rbm *h, const std::string &n) {
@@ -430,6 +484,25 @@ int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
     BM_CHECK(b, "unknown RBM variable '%s'", name ? name : "(null)");
     BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
     BM_HIP(hipMemcpy(b->p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// set a variable from DEVICE memory (dense, row-major), asynchronously, in stream order - no host synchronisation:
+// re-initialising a model between runs, or `init_from` another handle's variables, without idling the GPU
+int bm_rbm_set_param_dev(bm_rbm *h, const char *name, const float *src_dev, size_t n) {
+    const std::string nm(name ? name : "");
+    BM_CHECK(h && src_dev, "null argument");
+    if (nm == "W" || nm == "dW") {
+        BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
+        Mat &m = nm == "W" ? h->W : h->dW;
+        BM_HIP(hipMemcpy2DAsync(m.p, (size_t)m.ld * sizeof(float), src_dev, (size_t)m.cols * sizeof(float),
+                                (size_t)m.cols * sizeof(float), m.rows, hipMemcpyDeviceToDevice, h->stream));
+        return 0;
+    }
+    DevBuf *b = find_vec(h, nm);
+    BM_CHECK(b, "unknown RBM variable '%s'", name ? name : "(null)");
+    BM_CHECK(n == b->n, "variable '%s' has %zu elements, got %zu", name, b->n, n);
+    BM_HIP(hipMemcpyAsync(b->p, src_dev, n * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
 
@@ -604,6 +677,25 @@ int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_ste
     BM_CHECK(n_steps >= 1, "n_steps must be >= 1");
     // dense user buffers <-> pitched workspaces (hs / vs)
     hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)H_dev, h->H, h->hs.p, h->hs.ld, B, h->H);
+    struct FastScope { bm_rbm *h; ~FastScope() { h->fast_now = false; } } fast_scope{h};
+    if (h->fast && h->cfg.v_unit == BM_UNIT_BERNOULLI && !h->multinomial() && h->cfg.sample_v_states && h->cfg.sample_h_states &&
+        h->cfg.dropout < 0.f) {
+        // fast-binary sweep: both layers are sampled, so every contraction has a {0,1} operand (the caller's hidden
+        // states must be a bitmap as well: checked on the device, reported by bm_rbm_sync)
+        if (h->W3.rows != h->V) {
+            BM_TRY(h->W3.alloc(3, h->V, h->H)); BM_TRY(h->W3t.alloc(3, h->H, h->V));
+            BM_TRY(h->hs16.alloc(1, h->maxB, h->H)); BM_TRY(h->vs16.alloc(1, h->maxB, h->V));
+            BM_HIP(hipMalloc((void **)&h->nonbinary, sizeof(int)));
+            BM_HIP(hipMemsetAsync(h->nonbinary, 0, sizeof(int), h->stream));
+        }
+        hipLaunchKernelGGL(split3_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)h->W.p, h->W.ld, h->V, h->H,
+                           h->W3.p, h->W3.plane_stride(), h->W3.ld, 0);
+        hipLaunchKernelGGL(split3_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)h->W.p, h->W.ld, h->V, h->H,
+                           h->W3t.p, h->W3t.plane_stride(), h->W3t.ld, 1);
+        hipLaunchKernelGGL(shadow16_check_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)h->hs.p, h->hs.ld, B, h->H,
+                           h->hs16.p, h->hs16.ld, h->nonbinary);
+        h->fast_now = true;
+    }
     for (int t = 0; t < n_steps; ++t) {
         launch_down(h, h->hs.p, h->hs.ld, B, nullptr, h->vs.p, h->vs.ld, h->cfg.sample_v_states, SITE_V, t);
         launch_up(h, h->vs.p, h->vs.ld, B, nullptr, h->hs.p, h->hs.ld, h->cfg.sample_h_states, SITE_H, t);
@@ -612,6 +704,18 @@ int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_ste
     hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)h->vs.p, h->vs.ld, V_dev, h->V, B, h->V);
     h->call++;
     BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// the block -> tile map of a launch with tiles_i x tiles_j tiles (host evaluation of the device function, for tests and
+// tools): out_ti / out_tj [tiles_i * tiles_j] receive the tile of every block, out_map5 = {xi, xj, gj, tiles_i, tiles_j}
+int bm_debug_tile_map(int32_t tiles_i, int32_t tiles_j, double bytes_i, double bytes_j, int32_t *out_ti, int32_t *out_tj,
+                      int32_t *out_map5) {
+    BM_CHECK(tiles_i >= 1 && tiles_j >= 1 && out_ti && out_tj, "bad arguments");
+    const TileMap m = make_tile_map(tiles_i, tiles_j, bytes_i, bytes_j);
+    const int nb = tiles_i * tiles_j;
+    for (int b = 0; b < nb; ++b) { int ti = -1, tj = -1; tile_of_block(m, b, nb, ti, tj); out_ti[b] = ti; out_tj[b] = tj; }
+    if (out_map5) { out_map5[0] = m.xi; out_map5[1] = m.xj; out_map5[2] = m.gj; out_map5[3] = m.tiles_i; out_map5[4] = m.tiles_j; }
     return 0;
 }
 

@@ -69,6 +69,14 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_get_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
         return a
 
+    def set_fast_binary(self, on):
+        """opt-in exact-product bf16 x 3 mode of the sampling sweep (bm_rbm_set_fast_binary)"""
+        check(self.lib.bm_rbm_set_fast_binary(self._h, int(bool(on))))
+
+    def set_from_device(self, name, darr):
+        """variable <- dense DeviceArray, asynchronously on the engine's stream (bm_rbm_set_param_dev)"""
+        check(self.lib.bm_rbm_set_param_dev(self._h, name.encode(), darr.ptr, int(np.prod(darr.shape))))
+
     def device_view(self, name):
         p, n = C.c_void_p(), C.c_size_t()
         check(self.lib.bm_rbm_dev_ptr(self._h, name.encode(), C.byref(p), C.byref(n)))
@@ -345,6 +353,10 @@ class DbmEngine(object):
         all-reduced (max) on the device per sweep (bm_dbm_set_comm)"""
         self._comm = comm
         check(self.lib.bm_dbm_set_comm(self._h, comm._c if comm is not None else None))
+
+    def set_fast_binary(self, on):
+        """opt-in exact-product bf16 x 3 mode of AIS (bm_dbm_set_fast_binary)"""
+        check(self.lib.bm_dbm_set_fast_binary(self._h, int(bool(on))))
 
     def set_xchg(self, xchg):
         """like set_comm, with the per-sweep residual max over the direct peer-memory exchange (bm_dbm_set_xchg)"""

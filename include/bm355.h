@@ -43,6 +43,11 @@ int bm_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int bm_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int bm_dev_memset(void *dst_dev, int value, size_t bytes);
 
+/* XCD-aware block -> tile map of the tile kernels (csrc/bm_gemm.h tile_of_block), evaluated on the host: for tests
+ * and tools.  out_ti / out_tj: tile of every block of a tiles_i x tiles_j launch; out_map5 = {xi, xj, gj, tiles_i, tiles_j} */
+int bm_debug_tile_map(int32_t tiles_i, int32_t tiles_j, double bytes_i, double bytes_j, int32_t *out_ti,
+                      int32_t *out_tj, int32_t *out_map5);
+
 /* ------------------------------------------------------------------- RBM */
 typedef struct bm_rbm bm_rbm;
 
@@ -77,6 +82,9 @@ int bm_rbm_sync(bm_rbm *h);
  * restore tf_model.py:22-28): "W" [V*H], "vb" [V], "hb" [H], "dW", "dvb",
  * "dhb", "q_means" [H], "sigma" [V].  n = number of floats. */
 int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n);
+/* the same from DEVICE memory (dense, row-major), asynchronously on the handle's stream - no host synchronisation
+ * (re-initialising between runs, `init_from` another handle: base_rbm.py:668-685 without a host round trip) */
+int bm_rbm_set_param_dev(bm_rbm *h, const char *name, const float *src_dev, size_t n);
 int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n);
 /* device pointer of a variable / workspace for zero-copy interop (RCCL):
  * the variables above plus "grad" (fused [V*H + V + H + H] raw-sum buffer). */
@@ -342,6 +350,13 @@ int bm_rbm_xchg_create(bm_rbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
 int bm_dbm_xchg_create(bm_dbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
 int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x);
 int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
+/* Opt-in "fast-binary" mode (SURVEY §7 hard part 4; csrc/bm_bf3.h): contractions whose input states are {0,1}
+ * bitmaps (AIS with all layers sampled; the RBM sampling sweep with both layers sampled) split the fp32 weights
+ * EXACTLY into three bf16 planes and run on the bf16 matrix cores - exact products, fp32 accumulation in a
+ * different order than the default chain: results agree to fp32 round-off (free energy / log-weights 1e-5, bitmaps
+ * identical except where |u - p| is at round-off distance), NOT bit for bit.  Never the default. */
+int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on);
+int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on);
 /* like bm_dbm_set_comm, with the per-sweep residual max going through bm_xchg_allreduce_max1; NULL removes it */
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x);
 

@@ -263,3 +263,40 @@ def test_socket_allgather_world3():
     [p.join() for p in ps]
     for r in range(3):
         assert got[r] == [bytes([0]) * 256, bytes([1]) * 256, bytes([2]) * 256]
+
+
+def test_xcd_tile_map_is_a_bijection_and_cuts_modelled_traffic():
+    """csrc/bm_gemm.h tile_of_block (evaluated on the host through bm_debug_tile_map): every tile of a launch is
+    computed by exactly one block for any tile-matrix shape, XCD grid and column-group width; and for the two shapes
+    the round-2 verdict names, the number of operand panels the 8 L2s pull in drops as intended."""
+    import ctypes as C
+    from boltzmann_machines_amd import _ffi
+    lib = _ffi.load()
+
+    def tmap(ti, tj, bi, bj):
+        nb = ti * tj
+        a, b, m = (C.c_int32 * nb)(), (C.c_int32 * nb)(), (C.c_int32 * 5)()
+        _ffi.check(lib.bm_debug_tile_map(ti, tj, float(bi), float(bj), a, b, m))
+        return np.array(a[:]), np.array(b[:]), list(m[:])
+
+    rng = np.random.RandomState(0)
+    shapes = [(1, 1), (1, 7), (7, 1), (3, 3), (32, 8), (25, 8), (79, 48), (157, 8), (16, 625), (5, 5), (2, 200), (9, 17)]
+    shapes += [(int(rng.randint(1, 90)), int(rng.randint(1, 90))) for _ in range(40)]
+    for ti, tj in shapes:
+        for bi, bj in ((1e5, 2e5), (1.3e5, 1.3e5), (4e6, 1e3), (1e3, 4e6)):
+            a, b, m = tmap(ti, tj, bi, bj)
+            assert m[0] * m[1] == 8 and m[2] >= 1
+            assert a.min() >= 0 and a.max() < ti and b.min() >= 0 and b.max() < tj, (ti, tj, m)
+            assert len(set(zip(a.tolist(), b.tolist()))) == ti * tj, (ti, tj, m)
+
+    def panels(a, b):            # operand panels each XCD touches (block b runs on XCD b % 8), summed over the XCDs
+        pi = sum(len(set(a[x::8].tolist())) for x in range(8))
+        pj = sum(len(set(b[x::8].tolist())) for x in range(8))
+        return pi, pj
+    # prop-up 784x1024x512 (32 x 8 tiles of 32 x 64): 1-D slabs read 32 + 8*8 = 96 panel units; the 4 x 2 grid 64 + 32
+    a, b, m = tmap(32, 8, 784 * 32 * 4, 784 * 64 * 4)
+    pi, pj = panels(a, b)
+    assert (m[0], m[1]) == (4, 2) and pi * 100e3 + pj * 200e3 < 0.85 * (32 * 100e3 + 64 * 200e3)
+    # 3072x5000 outer products (79 x 48 tiles of 64 x 64, K = 512): column groups that fit the L2
+    a, b, m = tmap(79, 48, 512 * 64 * 4, 512 * 64 * 4)
+    assert m[2] * 512 * 64 * 4 <= 2.5 * 2 ** 20 and m[2] >= 8

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round-3 GPU pass C: tuned XCD grid vs the 1-D slabs of round 2, per config; tuner decisions; 20-step runs
+O=gpurun_out/r3c; mkdir -p $O
+run() { # label, env, args
+  env $2 python bench.py --no-cpu --no-others $3 2>>$O/err.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1', d['value'], d['ms_per_step'], r['frac'], r['frac_wall'], {k:v['avg_us'] for k,v in r.get('kernels',{}).items() if isinstance(v,dict)})" | tee -a $O/ab.log
+}
+for r in 1 2; do
+  for c in rbm gibbs grbm dbm; do
+    run "$c old1d" BM355_XCD_MAP=8 "--config $c"
+    run "$c tuned" BM355_NOP=1 "--config $c"
+  done
+  run "ais old1d" BM355_XCD_MAP=1 "--config ais --ais-betas 100 --steps 1 --warmup 1"
+  run "ais tuned" BM355_NOP=1 "--config ais --ais-betas 100 --steps 1 --warmup 1"
+done
+for r in 1 2 3; do run "rbm20" BM355_NOP=1 "--steps 20 --warmup 5"; done
+for c in rbm grbm dbm; do BM355_TUNE_LOG=1 python bench.py --no-cpu --no-others --config $c --steps 3 --warmup 1 2>&1 | grep "bm355 tune" | grep -i "xcd" | tee -a $O/tune.log; done
+BM355_TUNE_LOG=1 python bench.py --no-cpu --no-others --config ais --ais-betas 20 --steps 1 --warmup 1 2>&1 | grep "bm355 tune" | grep -i "xcd" | tee -a $O/tune.log
+python -m pytest tests -m gpu -q -x --timeout 900 -k "parity or geometr or full_size" > $O/pytest.log 2>&1; tail -3 $O/pytest.log
