@@ -189,7 +189,7 @@ template <int E, class Rng> struct ActSide {
 // persistent fast-binary kernel (act_bf3_kernel) can call it once per tile of its strip.
 template <class G, int ABL, class SideT>
 __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&acc)[G::MI][1], const SideT &side, int i0, int j0) {
-    constexpr int E = G::E, NH = G::MI;
+    constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
     const int g = lane >> 4, l15 = lane & 15;
@@ -314,7 +314,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&ac
 template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
-    constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
+    constexpr int E = G::E;
     BM_STAMP(0);
     // All hot kernel arguments in SGPRs after ONE scalar-memory round trip (hipcc otherwise
     // loads them lazily: five serialized kernarg waits before the first operand load goes out).
@@ -347,7 +347,6 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     const int g = lane >> 4, l15 = lane & 15;
     const int ib0 = i0 + wi * (16 * G::MI) + g * E;     // E consecutive outputs i = ib0 + e
 
-    const bool rng_fast = ((a.I & 3) == 0);
     KRange kr;
     kr.P1 = a.P1; kr.Q1 = a.Q1; kr.K1 = a.K1;
     kr.P2 = a.P2; kr.Q2 = a.Q2; kr.K2 = a.K2;
