@@ -166,7 +166,12 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
         if (ok) {
             a.b3 = r;
             const Mat16 *so = states ? fast_shadow(h, states) : nullptr;
-            if (so) { a.states16 = so->p; a.ld16 = so->ld; }
+            if (so) {
+                a.states16 = so->p; a.ld16 = so->ld;
+                // the fp32 copy of a state matrix that only fast-binary launches read is not written at all (the AIS
+                // visible / top-layer states: 145 MB per beta); x keeps it for the x.hb0 partial sums of the epilogue
+                if (!a.rowdot_out) a.states = nullptr;
+            }
         }
     }
     if (h->multinomial(layer) && a.kind != 2) {

@@ -127,6 +127,7 @@ using GeoActS = Geo<2, 2, 1, 1, 64>;     // 32 x 32 tile, 4 waves of 16 x 16, 64
 using GeoActS32 = Geo<2, 2, 1, 1, 32>;   // the same with BK = 32: 32 KiB LDS, up to four workgroups per CU
 using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 4 waves of 32 x 32, 128 KiB LDS
 using GeoGrad8 = Geo<2, 4, 2, 1, 64>;    // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD), 128 KiB LDS
+using GeoBf3S = Geo<1, 4, 2, 1, 64>;     // 32 x 64 tile, 4 waves of 32 x 16: the fast-binary path's two-workgroups-per-CU tile (bm_bf3.h)
 
 struct Operand {
     const float *ptr;

@@ -145,9 +145,13 @@ __device__ __forceinline__ void stream_store2(float *p, float x, float y) {
     else *reinterpret_cast<float2 *>(p) = make_float2(x, y);
 }
 
+template <bool CACHED = false>
 __device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int nvalid, bool v4) {
     if (v4) {
-        stream_store4(dst + o, v[0], v[1], v[2], v[3]);
+        // CACHED: plain write-back stores (a lane of the MI = 2 tile writes its 32 bytes as two 16-byte stores 16 bytes
+        // apart: as streaming stores each instruction leaves half-filled lines behind, WRITE_SIZE 1.8x the payload)
+        if (CACHED) *reinterpret_cast<float4 *>(dst + o) = make_float4(v[0], v[1], v[2], v[3]);
+        else stream_store4(dst + o, v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (r < nvalid) dst[o + r] = v[r];
@@ -187,7 +191,7 @@ template <int E, class Rng> struct ActSide {
 // act_kernel's epilogue for the lane's outputs of ONE output tile (i0, j0): activation, draw, stores, the per-row
 // partial sums.  Returns the lane's mean-field residual max|m - prev| (0 without a.prev).  A function so that the
 // persistent fast-binary kernel (act_bf3_kernel) can call it once per tile of its strip.
-template <class G, int ABL, class SideT>
+template <class G, int ABL, class SideT, bool HWMATH = false>
 __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&acc)[G::MI][1], const SideT &side, int i0, int j0) {
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -220,7 +224,8 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&ac
             for (int r = 0; r < 4; ++r) {
                 const float x = a.mult * z[4 * hlf + r];
                 const float b = a.bmult * bs[4 * hlf + r];
-                m[r] = (a.kind == 0) ? sigmoid(x + b) : (a.kind == 1 ? (x * sg[4 * hlf + r] + b) : (a.kind == 3 ? x + b : x));
+                m[r] = (a.kind == 0) ? (HWMATH ? sigmoid_hw(x + b) : sigmoid(x + b))
+                                     : (a.kind == 1 ? (x * sg[4 * hlf + r] + b) : (a.kind == 3 ? x + b : x));
                 s[r] = m[r];
             }
             if (a.sample) {
@@ -248,14 +253,14 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&ac
                     if (r < nvalid) dmax = fmaxf(dmax, fabsf(m[r] - side.pv[4 * hlf + r]));
             }
             const bool v4 = al_out && nvalid == 4;
-            if (a.means) store4(a.means, o, m, nvalid, v4 && (((uintptr_t)a.means & 15u) == 0));
+            if (a.means) store4<HWMATH>(a.means, o, m, nvalid, v4 && (((uintptr_t)a.means & 15u) == 0));
             if (a.negmeans) {
                 float nm[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) nm[r] = -m[r];
-                store4(a.negmeans, o, nm, nvalid, v4 && (((uintptr_t)a.negmeans & 15u) == 0));
+                store4<HWMATH>(a.negmeans, o, nm, nvalid, v4 && (((uintptr_t)a.negmeans & 15u) == 0));
             }
-            if (a.states) store4(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
+            if (a.states) store4<HWMATH>(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
             if (a.states16) {                  // bf16 shadow of the {0,1} states (exact), pitch ld16 % 64 == 0
                 uint16_t *d = a.states16 + (size_t)j * a.ld16 + ib;
                 if (nvalid == 4 && (ib & 3) == 0) {
@@ -286,7 +291,8 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&ac
                             qa += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
                         } else {
                             const float t = z[e] + bs[e];
-                            qa += softplus(a.beta_b * t) - softplus(a.beta_a * t);
+                            qa += HWMATH ? softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t)
+                                         : softplus(a.beta_b * t) - softplus(a.beta_a * t);
                         }
                     }
                     // the state of this element as it was just stored by this lane
@@ -405,8 +411,8 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
 // loads and the DMA plan of the weight planes are done once per strip.
 struct Bf3Strip { int tiles_i, tiles_j, strips; };      // grid = tiles_i * strips; strip s of row ti: blocks ti * strips + s
 
-template <class G, bool SEG2>
-__global__ __launch_bounds__(G::NT, 1) void act_bf3_kernel(ActArgs a, Bf3Strip sp) {
+template <class G, bool SEG2, int MINW>
+__global__ __launch_bounds__(G::NT, MINW) void act_bf3_kernel(ActArgs a, Bf3Strip sp) {
     __shared__ __attribute__((aligned(16))) float smem[Bf3Geo<G>::SMEM_FLOATS];
     constexpr int E = G::E;
     const int ti = (int)blockIdx.x / sp.strips, st = (int)blockIdx.x % sp.strips;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(G::NT, 1) void act_bf3_kernel(ActArgs a, Bf3Strip s
         if (a.sample) side.rng.fill();             // the lane's Philox blocks, while the tile's first chunks arrive
         pipe.run(acc);
         if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * G::TJ); pipe.prefetch(); }     // next tile's pipeline fill ...
-        (void)act_epilogue<G, 0>(a, acc, side, i0, j0);                                    // ... under this tile's epilogue
+        (void)act_epilogue<G, 0, decltype(side), true>(a, acc, side, i0, j0);              // ... under this tile's epilogue
     }
 }
 
@@ -1481,27 +1487,32 @@ static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
     }
 }
 
-// fast-binary launch (a.b3 filled): 64 x 64 tiles (8 waves) when they fill the chip, else 64 x 32 (4 waves); one
-// workgroup per CU (the ring takes most of the LDS), every workgroup a strip of tile columns
-template <class G>
+// fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
+// ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
+// sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
+// tile columns.  BM355_BF3_GEO=8|4|2 forces one.
+template <class G, int WGS_PER_CU>
 static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
     Bf3Strip sp;
     sp.tiles_i = (a.I + G::TI - 1) / G::TI; sp.tiles_j = (a.J + G::TJ - 1) / G::TJ;
-    sp.strips = ncu / sp.tiles_i;
+    sp.strips = (ncu * WGS_PER_CU) / sp.tiles_i;
     if (sp.strips < 1) sp.strips = 1;
     if (sp.strips > sp.tiles_j) sp.strips = sp.tiles_j;
     const dim3 grid(sp.tiles_i * sp.strips), blk(G::NT);
-    if (a.b3.K2 > 0) hipLaunchKernelGGL((act_bf3_kernel<G, true>), grid, blk, 0, st, a, sp);
-    else             hipLaunchKernelGGL((act_bf3_kernel<G, false>), grid, blk, 0, st, a, sp);
+    constexpr int MINW = WGS_PER_CU * G::NW / 4 > 0 ? WGS_PER_CU * G::NW / 4 : 1;          // waves per SIMD the grid needs
+    if (a.b3.K2 > 0) hipLaunchKernelGGL((act_bf3_kernel<G, true, MINW>), grid, blk, 0, st, a, sp);
+    else             hipLaunchKernelGGL((act_bf3_kernel<G, false, MINW>), grid, blk, 0, st, a, sp);
 }
 static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
     static int geo_env = -1;
     if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
-    const bool big = geo_env ? geo_env == 8 : tile_grid<GeoGrad8>(a.I, a.J) >= 256;
-    if (big) launch_act_bf3_geo<GeoGrad8>(a, st);
-    else     launch_act_bf3_geo<GeoAct>(a, st);
+    int geo = geo_env;
+    if (!geo) geo = tile_grid<GeoBf3S>(a.I, a.J) >= 1024 ? 2 : 4;
+    if (geo == 8)      launch_act_bf3_geo<GeoGrad8, 1>(a, st);
+    else if (geo == 2) launch_act_bf3_geo<GeoBf3S, 2>(a, st);
+    else               launch_act_bf3_geo<GeoAct, 1>(a, st);
 }
 
 // ---- act_kernel geometry choice ---------------------------------------------------------

@@ -66,4 +66,16 @@ __device__ __forceinline__ float softplus(float x) {
 }
 __device__ __forceinline__ float log_sigmoid(float x) { return -softplus(-x); }
 
+// Fast-binary mode only (bm_bf3.h; tolerance parity, never the default path): the same functions on the hardware
+// transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1e-7 relative), a third of the instructions of the
+// bit-pinned forms above - the epilogue, not the bf16 matrix work, bounds those kernels.
+__device__ __forceinline__ float sigmoid_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);      // exp(-x): inf for very negative x -> 0
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float softplus_hw(float x) {
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * -1.44269504088896341f);
+    return fmaxf(x, 0.0f) + 0.693147180559945309f * __builtin_amdgcn_logf(1.0f + e);
+}
+
 }  // namespace bm

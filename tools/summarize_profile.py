@@ -16,7 +16,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r2'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r2'
-configs = sys.argv[3:] or ['rbm', 'gibbs', 'grbm', 'dbm', 'ais']
+configs = sys.argv[3:] or ['rbm', 'gibbs', 'grbm', 'dbm', 'ais', 'aisfast']
 os.makedirs('profiles', exist_ok=True)
 
 
@@ -64,7 +64,8 @@ for cfg in configs:
             for k, dd in agg(f).items():
                 pmc.setdefault(k, {}).update(dd)
     # steps seen by the counter pass: one marker kernel per step
-    marker = {'rbm': 'grad_kernel', 'gibbs': None, 'grbm': 'maxnorm_kernel', 'dbm': 'dbm_bias_kernel', 'ais': 'ais_init_kernel'}[cfg]
+    marker = {'rbm': 'grad_kernel', 'gibbs': None, 'grbm': 'maxnorm_kernel', 'dbm': 'dbm_bias_kernel', 'ais': 'ais_init_kernel',
+              'aisfast': 'ais_init_kernel'}[cfg]
     if marker:
         per = {'dbm_bias_kernel': 3}.get(marker, 1)
         n_steps = max(1, sum(n for k, n in ndisp.items() if marker in k) // per)
@@ -72,18 +73,24 @@ for cfg in configs:
         n_steps = max(1, sum(n for k, n in ndisp.items() if 'act_kernel' in k) // 20)
     traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_steps
     lines = ['# rocprofv3 summary %s / %s - `python bench.py --config %s` on 1x MI355X' % (tag, cfg, cfg), '',
-             '| kernel | calls | avg us (kernel-trace) | total % | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | LDS bank-conflict cycles |',
-             '|---|---|---|---|---|---|---|---|---|']
+             '| kernel | calls | avg us (kernel-trace) | total % | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | issue-stalled % (WAIT_INST_ANY) | parked % (WAIT_ANY) | MFMA instr f32 / bf16 | LDS bank-conflict cycles |',
+             '|---|---|---|---|---|---|---|---|---|---|---|---|']
     names = sorted(set(pmc) | {k for k in stats if 'bm::' in k or 'bm64::' in k},
                    key=lambda k: -float(stats.get(k, {}).get('TotalDurationNs', 0) or 0))
     for k in names:
         dd, st = pmc.get(k, {}), stats.get(k, {})
         busy = 100.0 * dd.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / 1024.0 / max(dd.get('SQ_BUSY_CYCLES', 1) / 32.0, 1)
-        lines.append('| `%s` | %s | %.2f | %s | %.0f | %.1f | %.0f | %s | %s |' % (
+        wc = max(dd.get('SQ_WAVE_CYCLES', 0), 1)
+        lines.append('| `%s` | %s | %.2f | %s | %.0f | %.1f | %.0f | %s | %s | %s | %s | %s |' % (
             k.split('(')[0], st.get('Calls', '?'), float(st.get('AverageNs', 0) or 0) / 1e3, st.get('Percentage', '?'),
             dd.get('FETCH_SIZE', 0), 2 * dd.get('FETCH_SIZE', 0) * 1024 / 1e6, dd.get('WRITE_SIZE', 0),
-            ('%.1f' % busy) if 'SQ_BUSY_CYCLES' in dd else '-', ('%.0f' % dd['SQ_LDS_BANK_CONFLICT']) if 'SQ_LDS_BANK_CONFLICT' in dd else '-'))
-    lines += ['', 'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs).',
+            ('%.1f' % busy) if 'SQ_BUSY_CYCLES' in dd else '-',
+            ('%.1f' % (100.0 * dd['SQ_WAIT_INST_ANY'] / wc)) if 'SQ_WAIT_INST_ANY' in dd else '-',
+            ('%.1f' % (100.0 * dd['SQ_WAIT_ANY'] / wc)) if 'SQ_WAIT_ANY' in dd else '-',
+            ('%.0f / %.0f' % (dd.get('SQ_INSTS_VALU_MFMA_F32', 0), dd.get('SQ_INSTS_VALU_MFMA_BF16', 0))) if 'SQ_INSTS_VALU_MFMA_F32' in dd else '-',
+            ('%.0f' % dd['SQ_LDS_BANK_CONFLICT']) if 'SQ_LDS_BANK_CONFLICT' in dd else '-'))
+    lines += ['', 'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); issue-stalled / parked % = the counter / SQ_WAVE_CYCLES',
+              '(quad-cycle units, MI355X_MICROARCH.md); MFMA instr = wave instructions per launch.',
               'HBM-side traffic per bench step (all engine dispatches of the counter pass / %d steps, FETCH doubled + WRITE): %.1f MB' % (n_steps, traffic / 1e6),
               '(working sets up to 256 MB are Infinity-Cache resident; these are L2-miss side counters, not DRAM bytes).', '']
     b = os.path.join(src, cfg + '.bench.json')
