@@ -177,6 +177,11 @@ class Workload(object):
     def reset(self):
         pass
 
+    def run_steps(self, i0, n):
+        """steps i0 .. i0+n-1; a workload may hand runs of steps to the engine in one call"""
+        for i in range(i0, i0 + n):
+            self.step(i)
+
 
 class RbmCD(Workload):
     name = 'rbm'
@@ -225,6 +230,18 @@ class RbmCD(Workload):
             self.dp.train_step(self.Xd, LR, MOM, self.k, row=(i % N_BATCHES) * B)   # grad_step -> all-reduce -> apply_step
         else:
             self.eng.train_step(self.Xd, B, LR, MOM, self.k, row=(i % N_BATCHES) * B)
+
+    def run_steps(self, i0, n):
+        # consecutive minibatches go to the engine as ONE call, as BaseRBM.fit() hands them over (bm_rbm_train_epoch
+        # loops over the batches in C: the same launches and RNG call counters as n train_step calls, no Python between)
+        if self.use_dp:
+            return Workload.run_steps(self, i0, n)
+        i, end = i0, i0 + n
+        while i < end:
+            b0 = i % N_BATCHES
+            m = min(end - i, N_BATCHES - b0)
+            self.eng.train_epoch(self.Xd, m * B, B, LR, MOM, self.k, row=b0 * B)
+            i += m
 
     def precondition_steps(self, seconds):
         return int(seconds * 12500)
@@ -685,16 +702,13 @@ def measure(wl, steps, warmup, precondition_s, barrier, dist):
     # steady).  A FIXED number of steps (every rank of a data-parallel run must issue the same number of
     # collectives); untimed; the model is then put back to its initial state.
     if precondition_s > 0:
-        for i in range(wl.precondition_steps(precondition_s)):
-            wl.step(i)
+        wl.run_steps(0, wl.precondition_steps(precondition_s))
         wl.reset()              # (in stream order where the workload can: no idle gap before the warm-up steps)
-    for i in range(warmup):
-        wl.step(i)
+    wl.run_steps(0, warmup)
     barrier()
     t0 = time.perf_counter()
     eng.timer_start()
-    for i in range(steps):
-        wl.step(i)
+    wl.run_steps(0, steps)
     eng.timer_mark()                     # HIP event behind the last step (read after the clock has been stopped)
     barrier()
     dt = time.perf_counter() - t0

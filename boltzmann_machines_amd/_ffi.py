@@ -80,6 +80,7 @@ SIGNATURES = {
     'bm_dbm_allreduce_grads_direct': [_vp, _vp],
     'bm_dbm_set_xchg': [_vp, _vp],
     'bm_dbm_set_fast_binary': [_vp, _i32],
+    'bm_dbm_set_mf_persistent': [_vp, _i32],
     'bm_rbm_set_fast_binary': [_vp, _i32],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],

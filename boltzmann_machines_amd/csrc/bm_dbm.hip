@@ -8,6 +8,7 @@
 #include "../../include/bm355.h"
 #include "bm_common.h"
 #include "bm_kernels.h"
+#include "bm_mf.h"
 
 #include <math.h>
 
@@ -73,6 +74,13 @@ struct bm_dbm {
     DevBuf ais_send, ais_recv;                     // bm_dbm_ais_sharded: this rank's values / the all-gathered values
     // fast-binary mode (bm_bf3.h, bm_dbm_set_fast_binary): bf16 planes of W_l (x = below unit, k = above unit) and of
     // W_l^T, bf16 shadows of the AIS state matrices; `fast_now` is set while a sweep with all-binary states runs
+    // persistent mean-field kernel (bm_mf.h): a third set of mu buffers, its synchronisation block, a pinned mirror
+    Mat mu_wk[MAXL];
+    MfSync *mfp_sync = nullptr;
+    struct MfpHost { MfCtl ctl; int status; } *mfp_host = nullptr;
+    bool mfp_failed = false;
+    bool mfp_off = true;                           // opt-in (bm_dbm_set_mf_persistent / BM355_MF_PERSIST=1): measured no faster
+                                                   // than the per-layer launches (bm_mf.h); also set when a launch gave up
     int fast = 0;
     bool fast_now = false;
     Mat16 W3[MAXL], W3t[MAXL];
@@ -260,6 +268,76 @@ static int read_flag(bm_dbm *h, float *out) {
     return 0;
 }
 
+// The mean-field loop as ONE persistent kernel (bm_mf.h), for the shape family it tiles: two Bernoulli hidden layers
+// of 512 and 1024 units, N in {128, 256, 384, 512}, a 256-CU device, no communicator.  Called after the step-0
+// condition has been latched into h->ctl.  Returns 0 with *used = 1 when the kernel produced the result (h->mu,
+// *out_steps), 0 with *used = 0 when the launch-per-layer path has to run (not eligible, or the kernel gave up: the
+// persistent mu is untouched then), non-zero on a HIP error.
+static bool mfp_eligible(const bm_dbm *h) {
+    static int env = -1, ncu = -1;
+    if (env < 0) { const char *e = getenv("BM355_MF_PERSIST"); env = e ? atoi(e) : -2; }       // -2: unset
+    if (ncu < 0) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 0; }
+    if (env == 0 || (h->mfp_off && env != 1) || h->mfp_failed || ncu != 256) return false;
+    if (h->L != 2 || h->multinomial(0) || h->multinomial(1) || h->comm || h->xchg || h->mf_reduce) return false;
+    if (h->n[1] != MFP_H1 || h->n[2] != MFP_H2 || h->N % 128 != 0 || h->N > 512) return false;
+    return h->cfg.max_mf_updates >= 1 && h->cfg.max_mf_updates <= MFP_MAXS;
+}
+static int mf_persistent(bm_dbm *h, int *used, int *out_steps) {
+    *used = 0;
+    if (!h->mu_wk[0].p) for (int i = 0; i < 2; ++i) BM_TRY(h->mu_wk[i].alloc(h->N, h->n[i + 1]));
+    if (!h->mfp_sync) {
+        BM_HIP(hipMalloc((void **)&h->mfp_sync, sizeof(MfSync)));
+        BM_HIP(hipHostMalloc((void **)&h->mfp_host, sizeof(*h->mfp_host)));
+    }
+    BM_HIP(hipMemsetAsync(h->mfp_sync, 0, sizeof(MfSync), h->stream));
+    MfpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = h->N; a.RB = h->N / 8;
+    a.xw0 = h->xw0.p; a.ld_x = h->xw0.ld;
+    a.Wt1 = h->Wt[1].p; a.ld_wt = h->Wt[1].ld;
+    a.W1 = h->W[1].p; a.ld_w = h->W[1].ld;
+    a.hb0 = h->hb[0].p; a.hb1 = h->hb[1].p;
+    a.mu1[0] = h->mu[0].p; a.mu1[1] = h->mu_alt[0].p; a.mu1[2] = h->mu_wk[0].p; a.ld1 = h->mu[0].ld;
+    a.mu2[0] = h->mu[1].p; a.mu2[1] = h->mu_alt[1].p; a.mu2[2] = h->mu_wk[1].p; a.ld2 = h->mu[1].ld;
+    a.ctl = h->ctl; a.tol = h->cfg.mf_tol; a.max_steps = h->cfg.max_mf_updates;
+    a.sy = h->mfp_sync;
+    a.timeout = 200000000ll;                       // 2 s of the 100 MHz wall clock
+    {   // BM355_MF_DEBUG=1: wall-clock stamps of one workgroup, printed after the call (measurement only)
+        static const bool dbg = getenv("BM355_MF_DEBUG") != nullptr;
+        static long long *dbuf = nullptr;
+        if (dbg && !dbuf) { BM_HIP(hipMalloc((void **)&dbuf, MFP_MAXS * 8 * sizeof(long long))); }
+        if (dbg) { BM_HIP(hipMemsetAsync(dbuf, 0, MFP_MAXS * 8 * sizeof(long long), h->stream)); a.dbg = dbuf; }
+    }
+    hipLaunchKernelGGL(mf_persistent_kernel, dim3(256), dim3(256), 0, h->stream, a);
+    BM_HIP(hipMemcpyAsync(&h->mfp_host->ctl, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipMemcpyAsync(&h->mfp_host->status, &h->mfp_sync->status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    BM_HIP(hipStreamSynchronize(h->stream));
+    if (h->mfp_host->status != 0) {
+        h->mfp_off = true; h->mfp_failed = true;
+        fprintf(stderr, "bm355: the persistent mean-field kernel gave up (status %d: %s); this handle continues on the "
+                        "launch-per-layer path\n", h->mfp_host->status,
+                h->mfp_host->status == 2 ? "more than 32 workgroups on one XCD" : "a bounded wait expired");
+        return 0;
+    }
+    if (a.dbg) {
+        std::vector<long long> t(MFP_MAXS * 8);
+        BM_HIP(hipMemcpy(t.data(), a.dbg, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int s2 = 0; s2 < 6 && t[s2 * 8]; ++s2)
+            fprintf(stderr, "mfp sweep %d (us): wait-h2 %.2f | h1 loop %.2f | decision %.2f | h1 epilogue %.2f... arrive+wait %.2f | h2 loop+epilogue %.2f | publish %.2f\n", s2,
+                    (t[s2*8+1]-t[s2*8])*0.01, (t[s2*8+2]-t[s2*8+1])*0.01, (t[s2*8+3]-t[s2*8+2])*0.01, 0.0, (t[s2*8+4]-t[s2*8+3])*0.01,
+                    (t[s2*8+5]-t[s2*8+4])*0.01, (t[s2*8+6]-t[s2*8+5])*0.01);
+    }
+    const int steps = h->mfp_host->ctl.steps;
+    if (steps > 0) {                               // the result lives in work buffer 1 + ((steps - 1) & 1): make it h->mu
+        Mat *res = ((steps - 1) & 1) ? h->mu_wk : h->mu_alt;
+        for (int i = 0; i < 2; ++i) { Mat t = h->mu[i]; h->mu[i] = res[i]; res[i] = t; }
+    }
+    h->mf_pred = steps;
+    *out_steps = steps;
+    *used = 1;
+    return 0;
+}
+
 // `_make_mf` (dbm.py:429-478).  Leaves the result in h->mu; returns executed sweeps.
 // The loop trip count is data dependent (residual > tol).  The sweeps are enqueued in groups without host
 // round trips — a device-side control word (MfCtl) latches `done` and every later launch returns at once.
@@ -331,6 +409,11 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         const size_t set_sz = (size_t)MAXL * BM_MF_SLOTS;
         if (self_ctl) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * set_sz * sizeof(float), h->stream));
         BM_TRY(ctl_step(1));
+        if (hoist && mfp_eligible(h)) {            // the whole loop in one persistent kernel (bm_mf.h)
+            int used = 0, st = 0;
+            BM_TRY(mf_persistent(h, &used, &st));
+            if (used) { if (out_n) *out_n = st; return 0; }
+        }
         // Groups of sweeps are enqueued without host round trips; the loop-control record is copied to a pinned
         // mirror after each group and READ ONE GROUP LATE: group g+1 is already in the queue when the host looks at
         // group g, so the GPU never idles waiting for the host (sweeps enqueued past the end of the loop return at
@@ -633,6 +716,9 @@ int bm_dbm_destroy(bm_dbm *h) {
         h->W3[i].release(); h->W3t[i].release();
     }
     h->ax16.release(); h->ax2_16.release(); h->av16.release(); h->ah2_16.release();
+    for (int i = 0; i < MAXL; ++i) h->mu_wk[i].release();
+    if (h->mfp_sync) (void)hipFree(h->mfp_sync);
+    if (h->mfp_host) (void)hipHostFree(h->mfp_host);
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
     DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp,
@@ -796,6 +882,14 @@ int bm_dbm_set_comm(bm_dbm *h, bm_comm *c) {
 int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
     h->fast = on ? 1 : 0;
+    return 0;
+}
+
+// 0 (default): mean-field runs one launch per layer and sweep; 1: the persistent kernel (bm_mf.h) where the shape
+// allows it.  Both produce the same bits; the persistent form measured no faster (bm_mf.h header), so it is opt-in.
+int bm_dbm_set_mf_persistent(bm_dbm *h, int32_t on) {
+    BM_CHECK(h, "null argument");
+    h->mfp_off = !on;
     return 0;
 }
 

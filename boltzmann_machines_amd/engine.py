@@ -358,6 +358,10 @@ class DbmEngine(object):
         """opt-in exact-product bf16 x 3 mode of AIS (bm_dbm_set_fast_binary)"""
         check(self.lib.bm_dbm_set_fast_binary(self._h, int(bool(on))))
 
+    def set_mf_persistent(self, on):
+        """0 (default): the mean-field loop as one launch per layer and sweep; 1: the persistent kernel where it applies"""
+        check(self.lib.bm_dbm_set_mf_persistent(self._h, int(bool(on))))
+
     def set_xchg(self, xchg):
         """like set_comm, with the per-sweep residual max over the direct peer-memory exchange (bm_dbm_set_xchg)"""
         self._xchg = xchg

@@ -357,6 +357,10 @@ int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
  * identical except where |u - p| is at round-off distance), NOT bit for bit.  Never the default. */
 int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on);
 int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on);
+/* The mean-field loop of a 2-layer DBM can run as ONE persistent kernel where the shape tiles the chip (512 / 1024
+ * hidden units, N in {128, 256, 384, 512}; csrc/bm_mf.h) instead of one launch per layer and sweep; same bits either
+ * way.  Opt-in (1): on MI355X it measured no faster than the launches it replaces (bm_mf.h); 0 = default. */
+int bm_dbm_set_mf_persistent(bm_dbm *h, int32_t on);
 /* like bm_dbm_set_comm, with the per-sweep residual max going through bm_xchg_allreduce_max1; NULL removes it */
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x);
 
