@@ -44,6 +44,8 @@ struct ActArgs {
     float *negmeans;             // may be null: -means (P operand of the negative phase in grad_kernel form 0)
     int ldo;
     PhiloxKey key;
+    const unsigned *call_dev;    // null, or a device word ADDED to key.call by the kernel: the run-time part of the RNG call
+                                 // counter when the launch is replayed from a HIP graph (bm_rbm_train_epoch)
     long long row0;              // global row of local row 0 (rank-invariant bitmaps)
     const float *prev;           // mean-field: previous mu (same layout as means) or null
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
@@ -95,11 +97,11 @@ struct ActArgs {
 constexpr int BM_MF_SLOTS = 1024;      // per-workgroup residual slots per layer (ActArgs::maxdiff_blk)
 
 // draw for 4 consecutive outputs starting at flat index `flat` (multiple of 4 on the fast path)
-__device__ __forceinline__ void draw4(const ActArgs &a, unsigned long long flat, int ib, int nvalid,
+__device__ __forceinline__ void draw4(const ActArgs &a, const PhiloxKey &key, unsigned long long flat, int ib, int nvalid,
                                       const float *m, float *s, bool aligned) {
     if (aligned) {                  // the 4 outputs are exactly one Philox block
         uint32_t wds[4];
-        philox_block(a.key, flat >> 2, wds);
+        philox_block(key, flat >> 2, wds);
         if (a.kind == 0) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[r] = (u32_to_uniform(wds[r]) < m[r]) ? 1.f : 0.f;
@@ -116,7 +118,7 @@ __device__ __forceinline__ void draw4(const ActArgs &a, unsigned long long flat,
             if (r >= nvalid) break;
             const unsigned long long idx = flat + r;
             uint32_t wds[4];
-            philox_block(a.key, idx >> 2, wds);
+            philox_block(key, idx >> 2, wds);
             if (a.kind == 0) {
                 s[r] = (u32_to_uniform(wds[idx & 3]) < m[r]) ? 1.f : 0.f;
             } else {
@@ -192,7 +194,8 @@ template <int E, class Rng> struct ActSide {
 // partial sums.  Returns the lane's mean-field residual max|m - prev| (0 without a.prev).  A function so that the
 // persistent fast-binary kernel (act_bf3_kernel) can call it once per tile of its strip.
 template <class G, int ABL, class SideT, bool HWMATH = false>
-__device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&acc)[G::MI][1], const SideT &side, int i0, int j0) {
+__device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey &key, const f32x4 (&acc)[G::MI][1], const SideT &side,
+                                              int i0, int j0) {
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
@@ -243,7 +246,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const f32x4 (&ac
                     }
                 } else {
                     const unsigned long long flat = (unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib;
-                    draw4(a, flat, ib, nvalid, m, s, false);
+                    draw4(a, key, flat, ib, nvalid, m, s, false);
                 }
             }
             const size_t o = (size_t)j * a.ldo + ib;
@@ -363,7 +366,10 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     ActSide<E, typename PhiloxFor<G::MI>::type> side;
     side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
     side.prev_row = (a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
-    side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
+    // the RNG call counter: the launch's own part plus, when replayed from a HIP graph, a device word (a scalar load)
+    PhiloxKey key = a.key;
+    if (a.call_dev) key.call += *a.call_dev;
+    side.rng.init(key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
     f32x4 acc[G::MI][1];
 #pragma unroll
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
 #endif
     BM_STAMP(1);
-    float dmax = act_epilogue<G, ABL>(a, acc, side, i0, j0);
+    float dmax = act_epilogue<G, ABL>(a, key, acc, side, i0, j0);
     if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
                                // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
         __shared__ float s_wavemax[G::NT / 64];
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(G::NT, MINW) void act_bf3_kernel(ActArgs a, Bf3Stri
         if (a.sample) side.rng.fill();             // the lane's Philox blocks, while the tile's first chunks arrive
         pipe.run(acc);
         if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * G::TJ); pipe.prefetch(); }     // next tile's pipeline fill ...
-        (void)act_epilogue<G, 0, decltype(side), true>(a, acc, side, i0, j0);              // ... under this tile's epilogue
+        (void)act_epilogue<G, 0, decltype(side), true>(a, a.key, acc, side, i0, j0);       // ... under this tile's epilogue
     }
 }
 

@@ -66,6 +66,16 @@ struct bm_rbm {
     bool fast_now = false;
     Mat16 W3, W3t, hs16, vs16;
     int *nonbinary = nullptr;  // device flag: a state handed to the fast path was not a {0,1} bitmap
+    // bm_rbm_train_epoch as a HIP graph: runs of updates that recur with the same arguments (the minibatches of an
+    // epoch, epoch after epoch) are captured once and replayed.  The RNG call counter of a replayed launch is
+    // (baked step index) + (*call_dev); the last node of the graph adds the number of steps to *call_dev.
+    struct EpochGraph { const float *X; long long N; int batch, k; float lr, mom; uint64_t seed; int64_t row0; int steps, seen; hipGraphExec_t exec; };
+    std::vector<EpochGraph> graphs;
+    unsigned *call_dev = nullptr;    // device word; its value is tracked in call_dev_val
+    uint32_t call_dev_val = 0;
+    bool capturing = false;
+    uint32_t capture_call0 = 0;
+    int epoch_graph = -1;            // bm_rbm_set_epoch_graph: 1 on, 0 off, -1: BM355_EPOCH_GRAPH (default off)
     // optional per-kernel-class event timing
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; };
@@ -92,7 +102,7 @@ static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
     k.k0 = (uint32_t)h->seed;
     k.k1 = (uint32_t)(h->seed >> 32);
     k.site = site + 16u * (uint32_t)t;
-    k.call = h->call;
+    k.call = h->capturing ? h->call - h->capture_call0 : h->call;     // graph capture: the step index; *call_dev adds the rest
     return k;
 }
 
@@ -113,6 +123,7 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.sample = states ? sample : 0;               // no consumer of the states: no draw
     a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
+    a.call_dev = h->capturing ? h->call_dev : nullptr;
     a.row0 = h->row0;
     if (h->fast_now && v == h->vs.p) {           // fast-binary: W^T planes x the bf16 shadow of the visible bitmap
         a.b3.P1 = Bf3Operand{h->W3t.p, h->W3t.plane_stride(), h->W3t.ld, h->H};
@@ -154,6 +165,7 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
     a.sample = sample;
     a.means = means; a.states = states; a.ldo = ldo;
     a.key = make_key(h, site, t);
+    a.call_dev = h->capturing ? h->call_dev : nullptr;
     a.row0 = h->row0;
     if (h->fast_now && hs == h->hs.p) {          // fast-binary: W planes x the bf16 shadow of the hidden bitmap
         a.b3.P1 = Bf3Operand{h->W3.p, h->W3.plane_stride(), h->W3.ld, h->V};
@@ -429,6 +441,8 @@ int bm_rbm_destroy(bm_rbm *h) {
     for (DevBuf *b : all) b->release();
     h->W3.release(); h->W3t.release(); h->hs16.release(); h->vs16.release();
     if (h->nonbinary) (void)hipFree(h->nonbinary);
+    for (auto &e : h->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (h->call_dev) (void)hipFree(h->call_dev);
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -550,12 +564,85 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr
     return 0;
 }
 
-int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
-    BM_CHECK(batch >= 1 && N >= 1, "bad N=%lld batch=%d", (long long)N, batch);
+__global__ void bump_call_kernel(unsigned *p, unsigned n) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += n; }
+
+static int train_epoch_eager(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
     for (int64_t s = 0; s < N; s += batch) {
         const int B = (int)((N - s < batch) ? (N - s) : batch);
         BM_TRY(bm_rbm_train_step(h, X_dev + (size_t)s * h->V, B, lr, mom, k));
     }
+    return 0;
+}
+
+// OPT-IN (bm_rbm_set_epoch_graph / BM355_EPOCH_GRAPH=1): runs of >= 4 plain updates (Bernoulli units, no dropout: no
+// host-dependent side kernels) that recur with the same arguments are replayed from a HIP graph: captured at the second
+// occurrence (the first one ran eagerly and tuned every launch), kept in a small cache; the RNG call counter of a
+// replayed launch is its baked step index plus a device word.  Same kernels, same arguments, same counters: same bits
+// (tests/test_rbm_parity_gpu.py).  MEASURED SLOWER on MI355X / ROCm 7.2 at the north-star shape, so it is off by
+// default: 66.3 against 65.4 us per update in 20-update replays over 2000 updates, and 75 - 77 against 69 us when the
+// timed region is a single 20-update replay (the replay's start-up costs more than the 0.35 us per kernel boundary
+// that tools/probe_act measured for a graph of identical launches gives back).
+int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
+    BM_CHECK(batch >= 1 && N >= 1, "bad N=%lld batch=%d", (long long)N, batch);
+    static const bool env_on = getenv("BM355_EPOCH_GRAPH") && atoi(getenv("BM355_EPOCH_GRAPH")) == 1;
+    const bool off = h->epoch_graph < 0 ? !env_on : h->epoch_graph == 0;
+    const int steps = (int)((N + batch - 1) / batch);
+    const bool plain = h->cfg.v_unit == BM_UNIT_BERNOULLI && !h->multinomial() && h->cfg.dropout < 0.f && !h->prof;
+    if (off || !plain || steps < 4 || steps > 4096 || batch > h->maxB) return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
+    bm_rbm::EpochGraph *g = nullptr;
+    for (auto &e : h->graphs)
+        if (e.X == X_dev && e.N == N && e.batch == batch && e.k == k && e.lr == lr && e.mom == mom && e.seed == h->seed &&
+            e.row0 == h->row0) { g = &e; break; }        // (the seed and the row offset are baked into the launches)
+    if (!g) {                                   // first occurrence: remember it, run eagerly (this also tunes the launches)
+        if (h->graphs.size() >= 64) {           // cache full: drop the oldest entry
+            if (h->graphs.front().exec) (void)hipGraphExecDestroy(h->graphs.front().exec);
+            h->graphs.erase(h->graphs.begin());
+        }
+        h->graphs.push_back(bm_rbm::EpochGraph{X_dev, (long long)N, batch, k, lr, mom, h->seed, h->row0, steps, 1, nullptr});
+        return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
+    }
+    if (!h->call_dev) {
+        BM_HIP(hipMalloc((void **)&h->call_dev, sizeof(unsigned)));
+        BM_HIP(hipMemsetAsync(h->call_dev, 0, sizeof(unsigned), h->stream));
+        h->call_dev_val = 0;
+    }
+    if (!g->exec) {                             // second occurrence: capture
+        hipGraph_t graph = nullptr;
+        const uint32_t call0 = h->call;
+        BM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing = true; h->capture_call0 = call0;
+        int rc = train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
+        hipLaunchKernelGGL(bump_call_kernel, dim3(1), dim3(64), 0, h->stream, h->call_dev, (unsigned)steps);
+        h->capturing = false;
+        h->call = call0;                        // nothing ran: the counter moves when the graph does
+        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            g->exec = nullptr;
+            g->seen = -1000000;                 // this run is not capturable here: stay eager
+            return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
+        }
+        (void)hipGraphDestroy(graph);
+    }
+    if (g->seen < 0) return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
+    if (h->call_dev_val != h->call) {           // eager calls moved the host counter since the last replay
+        BM_HIP(hipMemsetD32Async((hipDeviceptr_t)h->call_dev, (int)h->call, 1, h->stream));
+        h->call_dev_val = h->call;
+    }
+    BM_HIP(hipGraphLaunch(g->exec, h->stream));
+    h->call += (uint32_t)steps;
+    h->call_dev_val += (uint32_t)steps;
+    g->seen++;
+    // what the eager path leaves in the handle
+    h->hm_is_neg = true;
+    h->Xin = X_dev + (size_t)(steps - 1) * batch * h->V; h->Xin_ld = h->V;
+    return 0;
+}
+
+int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on) {
+    BM_CHECK(h, "null argument");
+    h->epoch_graph = on ? 1 : 0;
     return 0;
 }
 

@@ -105,6 +105,10 @@ class RbmEngine(object):
         """N rows starting at `row`, consecutive batches of `batch` rows, driven from C (no Python per batch)"""
         check(self.lib.bm_rbm_train_epoch(self._h, Xd.offset_ptr(row * self.V), N, batch, lr, momentum, k))
 
+    def set_epoch_graph(self, on):
+        """train_epoch replays recurring runs of updates from a HIP graph (opt-in; measured slower, bm_rbm.hip)"""
+        check(self.lib.bm_rbm_set_epoch_graph(self._h, int(bool(on))))
+
     def grad_step(self, Xd, B, k, row=0):
         check(self.lib.bm_rbm_grad_step(self._h, Xd.offset_ptr(row * self.V), B, k))
 

@@ -121,6 +121,9 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
  * leaves the raw un-normalised sums in the "grad" buffer
  * [pos-neg (V*H) | sum(X-v) (V) | sum(h0-hk) (H) | sum(hk) (H)]; the caller
  * all-reduces that buffer (RCCL) and calls phase 2 with the GLOBAL batch. */
+/* bm_rbm_train_epoch may replay recurring runs of updates from a HIP graph (1) instead of launching them one by one
+ * (0, the default: the replay measured slower on MI355X / ROCm 7.2, csrc/bm_rbm.hip); same bits either way */
+int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on);
 int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B_local, int32_t n_gibbs_steps);
 int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float learning_rate, float momentum);
 

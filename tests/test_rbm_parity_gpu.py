@@ -339,3 +339,34 @@ def test_long_run_stays_bit_exact(gpu_lib):
     assert_state_equal(eng, twin)
     assert np.all(np.isfinite(eng.get('W')))
     eng.close()
+
+
+def test_train_epoch_graph_replay_bit_exact(gpu_lib):
+    """bm_rbm_train_epoch replays recurring runs of updates from a HIP graph (captured at the second occurrence, the
+    RNG call counter added on the device): eager, capturing and replaying calls, interleaved with single steps and a
+    re-seed, all stay bit-identical to the oracle stepping through the same minibatches."""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B, NB = 96, 64, 16, 6
+    eng, twin = make_pair(V, H, max_batch=B, sample_v_states=True, l2=1e-4)
+    eng.set_epoch_graph(True)                   # opt-in
+    X = synth_data(NB * B + 5, V, 3)            # a ragged last batch inside the run
+    Xd = as_device(X)
+    eng.seed(11); twin.set_seed(11)
+
+    def epoch(lr):
+        eng.train_epoch(Xd, len(X), B, lr, 0.5, 1)
+        for s in range(0, len(X), B):
+            twin.train_step(X[s:s + B], lr, 0.5, 1)
+    for rep in range(4):                        # eager, capture + replay, replay, replay
+        epoch(0.05)
+        assert_state_equal(eng, twin)
+    eng.train_step(Xd, B, 0.05, 0.5, 1)         # an eager step in between moves the host-side call counter
+    twin.train_step(X[:B], 0.05, 0.5, 1)
+    epoch(0.05)
+    assert_state_equal(eng, twin)
+    epoch(0.01); epoch(0.01); epoch(0.01)       # another learning rate: its own graph
+    assert_state_equal(eng, twin)
+    eng.seed(12); twin.set_seed(12)             # a new seed must not replay launches that baked the old one
+    epoch(0.05); epoch(0.05)
+    assert_state_equal(eng, twin)
+    eng.close()
