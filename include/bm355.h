@@ -113,17 +113,18 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B,
  * (base_rbm.py:549-571) behind ONE call: N rows, consecutive batches of `batch` rows (last one may be
  * short).  The library enqueues every update's four launches from a native loop, asynchronously on the
  * handle's stream (no synchronisation, no device-to-host traffic, one FFI crossing per run of batches);
- * the stream stays GPU-bound, a HIP graph of the same launches measured 0.35 us per kernel less. */
+ * the stream stays GPU-bound. */
 int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
                        float learning_rate, float momentum, int32_t n_gibbs_steps);
+
+/* bm_rbm_train_epoch may replay recurring runs of updates from a HIP graph (1) instead of launching them one by one
+ * (0, the default: the replay measured slower on MI355X / ROCm 7.2, csrc/bm_rbm.hip); same bits either way */
+int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on);
 
 /* Data-parallel split of a train step: phase 1 runs the chain and
  * leaves the raw un-normalised sums in the "grad" buffer
  * [pos-neg (V*H) | sum(X-v) (V) | sum(h0-hk) (H) | sum(hk) (H)]; the caller
  * all-reduces that buffer (RCCL) and calls phase 2 with the GLOBAL batch. */
-/* bm_rbm_train_epoch may replay recurring runs of updates from a HIP graph (1) instead of launching them one by one
- * (0, the default: the replay measured slower on MI355X / ROCm 7.2, csrc/bm_rbm.hip); same bits either way */
-int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on);
 int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B_local, int32_t n_gibbs_steps);
 int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float learning_rate, float momentum);
 
@@ -273,7 +274,9 @@ int bm_dbm_sample_v(bm_dbm *h, int32_t n_gibbs_steps, float *V_dev);
  * DBM: n_runs chains, n_betas temperatures, n_gibbs_steps transitions per
  * temperature.  values_host [n_runs] receives the per-chain log Z estimates
  * (host post-processing with log_mean_exp stays in Python, dbm.py:935-939).
- * chain0 = global index of this rank's first chain (chains shard over ranks). */
+ * chain0 = global index of this rank's first chain (chains shard over ranks).
+ * The per-beta terms are fp32 as in the reference; their sum over the betas is kept in DOUBLE on the device (the
+ * reference accumulates it in fp32, dbm.py:708-728, and loses nats at 1000 betas): a deliberate, documented deviation. */
 int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t n_gibbs_steps,
                uint64_t seed, int64_t chain0, float *values_host);
 /* log_proba op (dbm.py:738-759): MF then -E_q[E] + H(mu) per row of
