@@ -40,6 +40,11 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Host waits spin instead of sleeping (ROCclr polls for ROC_ACTIVE_WAIT_TIMEOUT microseconds before it blocks on an
+# interrupt; read when the runtime initialises, hence set before anything imports it): the barrier that ends the timed
+# region otherwise returns tens of microseconds after the last kernel - 1 % of a 20-update region.  Same policy as
+# bm_set_device's hipDeviceScheduleSpin.
+os.environ.setdefault('ROC_ACTIVE_WAIT_TIMEOUT', '1000000')
 
 V, H, B = 784, 1024, 512
 LR, MOM, L2 = 0.05, 0.9, 1e-5            # examples/rbm_mnist.py:160,166,55
@@ -604,6 +609,9 @@ def choose_collective(args, eng, rank, world, dist):
             return 'gloo', 'RCCL refuses two ranks on one device (dry run on a box with fewer GPUs than ranks)'
         return want, None
     note = None
+    # a lost rank or an unusable peer mapping must show up within seconds at start-up, not after the library's
+    # default 20 s per in-kernel wait
+    os.environ.setdefault('BM_XCHG_TIMEOUT_S', '4')
     try:
         x = parallel.DirectExchange(eng, rank, world)
         grad = eng.device_view('grad')
