@@ -415,7 +415,8 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
 // the AIS visible update, 1.3 us of it matrix time).  Here a workgroup owns tile row ti and a strip of tile columns
 // [tj0, tj1): the first chunks of tile tj+1 are requested BEFORE the epilogue of tile tj runs, the bias / sigma
 // loads and the DMA plan of the weight planes are done once per strip.
-struct Bf3Strip { int tiles_i, tiles_j, strips; };      // grid = tiles_i * strips; strip s of row ti: blocks ti * strips + s
+struct Bf3Strip { int tiles_i, tiles_j, strips, abl; };  // grid = tiles_i * strips; strip s of row ti: blocks ti * strips + s
+                                                         // abl (BM355_BF3_ABL, measurements only): 1 no epilogue, 2 no K loop
 
 template <class G, bool SEG2, int MINW>
 __global__ __launch_bounds__(G::NT, MINW) void act_bf3_kernel(ActArgs a, Bf3Strip sp) {
@@ -444,9 +445,57 @@ __global__ __launch_bounds__(G::NT, MINW) void act_bf3_kernel(ActArgs a, Bf3Stri
         for (int t = 0; t < G::MI; ++t) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
         side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
         if (a.sample) side.rng.fill();             // the lane's Philox blocks, while the tile's first chunks arrive
-        pipe.run(acc);
+        if (!(sp.abl & 2)) pipe.run(acc);
         if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * G::TJ); pipe.prefetch(); }     // next tile's pipeline fill ...
-        (void)act_epilogue<G, 0, decltype(side), true>(a, a.key, acc, side, i0, j0);       // ... under this tile's epilogue
+        if (!(sp.abl & 1)) (void)act_epilogue<G, 0, decltype(side), true>(a, a.key, acc, side, i0, j0);   // ... under this tile's epilogue
+    }
+}
+
+// the wide-tile form (bm_bf3.h Bf3W): 64 x 128 outputs per workgroup, a wave owns 32 x 64 = four row blocks of the
+// 32 x 16 epilogue tile; act_epilogue runs once per row block (its geometry argument only supplies the 32 x 16 lane
+// layout: GeoAct has the same 2-wide wave grid along i)
+template <bool SEG2>
+__global__ __launch_bounds__(256, 1) void act_bf3w_kernel(ActArgs a, Bf3Strip sp) {
+    __shared__ __attribute__((aligned(16))) float smem[Bf3W::SMEM_FLOATS];
+    using G = GeoAct;
+    constexpr int E = G::E;
+    const int ti = (int)blockIdx.x / sp.strips, st = (int)blockIdx.x % sp.strips;
+    const int per = sp.tiles_j / sp.strips, rem = sp.tiles_j % sp.strips;
+    const int tj0 = st * per + (st < rem ? st : rem), tj1 = tj0 + per + (st < rem ? 1 : 0);
+    const int i0 = ti * Bf3W::TI;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wi = w & 1, wj = w >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int ib0 = i0 + wi * 32 + g * E;
+    ActSide<E, typename PhiloxFor<G::MI>::type> side;
+    side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = 0;
+    side.prev_row = nullptr;
+    side.fill();
+    side.with_rng = a.sample;
+    Bf3wPipe<SEG2> pipe;
+    pipe.setup(a.b3, i0, smem);
+    if (tj0 < tj1) { pipe.set_tile(a.b3, tj0 * Bf3W::TJ); pipe.prefetch(); }
+    for (int tj = tj0; tj < tj1; ++tj) {
+        const int j0 = tj * Bf3W::TJ;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (!(sp.abl & 2)) pipe.run(acc);
+        if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * Bf3W::TJ); pipe.prefetch(); }
+        if (!(sp.abl & 1)) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int jn = j0 + wj * 64 + 16 * n;              // first row of this wave's row block n
+                const int j = jn + l15;
+                side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
+                if (a.sample) side.rng.fill();
+                f32x4 an[2][1] = {{acc[0][n]}, {acc[1][n]}};
+                // act_epilogue computes the row as j0' + (w / G::WI) * 16 + l15 with w / G::WI = wj here
+                (void)act_epilogue<G, 0, decltype(side), true>(a, a.key, an, side, i0, jn - wj * 16);
+            }
+        }
     }
 }
 
@@ -1496,13 +1545,15 @@ static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
 // fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
 // ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
 // sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
-// tile columns.  BM355_BF3_GEO=8|4|2 forces one.
+// tile columns.  BM355_BF3_GEO=8|4|2|16 forces one (16: the wide tile of act_bf3w_kernel, measured slower).
 template <class G, int WGS_PER_CU>
 static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
     Bf3Strip sp;
     sp.tiles_i = (a.I + G::TI - 1) / G::TI; sp.tiles_j = (a.J + G::TJ - 1) / G::TJ;
+    static const int abl_env = getenv("BM355_BF3_ABL") ? atoi(getenv("BM355_BF3_ABL")) : 0;
+    sp.abl = abl_env;
     sp.strips = (ncu * WGS_PER_CU) / sp.tiles_i;
     if (sp.strips < 1) sp.strips = 1;
     if (sp.strips > sp.tiles_j) sp.strips = sp.tiles_j;
@@ -1516,6 +1567,23 @@ static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
     if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
     int geo = geo_env;
     if (!geo) geo = tile_grid<GeoBf3S>(a.I, a.J) >= 1024 ? 2 : 4;
+    if (geo == 16) {               // the wide tile (64 x 128, 4 waves of 32 x 64), BM355_BF3_GEO=16 only: its K loop is faster
+                                   // (18.6 against 22 ms per 100 AIS betas) but one wave per SIMD runs four epilogues back to
+                                   // back with nothing to overlap them (26 against 15 ms): 61.8 against 44.5 ms in total
+        static int ncu = 0;
+        if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+        static const int abl_env = getenv("BM355_BF3_ABL") ? atoi(getenv("BM355_BF3_ABL")) : 0;
+        Bf3Strip sp;
+        sp.tiles_i = (a.I + Bf3W::TI - 1) / Bf3W::TI; sp.tiles_j = (a.J + Bf3W::TJ - 1) / Bf3W::TJ;
+        sp.abl = abl_env;
+        sp.strips = ncu / sp.tiles_i;
+        if (sp.strips < 1) sp.strips = 1;
+        if (sp.strips > sp.tiles_j) sp.strips = sp.tiles_j;
+        const dim3 grid(sp.tiles_i * sp.strips), blk(256);
+        if (a.b3.K2 > 0) hipLaunchKernelGGL((act_bf3w_kernel<true>), grid, blk, 0, st, a, sp);
+        else             hipLaunchKernelGGL((act_bf3w_kernel<false>), grid, blk, 0, st, a, sp);
+        return;
+    }
     if (geo == 8)      launch_act_bf3_geo<GeoGrad8, 1>(a, st);
     else if (geo == 2) launch_act_bf3_geo<GeoBf3S, 2>(a, st);
     else               launch_act_bf3_geo<GeoAct, 1>(a, st);
