@@ -266,15 +266,38 @@ class DirectExchange(object):
         lib = _ffi.load()
         self._dbm = isinstance(engine, DbmEngine)
         self._c = C.c_void_p()
-        create = lib.bm_dbm_xchg_create if self._dbm else lib.bm_rbm_xchg_create
-        _ffi.check(create(engine._h, rank, world, C.byref(self._c)))
+        # Set-up is COLLECTIVE and symmetric: every rank reaches the one gather, carrying its blob or its error; if
+        # any rank failed - before or after the gather - every rank raises (the second, cheap gather confirms the
+        # attach), so no rank is left waiting in a collective another rank never enters.
+        err, blob = None, None
+        try:
+            create = lib.bm_dbm_xchg_create if self._dbm else lib.bm_rbm_xchg_create
+            _ffi.check(create(engine._h, rank, world, C.byref(self._c)))
+            if world > 1:
+                buf = (C.c_char * 256)()
+                _ffi.check(lib.bm_xchg_export(self._c, buf))
+                blob = bytes(buf)
+        except Exception as e:      # noqa: BLE001
+            err = '%s: %s' % (type(e).__name__, e)
         if world > 1:
-            blob = (C.c_char * 256)()
-            _ffi.check(lib.bm_xchg_export(self._c, blob))
-            blobs = (gather or default_gather(rank, world))(bytes(blob))
-            assert len(blobs) == world and all(len(b) == 256 for b in blobs)
-            allb = (C.c_char * (256 * world)).from_buffer_copy(b''.join(blobs))
-            _ffi.check(lib.bm_xchg_attach(self._c, allb))
+            gather = gather or default_gather(rank, world)
+            got = gather((err, blob))
+            if err is None and not any(g[0] for g in got):
+                try:
+                    blobs = [g[1] for g in got]
+                    assert len(blobs) == world and all(b is not None and len(b) == 256 for b in blobs)
+                    allb = (C.c_char * (256 * world)).from_buffer_copy(b''.join(blobs))
+                    _ffi.check(lib.bm_xchg_attach(self._c, allb))
+                except Exception as e:      # noqa: BLE001
+                    err = '%s: %s' % (type(e).__name__, e)
+            errs = [g[0] for g in got if g[0]] + ([err] if err and not any(g[0] for g in got) else [])
+            confirm = gather((err if err else None, None))
+            errs = [c[0] for c in confirm if c[0]] or errs
+            if errs:
+                self.close()
+                raise _ffi.Bm355Error('direct exchange set-up failed on %d rank(s): %s' % (len(errs), errs[0]))
+        elif err:
+            raise _ffi.Bm355Error(err)
 
     def allreduce_grads(self, engine=None):
         """in-place all-reduce(sum) of the engine's fused grad buffer, one kernel on the engine's stream"""
@@ -321,13 +344,21 @@ def direct_allreduce_on_engine_stream(engine, xchg):
     return allreduce_
 
 
+_SOCKET_CALLS = [0]
+
+
 def socket_allgather(payload, rank, world, addr=None, port=None, timeout=120.0):
-    """every rank sends `payload` (bytes) to rank 0 over TCP and receives the list of all payloads (rank order)"""
+    """every rank sends `payload` (anything picklable) to rank 0 over TCP and receives the list of all payloads (rank order)"""
     import pickle
     import socket
     import time
     addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
-    port = int(port or int(os.environ.get('MASTER_PORT', '29533')) + 2)
+    if port is None:
+        # every call of a process takes the next port (all ranks call in the same order): a client of call n+1 must
+        # not land in the backlog of call n's listening socket, which rank 0 is about to close
+        port = int(os.environ.get('MASTER_PORT', '29533')) + 2 + _SOCKET_CALLS[0]
+        _SOCKET_CALLS[0] += 1
+    port = int(port)
 
     def recv_msg(c):
         buf = b''
