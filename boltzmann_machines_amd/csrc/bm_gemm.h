@@ -125,6 +125,8 @@ using GeoAct8 = Geo<2, 4, 1, 1, 64>;     // 32 x 64 tile, 8 waves of 16 x 16 (tw
 using GeoActS = Geo<2, 2, 1, 1, 64>;     // 32 x 32 tile, 4 waves of 16 x 16, 64 KiB LDS (two per CU): for
                                          // outputs too small to give every CU a larger tile
 using GeoActS32 = Geo<2, 2, 1, 1, 32>;   // the same with BK = 32: 32 KiB LDS, up to four workgroups per CU
+using GeoAct32 = Geo<2, 2, 2, 1, 32>;     // 64 x 32 tile, 4 waves of 32 x 16, BK = 32: 48 KiB LDS, three workgroups per CU;
+                                         // 3/4 of the operand bytes per flop of the 32 x 32 tile (k-major P only)
 using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 4 waves of 32 x 32, 128 KiB LDS
 using GeoGrad8 = Geo<2, 4, 2, 1, 64>;    // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD), 128 KiB LDS
 using GeoBf3S = Geo<1, 4, 2, 1, 64>;     // 32 x 64 tile, 4 waves of 32 x 16: the fast-binary path's two-workgroups-per-CU tile (bm_bf3.h)

@@ -1616,6 +1616,11 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     // 32 x 64 tile, for outputs large enough to fill the chip with tiles of that size
     if (geo == 6 && !a.p_xm) { launch_act_geo<GeoGrad8, 1, STG_DMA>(a, st); return; }
     if (geo == 6) geo = 8;
+    // 5: 64 x 32 tile with BK = 32, three workgroups per CU (k-major P only)
+    if (geo == 5 && !a.p_xm) { launch_act_geo<GeoAct32, 3, STG_DMA>(a, st); return; }
+    // 7: the same with two workgroups per CU (256 registers per wave: the two-segment variant spills 140 bytes at 168)
+    if (geo == 7 && !a.p_xm) { launch_act_geo<GeoAct32, 2, STG_DMA>(a, st); return; }
+    if (geo == 5 || geo == 7) geo = 3;
     const bool reg = geo >= 100;
     geo %= 100;
     if (a.p_xm && geo == 4) geo = 8;        // x-major P exists for the MI == 1 geometries only
@@ -1632,10 +1637,10 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     }
 }
 struct ActTune {
-    static constexpr int NC = 9;
+    static constexpr int NC = 11;
     int best = 0;
     int xi = 0;                  // XCD grid of the block -> tile map (TileMap), measured with the chosen geometry
-    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 // scratch pool of the tuning launches (per process and device; grown on demand, never on the hot path)
 struct TuneScratch {
@@ -1651,7 +1656,7 @@ struct TuneScratch {
     }
 };
 static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6};
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6, 5, 7};
     constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
     static TuneScratch pool;
     const size_t mat = ((size_t)a.J * (size_t)a.ldo + 3) & ~(size_t)3;
@@ -1674,10 +1679,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
-    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < TUNE_ROUNDS; ++round) {
         for (int c = 0; c < ActTune::NC; ++c) {
-            if (a.p_xm && (cand_geo[c] % 100 == 4 || cand_geo[c] == 6)) continue;   // not instantiated for an x-major P
+            if (a.p_xm && (cand_geo[c] % 100 == 4 || cand_geo[c] == 6 || cand_geo[c] == 5 || cand_geo[c] == 7)) continue;   // not instantiated for an x-major P
             launch_act_as(cand_geo[c], t, st);                    // warm (instruction cache, clocks)
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < TUNE_REP; ++r) launch_act_as(cand_geo[c], t, st);
@@ -1718,9 +1723,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us, dma: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; "
-                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f)\n",
+                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f; 64x32/bk32 x3: %.1f, x2: %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0] > 1e29f ? -1.f : T.t_us[0], T.t_us[1] > 1e29f ? -1.f : T.t_us[1], T.t_us[2], T.t_us[3],
-                T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7], T.t_us[8] > 1e29f ? -1.f : T.t_us[8]);
+                T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7], T.t_us[8] > 1e29f ? -1.f : T.t_us[8],
+                T.t_us[9] > 1e29f ? -1.f : T.t_us[9], T.t_us[10] > 1e29f ? -1.f : T.t_us[10]);
     if (log && tune_xi)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> XCD grid %d x %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.xi, T.xi ? 8 / T.xi : 0, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);

@@ -11,6 +11,8 @@ Unit types: Bernoulli or Gaussian visible layer; Bernoulli or Multinomial hidden
 model of examples/dbm_cifar.py is Gaussian-Bernoulli-Multinomial; `log_Z` / `log_proba` need all-Bernoulli
 layers like the reference, dbm.py:925-927, :947-948).
 """
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -203,6 +205,10 @@ class DBM(EngineModel):
                                  max_norm=self.max_norm, sparsity_target=self.sparsity_target,
                                  sparsity_cost=self.sparsity_cost, sparsity_damping=self.sparsity_damping,
                                  h_units=self.h_units_ or None, n_samples=self.h_n_samples_ or None)
+        # opt-in speed mode for log_Z (AIS): exact-product bf16 x 3 for the {0,1}-state contractions; tolerance parity
+        # (DESIGN.md 3.9).  The reference API has no switch for it, so it is read from the environment.
+        if os.environ.get('BM355_FAST_BINARY', '0') == '1':
+            self._engine.set_fast_binary(True)
         if self._pending_vars is None:          # fresh model (load_model uploads its checkpoint instead)
             self._upload_variables(self._initial_variables())
         # Multi-GPU job (one process per GPU): rank r owns rows [r*batch_size, ...) of every global
