@@ -411,6 +411,8 @@ class Grbm(_DbmBase):
         X = philox.normal(1, 100 + rank, 0, 4 * N_ * V_).reshape(4 * N_, V_).astype(np.float32)
         self.Xd = as_device(X)
         eng.seed(1)
+        self.fast = bool(getattr(args, 'fast_binary', False))
+        eng.set_fast_binary(self.fast)
         self.nmf = []
         self._dp_setup(args, rank, world, dist)
 
@@ -438,7 +440,10 @@ class Grbm(_DbmBase):
             'config': {'workload': 'Gaussian-Bernoulli RBM 3072x5000 PCD-5 batch=256 fp32 (BASELINE configs[2])',
                        'n_visible': self.GV, 'n_hidden': self.GH, 'batch_per_gpu': self.GN, 'n_particles_per_gpu': self.GN,
                        'n_gibbs_steps': self.GK, 'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world,
-                       'collective': COLLECTIVE_NAMES.get(self.collective, self.collective)},
+                       'collective': COLLECTIVE_NAMES.get(self.collective, self.collective),
+                       'fast_binary': (FAST_NOTE + ' Here: the 5 top-down (h -> v) contractions of the PCD sweeps; the '
+                                       'bottom-up ones read real-valued visibles and stay fp32, as do the data pass and '
+                                       'the outer products.') if self.fast else False},
             'flops_per_step': flops,
             'roofline_extra': {'scope': 'whole PCD-5 update = (2*5+3)*2*B*V*H = %.1f GFLOP (SURVEY 8d)' % (flops / 1e9),
                                'traffic': pmc_traffic('grbm')},
@@ -463,6 +468,8 @@ class Dbm(_DbmBase):
         X = (philox.uniform(1, 200 + rank, 0, 4 * N_ * V_) < 0.13).astype(np.float32).reshape(4 * N_, V_)
         self.Xd = as_device(X)
         eng.seed(1)
+        self.fast = bool(getattr(args, 'fast_binary', False))
+        eng.set_fast_binary(self.fast)
         self.nmf = []
         self._dp_setup(args, rank, world, dist)
 
@@ -494,7 +501,9 @@ class Dbm(_DbmBase):
                        'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world,
                        'collective': ('%s: all-reduce(max) of the mean-field residual per sweep + one all-reduce(sum) of '
                                       'the fused gradient buffer' % COLLECTIVE_NAMES.get(self.collective, self.collective))
-                       if self.comm is not None else None, 'collective_note': self.collective_note},
+                       if self.comm is not None else None, 'collective_note': self.collective_note,
+                       'fast_binary': (FAST_NOTE + ' Here: the PCD particle sweeps; mean-field (real-valued mu) and the '
+                                       'outer products stay fp32.') if self.fast else False},
             'flops_per_step': flops,
             'roofline_extra': {'scope': 'whole update, SURVEY 8d formula with T = %.1f executed mean-field sweeps = %.2f GFLOP'
                                         % (T, flops / 1e9), 'traffic': pmc_traffic('dbm')},
@@ -551,7 +560,8 @@ WORKLOADS = {w.name: w for w in (RbmCD, RbmGibbs, Grbm, Dbm, Ais)}
 DEFAULTS = {'rbm': (2000, 100), 'gibbs': (300, 30), 'grbm': (30, 5), 'dbm': (40, 5), 'ais': (2, 1)}
 # the short passes the default run adds behind the headline: (steps, warm-up, untimed precondition seconds)
 OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 20, 5, 0.2), ('ais', 1, 1, 0.0),
-          ('gibbs+fast_binary', 100, 10, 0.2), ('ais+fast_binary', 1, 1, 0.0))
+          ('gibbs+fast_binary', 100, 10, 0.2), ('ais+fast_binary', 1, 1, 0.0), ('grbm+fast_binary', 12, 3, 0.2),
+          ('dbm+fast_binary', 20, 5, 0.2))
 FAST_NOTE = ('NON-DEFAULT opt-in mode: exact-product bf16 x 3 on the bf16 matrix cores (csrc/bm_bf3.h); results agree with '
              'the f32 chain to fp32 round-off, not bit for bit; the roofline block still prices the algorithmic flops '
              'against the fp32-MFMA peak, so frac may exceed what an f32 kernel can reach')
@@ -764,7 +774,7 @@ def main():
     ap.add_argument('--ais-betas', type=int, default=1000)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--fast-binary', action='store_true',
-                    help='gibbs / ais: the opt-in exact-product bf16 x 3 mode (bm_*_set_fast_binary); a NON-default, '
+                    help='gibbs / ais / grbm / dbm: the opt-in exact-product bf16 x 3 mode (bm_*_set_fast_binary); a NON-default, '
                          'tolerance-parity mode, reported separately from the f32 figures')
     ap.add_argument('--no-others', action='store_true',
                     help='rbm: do not add the short passes of the other BASELINE configurations (`other_configs`)')

@@ -322,20 +322,45 @@ template <bool SEG2> struct Bf3wPipe {
 // fp32 matrix -> three bf16 planes (exact: w = hi + mid + lo), x-major with k contiguous.
 //   transpose == 0: out[plane][r][c] = split(W[r][c])  (rows of W are the x of the operand, columns its k)
 //   transpose == 1: out[plane][c][r] = split(W[r][c])
-// The padding (k >= the matrix extent, up to ld) is left as the caller zero-initialised it.
+// The padding beyond the 8-k group that holds the last k (up to ld) is left as the caller zero-initialised it; inside
+// that group it is written as zero.
+// One thread splits 8 consecutive k of one x and stores three 16-byte chunks (the planes' rows are 128-byte aligned);
+// for the transposed build adjacent threads take adjacent columns of W, so the 8 strided reads stay coalesced.
+__device__ __forceinline__ void split3(float w, uint32_t &h, uint32_t &m, uint32_t &l) {
+    const uint32_t hb = __float_as_uint(w) & 0xffff0000u;
+    const float r1 = w - __uint_as_float(hb);
+    const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    h = hb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
+}
 __global__ void split3_kernel(const float *W, int ldw, int rows, int cols, uint16_t *out, long long plane_stride, int ld, int transpose) {
-    const size_t n = (size_t)rows * cols;
+    const int nx = transpose ? cols : rows, nk = transpose ? rows : cols;      // operand rows / contraction length
+    const int kg = (nk + 7) >> 3;
+    const size_t n = (size_t)nx * kg;
+    const bool vec = !transpose && (ldw & 3) == 0 && (((uintptr_t)W & 15u) == 0);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(e / (size_t)cols), c = (int)(e % (size_t)cols);
-        const float w = W[(size_t)r * ldw + c];
-        const uint32_t hb = __float_as_uint(w) & 0xffff0000u;
-        const float r1 = w - __uint_as_float(hb);
-        const uint32_t mb = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mb);
-        const size_t o = transpose ? (size_t)c * ld + r : (size_t)r * ld + c;
-        out[o] = (uint16_t)(hb >> 16);
-        out[(size_t)plane_stride + o] = (uint16_t)(mb >> 16);
-        out[2 * (size_t)plane_stride + o] = (uint16_t)(__float_as_uint(r2) >> 16);
+        // transposed: x fastest across threads (coalesced reads of W rows); plain: k-group fastest (coalesced both ways)
+        const int x = transpose ? (int)(e % (size_t)nx) : (int)(e / (size_t)kg);
+        const int k0 = 8 * (transpose ? (int)(e / (size_t)nx) : (int)(e % (size_t)kg));
+        float w[8];
+        if (vec && k0 + 8 <= nk) {
+            const float4 a = *reinterpret_cast<const float4 *>(W + (size_t)x * ldw + k0);
+            const float4 b = *reinterpret_cast<const float4 *>(W + (size_t)x * ldw + k0 + 4);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q;
+                w[q] = k < nk ? (transpose ? W[(size_t)k * ldw + x] : W[(size_t)x * ldw + k]) : 0.f;
+            }
+        }
+        uint32_t h[8], m[8], l[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) split3(w[q], h[q], m[q], l[q]);
+        uint16_t *o = out + (size_t)x * ld + k0;                                 // ld % 64 == 0, k0 % 8 == 0: 16-byte aligned
+        *reinterpret_cast<uint4 *>(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        *reinterpret_cast<uint4 *>(o + plane_stride) = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+        *reinterpret_cast<uint4 *>(o + 2 * plane_stride) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
     }
 }
 

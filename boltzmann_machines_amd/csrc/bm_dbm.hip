@@ -83,8 +83,15 @@ struct bm_dbm {
                                                    // than the per-layer launches (bm_mf.h); also set when a launch gave up
     int fast = 0;
     bool fast_now = false;
+    bool fast_ais = false;                         // the running fast sweep is AIS (fp32 copies of v / h2 are not needed)
     Mat16 W3[MAXL], W3t[MAXL];
     Mat16 ax16, ax2_16, av16, ah2_16;
+    // PCD particles: one shadow per physical buffer (the Mat structs swap, the buffers keep their shadows)
+    Mat16 pv16[2], pH16[MAXL][2];
+    const float *pv_key[2] = {nullptr, nullptr}, *pH_key[MAXL][2] = {};
+    // a particle shadow is valid once a launch of the running call has written it (the particles a call starts from
+    // may be non-binary initial values: they are read in fp32)
+    bool pv_ok[2] = {false, false}, pH_ok[MAXL][2] = {};
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0, prow0 = 0;
@@ -99,23 +106,36 @@ static PhiloxKey dkey(const bm_dbm *h, uint32_t site, int t, uint64_t seed, uint
 }
 
 // the bf16 shadow of a state matrix of the running fast-binary sweep (null: none)
-static const Mat16 *fast_shadow(const bm_dbm *h, const float *p) {
+static const Mat16 *fast_shadow(bm_dbm *h, const float *p, bool **ok = nullptr) {
     if (p == h->ax.p) return &h->ax16;
     if (p == h->ax2.p) return &h->ax2_16;
     if (p == h->av.p) return &h->av16;
     if (p == h->ah2.p) return &h->ah2_16;
+    for (int b = 0; b < 2; ++b) {
+        if (p && p == h->pv_key[b]) { if (ok) *ok = &h->pv_ok[b]; return &h->pv16[b]; }
+        for (int i = 0; i < h->L; ++i) if (p && p == h->pH_key[i][b]) { if (ok) *ok = &h->pH_ok[i][b]; return &h->pH16[i][b]; }
+    }
     return nullptr;
 }
+// the shadow of an INPUT state matrix: only one whose contents are known to mirror the fp32 matrix
+static const Mat16 *fast_shadow_in(bm_dbm *h, const float *p) {
+    bool *ok = nullptr;
+    const Mat16 *m = fast_shadow(h, p, &ok);
+    return (m && (!ok || *ok)) ? m : nullptr;
+}
 
-// (re)build the bf16 weight planes from the current parameters (fast-binary mode; cheap next to any sweep)
-static int fast_build_planes(bm_dbm *h) {
+// (re)build the bf16 weight planes from the current parameters (fast-binary mode; cheap next to any sweep), on stream
+// `st`.  skip_t0: the planes of W_0^T are not needed (the visible layer of the sweep is not a bitmap)
+static int fast_build_planes(bm_dbm *h, hipStream_t st = nullptr, bool skip_t0 = false) {
+    if (!st) st = h->stream;
     for (int l = 0; l < h->L; ++l) {
         const int a = h->n[l], b = h->n[l + 1];
         if (h->W3[l].rows != a || h->W3[l].cols != b) { BM_TRY(h->W3[l].alloc(3, a, b)); BM_TRY(h->W3t[l].alloc(3, b, a)); }
-        hipLaunchKernelGGL(split3_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)h->W[l].p, h->W[l].ld, a, b,
+        hipLaunchKernelGGL(split3_kernel, dim3(1024), dim3(256), 0, st, (const float *)h->W[l].p, h->W[l].ld, a, b,
                            h->W3[l].p, h->W3[l].plane_stride(), h->W3[l].ld, 0);
-        hipLaunchKernelGGL(split3_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)h->W[l].p, h->W[l].ld, a, b,
-                           h->W3t[l].p, h->W3t[l].plane_stride(), h->W3t[l].ld, 1);
+        if (!(skip_t0 && l == 0))
+            hipLaunchKernelGGL(split3_kernel, dim3(1024), dim3(256), 0, st, (const float *)h->W[l].p, h->W[l].ld, a, b,
+                               h->W3t[l].p, h->W3t[l].plane_stride(), h->W3t[l].ld, 1);
     }
     BM_HIP(hipGetLastError());
     return 0;
@@ -157,8 +177,9 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
     a.prev = prev; a.maxdiff = maxdiff;
     if (h->fast_now && !h->multinomial(layer) && a.kind != 2) {
         // fast-binary: the same contraction from the bf16 weight planes and the bf16 shadows of the {0,1} inputs
-        // (every state matrix of the running sweep has a shadow; a missing one keeps the fp32 path)
-        const Mat16 *sb = below.p ? fast_shadow(h, below.p) : nullptr, *sa = above.p ? fast_shadow(h, above.p) : nullptr;
+        // (a state matrix without a valid shadow - real-valued visibles, the first PCD sweep - keeps the fp32 path)
+        const Mat16 *sb = below.p ? fast_shadow_in(h, below.p) : nullptr;
+        const Mat16 *sa = above.p ? fast_shadow_in(h, above.p) : nullptr;
         auto opnd = [](const Mat16 &m, int nx) { Bf3Operand o; o.p = m.p; o.plane_stride = m.plane_stride(); o.ld = m.ld; o.nx = nx; return o; };
         bool ok = false;
         Bf3Range r;
@@ -171,15 +192,16 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
             r.P1 = opnd(h->W3[0], a.I); r.Q1 = opnd(*sa, J); r.K1 = sa->ld;               // W_0: [i = v][k = h0]
             ok = true;
         }
-        if (ok) {
-            a.b3 = r;
-            const Mat16 *so = states ? fast_shadow(h, states) : nullptr;
-            if (so) {
-                a.states16 = so->p; a.ld16 = so->ld;
-                // the fp32 copy of a state matrix that only fast-binary launches read is not written at all (the AIS
-                // visible / top-layer states: 145 MB per beta); x keeps it for the x.hb0 partial sums of the epilogue
-                if (!a.rowdot_out) a.states = nullptr;
-            }
+        if (ok) a.b3 = r;
+        // the shadow of what this launch writes, when that is a sampled bitmap (written by either path's epilogue)
+        bool *so_ok = nullptr;
+        const Mat16 *so = (states && sample && a.kind == BM_UNIT_BERNOULLI) ? fast_shadow(h, states, &so_ok) : nullptr;
+        if (so) {
+            a.states16 = so->p; a.ld16 = so->ld;
+            if (so_ok) *so_ok = true;
+            // AIS: the fp32 copy of a state matrix that only fast-binary launches read is not written at all (visible /
+            // top-layer states: 145 MB per beta); x keeps it for the x.hb0 partial sums of the epilogue
+            if (ok && h->fast_ais && !a.rowdot_out) a.states = nullptr;
         }
     }
     if (h->multinomial(layer) && a.kind != 2) {
@@ -488,9 +510,39 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
 }
 
 // `_make_particles_update` (dbm.py:480-509)
+// fast-binary PCD: the hidden layers are sampled Bernoulli layers (bitmaps from the second sweep on), the visible one
+// may be real valued (then only the top-down half of each sweep runs on the bf16 cores)
+static bool fast_pcd_ok(const bm_dbm *h, bool sample) {
+    if (!h->fast || !sample) return false;
+    for (int i = 0; i < h->L; ++i) if (h->multinomial(i) || !h->cfg.sample_h_states[i]) return false;
+    return true;
+}
+static int fast_pcd_begin(bm_dbm *h) {
+    const bool vbits = h->cfg.v_unit == BM_UNIT_BERNOULLI && h->cfg.sample_v_states;
+    if (!h->pH_key[0][0]) {                       // one shadow per physical particle buffer
+        Mat *vb[2] = {&h->v, &h->v_new};
+        for (int b = 0; b < 2; ++b) {
+            if (vbits) { BM_TRY(h->pv16[b].alloc(1, h->M, h->V)); h->pv_key[b] = vb[b]->p; }
+            for (int i = 0; i < h->L; ++i) {
+                Mat *hb = b ? &h->H_new[i] : &h->H[i];
+                BM_TRY(h->pH16[i][b].alloc(1, h->M, h->n[i + 1])); h->pH_key[i][b] = hb->p;
+            }
+        }
+    }
+    for (int b = 0; b < 2; ++b) { h->pv_ok[b] = false; for (int i = 0; i < h->L; ++i) h->pH_ok[i][b] = false; }
+    return fast_build_planes(h, h->cur, !vbits);  // the parameters changed since the last update
+}
+
 static void particles_update(bm_dbm *h, int k, bool sample, bool update_only_v_at_end = false) {
     (void)update_only_v_at_end;
+    struct FastScope { bm_dbm *h; bool on; ~FastScope() { if (on) h->fast_now = false; } } scope{h, false};
+    if (fast_pcd_ok(h, sample)) {
+        if (fast_pcd_begin(h) == 0) { scope.on = true; h->fast_now = true; h->fast_ais = false; }
+        else h->failed = true;
+    }
     for (int t = 0; t < k; ++t) {
+        // (fast-binary: sweep 0 reads the particles it starts from in fp32 and leaves shadows of what it samples; from
+        // then on every sampled Bernoulli input is a bitmap with a valid shadow)
         gibbs_sweep(h, h->M, LayerIn{h->v.p, h->v.ld}, h->H, &h->v_new, h->H_new, true, sample, t, h->prow0);
         Mat tv = h->v; h->v = h->v_new; h->v_new = tv;                    // swap particles (:493)
         for (int i = 0; i < h->L; ++i) { Mat th = h->H[i]; h->H[i] = h->H_new[i]; h->H_new[i] = th; }
@@ -716,6 +768,7 @@ int bm_dbm_destroy(bm_dbm *h) {
         h->W3[i].release(); h->W3t[i].release();
     }
     h->ax16.release(); h->ax2_16.release(); h->av16.release(); h->ah2_16.release();
+    for (int b = 0; b < 2; ++b) { h->pv16[b].release(); for (int i = 0; i < MAXL; ++i) h->pH16[i][b].release(); }
     for (int i = 0; i < MAXL; ++i) h->mu_wk[i].release();
     if (h->mfp_sync) (void)hipFree(h->mfp_sync);
     if (h->mfp_host) (void)hipHostFree(h->mfp_host);
@@ -1091,7 +1144,7 @@ static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint6
             BM_TRY(h->av16.alloc(1, h->ais_rows, V)); BM_TRY(h->ah2_16.alloc(1, h->ais_rows, H2));
         }
         hipLaunchKernelGGL(shadow16_kernel, dim3(512), dim3(256), 0, h->stream, (const float *)x->p, x->ld, R, H1, h->ax16.p, h->ax16.ld);
-        h->fast_now = true;
+        h->fast_now = true; h->fast_ais = true;
     }
     hipLaunchKernelGGL(rowdot_kernel, dim3((R + 3) / 4), dim3(256), 0, h->stream, (const float *)x->p, x->ld, R, H1,
                        (const float *)h->hb[0].p, rdot_cur);

@@ -1562,11 +1562,7 @@ static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
     if (a.b3.K2 > 0) hipLaunchKernelGGL((act_bf3_kernel<G, true, MINW>), grid, blk, 0, st, a, sp);
     else             hipLaunchKernelGGL((act_bf3_kernel<G, false, MINW>), grid, blk, 0, st, a, sp);
 }
-static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
-    static int geo_env = -1;
-    if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
-    int geo = geo_env;
-    if (!geo) geo = tile_grid<GeoBf3S>(a.I, a.J) >= 1024 ? 2 : 4;
+static inline void launch_act_bf3_as(int geo, const ActArgs &a, hipStream_t st) {
     if (geo == 16) {               // the wide tile (64 x 128, 4 waves of 32 x 64), BM355_BF3_GEO=16 only: its K loop is faster
                                    // (18.6 against 22 ms per 100 AIS betas) but one wave per SIMD runs four epilogues back to
                                    // back with nothing to overlap them (26 against 15 ms): 61.8 against 44.5 ms in total
@@ -1655,16 +1651,15 @@ struct TuneScratch {
         return p;
     }
 };
-static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6, 5, 7};
-    constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
+// the caller's launch with every OUTPUT redirected into the scratch pool (false: no memory, keep the default choice)
+static inline bool tune_redirect(const ActArgs &a, ActArgs &t) {
     static TuneScratch pool;
     const size_t mat = ((size_t)a.J * (size_t)a.ldo + 3) & ~(size_t)3;
     const size_t rowv = (((size_t)((a.I + 15) / 16) * (size_t)(a.ld_part > a.J ? a.ld_part : a.J)) + 3) & ~(size_t)3;   // slot partials
-    float *s = pool.get(3 * mat + 2 * rowv + BM_MF_SLOTS + 4);
-    T.best = a.p_xm ? 8 : 4;
-    if (!s) return;                                  // no memory for the scratch outputs: keep the default
-    ActArgs t = a;
+    const size_t sh16 = a.states16 ? ((size_t)a.J * (size_t)a.ld16 / 2 + 4) & ~(size_t)3 : 0;                           // bf16 shadow, in floats
+    float *s = pool.get(3 * mat + 2 * rowv + BM_MF_SLOTS + 4 + sh16);
+    if (!s) return false;
+    t = a;
     t.skip = nullptr;
     t.chk_ctl = nullptr;
     if (a.means) t.means = s;
@@ -1674,9 +1669,18 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     if (a.rowdot_out) t.rowdot_out = s + 3 * mat + rowv;
     if (a.maxdiff_blk) t.maxdiff_blk = s + 3 * mat + 2 * rowv;
     if (a.maxdiff) t.maxdiff = reinterpret_cast<unsigned *>(s + 3 * mat + 2 * rowv + BM_MF_SLOTS);
+    if (a.states16) t.states16 = reinterpret_cast<uint16_t *>(s + 3 * mat + 2 * rowv + BM_MF_SLOTS + 4);
 #ifdef BM_PROBE
     t.dbg = nullptr;
 #endif
+    return true;
+}
+static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6, 5, 7};
+    constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
+    T.best = a.p_xm ? 8 : 4;
+    ActArgs t;
+    if (!tune_redirect(a, t)) return;                // no memory for the scratch outputs: keep the default
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
     float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
@@ -1730,6 +1734,53 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     if (log && tune_xi)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> XCD grid %d x %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.xi, T.xi ? 8 / T.xi : 0, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
+}
+// fast-binary launches: three tile geometries (2: 64 x 32 tiles, two workgroups per CU; 4: 64 x 64, one; 8: 128 x 32
+// with 8 waves), measured once per shape like the fp32 ones.  Which one wins follows the tile count and K, not one
+// rule: 20000 AIS chains take 2, the 3072 x 256 x 5000 top-down pass of BASELINE configs[2] takes 8 or 2 (68 / 71 us)
+// where 4 needs 117 us (192 tiles on 256 CUs).  BM355_BF3_GEO=8|4|2|16 forces one.
+static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
+    static int geo_env = -1;
+    if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
+    if (geo_env) { launch_act_bf3_as(geo_env, a, st); return; }
+    static std::mutex mu;
+    static std::map<std::array<long long, 6>, int> table;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const long long flags = (long long)((a.sample ? 1 : 0) | (a.kind << 1) | (a.rowacc ? 32 : 0) | (a.rowdot_out ? 256 : 0) |
+                                        (a.dot_mat ? 512 : 0) | (a.states ? 1024 : 0) | (a.means ? 2048 : 0));
+    const std::array<long long, 6> key = {a.I, a.J, a.b3.K1, a.b3.K2, flags, (long long)dev};
+    std::lock_guard<std::mutex> lk(mu);
+    int &geo = table[key];
+    if (!geo) {
+        static const int cand[3] = {2, 8, 4};
+        constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
+        geo = tile_grid<GeoBf3S>(a.I, a.J) >= 1024 ? 2 : 8;
+        ActArgs t;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (tune_redirect(a, t) && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+            float best[3] = {1e30f, 1e30f, 1e30f};
+            for (int round = 0; round < TUNE_ROUNDS; ++round)
+                for (int c = 0; c < 3; ++c) {
+                    launch_act_bf3_as(cand[c], t, st);
+                    (void)hipEventRecord(e0, st);
+                    for (int r = 0; r < TUNE_REP; ++r) launch_act_bf3_as(cand[c], t, st);
+                    (void)hipEventRecord(e1, st);
+                    if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && 1e3f * ms / TUNE_REP < best[c]) best[c] = 1e3f * ms / TUNE_REP;
+                }
+            int b = 0;
+            for (int c = 1; c < 3; ++c) if (best[c] < best[b]) b = c;
+            if (best[b] < 1e29f) geo = cand[b];
+            static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
+            if (log) fprintf(stderr, "bm355 tune: bf16x3 act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us: 64x32 %.1f, 128x32 8w %.1f, 64x64 %.1f)\n",
+                             a.I, a.J, a.b3.K1, a.b3.K2, flags, geo, best[0], best[1], best[2]);
+        } else (void)hipGetLastError();
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    launch_act_bf3_as(geo, a, st);
 }
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     if (a.b3.K1 > 0) { launch_act_bf3(a, st); return; }

@@ -357,7 +357,9 @@ int bm_dbm_xchg_create(bm_dbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
 int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x);
 int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
 /* Opt-in "fast-binary" mode (SURVEY §7 hard part 4; csrc/bm_bf3.h): contractions whose input states are {0,1}
- * bitmaps (AIS with all layers sampled; the RBM sampling sweep with both layers sampled) split the fp32 weights
+ * bitmaps (AIS with all layers sampled; the RBM sampling sweep with both layers sampled; in the PCD particle sweeps of
+ * bm_dbm_train_step / bm_dbm_sample_v every contraction over a Bernoulli layer sampled earlier in the same call - a
+ * real-valued visible layer and the particles a call starts from are read in fp32) split the fp32 weights
  * EXACTLY into three bf16 planes and run on the bf16 matrix cores - exact products, fp32 accumulation in a
  * different order than the default chain: results agree to fp32 round-off (free energy / log-weights 1e-5, bitmaps
  * identical except where |u - p| is at round-off distance), NOT bit for bit.  Never the default. */

@@ -151,3 +151,61 @@ def test_ais_estimate_consistent_at_config4_shape(gpu_lib):
     d = abs(est[True][0] - est[False][0])
     assert d < 5 * np.hypot(est[True][1], est[False][1]) + 1e-3 * abs(est[False][0]), est
     eng.close()
+
+
+PCD_CASES = [
+    (784, [512, 1024], 32, 64, dict(max_mf_updates=3, mf_tol=1e-7, l2=1e-7, max_norm=6.), 5),   # BASELINE config[3] layers
+    (20, [12, 16], 10, 10, dict(max_mf_updates=5, mf_tol=1e-5, l2=1e-3), 3),
+    (36, [24], 8, 12, dict(max_mf_updates=3, l2=1e-4), 4),                                        # 1 layer
+    (28, [20, 12, 8], 12, 8, dict(max_mf_updates=4, max_norm=2.0), 2),                            # 3 layers
+    (70, [33, 9], 17, 5, dict(max_mf_updates=2), 1),                                              # k = 1, K tails
+    (44, [28], 12, 12, dict(v_unit=1, sample_v_states=False, max_mf_updates=3, l2=1e-3), 3),      # Gaussian means
+    (3072, [5000], 16, 32, dict(v_unit=1, sample_v_states=True, max_mf_updates=1, l2=0.01), 5),   # BASELINE config[2] shape
+]
+
+
+@pytest.mark.parametrize('V,nh,N,M,kw,k', PCD_CASES)
+def test_pcd_sweeps_match_the_default_path_up_to_ties(gpu_lib, V, nh, N, M, kw, k):
+    """fast-binary in the PCD particle sweeps of a train step (bm_dbm.hip particles_update): every contraction whose
+    state operand is a bitmap SAMPLED EARLIER IN THE SAME CALL runs from its bf16 shadow; the particles a call starts
+    from (possibly real valued) and Gaussian visibles are read in fp32.  Same chains as the default path except where
+    a draw lands within round-off of its probability; parameters agree to the weight of the forked chains."""
+    from boltzmann_machines_amd.engine import as_device
+    gauss = kw.get('v_unit', 0) == 1
+    scale = 0.1 if V < 1000 else 0.008
+    out = {}
+    for mode in ('default', 'fast', 'fast2'):
+        eng, twin = D.make_pair(V, nh, N, M, **kw)
+        if V >= 1000:
+            eng.set('W', twin.p['W'] * np.float32(scale / 0.1))
+        if gauss:
+            eng.set('v', orc.normal(87654321, 77, 0, M * V).reshape(M, V))
+        eng.seed(42)
+        eng.set_fast_binary(mode != 'default')
+        X = orc.normal(87654321, 500, 0, N * V).reshape(N, V) if gauss else D.data(N, V, 0)
+        lr = 5e-3 if gauss else 0.05
+        for s in range(2):
+            eng.train_step(as_device(X), lr, 0.5, k)
+        names = ['v', 'vb', 'W', 'hb', 'h'] + [b + '_%d' % i for i in range(1, len(nh)) for b in ('W', 'hb', 'h')]
+        out[mode] = {nm: eng.get(nm).copy() for nm in names}
+        eng.close()
+    for nm, a in out['fast'].items():                       # the fast mode is deterministic
+        assert np.array_equal(a.view(np.uint32), out['fast2'][nm].view(np.uint32)), nm
+    ref, fast = out['default'], out['fast']
+    forked = np.zeros(M, bool)
+    for nm in ref:
+        if nm == 'h' or nm.startswith('h_'):
+            assert set(np.unique(fast[nm])) <= {0.0, 1.0}
+            forked |= np.any(ref[nm] != fast[nm], axis=1)
+    if gauss:
+        forked |= np.any(~np.isclose(ref['v'], fast['v'], rtol=1e-4, atol=1e-4), axis=1)
+    else:
+        forked |= np.any(ref['v'] != fast['v'], axis=1)
+    nf = int(forked.sum())
+    print('fast-binary PCD-%d %s, %d particles, 2 updates: %d chains forked on a tie' % (k, [V] + nh, M, nf))
+    assert nf <= max(1, M // 16)
+    # a forked chain moves the negative statistics by at most lr / M per element per update
+    atol = 1e-6 + 2.5 * (5e-3 if gauss else 0.05) * nf / M
+    for nm in ref:
+        if nm[0] in 'Wvh' and nm not in ('v', 'h') and not nm.startswith('h_'):
+            np.testing.assert_allclose(fast[nm], ref[nm], rtol=2e-5, atol=atol, err_msg=nm)
