@@ -749,6 +749,11 @@ struct GradArgs {
     int nbias;
     RbmBiasFusedArgs bias;
     int fetch_at_fill;                // 1: read W/dW of the lane's outputs during the pipeline fill (set by launch_grad)
+    // form 0 cut at the segment boundary of its chain (the second segment starts its own 16-blocks, so the cut is exact):
+    //   split == 1: the positive rows only, raw sums to `raw` (runs on a second stream under the Gibbs chain);
+    //   split == 2: the accumulators start from `acc_in` ([J][I], pitch ldw) and run the negative rows, usual epilogue
+    int split;
+    const float *acc_in;
     TileMap tmap;                     // block -> tile map (set by launch_grad_geo)
     int map_xi;                       // see ActArgs::map_xi
 #ifdef BM_PROBE
@@ -857,7 +862,33 @@ __global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
     side.on = a.fused != 0 && a.fetch_at_fill != 0;
     KRange kr;
     kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
-    if (a.form == 0) {
+    if (a.form == 0 && a.split == 1) {
+        kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0;
+        mainloop<KM, G, FAST, false, 0, KM, STG>(pos, kr, i0, j0, smem, side);
+    } else if (a.form == 0 && a.split == 2) {
+        if (ib0 < a.I) {
+#pragma unroll
+            for (int n = 0; n < NJ; ++n) {
+                if (side.jb[n] >= a.J) continue;
+                const float *src = a.acc_in + (size_t)side.jb[n] * a.ldw + ib0;
+                float v[8];
+                if (side.vec8) {
+                    const float4 x = *reinterpret_cast<const float4 *>(src), y = *reinterpret_cast<const float4 *>(src + 4);
+                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (ib0 + e < a.I) ? src[e] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) pos[t][n][r] = v[2 * r + t];          // inverse of lane_outputs
+            }
+        }
+        kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
+        kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = 0;
+        mainloop<KM, G, FAST, false, 0, KM, STG>(pos, kr, i0, j0, smem, side);
+    } else if (a.form == 0) {
         // RBM: ONE chain, positive rows then negative rows with the product negated: the caller
         // passes Pneg = -h_k (act_kernel's `negmeans` output), fma(-p, q, acc) == acc - p*q exactly
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
@@ -887,6 +918,11 @@ __global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
         lane_outputs<G>(neg, n, nv);
         const size_t o = (size_t)j * a.ldw + ib0;
         if (!a.fused) {
+            if (a.split == 1 && side.vec8) {       // re-read by the split == 2 launch: plain (cached) stores
+                *reinterpret_cast<float4 *>(a.raw + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                *reinterpret_cast<float4 *>(a.raw + o + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (ib0 + e >= a.I) break;
@@ -1906,7 +1942,7 @@ static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
         static std::map<std::array<long long, 7>, int> table;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1)), (long long)g.ldw, (long long)dev};
+        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1) | (g.split << 2)), (long long)g.ldw, (long long)dev};
         std::lock_guard<std::mutex> lk(mu);
         int &b = table[key];
         if (!b) b = tune_grad_shape(g, st);

@@ -76,6 +76,14 @@ struct bm_rbm {
     bool capturing = false;
     uint32_t capture_call0 = 0;
     int epoch_graph = -1;            // bm_rbm_set_epoch_graph: 1 on, 0 off, -1: BM355_EPOCH_GRAPH (default off)
+    // the positive outer products of a fused update on a second stream, under the Gibbs chain (bm_rbm_set_grad_overlap):
+    // the chain of the raw gradient is cut at its segment boundary (GradArgs::split), the accumulators cross in pos_acc
+    int grad_overlap = -1;           // 1 on, 0 off, -1: BM355_GRAD_OVERLAP (default off)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    Mat pos_acc;                     // [V][H] like W
+    bool pos_pending = false;
+    bool graph_mode = false;         // bm_rbm_train_epoch is on its graph path (eager pass included: it tunes the captured launches)
     // optional per-kernel-class event timing
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; };
@@ -182,7 +190,30 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
 // need_vm: the last step's visible MEANS are wanted (msre metric); a plain update only consumes the
 // visible states, and nothing consumes the hidden STATES of the last step: those stores (and their
 // share of the kernel-boundary L2 writeback) are skipped.
-static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true) {
+static void fill_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, GradArgs &g);
+static bool grad_overlap_on(bm_rbm *h) {
+    if (h->grad_overlap < 0) { const char *e = getenv("BM355_GRAD_OVERLAP"); h->grad_overlap = (e && atoi(e)) ? 1 : 0; }
+    return h->grad_overlap == 1 && !h->capturing && !h->prof && !h->graph_mode;
+}
+// fork: the positive rows of the raw gradient (X^T h0) on the side stream, as soon as h0 exists
+static int launch_grad_pos(bm_rbm *h, int B) {
+    if (!h->side_stream) {
+        BM_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        BM_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        BM_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        BM_TRY(h->pos_acc.alloc(h->V, h->H));
+    }
+    BM_HIP(hipEventRecord(h->ev_fork, h->stream));
+    BM_HIP(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    GradArgs g;
+    fill_grad(h, B, 0, (float)B, 0.f, 0.f, g);
+    g.split = 1; g.Kneg = 0; g.raw = h->pos_acc.p; g.ldw = h->pos_acc.ld;
+    bm::launch_grad(g, h->side_stream);
+    BM_HIP(hipEventRecord(h->ev_join, h->side_stream));
+    h->pos_pending = true;
+    return 0;
+}
+static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true, bool for_update = false) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
     const float *Xin = X_dev;
@@ -200,6 +231,7 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out,
     }
     h->Xin = Xin; h->Xin_ld = ldx;
     launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0);      // :421-422
+    if (for_update && grad_overlap_on(h)) BM_TRY(launch_grad_pos(h, B));
     const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
     for (int t = 0; t < k; ++t) {                                                 // :367-378
         const bool last = t == k - 1;
@@ -261,9 +293,7 @@ static void launch_update_fused(bm_rbm *h, int B, float lr, float mom) {
     }
 }
 
-static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, bool with_bias) {
-    ProfScope _ps(h, KC_GRAD);
-    GradArgs g;
+static void fill_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, GradArgs &g) {
     memset(&g, 0, sizeof(g));
     g.Ppos = make_operand(h->h0m.p, h->h0m.ld, h->H);   // h0 means [k=b][i=h]           :447
     g.Qpos = make_operand(h->Xin, h->Xin_ld, h->V);     // X        [k=b][j=v]
@@ -276,11 +306,21 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
     g.raw = h->grad.p; g.raw2 = nullptr;
     g.W = h->W.p; g.dW = h->dW.p; g.Wt = nullptr;
     g.ldw = h->W.ld; g.ldwt = 0;
-    g.pen = with_bias ? nullptr : h->pen.p;
     g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
+}
+static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, bool with_bias) {
+    ProfScope _ps(h, KC_GRAD);
+    GradArgs g;
+    fill_grad(h, B, fused, N, lr, mom, g);
+    g.pen = with_bias ? nullptr : h->pen.p;
     if (with_bias) {
         g.nbias = fill_bias_fused(h, B, lr, mom, g.bias);
         g.bias.raw_only = fused ? 0 : 1;      // split (data-parallel) step: raw column sums only
+    }
+    if (h->pos_pending) {                     // join: the chain continues from the side stream's accumulators
+        h->pos_pending = false;
+        (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
+        if (fused && h->pos_acc.ld == h->W.ld) { g.split = 2; g.acc_in = h->pos_acc.p; }
     }
     bm::launch_grad(g, h->stream);
 }
@@ -438,6 +478,10 @@ int bm_rbm_destroy(bm_rbm *h) {
         if (h->ev_reduced[i]) (void)hipEventDestroy(h->ev_reduced[i]);
     }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    h->pos_acc.release();
     for (DevBuf *b : all) b->release();
     h->W3.release(); h->W3t.release(); h->hs16.release(); h->vs16.release();
     if (h->nonbinary) (void)hipFree(h->nonbinary);
@@ -547,7 +591,7 @@ int bm_rbm_seed(bm_rbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 
 int bm_rbm_set_row_offset(bm_rbm *h, int64_t row0) { h->row0 = row0; return 0; }
 
 int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr, false));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, false, true));
     launch_update_fused(h, B, lr, mom);
     h->call++;
     BM_HIP(hipGetLastError());
@@ -589,6 +633,8 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, 
     const int steps = (int)((N + batch - 1) / batch);
     const bool plain = h->cfg.v_unit == BM_UNIT_BERNOULLI && !h->multinomial() && h->cfg.dropout < 0.f && !h->prof;
     if (off || !plain || steps < 4 || steps > 4096 || batch > h->maxB) return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
+    struct GraphMode { bm_rbm *h; ~GraphMode() { h->graph_mode = false; } } gm{h};
+    h->graph_mode = true;
     bm_rbm::EpochGraph *g = nullptr;
     for (auto &e : h->graphs)
         if (e.X == X_dev && e.N == N && e.batch == batch && e.k == k && e.lr == lr && e.mom == mom && e.seed == h->seed &&
@@ -640,6 +686,11 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, 
     return 0;
 }
 
+int bm_rbm_set_grad_overlap(bm_rbm *h, int32_t on) {
+    BM_CHECK(h, "null handle");
+    h->grad_overlap = on ? 1 : 0;
+    return 0;
+}
 int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
     h->epoch_graph = on ? 1 : 0;

@@ -109,6 +109,10 @@ class RbmEngine(object):
         """train_epoch replays recurring runs of updates from a HIP graph (opt-in; measured slower, bm_rbm.hip)"""
         check(self.lib.bm_rbm_set_epoch_graph(self._h, int(bool(on))))
 
+    def set_grad_overlap(self, on=True):
+        """positive outer products on a second stream under the Gibbs chain (bit-identical; bm355.h)"""
+        check(self.lib.bm_rbm_set_grad_overlap(self._h, int(bool(on))))
+
     def grad_step(self, Xd, B, k, row=0):
         check(self.lib.bm_rbm_grad_step(self._h, Xd.offset_ptr(row * self.V), B, k))
 

@@ -120,6 +120,10 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
 /* bm_rbm_train_epoch may replay recurring runs of updates from a HIP graph (1) instead of launching them one by one
  * (0, the default: the replay measured slower on MI355X / ROCm 7.2, csrc/bm_rbm.hip); same bits either way */
 int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on);
+/* bm_rbm_train_step / _train_epoch: run the positive outer products X^T h0 (base_rbm.py:447) on a second stream under
+ * the Gibbs chain; the chain of the raw gradient is cut at its segment boundary and continues from the stored fp32
+ * accumulators, so the update is bit-identical.  Default: BM355_GRAD_OVERLAP (off). */
+int bm_rbm_set_grad_overlap(bm_rbm *h, int32_t on);
 
 /* Data-parallel split of a train step: phase 1 runs the chain and
  * leaves the raw un-normalised sums in the "grad" buffer

@@ -370,3 +370,26 @@ def test_train_epoch_graph_replay_bit_exact(gpu_lib):
     epoch(0.05); epoch(0.05)
     assert_state_equal(eng, twin)
     eng.close()
+
+
+@pytest.mark.parametrize('V,H,B,kw', [(96, 64, 16, dict(sample_v_states=True, l2=1e-4)),
+                                      (784, 1024, 512, dict()),
+                                      (50, 37, 9, dict(sparsity_cost=0.1, sparsity_target=0.2, dropout=0.8))])
+def test_grad_overlap_bit_exact(gpu_lib, V, H, B, kw):
+    """bm_rbm_set_grad_overlap: X^T h0 on a second stream under the Gibbs chain, the gradient chain cut at its segment
+    boundary and continued from the stored accumulators - same bits as the one-launch chain and the oracle (opt-in:
+    measured slower at the north-star shape)"""
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, H, max_batch=B, **kw)
+    eng.set_grad_overlap(True)
+    X = synth_data(3 * B, V, 5)
+    Xd = as_device(X)
+    eng.seed(21); twin.set_seed(21)
+    for s in range(3):
+        eng.train_step(Xd, B, 0.05, 0.5, 1 + (s == 2), row=s * B)
+        twin.train_step(X[s * B:(s + 1) * B], 0.05, 0.5, 1 + (s == 2))
+    eng.train_epoch(Xd, 3 * B, B, 0.02, 0.9, 1)
+    for s in range(3):
+        twin.train_step(X[s * B:(s + 1) * B], 0.02, 0.9, 1)
+    assert_state_equal(eng, twin)
+    eng.close()
