@@ -333,35 +333,58 @@ __device__ __forceinline__ void split3(float w, uint32_t &h, uint32_t &m, uint32
     const float r2 = r1 - __uint_as_float(mb);
     h = hb >> 16; m = mb >> 16; l = __float_as_uint(r2) >> 16;
 }
-__global__ void split3_kernel(const float *W, int ldw, int rows, int cols, uint16_t *out, long long plane_stride, int ld, int transpose) {
-    const int nx = transpose ? cols : rows, nk = transpose ? rows : cols;      // operand rows / contraction length
-    const int kg = (nk + 7) >> 3;
-    const size_t n = (size_t)nx * kg;
-    const bool vec = !transpose && (ldw & 3) == 0 && (((uintptr_t)W & 15u) == 0);
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-        // transposed: x fastest across threads (coalesced reads of W rows); plain: k-group fastest (coalesced both ways)
-        const int x = transpose ? (int)(e % (size_t)nx) : (int)(e / (size_t)kg);
-        const int k0 = 8 * (transpose ? (int)(e / (size_t)nx) : (int)(e % (size_t)kg));
-        float w[8];
-        if (vec && k0 + 8 <= nk) {
-            const float4 a = *reinterpret_cast<const float4 *>(W + (size_t)x * ldw + k0);
-            const float4 b = *reinterpret_cast<const float4 *>(W + (size_t)x * ldw + k0 + 4);
-            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-        } else {
+template <bool VEC>
+__device__ __forceinline__ void split3_fetch(const float *W, int ldw, int nx, int nk, int kg, int transpose, size_t e, float (&w)[8]) {
+    // transposed: x fastest across threads (coalesced reads of W rows); plain: k-group fastest (coalesced both ways)
+    const int x = transpose ? (int)(e % (size_t)nx) : (int)(e / (size_t)kg);
+    const int k0 = 8 * (transpose ? (int)(e / (size_t)nx) : (int)(e % (size_t)kg));
+    if (VEC) {                                   // plain layout, whole 16-byte aligned groups only
+        const float4 a = *reinterpret_cast<const float4 *>(W + (size_t)x * ldw + k0);
+        const float4 b = *reinterpret_cast<const float4 *>(W + (size_t)x * ldw + k0 + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {                                     // clamped addresses, no branch around a load
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = k0 + q;
-                w[q] = k < nk ? (transpose ? W[(size_t)k * ldw + x] : W[(size_t)x * ldw + k]) : 0.f;
-            }
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q, kc = k < nk ? k : nk - 1;
+            const float v = transpose ? W[(size_t)kc * ldw + x] : W[(size_t)x * ldw + kc];
+            w[q] = k < nk ? v : 0.f;
         }
-        uint32_t h[8], m[8], l[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) split3(w[q], h[q], m[q], l[q]);
-        uint16_t *o = out + (size_t)x * ld + k0;                                 // ld % 64 == 0, k0 % 8 == 0: 16-byte aligned
-        *reinterpret_cast<uint4 *>(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        *reinterpret_cast<uint4 *>(o + plane_stride) = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
-        *reinterpret_cast<uint4 *>(o + 2 * plane_stride) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
     }
+}
+__device__ __forceinline__ void split3_emit(const float (&w)[8], uint16_t *out, long long plane_stride, int ld, int nx, int kg, int transpose, size_t e) {
+    const int x = transpose ? (int)(e % (size_t)nx) : (int)(e / (size_t)kg);
+    const int k0 = 8 * (transpose ? (int)(e / (size_t)nx) : (int)(e % (size_t)kg));
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) split3(w[q], h[q], m[q], l[q]);
+    uint16_t *o = out + (size_t)x * ld + k0;                                 // ld % 64 == 0, k0 % 8 == 0: 16-byte aligned
+    *reinterpret_cast<uint4 *>(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    *reinterpret_cast<uint4 *>(o + plane_stride) = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+    *reinterpret_cast<uint4 *>(o + 2 * plane_stride) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+template <bool VEC>
+__device__ __forceinline__ void split3_body(const float *W, int ldw, int nx, int nk, uint16_t *out, long long plane_stride, int ld, int transpose) {
+    const int kg = (nk + 7) >> 3;
+    const size_t n = (size_t)nx * kg, stride = (size_t)gridDim.x * blockDim.x;
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; e + stride < n; e += 2 * stride) {    // two groups per trip: four (sixteen) loads in flight per thread
+        float w0[8], w1[8];
+        split3_fetch<VEC>(W, ldw, nx, nk, kg, transpose, e, w0);
+        split3_fetch<VEC>(W, ldw, nx, nk, kg, transpose, e + stride, w1);
+        split3_emit(w0, out, plane_stride, ld, nx, kg, transpose, e);
+        split3_emit(w1, out, plane_stride, ld, nx, kg, transpose, e + stride);
+    }
+    if (e < n) {
+        float w0[8];
+        split3_fetch<VEC>(W, ldw, nx, nk, kg, transpose, e, w0);
+        split3_emit(w0, out, plane_stride, ld, nx, kg, transpose, e);
+    }
+}
+__global__ __launch_bounds__(256) void split3_kernel(const float *W, int ldw, int rows, int cols, uint16_t *out, long long plane_stride, int ld, int transpose) {
+    const int nx = transpose ? cols : rows, nk = transpose ? rows : cols;      // operand rows / contraction length
+    const bool vec = !transpose && (ldw & 3) == 0 && (((uintptr_t)W & 15u) == 0) && (nk & 7) == 0;
+    if (vec) split3_body<true>(W, ldw, nx, nk, out, plane_stride, ld, transpose);
+    else     split3_body<false>(W, ldw, nx, nk, out, plane_stride, ld, transpose);
 }
 
 // fp32 {0,1} states -> bf16 shadow (for states that were not produced by an act_kernel: AIS x_0, user input)

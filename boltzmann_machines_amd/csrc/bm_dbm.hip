@@ -389,7 +389,7 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
     // cond at step 0 compares the persistent mu with the init values (:449-452)
     BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
     for (int i = 0; i < L; ++i)
-        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 128 ? N : 128), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
+        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 256 ? N : 256), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
                            (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
     int step = 0;
     Mat *cur = h->mu, *alt = h->mu_alt;
@@ -662,7 +662,7 @@ static void launch_dbm_maxnorm(bm_dbm *h, int i) {
     m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = h->n[i + 1]; m.J = h->n[i]; m.ldw = h->W[i].ld; m.ldwt = h->Wt[i].ld;
     m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
     m.num = h->mn_fac[i].p; m.den = h->mn_fac[i].p + m.I;
-    hipLaunchKernelGGL(maxnorm_kernel, dim3((m.I + 15) / 16), dim3(NT), 0, h->stream, m);
+    hipLaunchKernelGGL(maxnorm_kernel, dim3((m.I + MN_COLS - 1) / MN_COLS), dim3(NT), 0, h->stream, m);
     hipLaunchKernelGGL(maxnorm_scale_kernel, dim3(((m.I + 31) / 32) * ((m.J + 31) / 32)), dim3(256), 0, h->stream, m);
 }
 

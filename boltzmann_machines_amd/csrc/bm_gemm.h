@@ -129,6 +129,7 @@ using GeoAct32 = Geo<2, 2, 2, 1, 32>;     // 64 x 32 tile, 4 waves of 32 x 16, B
                                          // 3/4 of the operand bytes per flop of the 32 x 32 tile (k-major P only)
 using GeoGrad = Geo<2, 2, 2, 2, 64>;     // 64 x 64 tile, 4 waves of 32 x 32, 128 KiB LDS
 using GeoGrad8 = Geo<2, 4, 2, 1, 64>;    // 64 x 64 tile, 8 waves of 32 x 16 (two per SIMD), 128 KiB LDS
+using GeoGrad8h = Geo<2, 4, 2, 1, 32>;   // the same with BK = 32: 64 KiB LDS, two workgroups per CU (one's epilogue under the other's K loop)
 using GeoBf3S = Geo<1, 4, 2, 1, 64>;     // 32 x 64 tile, 4 waves of 32 x 16: the fast-binary path's two-workgroups-per-CU tile (bm_bf3.h)
 
 struct Operand {

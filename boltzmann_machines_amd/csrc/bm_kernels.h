@@ -812,19 +812,22 @@ template <int NJ> struct GradSide {
     }
 };
 
-template <class G, bool FAST, int ABL = 0, int STG = STG_DMA>
-__global__ __launch_bounds__(G::NT, 1) void grad_kernel(GradArgs a) {
+template <class G, bool FAST, int ABL = 0, int STG = STG_DMA, int MINB = 1>
+__global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a) {
     constexpr int TI = G::TI, NJ = G::NJ;
     static_assert(G::MI == 2 && G::TI == 64 && G::TJ == 64, "grad_kernel: 64 x 64 tiles, 8 consecutive outputs per lane");
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
-    static_assert(G::SMEM_FLOATS >= CS_SMEM_FLOATS && G::NT >= NT, "bias path reuses the tile LDS");
+    constexpr bool kBias = G::SMEM_FLOATS >= CS_SMEM_FLOATS;      // the bias path reuses the tile LDS (launchers: nbias == 0 otherwise)
+    static_assert(G::NT >= NT, "bias path");
     // the bias/colsum workgroups sit BEHIND the tile workgroups in dispatch order: 208 tiles
     // (784x1024) take 208 CUs for the whole launch, the short bias groups cycle through
     // the CUs that are left and finish inside the tiles' shadow.
     const int ntile_blocks = (int)gridDim.x - a.nbias;
     if ((int)blockIdx.x >= ntile_blocks) {
-        if (G::NT > NT && threadIdx.x >= NT) return;      // the column-sum body is written for NT threads (whole waves leave)
-        rbm_bias_fused_block(a.bias, (int)blockIdx.x - ntile_blocks, smem);
+        if constexpr (kBias) {
+            if (G::NT > NT && threadIdx.x >= NT) return;      // the column-sum body is written for NT threads (whole waves leave)
+            rbm_bias_fused_block(a.bias, (int)blockIdx.x - ntile_blocks, smem);
+        }
         return;
     }
     // hot kernel arguments after ONE scalar-memory round trip (see act_kernel)
@@ -1403,48 +1406,96 @@ struct MaxNormArgs {
     float *norm_out;        // [I] column norms (W_norm metric) or null
     float *num, *den;       // [I] each: the column factors
 };
+// maxnorm_kernel: a workgroup owns 16 columns, its wave 0 runs their chain (768 dependent MFMAs for 3072 rows = 10 us
+// is the floor: the chain of a column is sequential over the rows); all four waves stream the rows
+// through two LDS slots in chunks of 256, up to THREE chunks ahead in registers (what 19 GB/s per chain need at
+// ~2.5 us of memory latency is 48 KiB in flight).  Every load is issued unconditionally from a clamped address and zeroed
+// afterwards: loads under divergent branches are waited for one by one.  History at 3072 x 5000: 80 us (load and
+// MFMA phases alternating, branchy loads), 95 / 70 us (64 columns per workgroup, one chunk ahead: latency bound),
+// 34 us now.
+constexpr int MN_CH = 256;                       // rows per chunk (512: 41 us against 34)
+constexpr int MN_COLS = 16;                      // columns per workgroup
+constexpr int MN_NV = MN_CH * (MN_COLS / 4) / NT;   // float4 per thread and chunk
+struct MnRegs { float4 v[MN_NV]; };
+__device__ __forceinline__ void maxnorm_load(const MaxNormArgs &a, int c0, int r0, bool full, MnRegs &r) {
+    const int tid = threadIdx.x;
+    if (full) {                                           // workgroup-uniform
+#pragma unroll
+        for (int n = 0; n < MN_NV; ++n) {
+            const int f = tid + n * NT, row = r0 + (f >> 2), c = c0 + 4 * (f & 3);
+            const int rc = row < a.J ? row : a.J - 1;
+            r.v[n] = *reinterpret_cast<const float4 *>(a.W + (size_t)rc * a.ldw + c);
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < MN_NV; ++n) {
+            const int f = tid + n * NT, row = r0 + (f >> 2), c = c0 + 4 * (f & 3);
+            const int rc = row < a.J ? row : a.J - 1;
+            const float *src = a.W + (size_t)rc * a.ldw;
+            const int last = a.I - 1;
+            r.v[n] = make_float4(src[c < last ? c : last], src[c + 1 < last ? c + 1 : last], src[c + 2 < last ? c + 2 : last],
+                                 src[c + 3 < last ? c + 3 : last]);
+        }
+    }
+}
+__device__ __forceinline__ void maxnorm_store(const MaxNormArgs &a, int c0, int r0, float *buf, MnRegs &r) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int n = 0; n < MN_NV; ++n) {
+        const int f = tid + n * NT, row = f >> 2, c4 = f & 3, c = c0 + 4 * c4;
+        const bool rok = r0 + row < a.J;
+        float4 v = r.v[n];
+        v.x = (rok && c < a.I) ? v.x : 0.f;
+        v.y = (rok && c + 1 < a.I) ? v.y : 0.f;
+        v.z = (rok && c + 2 < a.I) ? v.z : 0.f;
+        v.w = (rok && c + 3 < a.I) ? v.w : 0.f;
+        *reinterpret_cast<float4 *>(buf + row * 16 + 4 * c4) = v;
+    }
+}
 __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
-    constexpr int MN_ROWS = 512;
-    __shared__ __attribute__((aligned(16))) float sA[MN_ROWS * 16];
+    static_assert(NT == 256 && MN_NV >= 1 && MN_NV * NT == MN_CH * (MN_COLS / 4), "loader split");
+    __shared__ __attribute__((aligned(16))) float sA[2][MN_CH * 16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int c0 = blockIdx.x * 16;
+    const int c0 = blockIdx.x * MN_COLS;
+    const bool full = (a.ldw & 3) == 0 && (((uintptr_t)a.W) & 15u) == 0 && c0 + MN_COLS <= a.I;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r0 = 0; r0 < a.J; r0 += MN_ROWS) {
-        const int nr = (a.J - r0 < MN_ROWS) ? a.J - r0 : MN_ROWS;
-        // 16 columns x 512 rows per pass; 16-byte loads (eight in flight per thread) when the strip is whole
-        if (c0 + 16 <= a.I && (a.ldw & 3) == 0 && (((uintptr_t)a.W) & 15u) == 0) {
-#pragma unroll
-            for (int n = 0; n < MN_ROWS * 4 / NT; ++n) {
-                const int f = tid + n * NT, row = f >> 2, c4 = f & 3;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < nr) v = *reinterpret_cast<const float4 *>(a.W + (size_t)(r0 + row) * a.ldw + c0 + 4 * c4);
-                *reinterpret_cast<float4 *>(sA + row * 16 + 4 * c4) = v;
-            }
-        } else {
-            for (int e = tid; e < MN_ROWS * 16; e += NT) {
-                const int row = e >> 4, c = c0 + (e & 15);
-                sA[e] = (row < nr && c < a.I) ? a.W[(size_t)(r0 + row) * a.ldw + c] : 0.f;
-            }
-        }
-        __syncthreads();
-        if (w == 0) {
-            const int nsteps = (((nr + 3) / 4) + 7) & ~7;
-            for (int s = 0; s < nsteps; s += 8) {
-                float d[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) d[u] = sA[(4 * (s + u) + g) * 16 + l15];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], d[u], acc, 0, 0, 0);
-            }
-        }
-        __syncthreads();
+    const int nch = (a.J + MN_CH - 1) / MN_CH;
+    MnRegs R0, R1, R2;
+    maxnorm_load(a, c0, 0, full, R0);
+    if (nch > 1) maxnorm_load(a, c0, MN_CH, full, R1);
+    if (nch > 2) maxnorm_load(a, c0, 2 * MN_CH, full, R2);
+    // iteration ch: chunk ch's registers -> slot ch % 2, chunk ch + 3's loads issued, barrier, wave 0 runs chunk ch.
+    // Slot ch % 2 is written again in iteration ch + 2: wave 0 finished reading it before the barrier of iteration ch + 1.
+#define BM_MN_STEP(R, CH)                                                                         \
+    if ((CH) < nch) {                                                                             \
+        maxnorm_store(a, c0, (CH) * MN_CH, sA[(CH) & 1], R);                                      \
+        if ((CH) + 3 < nch) maxnorm_load(a, c0, ((CH) + 3) * MN_CH, full, R);                     \
+        wg_barrier();          /* not __syncthreads(): its fence would drain the chunks in flight */ \
+        if (w == 0) {                                                                             \
+            const float *img = sA[(CH) & 1];                                                      \
+            _Pragma("unroll 2")                                                                   \
+            for (int s = 0; s < MN_CH / 4; s += 8) {      /* rows beyond J are zero: fma(0, 0, acc) == acc */ \
+                float d[8];                                                                       \
+                _Pragma("unroll")                                                                 \
+                for (int u = 0; u < 8; ++u) d[u] = img[(4 * (s + u) + g) * 16 + l15];             \
+                _Pragma("unroll")                                                                 \
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d[u], d[u], acc, 0, 0, 0); \
+            }                                                                                     \
+        }                                                                                         \
     }
-    if (w == 0 && (l15 >> 2) == g && c0 + l15 < a.I) {       // diagonal element i == j == l15
+    for (int ch = 0; ch < nch; ch += 3) {
+        BM_MN_STEP(R0, ch)
+        BM_MN_STEP(R1, ch + 1)
+        BM_MN_STEP(R2, ch + 2)
+    }
+#undef BM_MN_STEP
+    const int c = c0 + l15;
+    if (w == 0 && (l15 >> 2) == g && c < a.I) {              // diagonal element i == j == l15
         const float nrm = sqrtf(acc[l15 & 3]);
-        a.num[c0 + l15] = fminf(nrm, a.max_norm);            // tf.minimum(T_norm, max_norm)
-        a.den[c0 + l15] = fmaxf(nrm, 1e-8f);                 // tf.maximum(T_norm, 1e-8)
-        if (a.norm_out) a.norm_out[c0 + l15] = nrm;
+        a.num[c] = fminf(nrm, a.max_norm);                   // tf.minimum(T_norm, max_norm)
+        a.den[c] = fmaxf(nrm, 1e-8f);                        // tf.maximum(T_norm, 1e-8)
+        if (a.norm_out) a.norm_out[c] = nrm;
     }
 }
 __global__ __launch_bounds__(256) void maxnorm_scale_kernel(MaxNormArgs a) {
@@ -1532,9 +1583,39 @@ __global__ void mf_latch_kernel(MfCtl *c, float tol, int init) {
 __global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda, const float *B, int ldb, int rows, int cols, unsigned *out) {
     __shared__ float s_m[4];
     float m = 0.f;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-        const float *pa = A + (size_t)r * lda, *pb = B + (size_t)r * ldb;
-        for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(pa[c] - pb[c]));
+    const bool vec = ((lda | ldb) & 3) == 0 && ((((uintptr_t)A) | ((uintptr_t)B)) & 15u) == 0;
+    if (vec) {
+        // 16-byte loads, four pairs in flight per thread (one row pair per 256 threads took 33 us for 256 x 5000:
+        // twenty dependent round trips)
+        const int c4n = cols >> 2;
+        const long long n = (long long)rows * c4n;
+        const long long stride = (long long)gridDim.x * 256;
+        long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+        for (; e + 3 * stride < n; e += 4 * stride) {
+            float4 x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long f = e + u * stride;
+                const int r = (int)(f / c4n), c = 4 * (int)(f % c4n);
+                x[u] = *reinterpret_cast<const float4 *>(A + (size_t)r * lda + c);
+                y[u] = *reinterpret_cast<const float4 *>(B + (size_t)r * ldb + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                m = fmaxf(m, fmaxf(fmaxf(fabsf(x[u].x - y[u].x), fabsf(x[u].y - y[u].y)), fmaxf(fabsf(x[u].z - y[u].z), fabsf(x[u].w - y[u].w))));
+        }
+        for (; e < n; e += stride) {
+            const int r = (int)(e / c4n), c = 4 * (int)(e % c4n);
+            const float4 x = *reinterpret_cast<const float4 *>(A + (size_t)r * lda + c), y = *reinterpret_cast<const float4 *>(B + (size_t)r * ldb + c);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(x.x - y.x), fabsf(x.y - y.y)), fmaxf(fabsf(x.z - y.z), fabsf(x.w - y.w))));
+        }
+        for (int r = blockIdx.x; r < rows; r += gridDim.x)           // the columns beyond the last whole quad
+            for (int c = 4 * c4n + threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(A[(size_t)r * lda + c] - B[(size_t)r * ldb + c]));
+    } else {
+        for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float *pa = A + (size_t)r * lda, *pb = B + (size_t)r * ldb;
+            for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, fabsf(pa[c] - pb[c]));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -1849,7 +1930,7 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
 // ---- grad_kernel geometry choice: 4 waves of 32 x 32 or 8 waves of 32 x 16 (bit-identical results), measured
 // once per shape like the act geometries (tune_act_shape), on scratch copies of every buffer the kernel writes.
 // BM355_GRAD_GEO=4|8 forces one.
-template <class G, int STG>
+template <class G, int STG, int MINB = 1>
 static inline void launch_grad_geo(const GradArgs &g_in, hipStream_t st) {
     GradArgs g = g_in;
     {
@@ -1859,12 +1940,16 @@ static inline void launch_grad_geo(const GradArgs &g_in, hipStream_t st) {
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
     const dim3 grid(tile_grid<G>(g.I, g.J) + g.nbias), blk(G::NT);
-    if (fast) hipLaunchKernelGGL((grad_kernel<G, true, 0, STG>), grid, blk, 0, st, g);
-    else      hipLaunchKernelGGL((grad_kernel<G, false, 0, STG_DMA>), grid, blk, 0, st, g);
+    if (fast) hipLaunchKernelGGL((grad_kernel<G, true, 0, STG, MINB>), grid, blk, 0, st, g);
+    else      hipLaunchKernelGGL((grad_kernel<G, false, 0, STG_DMA, MINB>), grid, blk, 0, st, g);
 }
 // geo: 4 | 8 waves, + 100 for register staging of the full chunks
 static inline void launch_grad_as(int geo, const GradArgs &g, hipStream_t st) {
-    if (geo == 208)      launch_grad_geo<GeoGrad8, STG_DMAH>(g, st);
+    // 9: 8 waves, BK = 32, two workgroups per CU - for outputs of many tiles per CU and a short K (3072 x 5000 x 512:
+    // a tile's fill and read-modify-write epilogue take as long as its K loop)
+    if (geo == 9 && g.nbias == 0) launch_grad_geo<GeoGrad8h, STG_DMA, 2>(g, st);
+    else if (geo == 9)   launch_grad_geo<GeoGrad8, STG_DMA>(g, st);
+    else if (geo == 208) launch_grad_geo<GeoGrad8, STG_DMAH>(g, st);
     else if (geo == 108) launch_grad_geo<GeoGrad8, STG_REG>(g, st);
     else if (geo == 104) launch_grad_geo<GeoGrad, STG_REG>(g, st);
     else if (geo == 8)   launch_grad_geo<GeoGrad8, STG_DMA>(g, st);
@@ -1885,9 +1970,9 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
 #endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return 4; }
-    constexpr int NC = 4;
-    const int cand[NC] = {4, 8, 104, 108};             // 208 (half-wave DMA) is forceable, never the fastest
-    float best_us[NC] = {1e30f, 1e30f, 1e30f, 1e30f};
+    constexpr int NC = 5;
+    const int cand[NC] = {4, 8, 104, 108, 9};          // 208 (half-wave DMA) is forceable, never the fastest
+    float best_us[NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < 3; ++round)
         for (int c = 0; c < NC; ++c) {
             launch_grad_as(cand[c], t, st);
@@ -1925,9 +2010,9 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
-        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f), "
+        fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f; 8w bk32 x2: %.1f), "
                         "XCD grid %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
-                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3], xi, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
+                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3], best_us[4], xi, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
     return best + 1000 * xi;
 }
 static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {

@@ -53,10 +53,11 @@ print('GEOMETRY_OK')
 '''
 
 
-@pytest.mark.parametrize('geo', ['8', '4', '1', '3', '108', '104', '101', '103', '208', '6', '5', '7', 'g4', 'g8', 'g104', 'g108', 'g208'])
+@pytest.mark.parametrize('geo', ['8', '4', '1', '3', '108', '104', '101', '103', '208', '6', '5', '7', 'g4', 'g8', 'g104', 'g108', 'g208', 'g9'])
 def test_forced_geometry_bit_exact(gpu_lib, geo):
     # 8 | 4 | 1 | 3: act_kernel tile geometries with LDS-DMA staging, + 100: the same with register staging;
-    # 'g4' / 'g8' (+ 100): the grad_kernel geometries (4 waves of 32 x 32, 8 waves of 32 x 16) through BM355_GRAD_GEO
+    # 'g4' / 'g8' (+ 100): the grad_kernel geometries (4 waves of 32 x 32, 8 waves of 32 x 16) through BM355_GRAD_GEO;
+    # 'g9': 8 waves with BK = 32, two workgroups per CU
     env = dict(os.environ, BM355_GRAD_GEO=geo[1:]) if geo.startswith('g') else dict(os.environ, BM355_ACT_GEO=geo)
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT)], env=env, capture_output=True, text=True,
                        timeout=600)

@@ -17,6 +17,7 @@ for c in $CONFIGS; do
     grbm)  A="--steps 10 --warmup 3";   P="--steps 4 --warmup 2";;
     dbm)   A="--steps 10 --warmup 3";   P="--steps 4 --warmup 2";;
     ais)   A="--steps 1 --warmup 1 --ais-betas 60"; P="--steps 1 --warmup 0 --ais-betas 20";;
+    grbmfast) cc=grbm; X="--fast-binary"; A="--steps 10 --warmup 3"; P="--steps 4 --warmup 2";;
     aisfast) cc=ais; X="--fast-binary"; A="--steps 1 --warmup 1 --ais-betas 60"; P="--steps 1 --warmup 0 --ais-betas 20";;
   esac
   B="python $R/bench.py --config $cc $X --no-cpu --no-others --precondition-s 0.1"

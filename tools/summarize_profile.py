@@ -16,7 +16,7 @@ import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof_r2'
 tag = sys.argv[2] if len(sys.argv) > 2 else 'r2'
-configs = sys.argv[3:] or ['rbm', 'gibbs', 'grbm', 'dbm', 'ais', 'aisfast']
+configs = sys.argv[3:] or ['rbm', 'gibbs', 'grbm', 'dbm', 'ais', 'aisfast', 'grbmfast']
 os.makedirs('profiles', exist_ok=True)
 
 
@@ -65,7 +65,7 @@ for cfg in configs:
                 pmc.setdefault(k, {}).update(dd)
     # steps seen by the counter pass: one marker kernel per step
     marker = {'rbm': 'grad_kernel', 'gibbs': None, 'grbm': 'maxnorm_kernel', 'dbm': 'dbm_bias_kernel', 'ais': 'ais_init_kernel',
-              'aisfast': 'ais_init_kernel'}[cfg]
+              'aisfast': 'ais_init_kernel', 'grbmfast': 'maxnorm_kernel'}[cfg]
     if marker:
         per = {'dbm_bias_kernel': 3}.get(marker, 1)
         n_steps = max(1, sum(n for k, n in ndisp.items() if marker in k) // per)
