@@ -1729,6 +1729,10 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     // 32 x 64 tile, for outputs large enough to fill the chip with tiles of that size
     if (geo == 6 && !a.p_xm) { launch_act_geo<GeoGrad8, 1, STG_DMA>(a, st); return; }
     if (geo == 6) geo = 8;
+    // 9: the 64 x 64 tile with BK = 32: 64 KiB LDS, two workgroups per CU (k-major P only)
+    // (the second template argument is the kernel's waves per SIMD: 2 workgroups x 8 waves / 4 SIMDs)
+    if (geo == 9 && !a.p_xm) { launch_act_geo<GeoGrad8h, 4, STG_DMA>(a, st); return; }
+    if (geo == 9) geo = 8;
     // 5: 64 x 32 tile with BK = 32, three workgroups per CU (k-major P only)
     if (geo == 5 && !a.p_xm) { launch_act_geo<GeoAct32, 3, STG_DMA>(a, st); return; }
     // 7: the same with two workgroups per CU (256 registers per wave: the two-segment variant spills 140 bytes at 168)
@@ -1750,10 +1754,10 @@ static inline void launch_act_as(int geo, const ActArgs &a, hipStream_t st) {
     }
 }
 struct ActTune {
-    static constexpr int NC = 11;
+    static constexpr int NC = 12;
     int best = 0;
     int xi = 0;                  // XCD grid of the block -> tile map (TileMap), measured with the chosen geometry
-    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float t_us[NC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 };
 // scratch pool of the tuning launches (per process and device; grown on demand, never on the hot path)
 struct TuneScratch {
@@ -1793,17 +1797,17 @@ static inline bool tune_redirect(const ActArgs &a, ActArgs &t) {
     return true;
 }
 static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, long long flags) {
-    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6, 5, 7};
+    static const int cand_geo[ActTune::NC] = {8, 4, 1, 3, 108, 104, 101, 103, 6, 5, 7, 9};
     constexpr int TUNE_REP = 4, TUNE_ROUNDS = 3;
     T.best = a.p_xm ? 8 : 4;
     ActArgs t;
     if (!tune_redirect(a, t)) return;                // no memory for the scratch outputs: keep the default
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return; }
-    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    float best_us[ActTune::NC] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < TUNE_ROUNDS; ++round) {
         for (int c = 0; c < ActTune::NC; ++c) {
-            if (a.p_xm && (cand_geo[c] % 100 == 4 || cand_geo[c] == 6 || cand_geo[c] == 5 || cand_geo[c] == 7)) continue;   // not instantiated for an x-major P
+            if (a.p_xm && (cand_geo[c] % 100 == 4 || cand_geo[c] == 6 || cand_geo[c] == 5 || cand_geo[c] == 7 || cand_geo[c] == 9)) continue;   // not instantiated for an x-major P
             launch_act_as(cand_geo[c], t, st);                    // warm (instruction cache, clocks)
             (void)hipEventRecord(e0, st);
             for (int r = 0; r < TUNE_REP; ++r) launch_act_as(cand_geo[c], t, st);
@@ -1844,10 +1848,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us, dma: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; "
-                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f; 64x32/bk32 x3: %.1f, x2: %.1f)\n",
+                        "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f; 64x32/bk32 x3: %.1f, x2: %.1f; 64x64/bk32 x2: %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.best, T.t_us[0] > 1e29f ? -1.f : T.t_us[0], T.t_us[1] > 1e29f ? -1.f : T.t_us[1], T.t_us[2], T.t_us[3],
                 T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7], T.t_us[8] > 1e29f ? -1.f : T.t_us[8],
-                T.t_us[9] > 1e29f ? -1.f : T.t_us[9], T.t_us[10] > 1e29f ? -1.f : T.t_us[10]);
+                T.t_us[9] > 1e29f ? -1.f : T.t_us[9], T.t_us[10] > 1e29f ? -1.f : T.t_us[10], T.t_us[11] > 1e29f ? -1.f : T.t_us[11]);
     if (log && tune_xi)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> XCD grid %d x %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
                 a.I, a.J, a.K1, a.K2, flags, T.xi, T.xi ? 8 / T.xi : 0, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
@@ -1947,7 +1951,7 @@ static inline void launch_grad_geo(const GradArgs &g_in, hipStream_t st) {
 static inline void launch_grad_as(int geo, const GradArgs &g, hipStream_t st) {
     // 9: 8 waves, BK = 32, two workgroups per CU - for outputs of many tiles per CU and a short K (3072 x 5000 x 512:
     // a tile's fill and read-modify-write epilogue take as long as its K loop)
-    if (geo == 9 && g.nbias == 0) launch_grad_geo<GeoGrad8h, STG_DMA, 2>(g, st);
+    if (geo == 9 && g.nbias == 0) launch_grad_geo<GeoGrad8h, STG_DMA, 4>(g, st);       // 4 waves per SIMD = 2 workgroups per CU
     else if (geo == 9)   launch_grad_geo<GeoGrad8, STG_DMA>(g, st);
     else if (geo == 208) launch_grad_geo<GeoGrad8, STG_DMAH>(g, st);
     else if (geo == 108) launch_grad_geo<GeoGrad8, STG_REG>(g, st);

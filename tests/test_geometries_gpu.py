@@ -53,7 +53,7 @@ print('GEOMETRY_OK')
 '''
 
 
-@pytest.mark.parametrize('geo', ['8', '4', '1', '3', '108', '104', '101', '103', '208', '6', '5', '7', 'g4', 'g8', 'g104', 'g108', 'g208', 'g9'])
+@pytest.mark.parametrize('geo', ['8', '4', '1', '3', '108', '104', '101', '103', '208', '6', '5', '7', '9', 'g4', 'g8', 'g104', 'g108', 'g208', 'g9'])
 def test_forced_geometry_bit_exact(gpu_lib, geo):
     # 8 | 4 | 1 | 3: act_kernel tile geometries with LDS-DMA staging, + 100: the same with register staging;
     # 'g4' / 'g8' (+ 100): the grad_kernel geometries (4 waves of 32 x 32, 8 waves of 32 x 16) through BM355_GRAD_GEO;
