@@ -320,6 +320,8 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
     return dmax;
 }
 
+// MINB: HIP's second __launch_bounds__ argument = WAVES PER SIMD the register budget must allow (for the 4-wave
+// geometries that equals the workgroups per CU; an 8-wave workgroup that should run twice per CU passes 4)
 template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if ((threadIdx.x & 63) == 0) s_chk[threadIdx.x >> 6] = m;
-        __syncthreads();
+        wg_barrier();               // LDS-only hand-over: no fence that waits for the global stores / loads in flight
 #pragma unroll
         for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_chk[q]);
         const int was_done = a.chk_ctl->done;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
         if (lane == 0) s_wavemax[w] = dmax;
-        __syncthreads();
+        wg_barrier();               // LDS-only hand-over: no fence that waits for the global stores / loads in flight
         if (tid == 0) {
             float m = 0.f;
 #pragma unroll
@@ -590,7 +592,7 @@ __device__ __forceinline__ void block_colsum(const float *A, int lda, const floa
                 sB[row * CS_LD + cc] = (ok && Bm) ? Bm[(size_t)(r0 + row) * ldb + c] : 0.f;
             }
         }
-        __syncthreads();
+        wg_barrier();               // LDS-only hand-over: no fence that waits for the global stores / loads in flight
         // next chunk in flight under the chain (clamped loads are legal for any r0)
         if (vec) cs_fetch(regs, A, lda, Bm, ldb, c0, ncols, nrows, r0 + CS_ROWS, tid);
         // rows >= nr are zero in LDS, so the chain may run to a multiple of 8 steps:
@@ -611,7 +613,7 @@ __device__ __forceinline__ void block_colsum(const float *A, int lda, const floa
                 if (want2) sum2 = __builtin_amdgcn_mfma_f32_16x16x4f32(e[u], 1.0f, sum2, 0, 0, 0);
             }
         }
-        __syncthreads();
+        wg_barrier();               // LDS-only hand-over: no fence that waits for the global stores / loads in flight
     }
     if (negB) sum2 = -sum2;
 }
