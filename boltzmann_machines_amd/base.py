@@ -234,16 +234,50 @@ class EngineModel(BaseModel, DtypeMixin):
         params = self.get_params(deep=False)
         params = self._serialize(dict(params))
         params['__class_name__'] = self.__class__.__name__
-        self._join_save()
         params_json = json.dumps(params, **self.json_params)
         rng_json = json.dumps(self._rng.get_state()) if self.random_seed is not None else None
         variables = self._variables()            # device -> host snapshot, taken NOW (synchronises the stream)
         paths = (self._params_filepath, self._random_state_filepath, self._model_filepath + '.npz')
+        job = (params_json, rng_json, variables, paths)
+        # fit() saves once more after the last epoch's save (as the reference does): when nothing changed in between,
+        # the files on disk (or on their way there) already hold exactly this state
+        last = self.__dict__.get('_save_last')
+        if last is not None and self.__dict__.get('_save_exc') is None and self._same_checkpoint(last, job):
+            return
+        self._save_last = job
+        # The files are written by a background thread while the next epoch trains (the snapshot above is what they
+        # contain); every public call joins it before it returns, so callers never see half-written files.  When a
+        # snapshot arrives while the previous one is still being written (an epoch shorter than the ~6 ms write of a
+        # 784 x 1024 model), it waits in a one-deep slot and REPLACES an older waiting one: the training loop never
+        # blocks on the disk, and the newest state is what ends up on it.
+        import threading
+        lock = self.__dict__.setdefault('_save_lock', threading.Lock())
+        with lock:
+            if self.__dict__.get('_save_busy'):
+                self._save_pending = job
+                return
+            self._save_busy = True
+        self._save_thread = threading.Thread(target=self._save_writer, args=(job, lock), daemon=False)
+        self._save_thread.start()
 
-        def write():
+    @staticmethod
+    def _same_checkpoint(a, b):
+        if a[0] != b[0] or a[1] != b[1] or a[3] != b[3]:
+            return False
+        try:
+            va, vb = a[2], b[2]
+            if sorted(va.keys()) != sorted(vb.keys()):
+                return False
+            return all(np.array_equal(va[k], vb[k]) for k in va.keys())
+        except Exception:       # noqa: BLE001 - anything unusual about the snapshot: write it
+            return False
+
+    def _save_writer(self, job, lock):
+        while True:
             # every file goes to a temporary name first and is renamed into place: a failed write (disk full,
             # directory removed) never leaves a half-written checkpoint behind, and its exception is kept for
             # _join_save() to re-raise in the calling thread (the reference's synchronous save raises there)
+            params_json, rng_json, variables, paths = job
             try:
                 tmp = paths[0] + '.tmp'
                 with open(tmp, 'w') as f:
@@ -259,17 +293,19 @@ class EngineModel(BaseModel, DtypeMixin):
                 np.savez(tmp, **variables)
                 os.replace(tmp, paths[2])
             except BaseException as e:      # noqa: BLE001 - handed to the caller by _join_save
-                self._save_exc = e
-        # the files are written by a background thread while the next epoch trains (the snapshot above is what
-        # they contain); every public call joins it before it returns, so callers never see half-written files
-        import threading
-        self._save_thread = threading.Thread(target=write, daemon=False)
-        self._save_thread.start()
+                if self.__dict__.get('_save_exc') is None:
+                    self._save_exc = e
+                self._save_last = None      # nothing is known to be on disk: the next save writes, whatever it holds
+            with lock:
+                job = self.__dict__.pop('_save_pending', None)
+                if job is None:
+                    self._save_busy = False
+                    return
 
     def _join_save(self):
         t = self.__dict__.pop('_save_thread', None)
         if t is not None:
-            t.join()
+            t.join()                        # (the writer drains the waiting snapshot before it ends)
         e = self.__dict__.pop('_save_exc', None)
         if e is not None:
             raise e

@@ -220,10 +220,53 @@ def test_checkpoint_write_is_atomic_and_errors_reach_the_caller(tmp_path):
     with pytest.raises(IOError, match='disk full'):
         m._join_save()
     m._join_save()                                   # the error is reported once
+    m._variables = lambda: {'W': np.arange(6, dtype=np.float32).reshape(2, 3)}
+    m._save_model()                                  # a retry after a failure writes (even an unchanged state)
+    m._join_save()
     assert not [f for f in os.listdir(d) if f.endswith('.tmp')]
     with np.load(os.path.join(d, 'model.npz')) as z:     # the previous checkpoint is intact
         assert np.array_equal(z['W'], np.arange(6, dtype=np.float32).reshape(2, 3))
     assert json.loads(open(os.path.join(d, 'params.json')).read()).keys() == json.loads(before).keys()
+
+
+def test_checkpoint_writer_never_blocks_the_training_loop(tmp_path, monkeypatch):
+    """an epoch shorter than a checkpoint write (6 ms at 784 x 1024) must not wait for the disk: a snapshot that arrives
+    while the writer is busy waits in a one-deep slot, a newer one replaces it, the newest state ends up on disk"""
+    import time
+    from boltzmann_machines_amd import base
+    m = _StubModel.make(tmp_path)
+    n = {'snap': 0, 'written': []}
+
+    def variables():
+        n['snap'] += 1
+        return {'W': np.full((2, 3), n['snap'], dtype=np.float32)}
+    m._variables = variables
+    real = np.savez
+
+    def slow_savez(path, **kw):
+        time.sleep(0.25)
+        n['written'].append(int(kw['W'][0, 0]))
+        return real(path, **kw)
+    monkeypatch.setattr(base.np, 'savez', slow_savez)
+    t0 = time.perf_counter()
+    for _ in range(4):
+        m._save_model()
+    assert time.perf_counter() - t0 < 0.2            # four epoch ends, no wait
+    m._join_save()
+    assert n['written'] == [1, 4]                    # the first snapshot and the newest one; 2 and 3 were superseded
+    with np.load(os.path.join(str(tmp_path / 'm'), 'model.npz')) as z:
+        assert float(z['W'][0, 0]) == 4.0
+    m._save_model()                                  # the writer starts again after it went idle
+    m._join_save()
+    assert n['written'] == [1, 4, 5]
+    m._variables = lambda: {'W': np.full((2, 3), 5, dtype=np.float32)}
+    m._save_model()                                  # fit()'s closing save right after the last epoch's: same state,
+    m._join_save()                                   # nothing is written again
+    assert n['written'] == [1, 4, 5]
+    m._variables = lambda: {'W': np.full((2, 3), 6, dtype=np.float32)}
+    m._save_model()
+    m._join_save()
+    assert n['written'] == [1, 4, 5, 6]
 
 
 def test_data_parallel_is_opt_in(monkeypatch):
