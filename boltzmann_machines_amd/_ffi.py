@@ -107,6 +107,8 @@ SIGNATURES = {
     'bm_rbm_train_step_metrics': [_vp, _vp, _i32, _f32, _f32, _i32, _fp],
     'bm_rbm_train_epoch': [_vp, _vp, _i64, _i32, _f32, _f32, _i32],
     'bm_rbm_set_epoch_graph': [_vp, _i32],
+    'bm_rbm_stage': [_vp, _i32],
+    'bm_rbm_get_staged': [_vp, _i32, C.c_char_p, _vp, _sz],
     'bm_rbm_set_grad_overlap': [_vp, _i32],
     'bm_rbm_grad_step': [_vp, _vp, _i32, _i32],
     'bm_rbm_apply_step': [_vp, _i32, _f32, _f32],

@@ -236,33 +236,47 @@ class EngineModel(BaseModel, DtypeMixin):
         params['__class_name__'] = self.__class__.__name__
         params_json = json.dumps(params, **self.json_params)
         rng_json = json.dumps(self._rng.get_state()) if self.random_seed is not None else None
-        variables = self._variables()            # device -> host snapshot, taken NOW (synchronises the stream)
         paths = (self._params_filepath, self._random_state_filepath, self._model_filepath + '.npz')
-        job = (params_json, rng_json, variables, paths)
-        # fit() saves once more after the last epoch's save (as the reference does): when nothing changed in between,
-        # the files on disk (or on their way there) already hold exactly this state
-        last = self.__dict__.get('_save_last')
-        if last is not None and self.__dict__.get('_save_exc') is None and self._same_checkpoint(last, job):
-            return
-        self._save_last = job
-        # The files are written by a background thread while the next epoch trains (the snapshot above is what they
-        # contain); every public call joins it before it returns, so callers never see half-written files.  When a
-        # snapshot arrives while the previous one is still being written (an epoch shorter than the ~6 ms write of a
-        # 784 x 1024 model), it waits in a one-deep slot and REPLACES an older waiting one: the training loop never
-        # blocks on the disk, and the newest state is what ends up on it.
+        # The files are written by a background thread while the next epoch trains; every public call joins it before
+        # it returns, so callers never see half-written files.  When a snapshot arrives while the previous one is still
+        # being written (an epoch shorter than the ~5 ms write of a 784 x 1024 model), it waits in a one-deep slot and
+        # REPLACES an older waiting one: the training loop never blocks on the disk, and the newest state is what ends
+        # up on it.  Models whose engine can stage a snapshot on the device (`_stage_variables`) do not even stop the
+        # stream: the variables are copied device-to-device in stream order into one of two slots and the WRITER reads
+        # them back, while the next epoch is already running.
         import threading
         lock = self.__dict__.setdefault('_save_lock', threading.Lock())
         with lock:
-            if self.__dict__.get('_save_busy'):
+            busy = bool(self.__dict__.get('_save_busy'))
+            pending = self.__dict__.get('_save_pending')
+            # the slot a staged snapshot may use: the waiting job's (it is replaced anyway), else the one the writer
+            # is not reading
+            if busy and pending is not None and pending[4] is not None:
+                slot = pending[4]
+            else:
+                slot = 1 - self.__dict__.get('_save_inflight_slot', 1) if busy else 0
+            staged = self._stage_variables(slot)         # None: no staging, take the snapshot on the host now
+            if staged is None:
+                variables, slot = self._variables(), None    # (synchronises the stream)
+            else:
+                variables = staged
+            job = (params_json, rng_json, variables, paths, slot)
+            if busy:
                 self._save_pending = job
                 return
             self._save_busy = True
+            self._save_inflight_slot = slot if slot is not None else 1
         self._save_thread = threading.Thread(target=self._save_writer, args=(job, lock), daemon=False)
         self._save_thread.start()
 
+    def _stage_variables(self, slot):
+        """engines with device-side snapshot slots: stage the variables into `slot` and return a callable that reads
+        them back (called by the writer thread); None = not supported, the caller snapshots on the host"""
+        return None
+
     @staticmethod
     def _same_checkpoint(a, b):
-        if a[0] != b[0] or a[1] != b[1] or a[3] != b[3]:
+        if a is None or a[0] != b[0] or a[1] != b[1] or a[3] != b[3]:
             return False
         try:
             va, vb = a[2], b[2]
@@ -277,30 +291,38 @@ class EngineModel(BaseModel, DtypeMixin):
             # every file goes to a temporary name first and is renamed into place: a failed write (disk full,
             # directory removed) never leaves a half-written checkpoint behind, and its exception is kept for
             # _join_save() to re-raise in the calling thread (the reference's synchronous save raises there)
-            params_json, rng_json, variables, paths = job
+            params_json, rng_json, variables, paths, _slot = job
             try:
-                tmp = paths[0] + '.tmp'
-                with open(tmp, 'w') as f:
-                    f.write(params_json)
-                os.replace(tmp, paths[0])
-                if rng_json is not None:
-                    tmp = paths[1] + '.tmp'
+                if callable(variables):                  # a staged snapshot: read it back here, off the training thread
+                    variables = variables()
+                job = (params_json, rng_json, variables, paths, None)
+                # fit() saves once more after the last epoch's save (as the reference does): when nothing changed in
+                # between, the files on disk already hold exactly this state
+                if not self._same_checkpoint(self.__dict__.get('_save_written'), job):
+                    tmp = paths[0] + '.tmp'
                     with open(tmp, 'w') as f:
-                        f.write(rng_json)
-                    os.replace(tmp, paths[1])
-                # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
-                tmp = paths[2] + '.tmp.npz'
-                np.savez(tmp, **variables)
-                os.replace(tmp, paths[2])
+                        f.write(params_json)
+                    os.replace(tmp, paths[0])
+                    if rng_json is not None:
+                        tmp = paths[1] + '.tmp'
+                        with open(tmp, 'w') as f:
+                            f.write(rng_json)
+                        os.replace(tmp, paths[1])
+                    # where the reference calls tf.train.Saver.save(session, model_filepath, global_step)
+                    tmp = paths[2] + '.tmp.npz'
+                    np.savez(tmp, **variables)
+                    os.replace(tmp, paths[2])
+                    self._save_written = job
             except BaseException as e:      # noqa: BLE001 - handed to the caller by _join_save
                 if self.__dict__.get('_save_exc') is None:
                     self._save_exc = e
-                self._save_last = None      # nothing is known to be on disk: the next save writes, whatever it holds
+                self._save_written = None   # nothing is known to be on disk: the next save writes, whatever it holds
             with lock:
                 job = self.__dict__.pop('_save_pending', None)
                 if job is None:
                     self._save_busy = False
                     return
+                self._save_inflight_slot = job[4] if job[4] is not None else 1
 
     def _join_save(self):
         t = self.__dict__.pop('_save_thread', None)

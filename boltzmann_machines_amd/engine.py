@@ -69,6 +69,16 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_get_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
         return a
 
+    def stage(self, slot):
+        """snapshot of every variable into device-side slot 0 | 1, in stream order, without a host wait (bm_rbm_stage)"""
+        check(self.lib.bm_rbm_stage(self._h, int(slot)))
+
+    def get_staged(self, slot, name):
+        """one variable of a staged snapshot; waits for the staged copies only, callable from another thread"""
+        a = np.empty(self._shape(name), dtype=np.float32)
+        check(self.lib.bm_rbm_get_staged(self._h, int(slot), name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
     def set_fast_binary(self, on):
         """opt-in exact-product bf16 x 3 mode of the sampling sweep (bm_rbm_set_fast_binary)"""
         check(self.lib.bm_rbm_set_fast_binary(self._h, int(bool(on))))

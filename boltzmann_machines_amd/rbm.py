@@ -10,6 +10,8 @@ of `_make_train_op` (:415-525) is executed by libbm355 (csrc/bm_rbm.hip).
 
 MultinomialRBM is out of scope of the hot path.
 """
+import os
+
 import numpy as np
 
 from . import _ffi
@@ -225,6 +227,16 @@ class BaseRBM(EngineModel):
 
     def _scoped_variables(self):
         return {name: (scope, self._engine.get(name)) for name, scope in self._VAR_SCOPES}
+
+    def _stage_variables(self, slot):
+        """checkpoint snapshot without stopping the stream (bm_rbm_stage): float32 engine only; BM355_STAGED_SAVE=0
+        restores the host-side snapshot"""
+        eng = self._engine
+        if not isinstance(eng, RbmEngine) or os.environ.get('BM355_STAGED_SAVE', '1') == '0':
+            return None
+        eng.stage(slot)
+        names = [name for name, _ in self._VAR_SCOPES]
+        return lambda: {name: eng.get_staged(slot, name) for name in names}
 
     def set_params(self, **params):
         # the handle bakes in the graph constants: rebuild it if one of them changes

@@ -157,3 +157,42 @@ def test_display_dumps_do_not_change_the_run(gpu_lib, dirs):
     W = a.get_tf_params(scope='weights')['W']
     assert_allclose(f[:, :, :, 0].reshape(3, 12), W.T[:3], rtol=1e-6)
     assert not os.path.exists(os.path.join(dirs[1], 'logs/train', 'W_filters_epoch0001.npy'))
+
+
+def test_staged_checkpoints_hold_epoch_end_states(gpu_lib, dirs, monkeypatch):
+    """per-epoch checkpoints are staged on the device in stream order (bm_rbm_stage) and read back by the writer thread
+    while the next epoch runs: every snapshot that reaches the disk is the state at AN epoch end (never a mix of two),
+    the last one is the final state, and the run equals the one with host-side snapshots (BM355_STAGED_SAVE=0)."""
+    import time
+    from boltzmann_machines_amd import base
+    written = []
+    real = np.savez
+
+    def slow_savez(path, **kw):          # a slow disk: several epochs pass per write, slots get reused under the writer
+        time.sleep(0.02)
+        written.append({k: np.array(v) for k, v in kw.items()})
+        return real(path, **kw)
+    monkeypatch.setattr(base.np, 'savez', slow_savez)
+    runs = {}
+    for tag, env, d in (('staged', '1', dirs[0]), ('host', '0', dirs[1])):
+        monkeypatch.setenv('BM355_STAGED_SAVE', env)
+        del written[:]
+        rbm = BernoulliRBM(max_epoch=14, model_path=d, **CONFIG)
+        states = []
+        orig = rbm._save_model
+
+        def spy(*a, _orig=orig, _rbm=rbm, _states=states, **k):
+            _states.append(_rbm._engine.get('W').copy())      # the true epoch-end state (a host sync; the test only)
+            return _orig(*a, **k)
+        rbm._save_model = spy
+        rbm.fit(X)
+        runs[tag] = (rbm.get_tf_params(scope='weights')['W'].copy(), [w['W'] for w in written], states)
+    for tag in ('staged', 'host'):
+        final, snaps, states = runs[tag]
+        assert len(snaps) >= 2
+        for s_ in snaps:                                      # each file content is some epoch-end state, whole
+            assert any(np.array_equal(s_, st) for st in states), tag
+        assert np.array_equal(snaps[-1], final), tag
+    assert np.array_equal(runs['staged'][0], runs['host'][0])
+    with np.load(os.path.join(dirs[0], 'model.npz')) as z:
+        assert np.array_equal(z['W'], runs['staged'][0])
