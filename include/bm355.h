@@ -119,7 +119,7 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
 
 /* bm_rbm_train_epoch may replay recurring runs of updates from a HIP graph (1) instead of launching them one by one
  * (0, the default: the replay measured slower on MI355X / ROCm 7.2, csrc/bm_rbm.hip); same bits either way */
-/* A snapshot of every variable that does not stop the stream (the per-epoch checkpoint of base_rbm.py:651-653 while
+/* A snapshot of every variable that does not stop the stream (the per-epoch checkpoint of base_rbm.py:665-666 while
  * the next epoch already runs): bm_rbm_stage copies them device-to-device into slot 0 | 1 in stream order and returns;
  * bm_rbm_get_staged reads one variable of that snapshot (dense, like bm_rbm_get_param) on its own stream - it waits
  * for the staged copies only - and may be called from another host thread.  Do not re-stage a slot being read. */
