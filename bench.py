@@ -812,6 +812,12 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # The contract is ONE JSON line on stdout.  Libraries write there too (gloo prints "[Gloo] Rank 0 is connected to
+    # 1 peer ranks" from C++ when a process group forms, RCCL its banner under NCCL_DEBUG): from here on file
+    # descriptor 1 IS stderr, and the line goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
 
@@ -861,8 +867,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out))
-        sys.stdout.flush()
+        line_out.write(json.dumps(out) + '\n')
+        line_out.flush()
 
     # ---- the other BASELINE configurations, short passes, embedded in the same line (rbm default run only).
     # Every rank runs the same sequence.  A watchdog bounds the whole block: if a pass hangs (a collective that
