@@ -343,3 +343,16 @@ def test_xcd_tile_map_is_a_bijection_and_cuts_modelled_traffic():
     # 3072x5000 outer products (79 x 48 tiles of 64 x 64, K = 512): column groups that fit the L2
     a, b, m = tmap(79, 48, 512 * 64 * 4, 512 * 64 * 4)
     assert m[2] * 512 * 64 * 4 <= 2.5 * 2 ** 20 and m[2] >= 8
+
+
+def test_bench_fails_loudly_without_a_gpu_and_keeps_stdout_clean():
+    """bench.py's stdout is the ONE JSON line of the contract and nothing else; without a HIP device there is no line
+    at all and no CPU fallback - a non-zero exit and a message on stderr."""
+    from boltzmann_machines_amd import _ffi
+    if _ffi.load().bm_device_count() > 0:
+        pytest.skip('a GPU is visible: the bench would run')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--no-cpu', '--no-others'], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout == ''
+    assert 'no HIP device' in r.stderr and 'no CPU fallback' in r.stderr
