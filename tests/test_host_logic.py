@@ -348,6 +348,8 @@ def test_xcd_tile_map_is_a_bijection_and_cuts_modelled_traffic():
 def test_bench_fails_loudly_without_a_gpu_and_keeps_stdout_clean():
     """bench.py's stdout is the ONE JSON line of the contract and nothing else; without a HIP device there is no line
     at all and no CPU fallback - a non-zero exit and a message on stderr."""
+    import subprocess
+    import sys
     from boltzmann_machines_amd import _ffi
     if _ffi.load().bm_device_count() > 0:
         pytest.skip('a GPU is visible: the bench would run')
