@@ -907,10 +907,13 @@ __device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[G::MI][G::NJ], i
 // Rectangle sizes and the number of blocks an XCD receives differ by a few tiles: tiles beyond an XCD's block count
 // are handed, in a fixed order, to the XCDs with spare blocks.
 struct TileMap {
-    int tiles_i, tiles_j, xi, xj, gj;
-    // per XCD (host-computed: no divisions on the device beyond the two of the in-rectangle walk): the rectangle,
-    // the number of spare blocks in the XCDs before this one, and the number of tiles its own blocks do not reach
-    short i0[8], hi[8], j0[8], wj[8], spare_before[8], left[8];
+    int tiles_i, tiles_j, xi, xj, gj, pad_;
+    // per XCD, host-computed and packed so that the device reads them as 12 scalar registers (see tile_of_block):
+    //   rect[x]  = i0 | hi << 16 | j0 << 32 | wj << 48      the XCD's rectangle of tiles
+    //   spare[x] = spare_before | left << 16                 spare blocks in the XCDs before this one, and the number
+    //                                                        of tiles of this rectangle its own blocks do not reach
+    unsigned long long rect[8];
+    unsigned int spare[8];
 };
 
 // force_xi: 0 = the traffic model's choice (or BM355_XCD_MAP=xi[:gj]); 8 / 4 / 2 / 1 = that grid (the launch tuner
@@ -942,51 +945,98 @@ static inline TileMap make_tile_map(int tiles_i, int tiles_j, double bytes_i, do
         const double cost = 8.0 * (hi * bytes_i * groups + wj * bytes_j);
         if (best_cost < 0.0 || cost < best_cost * 0.999) { best_cost = cost; best.xi = xi; best.xj = xj; best.gj = gj; }
     }
+    if (best.gj < 1) best.gj = 1;
     const int nb = tiles_i * tiles_j, q = nb / 8, r = nb % 8;
     int spare = 0;
     for (int x = 0; x < 8; ++x) {
         const int a = x % best.xi, c = x / best.xi;
         const int i0 = a * tiles_i / best.xi, hi = (a + 1) * tiles_i / best.xi - i0;
         const int j0 = c * tiles_j / best.xj, wj = (c + 1) * tiles_j / best.xj - j0;
-        best.i0[x] = (short)i0; best.hi[x] = (short)hi; best.j0[x] = (short)j0; best.wj[x] = (short)wj;
+        best.rect[x] = (unsigned long long)(i0 & 0xFFFF) | (unsigned long long)(hi & 0xFFFF) << 16 |
+                       (unsigned long long)(j0 & 0xFFFF) << 32 | (unsigned long long)(wj & 0xFFFF) << 48;
         const int cap = q + (x < r ? 1 : 0), sz = hi * wj;
-        best.spare_before[x] = (short)spare;
+        const int left = sz > cap ? sz - cap : 0;
+        best.spare[x] = (unsigned int)(spare & 0xFFFF) | (unsigned int)(left & 0xFFFF) << 16;
         if (cap > sz) spare += cap - sz;
-        best.left[x] = (short)(sz > cap ? sz - cap : 0);
     }
     return best;
 }
 
-__host__ __device__ __forceinline__ void tile_of_block(const TileMap &m, int b, int nb, int &ti, int &tj) {
+// a / b for 0 <= a < 2^23, 0 < b < 2^23 without the 32-bit division expansion: float quotient + one-step fix-up
+__host__ __device__ __forceinline__ int small_div(int a, int b) {
+    int q = (int)((float)a / (float)b);
+    q -= (q * b > a);
+    q += ((q + 1) * b <= a);
+    return q;
+}
+
+template <class T>
+__host__ __device__ __forceinline__ T sel8(const T (&a)[8], int x) {
+    T v = a[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) v = (x == c) ? a[c] : v;
+    return v;
+}
+
+// R / S: the map's per-XCD words as VALUES (registers), gj its group width
+__host__ __device__ __forceinline__ void tile_of_block_core(const unsigned long long (&R)[8], const unsigned int (&S)[8],
+                                                            int gj, int b, int nb, int &ti, int &tj) {
     const int q = nb >> 3, r = nb & 7;
     int x = b & 7, l = b >> 3;
-    int i0 = m.i0[x], hi = m.hi[x], j0 = m.j0[x], wj = m.wj[x];
+    unsigned long long e = sel8(R, x);
+    int hi = (int)(e >> 16) & 0xFFFF, wj = (int)(e >> 48) & 0xFFFF;
     if (l >= hi * wj) {
         // a spare block of this XCD: its rank among all spare blocks (XCD order, then local order) takes the tile of
         // the same rank among the tiles no block of their own XCD reaches
-        int k = l - hi * wj + m.spare_before[x];
+        int k = l - hi * wj + (int)(sel8(S, x) & 0xFFFF);
 #pragma unroll
         for (int xc = 0; xc < 8; ++xc) {
-            const int lf = m.left[xc];
+            const int lf = (int)(S[xc] >> 16);
             if (k >= 0 && k < lf) {
-                x = xc; l = q + (xc < r ? 1 : 0) + k;
-                i0 = m.i0[xc]; hi = m.hi[xc]; j0 = m.j0[xc]; wj = m.wj[xc];
+                l = q + (xc < r ? 1 : 0) + k;
+                e = R[xc];
                 k = -1;
             } else if (k >= 0) {
                 k -= lf;
             }
         }
+        hi = (int)(e >> 16) & 0xFFFF; wj = (int)(e >> 48) & 0xFFFF;
     }
+    const int i0 = (int)e & 0xFFFF, j0 = (int)(e >> 32) & 0xFFFF;
     // l-th tile of the rectangle: j-groups of gj columns, inside a group row by row
-    const int gj = m.gj < 1 ? 1 : m.gj;
-    const int nfull = wj / gj, per = hi * gj;
+    const int nfull = small_div(wj, gj), per = hi * gj;
     if (l < nfull * per) {
-        const int g = l / per, rem = l - g * per, row = rem / gj;
+        const int g = small_div(l, per), rem = l - g * per, row = small_div(rem, gj);
         ti = i0 + row; tj = j0 + g * gj + (rem - row * gj);
     } else {
-        const int wl = wj - nfull * gj > 0 ? wj - nfull * gj : 1, rem = l - nfull * per, row = rem / wl;
+        const int wl = wj - nfull * gj > 0 ? wj - nfull * gj : 1, rem = l - nfull * per, row = small_div(rem, wl);
         ti = i0 + row; tj = j0 + nfull * gj + (rem - row * wl);
     }
+}
+
+// Host evaluation (tests, tools).
+static inline void tile_of_block(const TileMap &m, int b, int nb, int &ti, int &tj) {
+    tile_of_block_core(m.rect, m.spare, m.gj, b, nb, ti, tj);
+}
+
+// Device evaluation.  The 12 per-XCD words pass through an empty asm statement as SGPR operands: they are then opaque
+// register values, fetched from the kernel-argument segment by scalar loads that go out with the first batch of
+// arguments, and the selection by blockIdx & 7 is a chain of s_cselect.  Indexing the arrays in the argument segment
+// instead (round 3, also when written as a compare chain - LLVM folds that back into an indexed load) made hipcc
+// fetch the entries with DEPENDENT global loads before the first operand load could be issued: ~0.4 us per launch
+// (same-box A/B against the round-2 library, round 4).
+struct TileRegs { unsigned long long R[8]; unsigned int S[8]; int gj; };
+__device__ __forceinline__ void load_tile_regs(const TileMap &m, TileRegs &t) {
+    t.gj = m.gj;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { t.R[c] = m.rect[c]; t.S[c] = m.spare[c]; }
+    asm volatile("" : "+s"(t.R[0]), "+s"(t.R[1]), "+s"(t.R[2]), "+s"(t.R[3]), "+s"(t.R[4]), "+s"(t.R[5]), "+s"(t.R[6]),
+                      "+s"(t.R[7]), "+s"(t.gj));
+    asm volatile("" : "+s"(t.S[0]), "+s"(t.S[1]), "+s"(t.S[2]), "+s"(t.S[3]), "+s"(t.S[4]), "+s"(t.S[5]), "+s"(t.S[6]),
+                      "+s"(t.S[7]));
+}
+__device__ __forceinline__ void tile_of_block_dev(const TileRegs &t, int b, int nb, int &ti, int &tj) {
+    tile_of_block_core(t.R, t.S, t.gj, b, nb, ti, tj);
 }
 
 // round-2 form (1-D slabs), still used by the kernels without a TileMap argument (free-energy GEMM)

@@ -1,0 +1,293 @@
+"""Scenarios of public-API calls that are executed, line for line, against BOTH packages:
+
+  * the UNMODIFIED reference (`/root/reference/boltzmann_machines`) running on the NumPy TF-1 stand-in
+    (tests/tf1_shim) - `tests/golden/make_golden_from_reference.py` records what it returns in
+    `tests/golden/ref_<scenario>.npz`;
+  * `boltzmann_machines_amd` - on the GPU (`tests/test_reference_fixtures_gpu.py`) and, with the C oracle standing in
+    for the device engine, on the CPU (`tests/test_reference_fixtures.py`).
+
+A scenario is a function `f(pkg, workdir) -> {name: ndarray}`; `pkg` offers BernoulliRBM, GaussianRBM,
+MultinomialRBM, DBM and RNG with the reference's signatures.  Everything a scenario touches is the drop-in surface:
+constructor keywords, fit / transform / init_from / set_params / load_model / get_tf_params, DBM.reconstruct /
+sample_v / log_Z / log_proba, the progress lines (metrics), epoch_ / iter_ bookkeeping.  Test infrastructure."""
+import contextlib
+import io
+import os
+import re
+
+import numpy as np
+
+_FLOAT = r'[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|nan|inf)'
+
+
+class Capture(object):
+    """progress lines the models print per epoch (`epoch: 1/2; msre: ...`): the reference's only scalar outlet of
+    its train / validation metrics besides TensorBoard"""
+
+    def __init__(self):
+        self.buf = io.StringIO()
+
+    def __enter__(self):
+        self._cm = contextlib.redirect_stdout(self.buf)
+        self._cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._cm.__exit__(*exc)
+
+    def metrics(self):
+        """[n_epoch_lines, n_numbers] array of every number on the `epoch:` lines, and the key names"""
+        rows, keys = [], None
+        for line in self.buf.getvalue().replace('\r', '\n').split('\n'):
+            line = line.strip()
+            if not line.startswith('epoch:'):
+                continue
+            parts = [p.strip() for p in line.split(';')]
+            k, v = [], []
+            for p in parts[1:]:
+                m = re.match(r'^([\w.]+)\s*:\s*(%s)$' % _FLOAT, p)
+                if m:
+                    k.append(m.group(1))
+                    v.append(float(m.group(2)))
+            rows.append(v)
+            keys = k if keys is None or len(k) > len(keys) else keys
+        width = max([len(r) for r in rows] + [0])
+        out = np.full((len(rows), width), np.nan)
+        for i, r in enumerate(rows):
+            out[i, :len(r)] = r
+        return out, keys or []
+
+
+def _params(model, out, tag, stride=None):
+    for k, v in model.get_tf_params().items():
+        a = np.asarray(v)
+        if stride and a.ndim == 2 and a.size > 20000:
+            a = a[::stride[0], ::stride[1]]
+        out['%s:%s' % (tag, k)] = a
+    out['%s:epoch_iter' % tag] = np.array([model.epoch_, model.iter_])
+
+
+def _metrics_cfg(**kw):
+    d = dict(l2_loss=True, msre=True, pll=True, feg=True, l2_loss_fmt='.8e', msre_fmt='.8e', pll_fmt='.8e',
+             feg_fmt='.8e', train_metrics_every_iter=1, val_metrics_every_epoch=1, feg_every_epoch=1,
+             n_batches_for_feg=2)
+    d.update(kw)
+    return d
+
+
+# ------------------------------------------------------------------------------------------------ RBM scenarios
+def rbm_reference_test_config(pkg, d, cls_name='BernoulliRBM', dtype='float32', **extra):
+    """the configuration of the reference's own test (rbm/tests/test_rbm.py:12-22, :69-114): real-valued inputs,
+    dropout, both layers sampled, a short last batch; fit - transform - resume - load_model - resume, all metrics on"""
+    X = pkg.RNG(seed=1337).rand(16, 12)
+    X_val = pkg.RNG(seed=42).rand(8, 12)
+    cfg = dict(n_visible=12, n_hidden=8, sample_v_states=True, sample_h_states=True, dropout=0.9, verbose=True,
+               display_filters=False, random_seed=1337, dtype=dtype, max_epoch=2, metrics_config=_metrics_cfg(),
+               model_path=os.path.join(d, 'm/'))
+    cfg.update(extra)
+    C = getattr(pkg, cls_name)
+    out = {}
+    cap = Capture()
+    with cap:
+        rbm = C(**cfg)
+        rbm.fit(X, X_val)
+    _params(rbm, out, 'fit2')
+    with cap:
+        out['transform2'] = rbm.transform(X_val)
+        rbm.set_params(max_epoch=3).fit(X, X_val)
+    _params(rbm, out, 'fit3')
+    rbm = C.load_model(os.path.join(d, 'm/'))
+    _params(rbm, out, 'loaded')
+    with cap:
+        out['transform3'] = rbm.transform(X_val)
+        rbm.set_params(max_epoch=4).fit(X)
+    _params(rbm, out, 'fit4')
+    out['metrics'], _ = cap.metrics()
+    return out
+
+
+def rbm_float64(pkg, d):
+    return rbm_reference_test_config(pkg, d, dtype='float64')
+
+
+def rbm_multinomial(pkg, d):
+    return rbm_reference_test_config(pkg, d, cls_name='MultinomialRBM', n_samples=7)
+
+
+def rbm_gaussian(pkg, d):
+    """GaussianRBM with a per-unit sigma (rbm.py:88-116): input / sigma once, reconstructions `x * sigma + b` not
+    re-divided (layers.py:84-86); Normal sampling of the visibles"""
+    sigma = list(np.linspace(0.6, 1.4, 12))
+    return rbm_reference_test_config(pkg, d, cls_name='GaussianRBM', sigma=sigma, learning_rate=0.01, dropout=None)
+
+
+def rbm_schedules(pkg, d):
+    """per-epoch schedules (1-based index, base_rbm.py:535-541), the tf.while_loop chain (n_gibbs_steps is a list),
+    sparsity penalty, momentum / learning-rate lists, binary data, no dropout, init_from"""
+    V, H, N, bs = 20, 12, 37, 10
+    X = (pkg.RNG(seed=5).rand(N, V) < 0.3).astype(np.float32)
+    X_val = (pkg.RNG(seed=6).rand(14, V) < 0.3).astype(np.float32)
+    kw = dict(n_visible=V, n_hidden=H, batch_size=bs, max_epoch=3, learning_rate=[0.3, 0.05, 0.02],
+              momentum=[0.1, 0.5, 0.9], n_gibbs_steps=[4, 1, 2], l2=1e-3, sample_v_states=True, random_seed=77,
+              verbose=True, sparsity_cost=0.01, sparsity_target=0.2, metrics_config=_metrics_cfg(train_metrics_every_iter=3))
+    out = {}
+    cap = Capture()
+    with cap:
+        rbm = pkg.BernoulliRBM(model_path=os.path.join(d, 'a/'), **kw)
+        rbm.fit(X, X_val)
+    _params(rbm, out, 'fit3')
+    with cap:
+        out['transform'] = rbm.transform(X_val)
+        rbm2 = pkg.BernoulliRBM(model_path=os.path.join(d, 'b/'), **dict(kw, max_epoch=4, random_seed=78))
+        rbm2.init_from(rbm)
+        # init_from copies EVERY trailing-underscore attribute (base_rbm.py:682-685), `initialized_` included, and the
+        # reference's next fit() would then import a meta graph that was never written for the new model path
+        # (tf_model.py:22-23): a warm-started model trains only after the flag is cleared
+        rbm2.initialized_ = False
+        rbm2.fit(X)
+    _params(rbm2, out, 'init_from_fit4')
+    out['metrics'], _ = cap.metrics()
+    return out
+
+
+def rbm_means_only(pkg, d):
+    """neither layer sampled inside the chain (sample_h_states=False: h0 means feed the chain, base_rbm.py:422-424),
+    CD-3 unrolled (scalar n_gibbs_steps), dbm_first / dbm_last multipliers (base_rbm.py:256-262)"""
+    V, H, N = 16, 10, 30
+    X = pkg.RNG(seed=9).rand(N, V).astype(np.float32)
+    out = {}
+    for tag, kw in (('first', dict(dbm_first=True)), ('last', dict(dbm_last=True, sample_h_states=False)),
+                    ('both_sampled', dict(dbm_first=True, dbm_last=True, sample_v_states=True))):
+        rbm = pkg.BernoulliRBM(n_visible=V, n_hidden=H, batch_size=8, max_epoch=2, n_gibbs_steps=3, learning_rate=0.1,
+                               random_seed=21, verbose=False, model_path=os.path.join(d, tag + '/'), **kw)
+        rbm.fit(X)
+        _params(rbm, out, tag)
+        out[tag + ':transform'] = rbm.transform(X[:8])
+    return out
+
+
+def rbm_config0_shape(pkg, d):
+    """BASELINE configs[0]: BernoulliRBM 784 x 128, CD-1, batch 100 (examples/rbm_mnist.py: lr 0.05, momentum
+    0.5 -> 0.9, l2 1e-5, hidden states sampled, visible means) on 100 synthetic binary rows, 2 epochs; matrices stored
+    with a stride.  (Kept this short on purpose: a run with ~10^6 Bernoulli draws always contains one within 1e-6 of
+    a tie, where the float32 round-off of the matmul order decides the sample.)"""
+    V, H, N = 784, 128, 100
+    X = (pkg.RNG(seed=50).rand(N, V) < 0.1307).astype(np.float32)
+    rbm = pkg.BernoulliRBM(n_visible=V, n_hidden=H, batch_size=100, max_epoch=2, learning_rate=0.05,
+                           momentum=[0.5, 0.5, 0.9], l2=1e-5, W_init=0.01, random_seed=1337, verbose=False,
+                           model_path=os.path.join(d, 'm/'))
+    rbm.fit(X)
+    out = {}
+    _params(rbm, out, 'fit2', stride=(7, 3))
+    out['transform'] = rbm.transform(X[:100])[::5, ::3]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DBM scenarios
+def _pretrain(pkg, d, X, sizes, v_cls='BernoulliRBM', top_cls='BernoulliRBM', epochs=2, seeds=(11, 12, 13), **top_kw):
+    rbms, Q = [], X
+    for i in range(len(sizes) - 1):
+        last = i == len(sizes) - 2
+        C = getattr(pkg, v_cls if i == 0 else (top_cls if last else 'BernoulliRBM'))
+        kw = dict(n_visible=sizes[i], n_hidden=sizes[i + 1], dbm_first=(i == 0 and len(sizes) > 2),
+                  dbm_last=(last and len(sizes) > 2), max_epoch=epochs, batch_size=10, learning_rate=0.05,
+                  random_seed=seeds[i], verbose=False, model_path=os.path.join(d, 'rbm%d/' % i))
+        if last:
+            kw.update(top_kw)
+        if i == 0 and v_cls == 'GaussianRBM':
+            kw.update(learning_rate=0.005, sigma=1.)
+        r = C(**kw)
+        r.fit(Q)
+        rbms.append(r)
+        Q = r.transform(Q)
+    return rbms, Q
+
+
+def _dbm_walk(pkg, d, dbm, X, X_val, out, ais=True):
+    """the public inference calls of dbm.py:859-957 in a fixed order, then a resumed fit"""
+    cap = Capture()
+    with cap:
+        dbm.fit(X, X_val)
+    _params(dbm, out, 'fit2')
+    with cap:
+        out['transform'] = dbm.transform(X_val)
+        out['reconstruct'] = dbm.reconstruct(X_val)
+        out['sample_v_0'] = dbm.sample_v(n_gibbs_steps=0)
+        out['sample_v_3'] = dbm.sample_v(n_gibbs_steps=3)
+        out['sample_v_2_saved'] = dbm.sample_v(n_gibbs_steps=2, save_model=True)
+    out['n_samples_generated'] = np.array([dbm.n_samples_generated_])
+    _params(dbm, out, 'after_sample_v')
+    if ais:
+        with cap:
+            log_mean, (log_low, log_high), values = dbm.log_Z(n_betas=40, n_runs=6, n_gibbs_steps=2)
+            out['log_Z'] = np.array([log_mean, log_low, log_high])
+            out['log_Z_values'] = np.asarray(values)
+            out['log_proba'] = dbm.log_proba(X_val, log_Z=log_mean)
+    with cap:
+        dbm.set_params(max_epoch=3).fit(X)
+    _params(dbm, out, 'fit3')
+    dbm2 = pkg.DBM.load_model(os.path.join(d, 'dbm/'))
+    with cap:
+        out['loaded:transform'] = dbm2.transform(X_val)
+        dbm2.set_params(max_epoch=4).fit(X)
+    _params(dbm2, out, 'loaded_fit4')
+    out['metrics'], _ = cap.metrics()
+    return out
+
+
+def dbm_two_layers(pkg, d):
+    """20-12-16 DBM from two pre-trained RBMs (dbm.py:266-291), mean-field + PCD with a per-epoch sweep schedule,
+    max-norm, per-layer sparsity (incl. the q_means[i] scalar-index quirk, dbm.py:581-590), validation fetches that
+    advance the particles (dbm.py:810-816 under :521-523), all inference calls, AIS, ELBO, resume, load_model"""
+    V, N = 20, 40
+    X = (pkg.RNG(seed=5).rand(N, V) < 0.3).astype(np.float32)
+    X_val = (pkg.RNG(seed=6).rand(20, V) < 0.3).astype(np.float32)
+    rbms, _ = _pretrain(pkg, d, X, (V, 12, 16))
+    dbm = pkg.DBM(rbms=rbms, n_particles=10, batch_size=10, n_gibbs_steps=[1, 2, 3], max_mf_updates=20, mf_tol=1e-5,
+                  learning_rate=[0.02, 0.01], momentum=[0.5, 0.9], max_epoch=2, l2=1e-4, max_norm=0.6,
+                  sparsity_cost=[0.01, 0.02], sparsity_target=[0.2, 0.1], random_seed=13, verbose=True,
+                  train_metrics_every_iter=2, model_path=os.path.join(d, 'dbm/'))
+    return _dbm_walk(pkg, d, dbm, X, X_val, {})
+
+
+def dbm_three_layers(pkg, d):
+    """16-10-8-6: the intermediate RBM is halved (dbm.py:277-280), middle layers read the NEW layer below and the OLD
+    layer above (dbm.py:400-407); particles initialised from data / features (examples/dbm_mnist.py:137-141);
+    visible states not sampled"""
+    V, N = 16, 30
+    X = (pkg.RNG(seed=15).rand(N, V) < 0.4).astype(np.float32)
+    X_val = (pkg.RNG(seed=16).rand(10, V) < 0.4).astype(np.float32)
+    rbms, _ = _pretrain(pkg, d, X, (V, 10, 8, 6))
+    Q = rbms[0].transform(X[:10])
+    G = rbms[1].transform(Q)
+    T = rbms[2].transform(G)
+    dbm = pkg.DBM(rbms=rbms, n_particles=10, v_particle_init=X[:10].copy(), h_particles_init=(Q, G, T),
+                  batch_size=10, n_gibbs_steps=2, max_mf_updates=8, mf_tol=1e-7, learning_rate=0.01, max_epoch=2,
+                  l2=1e-5, sample_v_states=False, sample_h_states=(True, True, False), sparsity_cost=0.005,
+                  random_seed=31, verbose=True, train_metrics_every_iter=1, model_path=os.path.join(d, 'dbm/'))
+    return _dbm_walk(pkg, d, dbm, X, X_val, {}, ais=False)
+
+
+def dbm_gaussian_bernoulli_multinomial(pkg, d):
+    """the unit types of examples/dbm_cifar.py: Gaussian visible, Bernoulli middle, Multinomial top layer.
+    (A ONE-layer DBM - the README's "DBM class can be used also for training RBM", README.md:96, i.e. the PCD form of
+    BASELINE configs[2] - cannot be built by the reference as written: `_make_tf_model` always builds the AIS and ELBO
+    graphs, which index W[1] / hb[1], dbm.py:674,757-768 -> IndexError.  The Gaussian-visible particle path is covered
+    here instead; the engine's 1-layer path is checked against the oracle, tests/test_dbm_parity_gpu.py.)"""
+    V, N = 12, 30
+    X = pkg.RNG(seed=45).randn(N, V).astype(np.float32)
+    X_val = pkg.RNG(seed=46).randn(10, V).astype(np.float32)
+    rbms, _ = _pretrain(pkg, d, X, (V, 10, 6), v_cls='GaussianRBM', top_cls='MultinomialRBM', n_samples=5)
+    dbm = pkg.DBM(rbms=rbms, n_particles=10, batch_size=10, n_gibbs_steps=2, max_mf_updates=6, learning_rate=0.002,
+                  max_epoch=2, l2=1e-3, random_seed=51, verbose=True, train_metrics_every_iter=1,
+                  model_path=os.path.join(d, 'dbm/'))
+    return _dbm_walk(pkg, d, dbm, X, X_val, {}, ais=False)
+
+
+SCENARIOS = dict((f.__name__, f) for f in (
+    rbm_reference_test_config, rbm_float64, rbm_multinomial, rbm_gaussian, rbm_schedules, rbm_means_only,
+    rbm_config0_shape, dbm_two_layers, dbm_three_layers, dbm_gaussian_bernoulli_multinomial))
+
+# scenarios whose trajectories contain Normal draws: the Box-Muller transcendentals differ in the last bits
+# between NumPy, glibc and the device, so reals are compared a little looser there
+GAUSSIAN = {'rbm_gaussian', 'dbm_gaussian_bernoulli_multinomial'}
