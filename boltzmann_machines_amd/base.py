@@ -111,8 +111,11 @@ def run_on_engine(check_initialized=True, update_seed=False):
         @wraps(f)
         def wrapped_f(model, *args, **kwargs):
             model._graph_seed = model.make_random_seed() if update_seed else None
-            if not model.initialized_ and check_initialized:
-                raise RuntimeError('`fit` or `init` must be called before calling `{0}`'.format(f.__name__))
+            if not model.initialized_:
+                if check_initialized:
+                    raise RuntimeError('`fit` or `init` must be called before calling `{0}`'.format(f.__name__))
+                # the reference builds its graph here (`_make_tf_model()`, tf_model.py:31-35) - after the seed above
+                model._on_graph_build()
             model._ensure_engine()
             if update_seed:
                 model._seed_engine(model._graph_seed)
@@ -220,6 +223,9 @@ class EngineModel(BaseModel, DtypeMixin):
 
     def _needs_device(self):
         return True
+
+    def _on_graph_build(self):
+        """what building the TF graph does to HOST state in the reference (nothing, for most models)"""
 
     def _upload_variables(self, d):
         raise NotImplementedError
@@ -424,14 +430,22 @@ class EngineModel(BaseModel, DtypeMixin):
 
     @run_on_engine()
     def get_tf_params(self, scope=None):
-        """Variables by TF scope, as the reference's get_tf_params (tf_model.py:183-202)."""
+        """Variables by TF name, as the reference's get_tf_params (tf_model.py:183-202): the variables whose full
+        name matches `scope` as a prefix regex (`tf.get_collection(GLOBAL_VARIABLES, scope=scope)`), keyed by that
+        name with every occurrence of `scope` and a leading '/' removed."""
+        import re
         out = {}
-        for key, (var_scope, value) in self._scoped_variables().items():
-            if scope is None:
-                out['{0}/{1}'.format(var_scope, key)] = value
-            elif scope in var_scope:
-                out[key] = value
+        for _, (tf_name, value) in self._scoped_variables().items():
+            if tf_name is None or (scope is not None and not re.match(scope, tf_name)):
+                continue
+            key = tf_name
+            if scope and scope in key:
+                key = key.replace(scope, '')
+            if key.startswith('/'):
+                key = key[1:]
+            out[key] = value
         return out
 
     def _scoped_variables(self):
+        """engine variable name -> (full TF variable name in the reference's graph | None, value)"""
         raise NotImplementedError

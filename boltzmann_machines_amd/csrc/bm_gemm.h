@@ -970,31 +970,22 @@ __host__ __device__ __forceinline__ int small_div(int a, int b) {
     return q;
 }
 
-template <class T>
-__host__ __device__ __forceinline__ T sel8(const T (&a)[8], int x) {
-    T v = a[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) v = (x == c) ? a[c] : v;
-    return v;
-}
-
-// R / S: the map's per-XCD words as VALUES (registers), gj its group width
-__host__ __device__ __forceinline__ void tile_of_block_core(const unsigned long long (&R)[8], const unsigned int (&S)[8],
-                                                            int gj, int b, int nb, int &ti, int &tj) {
+// e / sp: the words of the block's own XCD (rect[b & 7], spare[b & 7]), already fetched by the caller
+__host__ __device__ __forceinline__ void tile_of_block_pre(const TileMap &m, unsigned long long e, unsigned int sp,
+                                                           int gj, int b, int nb, int &ti, int &tj) {
     const int q = nb >> 3, r = nb & 7;
-    int x = b & 7, l = b >> 3;
-    unsigned long long e = sel8(R, x);
+    int l = b >> 3;
     int hi = (int)(e >> 16) & 0xFFFF, wj = (int)(e >> 48) & 0xFFFF;
     if (l >= hi * wj) {
         // a spare block of this XCD: its rank among all spare blocks (XCD order, then local order) takes the tile of
         // the same rank among the tiles no block of their own XCD reaches
-        int k = l - hi * wj + (int)(sel8(S, x) & 0xFFFF);
+        int k = l - hi * wj + (int)(sp & 0xFFFF);
 #pragma unroll
         for (int xc = 0; xc < 8; ++xc) {
-            const int lf = (int)(S[xc] >> 16);
+            const int lf = (int)(m.spare[xc] >> 16);
             if (k >= 0 && k < lf) {
                 l = q + (xc < r ? 1 : 0) + k;
-                e = R[xc];
+                e = m.rect[xc];
                 k = -1;
             } else if (k >= 0) {
                 k -= lf;
@@ -1016,28 +1007,21 @@ __host__ __device__ __forceinline__ void tile_of_block_core(const unsigned long 
 
 // Host evaluation (tests, tools).
 static inline void tile_of_block(const TileMap &m, int b, int nb, int &ti, int &tj) {
-    tile_of_block_core(m.rect, m.spare, m.gj, b, nb, ti, tj);
+    tile_of_block_pre(m, m.rect[b & 7], m.spare[b & 7], m.gj, b, nb, ti, tj);
 }
 
-// Device evaluation.  The 12 per-XCD words pass through an empty asm statement as SGPR operands: they are then opaque
-// register values, fetched from the kernel-argument segment by scalar loads that go out with the first batch of
-// arguments, and the selection by blockIdx & 7 is a chain of s_cselect.  Indexing the arrays in the argument segment
-// instead (round 3, also when written as a compare chain - LLVM folds that back into an indexed load) made hipcc
-// fetch the entries with DEPENDENT global loads before the first operand load could be issued: ~0.4 us per launch
-// (same-box A/B against the round-2 library, round 4).
-struct TileRegs { unsigned long long R[8]; unsigned int S[8]; int gj; };
-__device__ __forceinline__ void load_tile_regs(const TileMap &m, TileRegs &t) {
-    t.gj = m.gj;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { t.R[c] = m.rect[c]; t.S[c] = m.spare[c]; }
-    asm volatile("" : "+s"(t.R[0]), "+s"(t.R[1]), "+s"(t.R[2]), "+s"(t.R[3]), "+s"(t.R[4]), "+s"(t.R[5]), "+s"(t.R[6]),
-                      "+s"(t.R[7]), "+s"(t.gj));
-    asm volatile("" : "+s"(t.S[0]), "+s"(t.S[1]), "+s"(t.S[2]), "+s"(t.S[3]), "+s"(t.S[4]), "+s"(t.S[5]), "+s"(t.S[6]),
-                      "+s"(t.S[7]));
-}
-__device__ __forceinline__ void tile_of_block_dev(const TileRegs &t, int b, int nb, int &ti, int &tj) {
-    tile_of_block_core(t.R, t.S, t.gj, b, nb, ti, tj);
-}
+// Device: the block's two words are fetched by SCALAR loads with a register offset (blockIdx & 7 is known when the wave
+// starts, so they go out with the first batch of kernel arguments; TILE_WORDS right after the argument asm of the
+// kernel).  Round 3 kept the per-XCD entries as six arrays of shorts: there is no 16-bit scalar load, so hipcc fetched
+// them with DEPENDENT global loads before the first operand load could be issued, ~0.4 us per launch (same-box A/B
+// against the round-2 library, round 4; holding all 8 entries in SGPRs instead costs 25 registers and spills).
+#define TILE_WORDS(tmap_, blk_)                                                                                      \
+    const unsigned long long tile_rect_ = (tmap_).rect[(blk_) & 7];                                                 \
+    const unsigned int tile_spare_ = (tmap_).spare[(blk_) & 7];                                                     \
+    const int tile_gj_ = (tmap_).gj;                                                                                \
+    asm volatile("" :: "s"(tile_rect_), "s"(tile_spare_), "s"(tile_gj_))
+#define TILE_OF_BLOCK(tmap_, blk_, nb_, ti_, tj_) \
+    tile_of_block_pre((tmap_), tile_rect_, tile_spare_, tile_gj_, (blk_), (nb_), (ti_), (tj_))
 
 // round-2 form (1-D slabs), still used by the kernels without a TileMap argument (free-energy GEMM)
 __device__ __forceinline__ void block_to_tile(int tiles_j, int &ti, int &tj, int skip = 0, int trail = 0,

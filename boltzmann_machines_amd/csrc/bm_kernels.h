@@ -332,8 +332,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     asm volatile("" :: "s"(a.P1.ptr), "s"(a.Q1.ptr), "s"(a.P1.ld), "s"(a.Q1.ld), "s"(a.P1.nx), "s"(a.Q1.nx),
                        "s"(a.K1), "s"(a.K2), "s"(a.bias), "s"(a.sigma), "s"(a.means), "s"(a.states), "s"(a.ldo),
                        "s"(a.sample), "s"(a.kind), "s"(a.row0), "s"(a.I), "s"(a.J), "s"(a.skip));
-    TileRegs tmap;                                 // the block -> tile map words, fetched with the same batch
-    load_tile_regs(a.tmap, tmap);
+    TILE_WORDS(a.tmap, (int)blockIdx.x);           // the block's tile-map words, fetched with the same batch
     const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
     int ti, tj;
     if (a.chk_ctl) {                               // wave-uniform: Check(s-1), see ActArgs::chk_ctl
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     } else if (a.skip && *a.skip) return;          // wave-uniform: converged mean-field loop
     // tile order: 2-D XCD rectangles, L2-sized column groups (tile_of_block)
     (void)tiles_j;
-    tile_of_block_dev(tmap, (int)blockIdx.x, (int)gridDim.x, ti, tj);
+    TILE_OF_BLOCK(a.tmap, (int)blockIdx.x, (int)gridDim.x, ti, tj);
     const int i0 = ti * G::TI, j0 = tj * G::TJ;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
@@ -840,9 +839,8 @@ __global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a) {
                        "s"(a.I), "s"(a.J), "s"(a.W), "s"(a.dW), "s"(a.ldw), "s"(a.form), "s"(a.fused));
     constexpr int TJ2 = G::TJ;                    // NJ = 2: 64 x 64 tiles
     int ti, tj;
-    TileRegs tmap;
-    load_tile_regs(a.tmap, tmap);
-    tile_of_block_dev(tmap, (int)blockIdx.x, ntile_blocks, ti, tj);
+    TILE_WORDS(a.tmap, (int)blockIdx.x);
+    TILE_OF_BLOCK(a.tmap, (int)blockIdx.x, ntile_blocks, ti, tj);
     const int i0 = ti * TI, j0 = tj * TJ2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;

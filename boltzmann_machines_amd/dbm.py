@@ -222,6 +222,14 @@ class DBM(EngineModel):
                                                 parallel.native_allreduce_on_engine_stream(self._engine, self._comm),
                                                 comm=self._comm)
 
+    def _on_graph_build(self):
+        # `_make_ais` draws the op-level seed of x_0 from the host MT stream WHILE THE GRAPH IS BUILT
+        # (`Bernoulli(logits).sample(seed=self.make_random_seed())`, dbm.py:701): the first fit() / init() of a DBM
+        # advances the stream by one more draw than the call's own graph seed, and every later public call sees the
+        # seed sequence shifted by it.  (The engine addresses x_0 by site 13 of the log_Z call's key, DESIGN.md 4;
+        # the drawn value itself is not used.)  Found by running the reference's graph builders, round 4.
+        self._ais_op_seed = self.make_random_seed()
+
     def _upload_variables(self, d):
         for name, _ in self._var_names():
             if name in d:
@@ -234,7 +242,21 @@ class DBM(EngineModel):
         return {name: self._engine.get(name) for name, _ in self._var_names()}
 
     def _scoped_variables(self):
-        return {name: (scope, self._engine.get(name)) for name, scope in self._var_names()}
+        """the reference's variable names (dbm.py:294-383): layer i > 0 gets TF's `_i` suffix, the hidden particles live
+        under `negative_particles/h_particle[_i]/{h, h_new}`; sigma is not a variable of the DBM graph"""
+        out = {}
+        for name, scope in self._var_names():
+            base, i = name, 0
+            if '_' in name and name.rsplit('_', 1)[1].isdigit():
+                base, i = name.rsplit('_', 1)[0], int(name.rsplit('_', 1)[1])
+            if name == 'sigma':
+                tf_name = None
+            elif base in ('h', 'h_new'):
+                tf_name = 'negative_particles/h_particle%s/%s' % (self._sfx(i), base)
+            else:
+                tf_name = '%s/%s' % (scope, name)
+            out[name] = (tf_name, self._engine.get(name))
+        return out
 
     @classmethod
     def load_model(cls, model_path):

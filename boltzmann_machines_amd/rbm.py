@@ -226,7 +226,11 @@ class BaseRBM(EngineModel):
         return {name: self._engine.get(name) for name, _ in self._VAR_SCOPES}
 
     def _scoped_variables(self):
-        return {name: (scope, self._engine.get(name)) for name, scope in self._VAR_SCOPES}
+        # the reference's variable names (base_rbm.py:271-327); `sigma` is a variable of the GaussianRBM only, created
+        # under a second 'input_data' name scope (rbm.py:101-105 -> 'input_data_1/sigma')
+        names = {name: '%s/%s' % (scope, name) for name, scope in self._VAR_SCOPES}
+        names['sigma'] = 'input_data_1/sigma' if self._V_UNIT == _ffi.UNIT_GAUSSIAN else None
+        return {name: (names[name], self._engine.get(name)) for name, _ in self._VAR_SCOPES}
 
     def _stage_variables(self, slot):
         """checkpoint snapshot without stopping the stream (bm_rbm_stage): float32 engine only; BM355_STAGED_SAVE=0

@@ -112,7 +112,7 @@ def test_gaussian_bernoulli_multinomial_stack(gpu_lib, tmp_path):
     w1, w2 = d1.get_tf_params('weights'), d2.get_tf_params('weights')
     for k in ('W', 'W_1', 'hb', 'hb_1', 'vb'):
         assert np.all(np.isfinite(w1[k])) and np.array_equal(w1[k], w2[k])
-    h_top = d1.get_tf_params('negative_particles')['h_1']
+    h_top = d1.get_tf_params('negative_particles')['h_particle_1/h']
     assert np.all(h_top.sum(axis=1) == 6)                                     # multinomial counts
     T = d1.transform(Xg)
     assert T.shape == (N, H2)

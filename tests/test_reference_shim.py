@@ -1,0 +1,54 @@
+"""The reference's OWN tests, run against the unmodified reference package on the NumPy TF-1 stand-in
+(tests/tf1_shim): if these pass, the stand-in carries the reference's graph builders, session / Saver round trips,
+`load_model` and resume correctly - which is what entitles the fixtures it generates (tests/golden/ref_*.npz) to be
+called reference output.  Runs where /root/reference exists (the build container); skipped on the GPU box."""
+import os
+import sys
+
+import pytest
+
+from tests import reference_shim
+
+pytestmark = pytest.mark.skipif(not reference_shim.available(), reason='the reference checkout is not on this box')
+
+
+@pytest.fixture()
+def reference_tests(tmp_path, monkeypatch):
+    tf, bm = reference_shim.activate()
+    from tests.golden import reference_rng_policy
+    tf.set_rng_policy(reference_rng_policy.policy)
+    import boltzmann_machines.rbm
+    import boltzmann_machines.utils
+    # rbm/tests/test_rbm.py imports `rbm` and `utils` as top-level packages (nose ran it from inside the package)
+    monkeypatch.setitem(sys.modules, 'rbm', boltzmann_machines.rbm)
+    monkeypatch.setitem(sys.modules, 'utils', boltzmann_machines.utils)
+    monkeypatch.syspath_prepend(os.path.join(reference_shim.REFERENCE, 'boltzmann_machines', 'rbm', 'tests'))
+    monkeypatch.chdir(tmp_path)                       # the tests write test_rbm_1/ and test_rbm_2/ into the cwd
+    sys.modules.pop('test_rbm', None)
+    import test_rbm
+    return test_rbm.TestRBM()
+
+
+@pytest.mark.parametrize('case', ['test_W_init', 'test_initialization', 'test_consistency', 'test_consistency_val'])
+def test_reference_test_rbm(reference_tests, case):
+    """rbm/tests/test_rbm.py:29-131: constructor errors, the W-init known answers through the reference's `init()`
+    (-0.0094548017 float32 / -0.0077341544416 float64), determinism + resume + load_model for BernoulliRBM
+    (float32, float64), MultinomialRBM, GaussianRBM"""
+    try:
+        getattr(reference_tests, case)()
+    finally:
+        reference_tests.cleanup()
+
+
+def test_reference_path_table(monkeypatch):
+    """base/tests/test_tf_model.py: the working-path table of TensorFlowModel.compute_working_paths"""
+    reference_shim.activate()
+    monkeypatch.syspath_prepend(os.path.join(reference_shim.REFERENCE, 'boltzmann_machines', 'base', 'tests'))
+    sys.modules.pop('test_tf_model', None)
+    import test_tf_model
+    t, ran = test_tf_model.TestWorkingPaths(), 0
+    for name in dir(t):
+        if name.startswith('test'):
+            getattr(t, name)()
+            ran += 1
+    assert ran >= 3

@@ -1,10 +1,5 @@
-"""stand-in for `nose` (the reference's utils/testing.py imports it at module level; not installable offline)"""
-
-
-class tools(object):
-    @staticmethod
-    def nottest(f):
-        return f
+"""stand-in for `nose` (the reference's utils/testing.py and base/tests import it; not installable offline)"""
+from . import tools  # noqa: F401
 
 
 def run(*a, **kw):
