@@ -218,8 +218,12 @@ class RbmCD(Workload):
                 return
             mode, note = choose_collective(args, eng, rank, world, dist)
             self.collective, self.collective_note = mode, note
+            fused = None
             if mode == 'direct':
                 ar = parallel.direct_allreduce_on_engine_stream(eng, args._xchg[id(eng)])
+                if not args.no_fused_exchange:      # exchange + update in ONE kernel per rank (bm_rbm_exchange_apply_direct)
+                    fused = args._xchg[id(eng)]
+                    self.collective_note = (note or '') + '; reduce-scatter -> update of the owned slice -> all-gather of W fused in one launch'
             elif mode == 'rccl':
                 self.comm = get_comm(rank, world)
                 ar = parallel.native_allreduce_on_engine_stream(eng, self.comm)
@@ -228,7 +232,7 @@ class RbmCD(Workload):
                 ar = parallel.torch_allreduce_on_engine_stream(eng, dev, group=dist.new_group(backend='nccl'))
             else:                   # 'gloo': staged through the host (no device collective usable)
                 ar = gloo_staged_allreduce(eng, dist)
-            self.dp = parallel.DataParallelRBM(eng, rank, world, B, ar)
+            self.dp = parallel.DataParallelRBM(eng, rank, world, B, ar, fused=fused)
 
     def step(self, i):
         if self.use_dp:
@@ -619,11 +623,11 @@ def choose_collective(args, eng, rank, world, dist):
             return 'gloo', 'RCCL refuses two ranks on one device (dry run on a box with fewer GPUs than ranks)'
         return want, None
     note = None
-    # a lost rank or an unusable peer mapping must show up within seconds at start-up, not after the library's
-    # default 20 s per in-kernel wait
-    os.environ.setdefault('BM_XCHG_TIMEOUT_S', '4')
     try:
         x = parallel.DirectExchange(eng, rank, world)
+        # a lost rank or an unusable peer mapping must show up within a second at start-up (a wait that expires is
+        # fatal for the exchange object: sticky status, NaN results); the timed run gets the library's default back
+        x.set_timeout(1.0)
         grad = eng.device_view('grad')
         n = grad.shape[0]
         ok_local = True
@@ -645,6 +649,7 @@ def choose_collective(args, eng, rank, world, dist):
         _h2d(grad, np.zeros(n, dtype=np.float32))
         if int(flag.item()) == 0:
             args._xchg[id(eng)] = x
+            x.set_timeout(float(os.environ.get('BM_XCHG_TIMEOUT_S', '20')))
             note = 'start-up self-check against the gloo all-reduce passed on every rank'
             if world > 1 and not args._shared_devices and not args.no_collective_race:
                 # ... and the faster of the two device collectives is used, by measurement on this very buffer
@@ -679,6 +684,34 @@ def choose_collective(args, eng, rank, world, dist):
         if world > 1:
             dist.all_reduce(flag)
     return fallback, note
+
+
+def check_data_parallel_run(wl, args, rank, world, dist):
+    """After the timed region of a data-parallel run: (1) no in-kernel wait of the direct exchange ever expired - a
+    wait that expires is fatal (sticky status word, NaN results): the run is then INVALID and the bench exits non-zero
+    on every rank instead of printing a throughput built on partial sums; (2) the replicas hold identical parameters
+    (CRC of W / vb / hb of every rank through gloo).  Returns a short record for the JSON line, None at world 1."""
+    if dist is None or world <= 1 or not getattr(wl, 'use_dp', True) or not hasattr(wl, 'eng'):
+        return None
+    import zlib
+    import torch
+    status = 0
+    for x in getattr(args, '_xchg', {}).values():
+        status = max(status, int(x.status()))
+    crc = 0
+    try:
+        names = ('W', 'vb', 'hb') if hasattr(wl.eng, 'H') else ('W', 'vb', 'hb', 'W_1', 'hb_1')
+        for n in names:
+            crc = zlib.crc32(np.ascontiguousarray(wl.eng.get(n)).tobytes(), crc)
+    except Exception:       # noqa: BLE001 - a workload without these variables
+        crc = -1
+    t = torch.tensor([status, crc & 0x7FFFFFFF, -(crc & 0x7FFFFFFF)], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    worst, hi, neg_lo = int(t[0]), int(t[1]), int(t[2])
+    if worst != 0:
+        sys.stderr.write('bench: a wait of the direct exchange expired (status %d): the run is invalid\n' % worst)
+        sys.exit(3)
+    return {'exchange_status': 0, 'replicas_identical': bool(hi == -neg_lo)}
 
 
 def _h2d(darr, host):
@@ -789,6 +822,9 @@ def main():
                     help='exchange step of the data-parallel configurations at N > 1: the library\'s one-shot peer-memory '
                          'exchange (bm_xchg_*, default, behind a start-up self-check with a fallback to rccl), the '
                          'library\'s RCCL all-reduce (bm_comm_*), torch.distributed nccl, or gloo staged through the host')
+    ap.add_argument('--no-fused-exchange', action='store_true',
+                    help='--collective direct, rbm: all-reduce and bm_rbm_apply_step as two launches instead of the fused '
+                         'reduce-scatter -> update -> all-gather kernel (bm_rbm_exchange_apply_direct; same bits)')
     ap.add_argument('--no-collective-race', action='store_true',
                     help='--collective direct: do not time the direct exchange against RCCL at start-up (use direct)')
     ap.add_argument('--native-comm', action='store_true', help='(kept for old command lines) same as --collective rccl')
@@ -848,12 +884,15 @@ def main():
 
     wl = WORKLOADS[args.config](args, rank, world, device, dist)
     dt, ev_ms = measure(wl, args.steps, args.warmup, args.precondition_s, barrier, dist)
+    dp_check = check_data_parallel_run(wl, args, rank, world, dist)      # (after the clock stopped)
     rep = wl.report(args, world, dt, ev_ms) if rank == 0 else None
     barrier()
     out = make_record(wl, rep, world, args.steps, args.warmup, args.precondition_s, dt, ev_ms) if rank == 0 else None
     if rank == 0 and args.config == 'rbm':
         out['unit'] += '; steady state: %.1f s of untimed updates precede the warm-up steps' % args.precondition_s \
             if args.precondition_s > 0 else ''
+    if rank == 0 and dp_check is not None:
+        out['config']['data_parallel_check'] = dp_check
     if rank == 0 and args.config == 'rbm' and args._shared_devices:
         out['config']['devices_shared'] = 'DRY RUN: %d ranks on %d device(s); not a scaling figure' % (world, ndev)
 

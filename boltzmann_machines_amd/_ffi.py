@@ -78,9 +78,12 @@ SIGNATURES = {
     'bm_dbm_xchg_create': [_vp, C.c_int32, C.c_int32, C.POINTER(_vp)],
     'bm_rbm_allreduce_grads_direct': [_vp, _vp],
     'bm_dbm_allreduce_grads_direct': [_vp, _vp],
+    'bm_rbm_exchange_apply_direct': [_vp, _vp, _i32, C.c_float, C.c_float],
+    'bm_rbm_exchange_gather_dw': [_vp, _vp],
+    'bm_xchg_set_timeout': [_vp, C.c_double],
     'bm_dbm_set_xchg': [_vp, _vp],
     'bm_dbm_set_fast_binary': [_vp, _i32],
-    'bm_dbm_set_mf_persistent': [_vp, _i32],
+    'bm_dbm_set_ais_literal': [_vp, _i32],
     'bm_rbm_set_fast_binary': [_vp, _i32],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],
@@ -106,10 +109,8 @@ SIGNATURES = {
     'bm_rbm_train_step': [_vp, _vp, _i32, _f32, _f32, _i32],
     'bm_rbm_train_step_metrics': [_vp, _vp, _i32, _f32, _f32, _i32, _fp],
     'bm_rbm_train_epoch': [_vp, _vp, _i64, _i32, _f32, _f32, _i32],
-    'bm_rbm_set_epoch_graph': [_vp, _i32],
     'bm_rbm_stage': [_vp, _i32],
     'bm_rbm_get_staged': [_vp, _i32, C.c_char_p, _vp, _sz],
-    'bm_rbm_set_grad_overlap': [_vp, _i32],
     'bm_rbm_grad_step': [_vp, _vp, _i32, _i32],
     'bm_rbm_apply_step': [_vp, _i32, _f32, _f32],
     'bm_rbm_transform': [_vp, _vp, _i32, _i32, _vp],

@@ -195,130 +195,6 @@ template <class G, bool SEG2> struct Bf3Pipe {
     }
 };
 
-// ---- the wide tile: 64 (i) x 128 (j) per workgroup, 4 waves (one per SIMD) of 32 x 64 = 2 x 4 MFMA tiles.
-// The weight planes are 3/4 of what the 32 x 16 wave tile streams per MFMA; here a wave re-uses its 6 plane fragments
-// of a 32-k block for 4 row blocks: 28 KiB of planes + 12 KiB of states per 64-k chunk and 48 MFMAs per wave, a third of
-// the bytes per MFMA of the narrow tiles, and 20 ds_read_b128 per 48 MFMAs instead of 14 per 12.  Three ring slots of
-// 40 KiB; the pipeline is the plain one (wait for chunk c, barrier, request chunk c+2, read the fragments of chunk c,
-// 48 MFMAs): with 768 matrix cycles per chunk the exposed LDS read latency of a chunk is noise.
-struct Bf3W {
-    static constexpr int TI = 64, TJ = 128, NW = 4, NBUF = 3;
-    static constexpr int P_FLOATS = 3 * TI * 32, Q_FLOATS = TJ * 32, SLOT_FLOATS = P_FLOATS + Q_FLOATS;
-    static constexpr int SMEM_FLOATS = NBUF * SLOT_FLOATS;                               // 120 KiB
-    static constexpr int NPP = P_FLOATS * 4 / (1024 * NW), NPQ = Q_FLOATS * 4 / (1024 * NW), NPW = NPP + NPQ;   // 6 + 4
-};
-
-template <bool SEG2> struct Bf3wPipe {
-    using B = Bf3W;
-    uint32_t p1[B::NPP], p2[B::NPP], q1[B::NPQ], q2[B::NPQ];
-    const char *P1, *P2, *Q1, *Q2;
-    float *smem;
-    unsigned ldsPw, ldsQw;
-    int nch1, nch, w, wi, wj, lane;
-
-    __device__ __forceinline__ void setup(const Bf3Range &kr, int i0, float *smem_) {
-        smem = smem_;
-        const int tid = threadIdx.x;
-        lane = tid & 63;
-        w = __builtin_amdgcn_readfirstlane(tid >> 6);
-        wi = w & 1; wj = w >> 1;
-        nch1 = kr.K1 / 64; nch = nch1 + (SEG2 ? kr.K2 / 64 : 0);
-        P1 = (const char *)kr.P1.p; Q1 = (const char *)kr.Q1.p;
-        P2 = SEG2 ? (const char *)kr.P2.p : P1; Q2 = SEG2 ? (const char *)kr.Q2.p : Q1;
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
-        ldsPw = lds0 + (unsigned)w * 1024u; ldsQw = lds0 + (unsigned)(B::P_FLOATS * 4) + (unsigned)w * 1024u;
-        plan_p(p1, kr.P1, i0);
-        if (SEG2) plan_p(p2, kr.P2, i0);
-    }
-    __device__ __forceinline__ void plan_p(uint32_t (&o)[B::NPP], const Bf3Operand &P, int i0) {
-#pragma unroll
-        for (int n = 0; n < B::NPP; ++n) {
-            const int row = (w + n * B::NW) * 8 + (lane >> 3), slot = lane & 7;
-            const int plane = row / B::TI, rr = row % B::TI;
-            const int i = 32 * (rr >> 5) + 2 * (rr & 15) + ((rr >> 4) & 1);            // de-interleaved wave tiles (header)
-            const int c4 = slot ^ fx<32>(row);
-            o[n] = (uint32_t)(((long long)plane * P.plane_stride + (long long)min(i0 + i, P.nx - 1) * P.ld + c4 * 8) * 2);
-        }
-    }
-    __device__ __forceinline__ void plan_q(uint32_t (&o)[B::NPQ], const Bf3Operand &Q, int j0) {
-#pragma unroll
-        for (int n = 0; n < B::NPQ; ++n) {
-            const int row = (w + n * B::NW) * 8 + (lane >> 3), slot = lane & 7;
-            const int c4 = slot ^ fx<32>(row);
-            o[n] = (uint32_t)(((long long)min(j0 + row, Q.nx - 1) * Q.ld + c4 * 8) * 2);
-        }
-    }
-    __device__ __forceinline__ void set_tile(const Bf3Range &kr, int j0) {
-        plan_q(q1, kr.Q1, j0);
-        if (SEG2) plan_q(q2, kr.Q2, j0);
-    }
-    __device__ __forceinline__ void dma(int c, int slot) {
-        const bool s2 = SEG2 && c >= nch1;
-        const int kc = s2 ? c - nch1 : c;
-        const char *pb = (s2 ? P2 : P1) + (size_t)kc * 128, *qb = (s2 ? Q2 : Q1) + (size_t)kc * 128;
-        const unsigned so = (unsigned)(slot * B::SLOT_FLOATS * 4);
-        if (s2) {
-#pragma unroll
-            for (int n = 0; n < B::NPP; ++n) dma16s(pb, p2[n], ldsPw + so + (unsigned)(n * B::NW * 1024));
-#pragma unroll
-            for (int n = 0; n < B::NPQ; ++n) dma16s(qb, q2[n], ldsQw + so + (unsigned)(n * B::NW * 1024));
-        } else {
-#pragma unroll
-            for (int n = 0; n < B::NPP; ++n) dma16s(pb, p1[n], ldsPw + so + (unsigned)(n * B::NW * 1024));
-#pragma unroll
-            for (int n = 0; n < B::NPQ; ++n) dma16s(qb, q1[n], ldsQw + so + (unsigned)(n * B::NW * 1024));
-        }
-    }
-    __device__ __forceinline__ void prefetch() {           // chunks 0, 1 of the current tile -> slots 0, 1 (all slots free)
-        if (0 < nch) dma(0, 0);
-        if (1 < nch) dma(1, 1);
-    }
-    // one chunk out of ring slot S (compile-time): fragments, then 48 MFMAs
-    template <int S> __device__ __forceinline__ void chunk(f32x4 (&acc)[2][4]) {
-        const float *sP = smem + S * B::SLOT_FLOATS, *sQ = sP + B::P_FLOATS;
-        const int g = lane >> 4, l15 = lane & 15;
-        f32x4 a[2][3][2], b[2][4];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    a[kb][p][t] = *reinterpret_cast<const f32x4 *>(sP + img_off<XM, 0, 32, 0>(p * B::TI + wi * 32 + 16 * t + l15, 4 * kb + g));
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                b[kb][n] = *reinterpret_cast<const f32x4 *>(sQ + img_off<XM, 0, 32, 0>(wj * 64 + 16 * n + l15, 4 * kb + g));
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[kb][p][t]),
-                                                                            __builtin_bit_cast(bf16x8, b[kb][n]), acc[t][n], 0, 0, 0);
-    }
-    template <int S> __device__ __forceinline__ void step(f32x4 (&acc)[2][4], int c) {
-        // chunk c has landed: only the DMA of chunk c+1 (requested one step ago) may still be in flight
-        if (c == 0) BM_WAIT_VM(0);                  // (also the stores of the previous tile's epilogue: same counter)
-        else if (c + 1 < nch) BM_WAIT_VM(B::NPW);
-        else BM_WAIT_VM(0);
-        wg_barrier();                               // every wave's pieces of chunk c; everybody is done with chunk c-1
-        if (c + 2 < nch) dma(c + 2, (S + 2) % 3);
-        chunk<S>(acc);
-    }
-    __device__ __forceinline__ void run(f32x4 (&acc)[2][4]) {
-        int c = 0;
-#pragma unroll 1
-        for (; c + 3 <= nch; c += 3) { step<0>(acc, c); step<1>(acc, c + 1); step<2>(acc, c + 2); }
-        if (c < nch) { step<0>(acc, c); ++c; }
-        if (c < nch) { step<1>(acc, c); ++c; }
-        wg_barrier();                               // the next tile's prefetch must not overtake the last fragment reads
-    }
-};
-
 // fp32 matrix -> three bf16 planes (exact: w = hi + mid + lo), x-major with k contiguous.
 //   transpose == 0: out[plane][r][c] = split(W[r][c])  (rows of W are the x of the operand, columns its k)
 //   transpose == 1: out[plane][c][r] = split(W[r][c])

@@ -8,7 +8,6 @@
 #include "../../include/bm355.h"
 #include "bm_common.h"
 #include "bm_kernels.h"
-#include "bm_mf.h"
 
 #include <math.h>
 
@@ -22,6 +21,7 @@ constexpr int MAXL = BM_DBM_MAX_LAYERS;
 
 struct bm_dbm {
     bm_dbm_config cfg;
+    bm_xchg *xchg_used = nullptr;          // the direct exchange this engine last used (bm_dbm_sync checks its status word)
     int L, V, N, M;
     int n[MAXL + 1];                       // n[0] = V, n[i+1] = hidden layer i
     hipStream_t stream = nullptr;
@@ -74,13 +74,7 @@ struct bm_dbm {
     DevBuf ais_send, ais_recv;                     // bm_dbm_ais_sharded: this rank's values / the all-gathered values
     // fast-binary mode (bm_bf3.h, bm_dbm_set_fast_binary): bf16 planes of W_l (x = below unit, k = above unit) and of
     // W_l^T, bf16 shadows of the AIS state matrices; `fast_now` is set while a sweep with all-binary states runs
-    // persistent mean-field kernel (bm_mf.h): a third set of mu buffers, its synchronisation block, a pinned mirror
-    Mat mu_wk[MAXL];
-    MfSync *mfp_sync = nullptr;
-    struct MfpHost { MfCtl ctl; int status; } *mfp_host = nullptr;
-    bool mfp_failed = false;
-    bool mfp_off = true;                           // opt-in (bm_dbm_set_mf_persistent / BM355_MF_PERSIST=1): measured no faster
-                                                   // than the per-layer launches (bm_mf.h); also set when a launch gave up
+    int ais_literal = 0;                           // bm_dbm_set_ais_literal: float32 accumulation in the reference's order
     int fast = 0;
     bool fast_now = false;
     bool fast_ais = false;                         // the running fast sweep is AIS (fp32 copies of v / h2 are not needed)
@@ -290,76 +284,6 @@ static int read_flag(bm_dbm *h, float *out) {
     return 0;
 }
 
-// The mean-field loop as ONE persistent kernel (bm_mf.h), for the shape family it tiles: two Bernoulli hidden layers
-// of 512 and 1024 units, N in {128, 256, 384, 512}, a 256-CU device, no communicator.  Called after the step-0
-// condition has been latched into h->ctl.  Returns 0 with *used = 1 when the kernel produced the result (h->mu,
-// *out_steps), 0 with *used = 0 when the launch-per-layer path has to run (not eligible, or the kernel gave up: the
-// persistent mu is untouched then), non-zero on a HIP error.
-static bool mfp_eligible(const bm_dbm *h) {
-    static int env = -1, ncu = -1;
-    if (env < 0) { const char *e = getenv("BM355_MF_PERSIST"); env = e ? atoi(e) : -2; }       // -2: unset
-    if (ncu < 0) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 0; }
-    if (env == 0 || (h->mfp_off && env != 1) || h->mfp_failed || ncu != 256) return false;
-    if (h->L != 2 || h->multinomial(0) || h->multinomial(1) || h->comm || h->xchg || h->mf_reduce) return false;
-    if (h->n[1] != MFP_H1 || h->n[2] != MFP_H2 || h->N % 128 != 0 || h->N > 512) return false;
-    return h->cfg.max_mf_updates >= 1 && h->cfg.max_mf_updates <= MFP_MAXS;
-}
-static int mf_persistent(bm_dbm *h, int *used, int *out_steps) {
-    *used = 0;
-    if (!h->mu_wk[0].p) for (int i = 0; i < 2; ++i) BM_TRY(h->mu_wk[i].alloc(h->N, h->n[i + 1]));
-    if (!h->mfp_sync) {
-        BM_HIP(hipMalloc((void **)&h->mfp_sync, sizeof(MfSync)));
-        BM_HIP(hipHostMalloc((void **)&h->mfp_host, sizeof(*h->mfp_host)));
-    }
-    BM_HIP(hipMemsetAsync(h->mfp_sync, 0, sizeof(MfSync), h->stream));
-    MfpArgs a;
-    memset(&a, 0, sizeof(a));
-    a.N = h->N; a.RB = h->N / 8;
-    a.xw0 = h->xw0.p; a.ld_x = h->xw0.ld;
-    a.Wt1 = h->Wt[1].p; a.ld_wt = h->Wt[1].ld;
-    a.W1 = h->W[1].p; a.ld_w = h->W[1].ld;
-    a.hb0 = h->hb[0].p; a.hb1 = h->hb[1].p;
-    a.mu1[0] = h->mu[0].p; a.mu1[1] = h->mu_alt[0].p; a.mu1[2] = h->mu_wk[0].p; a.ld1 = h->mu[0].ld;
-    a.mu2[0] = h->mu[1].p; a.mu2[1] = h->mu_alt[1].p; a.mu2[2] = h->mu_wk[1].p; a.ld2 = h->mu[1].ld;
-    a.ctl = h->ctl; a.tol = h->cfg.mf_tol; a.max_steps = h->cfg.max_mf_updates;
-    a.sy = h->mfp_sync;
-    a.timeout = 200000000ll;                       // 2 s of the 100 MHz wall clock
-    {   // BM355_MF_DEBUG=1: wall-clock stamps of one workgroup, printed after the call (measurement only)
-        static const bool dbg = getenv("BM355_MF_DEBUG") != nullptr;
-        static long long *dbuf = nullptr;
-        if (dbg && !dbuf) { BM_HIP(hipMalloc((void **)&dbuf, MFP_MAXS * 8 * sizeof(long long))); }
-        if (dbg) { BM_HIP(hipMemsetAsync(dbuf, 0, MFP_MAXS * 8 * sizeof(long long), h->stream)); a.dbg = dbuf; }
-    }
-    hipLaunchKernelGGL(mf_persistent_kernel, dim3(256), dim3(256), 0, h->stream, a);
-    BM_HIP(hipMemcpyAsync(&h->mfp_host->ctl, h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipMemcpyAsync(&h->mfp_host->status, &h->mfp_sync->status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipStreamSynchronize(h->stream));
-    if (h->mfp_host->status != 0) {
-        h->mfp_off = true; h->mfp_failed = true;
-        fprintf(stderr, "bm355: the persistent mean-field kernel gave up (status %d: %s); this handle continues on the "
-                        "launch-per-layer path\n", h->mfp_host->status,
-                h->mfp_host->status == 2 ? "more than 32 workgroups on one XCD" : "a bounded wait expired");
-        return 0;
-    }
-    if (a.dbg) {
-        std::vector<long long> t(MFP_MAXS * 8);
-        BM_HIP(hipMemcpy(t.data(), a.dbg, t.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        for (int s2 = 0; s2 < 6 && t[s2 * 8]; ++s2)
-            fprintf(stderr, "mfp sweep %d (us): wait-h2 %.2f | h1 loop %.2f | decision %.2f | h1 epilogue %.2f... arrive+wait %.2f | h2 loop+epilogue %.2f | publish %.2f\n", s2,
-                    (t[s2*8+1]-t[s2*8])*0.01, (t[s2*8+2]-t[s2*8+1])*0.01, (t[s2*8+3]-t[s2*8+2])*0.01, 0.0, (t[s2*8+4]-t[s2*8+3])*0.01,
-                    (t[s2*8+5]-t[s2*8+4])*0.01, (t[s2*8+6]-t[s2*8+5])*0.01);
-    }
-    const int steps = h->mfp_host->ctl.steps;
-    if (steps > 0) {                               // the result lives in work buffer 1 + ((steps - 1) & 1): make it h->mu
-        Mat *res = ((steps - 1) & 1) ? h->mu_wk : h->mu_alt;
-        for (int i = 0; i < 2; ++i) { Mat t = h->mu[i]; h->mu[i] = res[i]; res[i] = t; }
-    }
-    h->mf_pred = steps;
-    *out_steps = steps;
-    *used = 1;
-    return 0;
-}
-
 // `_make_mf` (dbm.py:429-478).  Leaves the result in h->mu; returns executed sweeps.
 // The loop trip count is data dependent (residual > tol).  The sweeps are enqueued in groups without host
 // round trips — a device-side control word (MfCtl) latches `done` and every later launch returns at once.
@@ -431,11 +355,6 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         const size_t set_sz = (size_t)MAXL * BM_MF_SLOTS;
         if (self_ctl) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * set_sz * sizeof(float), h->stream));
         BM_TRY(ctl_step(1));
-        if (hoist && mfp_eligible(h)) {            // the whole loop in one persistent kernel (bm_mf.h)
-            int used = 0, st = 0;
-            BM_TRY(mf_persistent(h, &used, &st));
-            if (used) { if (out_n) *out_n = st; return 0; }
-        }
         // Groups of sweeps are enqueued without host round trips; the loop-control record is copied to a pinned
         // mirror after each group and READ ONE GROUP LATE: group g+1 is already in the queue when the host looks at
         // group g, so the GPU never idles waiting for the host (sweeps enqueued past the end of the loop return at
@@ -759,6 +678,7 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
 int bm_dbm_destroy(bm_dbm *h) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->stream);
+    if (h->xchg_used) xchg_bind_user(h->xchg_used, nullptr);
     for (int i = 0; i < h->L; ++i) {
         Mat *ms[] = {&h->W[i], &h->Wt[i], &h->dW[i], &h->mu[i], &h->mu_alt[i], &h->mu_new[i], &h->H[i], &h->H_new[i]};
         for (Mat *m : ms) m->release();
@@ -769,9 +689,6 @@ int bm_dbm_destroy(bm_dbm *h) {
     }
     h->ax16.release(); h->ax2_16.release(); h->av16.release(); h->ah2_16.release();
     for (int b = 0; b < 2; ++b) { h->pv16[b].release(); for (int i = 0; i < MAXL; ++i) h->pH16[i][b].release(); }
-    for (int i = 0; i < MAXL; ++i) h->mu_wk[i].release();
-    if (h->mfp_sync) (void)hipFree(h->mfp_sync);
-    if (h->mfp_host) (void)hipHostFree(h->mfp_host);
     Mat *ms[] = {&h->v, &h->v_new, &h->recon, &h->ax, &h->ax2, &h->av, &h->ah2};
     for (Mat *m : ms) m->release();
     DevBuf *bs[] = {&h->vb, &h->dvb, &h->sigma, &h->grad, &h->apart_v, &h->apart_h, &h->apart_x[0], &h->apart_x[1], &h->rowtmp,
@@ -794,7 +711,11 @@ int bm_dbm_destroy(bm_dbm *h) {
     return 0;
 }
 
-int bm_dbm_sync(bm_dbm *h) { BM_HIP(hipStreamSynchronize(h->stream)); return 0; }
+int bm_dbm_sync(bm_dbm *h) {
+    BM_HIP(hipStreamSynchronize(h->stream));
+    if (h->xchg_used) BM_TRY(xchg_check_status(h->xchg_used));      // a lost rank is an ERROR here, never a silent wrong sum
+    return 0;
+}
 int bm_dbm_seed(bm_dbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 0; }
 int bm_dbm_set_row_offset(bm_dbm *h, int64_t row0, int64_t particle0) { h->row0 = row0; h->prow0 = particle0; return 0; }
 
@@ -938,17 +859,20 @@ int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on) {
     return 0;
 }
 
-// 0 (default): mean-field runs one launch per layer and sweep; 1: the persistent kernel (bm_mf.h) where the shape
-// allows it.  Both produce the same bits; the persistent form measured no faster (bm_mf.h header), so it is opt-in.
-int bm_dbm_set_mf_persistent(bm_dbm *h, int32_t on) {
+// 1: the AIS log-weights are accumulated as the reference's graph does it - every log p*_beta(x) formed and added /
+// subtracted in float32, in the order of dbm.py:708-728 (two extra score-only passes per beta); 0 (default): the
+// difference of the two softplus terms per element, summed in double (deterministic, closer to the exactly
+// enumerable log Z; the reference's README admits the nats its float32 loop loses at many betas)
+int bm_dbm_set_ais_literal(bm_dbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
-    h->mfp_off = !on;
+    h->ais_literal = on ? 1 : 0;
     return 0;
 }
 
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x) {
     BM_CHECK(h, "null argument");
     h->xchg = x;
+    if (x) { h->xchg_used = x; xchg_bind_user(x, &h->xchg_used); }
     return 0;
 }
 
@@ -1118,6 +1042,26 @@ __global__ __launch_bounds__(256) void ais_score_kernel(double *logw, int J, int
     }
 }
 
+// LITERAL accumulation (bm_dbm_set_ais_literal; the reference's arithmetic, dbm.py:650-660 and :708-728): one call
+// adds or subtracts ONE log p*_beta(x) to the running log-weight, everything in float32 -
+//   lp = (x.hb0 * beta + sum_i softplus(beta (x W0^T + vb)_i)) + sum_k softplus(beta (x W1 + hb1)_k);   lz = lz -/+ lp
+// (`T1 *= beta; log_p = T1; log_p += reduce_sum(..); log_p += reduce_sum(..)`; `log_Z += / -= ...`).  The row sums
+// are the slot partials added in ascending order in float32.  logw holds the float value (exactly) in its double.
+__global__ __launch_bounds__(256) void ais_score_literal_kernel(double *logw, int J, int ld, const float *pv, int nv, const float *ph,
+                                                                int nh, const float *pd, int nd, float beta, int sign) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    float sv = 0.f, sh = 0.f, dot = 0.f;
+    for (int q = 0; q < nv; ++q) sv = sv + pv[(size_t)q * ld + j];
+    for (int q = 0; q < nh; ++q) sh = sh + ph[(size_t)q * ld + j];
+    for (int q = 0; q < nd; ++q) dot = dot + pd[(size_t)q * ld + j];
+    float lp = dot * beta;
+    lp = lp + sv;
+    lp = lp + sh;
+    const float lz = (float)logw[j];
+    logw[j] = (double)(sign > 0 ? lz + lp : lz - lp);
+}
+
 // the AIS run itself: leaves the per-chain log-weights (without log Z_0) in h->alogw [n_runs] (device, double)
 static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t seed, int64_t chain0) {
     BM_CHECK(h->L == 2, "AIS is implemented for 2-layer DBMs only (dbm.py:925)");
@@ -1151,7 +1095,30 @@ static int ais_core(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint6
 
     // visit(x; beta_a, beta_b, beta_c): logw += log p*_{beta_b}(x) - log p*_{beta_a}(x) (score != 0),
     // then k transitions T_{beta_c} (dbm.py:662-694).  `step` feeds the RNG call counter.
+    const bool literal = h->ais_literal != 0;
+    // literal mode: -log p*_{ba}(x) as its own pair of score-only launches (the default path shares the pre-activations
+    // of the transition and accumulates the DIFFERENCE of the two softplus terms per element, in double)
+    auto score_only = [&](float bscore, int sign) -> int {
+        ActArgs e;
+        memset(&e, 0, sizeof(e));
+        e.rowacc = h->apart_v.p; e.ld_part = ldp; e.beta_b = bscore; e.rowacc_single = 1;
+        layer_update(h, -1, R, LayerIn{nullptr, 0}, LayerIn{x->p, x->ld}, bscore, bscore, 0, nullptr, nullptr, h->av.ld,
+                     dkey(h, SITE_DBM_V, 0, seed, 0), chain0, nullptr, nullptr, &e);
+        memset(&e, 0, sizeof(e));
+        e.rowacc = h->apart_h.p; e.ld_part = ldp; e.beta_b = bscore; e.rowacc_single = 1;
+        layer_update(h, 1, R, LayerIn{x->p, x->ld}, LayerIn{nullptr, 0}, bscore, bscore, 0, nullptr, nullptr, h->ah2.ld,
+                     dkey(h, SITE_DBM_H + 1, 0, seed, 0), chain0, nullptr, nullptr, &e);
+        hipLaunchKernelGGL(ais_score_literal_kernel, dim3((R + 255) / 256), dim3(256), 0, h->stream, h->alogw, R, ldp,
+                           (const float *)h->apart_v.p, nslots(V), (const float *)h->apart_h.p, nslots(H2),
+                           (const float *)rdot_cur, nd_cur, bscore, sign);
+        return 0;
+    };
     auto visit = [&](bool score, float ba, float bb, bool transit, float bc, uint32_t step) -> int {
+        if (literal && score) {                 // log_Z -= log p*_{ba}(x); log_Z += log p*_{bb}(x)   (:708, :714, :718, :728)
+            BM_TRY(score_only(ba, -1));
+            BM_TRY(score_only(bb, +1));
+            score = false;
+        }
         for (int t = 0; t < (transit ? k : 1); ++t) {
             const bool sc = score && t == 0;
             ActArgs e;
@@ -1215,14 +1182,19 @@ int bm_dbm_ais(bm_dbm *h, int32_t n_betas, int32_t n_runs, int32_t k, uint64_t s
     BM_HIP(hipMemcpyAsync(w.data(), h->alogw, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
     const double logZ0 = ais_log_Z0(h);
-    for (int r = 0; r < R; ++r) values_host[r] = (float)(w[r] + logZ0);
+    if (h->ais_literal) {                        // log_Z += log_Z0 in float32 (:731-734)
+        const float z0 = (float)(h->V + h->n[1] + h->n[2]) * logf(2.0f);
+        for (int r = 0; r < R; ++r) values_host[r] = (float)w[r] + z0;
+    } else {
+        for (int r = 0; r < R; ++r) values_host[r] = (float)(w[r] + logZ0);
+    }
     return 0;
 }
 
 // values[r] = (float)(logw[r] + log Z_0) for r < n, 0 in the padding up to npad
-__global__ void ais_finish_kernel(const double *logw, float *out, int n, int npad, double logZ0) {
+__global__ void ais_finish_kernel(const double *logw, float *out, int n, int npad, double logZ0, int literal) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < npad) out[r] = (r < n) ? (float)(logw[r] + logZ0) : 0.f;
+    if (r < npad) out[r] = (r < n) ? (literal ? (float)logw[r] + (float)logZ0 : (float)(logw[r] + logZ0)) : 0.f;
 }
 
 // Chain-sharded AIS: this rank runs chains [start, stop) of n_runs_total (contiguous slices, the
@@ -1258,8 +1230,9 @@ int bm_dbm_ais_sharded(bm_dbm *h, bm_comm *c, int32_t n_betas, int32_t n_runs_to
         (void)hipMemcpyAsync(send, nan.data(), nan.size() * sizeof(float), hipMemcpyHostToDevice, h->stream);
         (void)hipStreamSynchronize(h->stream);
     } else {
+        const double z0 = h->ais_literal ? (double)((float)(h->V + h->n[1] + h->n[2]) * logf(2.0f)) : ais_log_Z0(h);
         hipLaunchKernelGGL(ais_finish_kernel, dim3((npad + 255) / 256), dim3(256), 0, h->stream, (const double *)h->alogw, send,
-                           n, npad, ais_log_Z0(h));
+                           n, npad, z0, h->ais_literal);
     }
     const int rc_c = bm_comm_allgather(c, send, recv, (size_t)npad, (void *)h->stream);
     if (rc_c && first_err.empty()) first_err = bm_last_error();

@@ -907,7 +907,11 @@ __device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[G::MI][G::NJ], i
 // Rectangle sizes and the number of blocks an XCD receives differ by a few tiles: tiles beyond an XCD's block count
 // are handed, in a fixed order, to the XCDs with spare blocks.
 struct TileMap {
-    int tiles_i, tiles_j, xi, xj, gj, pad_;
+    int tiles_i, tiles_j, xi, xj, gj;
+    int slab;       // 1: the round-2 order (block_to_tile: every XCD a contiguous run of tiles in row-major order, no table):
+                    // the choice of the launch tuner unless a grid measures at least 2 % faster - the grids only pay where
+                    // an XCD's panels overflow its L2 (3072 x 5000, AIS); at the 784 x 1024 shapes the table walk in the
+                    // kernel prologue cost ~0.5 us per launch for nothing (same-box A/B, round 4)
     // per XCD, host-computed and packed so that the device reads them as 12 scalar registers (see tile_of_block):
     //   rect[x]  = i0 | hi << 16 | j0 << 32 | wj << 48      the XCD's rectangle of tiles
     //   spare[x] = spare_before | left << 16                 spare blocks in the XCDs before this one, and the number
@@ -916,8 +920,8 @@ struct TileMap {
     unsigned int spare[8];
 };
 
-// force_xi: 0 = the traffic model's choice (or BM355_XCD_MAP=xi[:gj]); 8 / 4 / 2 / 1 = that grid (the launch tuner
-// measures them per shape)
+// force_xi: 0 = the traffic model's choice (or BM355_XCD_MAP=xi[:gj]); 8 / 4 / 2 / 1 = that grid; -1 = the slab order
+// (the launch tuner measures all five per shape)
 static inline TileMap make_tile_map(int tiles_i, int tiles_j, double bytes_i, double bytes_j, int force_xi = 0) {
     // bytes_i / bytes_j: operand bytes one tile row / column pulls in (K * tile extent * 4)
     static int env_xi = -1, env_gj = 0;
@@ -927,10 +931,13 @@ static inline TileMap make_tile_map(int tiles_i, int tiles_j, double bytes_i, do
         if (e) { env_xi = atoi(e); const char *c = strchr(e, ':'); env_gj = c ? atoi(c + 1) : 0; }
     }
     if (env_xi > 0) force_xi = env_xi;
+    const bool slab = force_xi < 0;
+    if (slab) force_xi = 0;
     const double l2_budget = 2.5 * 1024 * 1024;          // of 4 MiB: the rest holds the streaming panels and outputs
     TileMap best;
     memset(&best, 0, sizeof(best));
     best.tiles_i = tiles_i; best.tiles_j = tiles_j; best.xi = 8; best.xj = 1; best.gj = tiles_j;
+    best.slab = slab ? 1 : 0;
     double best_cost = -1.0;
     for (int xi = 8; xi >= 1; xi >>= 1) {
         const int xj = 8 / xi;

@@ -44,8 +44,6 @@ struct ActArgs {
     float *negmeans;             // may be null: -means (P operand of the negative phase in grad_kernel form 0)
     int ldo;
     PhiloxKey key;
-    const unsigned *call_dev;    // null, or a device word ADDED to key.call by the kernel: the run-time part of the RNG call
-                                 // counter when the launch is replayed from a HIP graph (bm_rbm_train_epoch)
     long long row0;              // global row of local row 0 (rank-invariant bitmaps)
     const float *prev;           // mean-field: previous mu (same layout as means) or null
     unsigned *maxdiff;           // mean-field: atomicMax target for ||mu_new - mu||_inf (float bits)
@@ -61,6 +59,7 @@ struct ActArgs {
     float *rowacc;               // [ceil(I/16)][ld_part]: sum_i softplus(beta_b*(z+b)) - softplus(beta_a*(z+b))  (AIS)
                                  //     or sum_i z * dot_mat[j][i]                                                 (ELBO, dot_mat set)
     float beta_a, beta_b;
+    int rowacc_single;           // 1: rowacc = sum_i softplus(beta_b*(z+b)) alone (literal fp32 AIS, bm_dbm_set_ais_literal)
     float *rowdot_out;           // [ceil(I/16)][ld_part]: sum_i states[j][i] * dot_vec[i]
     int ld_part;                 // pitch of the partial-sum buffers (>= J)
     const float *dot_vec;        // [I]
@@ -82,8 +81,7 @@ struct ActArgs {
     // the bf16 shadow of the states this launch writes (null: none)
     Bf3Range b3;
     uint16_t *states16; int ld16;
-    TileMap tmap;                // block -> tile map of this launch (set by launch_act_geo for its geometry)
-    int map_xi;                  // XCD grid of the map: 0 = the traffic model's choice, 8 / 4 / 2 / 1 forced (launch tuner)
+    int map_xi;                  // block -> tile map: 0 = the traffic model's XCD grid, 8 / 4 / 2 / 1 that grid, -1 the slab order (launch tuner)
 #ifdef BM_PROBE
     long long *dbg;              // [grid][4] s_memtime stamps (tools/probe_act.hip only)
 #endif
@@ -264,7 +262,8 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                 store4<HWMATH>(a.negmeans, o, nm, nvalid, v4 && (((uintptr_t)a.negmeans & 15u) == 0));
             }
             if (a.states) store4<HWMATH>(a.states, o, s, nvalid, v4 && (((uintptr_t)a.states & 15u) == 0));
-            if (a.states16) {                  // bf16 shadow of the {0,1} states (exact), pitch ld16 % 64 == 0
+            if (HWMATH && a.states16) {        // fast-binary strip kernel only: bf16 shadow of the {0,1} states (exact),
+                                               // pitch ld16 % 64 == 0; fp32 launches get it from shadow16_kernel (launch_act)
                 uint16_t *d = a.states16 + (size_t)j * a.ld16 + ib;
                 if (nvalid == 4 && (ib & 3) == 0) {
                     uint2 pk;
@@ -294,8 +293,9 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                             qa += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
                         } else {
                             const float t = z[e] + bs[e];
-                            qa += HWMATH ? softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t)
-                                         : softplus(a.beta_b * t) - softplus(a.beta_a * t);
+                            if (a.rowacc_single) qa += HWMATH ? softplus_hw(a.beta_b * t) : softplus(a.beta_b * t);
+                            else qa += HWMATH ? softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t)
+                                              : softplus(a.beta_b * t) - softplus(a.beta_a * t);
                         }
                     }
                     // the state of this element as it was just stored by this lane
@@ -323,7 +323,10 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
 // MINB: HIP's second __launch_bounds__ argument = WAVES PER SIMD the register budget must allow (for the 4-wave
 // geometries that equals the workgroups per CU; an 8-wave workgroup that should run twice per CU passes 4)
 template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
-__global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
+__global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tmap) {
+    // (the block -> tile map is an argument of its own: the grid path indexes it with blockIdx & 7, and a dynamically
+    //  indexed member made hipcc fetch EVERY ActArgs field lazily in small pieces - 50 scalar loads with their waits
+    //  instead of 22, +1 us on the prop-down; round 4, same-box A/B)
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
     constexpr int E = G::E;
     BM_STAMP(0);
@@ -332,7 +335,6 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     asm volatile("" :: "s"(a.P1.ptr), "s"(a.Q1.ptr), "s"(a.P1.ld), "s"(a.Q1.ld), "s"(a.P1.nx), "s"(a.Q1.nx),
                        "s"(a.K1), "s"(a.K2), "s"(a.bias), "s"(a.sigma), "s"(a.means), "s"(a.states), "s"(a.ldo),
                        "s"(a.sample), "s"(a.kind), "s"(a.row0), "s"(a.I), "s"(a.J), "s"(a.skip));
-    TILE_WORDS(a.tmap, (int)blockIdx.x);           // the block's tile-map words, fetched with the same batch
     const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
     int ti, tj;
     if (a.chk_ctl) {                               // wave-uniform: Check(s-1), see ActArgs::chk_ctl
@@ -351,8 +353,12 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
         if (done) return;
     } else if (a.skip && *a.skip) return;          // wave-uniform: converged mean-field loop
     // tile order: 2-D XCD rectangles, L2-sized column groups (tile_of_block)
-    (void)tiles_j;
-    TILE_OF_BLOCK(a.tmap, (int)blockIdx.x, (int)gridDim.x, ti, tj);
+    if (tmap.slab) {                               // wave-uniform; the launch tuner's choice per shape (TileMap::slab)
+        block_to_tile(tiles_j, ti, tj, 0, 0, a.J > 2 * a.I, (a.I + G::TI - 1) / G::TI);
+    } else {
+        TILE_WORDS(tmap, (int)blockIdx.x);
+        TILE_OF_BLOCK(tmap, (int)blockIdx.x, (int)gridDim.x, ti, tj);
+    }
     const int i0 = ti * G::TI, j0 = tj * G::TJ;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
@@ -369,9 +375,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a) {
     ActSide<E, typename PhiloxFor<G::MI>::type> side;
     side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
     side.prev_row = (a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
-    // the RNG call counter: the launch's own part plus, when replayed from a HIP graph, a device word (a scalar load)
-    PhiloxKey key = a.key;
-    if (a.call_dev) key.call += *a.call_dev;
+    const PhiloxKey key = a.key;
     side.rng.init(key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
     f32x4 acc[G::MI][1];
@@ -451,54 +455,6 @@ __global__ __launch_bounds__(G::NT, MINW) void act_bf3_kernel(ActArgs a, Bf3Stri
         if (!(sp.abl & 2)) pipe.run(acc);
         if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * G::TJ); pipe.prefetch(); }     // next tile's pipeline fill ...
         if (!(sp.abl & 1)) (void)act_epilogue<G, 0, decltype(side), true>(a, a.key, acc, side, i0, j0);   // ... under this tile's epilogue
-    }
-}
-
-// the wide-tile form (bm_bf3.h Bf3W): 64 x 128 outputs per workgroup, a wave owns 32 x 64 = four row blocks of the
-// 32 x 16 epilogue tile; act_epilogue runs once per row block (its geometry argument only supplies the 32 x 16 lane
-// layout: GeoAct has the same 2-wide wave grid along i)
-template <bool SEG2>
-__global__ __launch_bounds__(256, 1) void act_bf3w_kernel(ActArgs a, Bf3Strip sp) {
-    __shared__ __attribute__((aligned(16))) float smem[Bf3W::SMEM_FLOATS];
-    using G = GeoAct;
-    constexpr int E = G::E;
-    const int ti = (int)blockIdx.x / sp.strips, st = (int)blockIdx.x % sp.strips;
-    const int per = sp.tiles_j / sp.strips, rem = sp.tiles_j % sp.strips;
-    const int tj0 = st * per + (st < rem ? st : rem), tj1 = tj0 + per + (st < rem ? 1 : 0);
-    const int i0 = ti * Bf3W::TI;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w & 1, wj = w >> 1;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int ib0 = i0 + wi * 32 + g * E;
-    ActSide<E, typename PhiloxFor<G::MI>::type> side;
-    side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = 0;
-    side.prev_row = nullptr;
-    side.fill();
-    side.with_rng = a.sample;
-    Bf3wPipe<SEG2> pipe;
-    pipe.setup(a.b3, i0, smem);
-    if (tj0 < tj1) { pipe.set_tile(a.b3, tj0 * Bf3W::TJ); pipe.prefetch(); }
-    for (int tj = tj0; tj < tj1; ++tj) {
-        const int j0 = tj * Bf3W::TJ;
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (!(sp.abl & 2)) pipe.run(acc);
-        if (tj + 1 < tj1) { pipe.set_tile(a.b3, (tj + 1) * Bf3W::TJ); pipe.prefetch(); }
-        if (!(sp.abl & 1)) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int jn = j0 + wj * 64 + 16 * n;              // first row of this wave's row block n
-                const int j = jn + l15;
-                side.rng.init(a.key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
-                if (a.sample) side.rng.fill();
-                f32x4 an[2][1] = {{acc[0][n]}, {acc[1][n]}};
-                // act_epilogue computes the row as j0' + (w / G::WI) * 16 + l15 with w / G::WI = wj here
-                (void)act_epilogue<G, 0, decltype(side), true>(a, a.key, an, side, i0, jn - wj * 16);
-            }
-        }
     }
 }
 
@@ -752,12 +708,6 @@ struct GradArgs {
     int nbias;
     RbmBiasFusedArgs bias;
     int fetch_at_fill;                // 1: read W/dW of the lane's outputs during the pipeline fill (set by launch_grad)
-    // form 0 cut at the segment boundary of its chain (the second segment starts its own 16-blocks, so the cut is exact):
-    //   split == 1: the positive rows only, raw sums to `raw` (runs on a second stream under the Gibbs chain);
-    //   split == 2: the accumulators start from `acc_in` ([J][I], pitch ldw) and run the negative rows, usual epilogue
-    int split;
-    const float *acc_in;
-    TileMap tmap;                     // block -> tile map (set by launch_grad_geo)
     int map_xi;                       // see ActArgs::map_xi
 #ifdef BM_PROBE
     long long *dbg;
@@ -816,7 +766,7 @@ template <int NJ> struct GradSide {
 };
 
 template <class G, bool FAST, int ABL = 0, int STG = STG_DMA, int MINB = 1>
-__global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a) {
+__global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a, TileMap tmap) {
     constexpr int TI = G::TI, NJ = G::NJ;
     static_assert(G::MI == 2 && G::TI == 64 && G::TJ == 64, "grad_kernel: 64 x 64 tiles, 8 consecutive outputs per lane");
     __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
@@ -839,8 +789,12 @@ __global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a) {
                        "s"(a.I), "s"(a.J), "s"(a.W), "s"(a.dW), "s"(a.ldw), "s"(a.form), "s"(a.fused));
     constexpr int TJ2 = G::TJ;                    // NJ = 2: 64 x 64 tiles
     int ti, tj;
-    TILE_WORDS(a.tmap, (int)blockIdx.x);
-    TILE_OF_BLOCK(a.tmap, (int)blockIdx.x, ntile_blocks, ti, tj);
+    if (tmap.slab) {                               // wave-uniform (TileMap::slab)
+        block_to_tile((a.J + TJ2 - 1) / TJ2, ti, tj, 0, a.nbias);
+    } else {
+        TILE_WORDS(tmap, (int)blockIdx.x);
+        TILE_OF_BLOCK(tmap, (int)blockIdx.x, ntile_blocks, ti, tj);
+    }
     const int i0 = ti * TI, j0 = tj * TJ2;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wi = w % G::WI, wj = w / G::WI;
@@ -869,33 +823,7 @@ __global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a) {
     side.on = a.fused != 0 && a.fetch_at_fill != 0;
     KRange kr;
     kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
-    if (a.form == 0 && a.split == 1) {
-        kr.P2 = a.Ppos; kr.Q2 = a.Qpos; kr.K2 = 0;
-        mainloop<KM, G, FAST, false, 0, KM, STG>(pos, kr, i0, j0, smem, side);
-    } else if (a.form == 0 && a.split == 2) {
-        if (ib0 < a.I) {
-#pragma unroll
-            for (int n = 0; n < NJ; ++n) {
-                if (side.jb[n] >= a.J) continue;
-                const float *src = a.acc_in + (size_t)side.jb[n] * a.ldw + ib0;
-                float v[8];
-                if (side.vec8) {
-                    const float4 x = *reinterpret_cast<const float4 *>(src), y = *reinterpret_cast<const float4 *>(src + 4);
-                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (ib0 + e < a.I) ? src[e] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) pos[t][n][r] = v[2 * r + t];          // inverse of lane_outputs
-            }
-        }
-        kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
-        kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = 0;
-        mainloop<KM, G, FAST, false, 0, KM, STG>(pos, kr, i0, j0, smem, side);
-    } else if (a.form == 0) {
+    if (a.form == 0) {
         // RBM: ONE chain, positive rows then negative rows with the product negated: the caller
         // passes Pneg = -h_k (act_kernel's `negmeans` output), fma(-p, q, acc) == acc - p*q exactly
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
@@ -925,11 +853,6 @@ __global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a) {
         lane_outputs<G>(neg, n, nv);
         const size_t o = (size_t)j * a.ldw + ib0;
         if (!a.fused) {
-            if (a.split == 1 && side.vec8) {       // re-read by the split == 2 launch: plain (cached) stores
-                *reinterpret_cast<float4 *>(a.raw + o) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                *reinterpret_cast<float4 *>(a.raw + o + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
-                continue;
-            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (ib0 + e >= a.I) break;
@@ -1636,10 +1559,11 @@ template <class G> static inline int tile_grid(int I, int J) { return ((I + G::T
 
 template <class G, int MINB, int STG>
 static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
-    ActArgs a = a_in;
+    const ActArgs &a = a_in;
+    TileMap tmap;
     {   // operand bytes one tile row (TI outputs along i) / one tile column (TJ rows) pulls through the L2
         const double kt = (double)a.K1 + (double)a.K2;
-        a.tmap = make_tile_map((a.I + G::TI - 1) / G::TI, (a.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, a.map_xi);
+        tmap = make_tile_map((a.I + G::TI - 1) / G::TI, (a.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, a.map_xi);
     }
     const bool seg2 = a.K2 > 0;
     const int pl = a.p_xm ? XM : KM;
@@ -1649,24 +1573,24 @@ static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
     // (shapes without 16-byte loads have ONE flavour: every chunk passes through registers)
     if constexpr (G::MI == 1) {
         if (a.p_xm) {                       // x-major P: single segment only (RBM prop-down from W)
-            if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, XM, STG>), grid, blk, 0, st, a);
-            else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, XM, STG_DMA>), grid, blk, 0, st, a);
+            if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, XM, STG>), grid, blk, 0, st, a, tmap);
+            else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, XM, STG_DMA>), grid, blk, 0, st, a, tmap);
             return;
         }
     }
     if (seg2) {
-        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true, 0, KM, STG>), grid, blk, 0, st, a);
-        else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false, 0, KM, STG_DMA>), grid, blk, 0, st, a);
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true, 0, KM, STG>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false, 0, KM, STG_DMA>), grid, blk, 0, st, a, tmap);
     } else {
-        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, KM, STG>), grid, blk, 0, st, a);
-        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, KM, STG_DMA>), grid, blk, 0, st, a);
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, KM, STG>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, KM, STG_DMA>), grid, blk, 0, st, a, tmap);
     }
 }
 
 // fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
 // ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
 // sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
-// tile columns.  BM355_BF3_GEO=8|4|2|16 forces one (16: the wide tile of act_bf3w_kernel, measured slower).
+// tile columns.  BM355_BF3_GEO=8|4|2 forces one.
 template <class G, int WGS_PER_CU>
 static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
     static int ncu = 0;
@@ -1684,23 +1608,6 @@ static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
     else             hipLaunchKernelGGL((act_bf3_kernel<G, false, MINW>), grid, blk, 0, st, a, sp);
 }
 static inline void launch_act_bf3_as(int geo, const ActArgs &a, hipStream_t st) {
-    if (geo == 16) {               // the wide tile (64 x 128, 4 waves of 32 x 64), BM355_BF3_GEO=16 only: its K loop is faster
-                                   // (18.6 against 22 ms per 100 AIS betas) but one wave per SIMD runs four epilogues back to
-                                   // back with nothing to overlap them (26 against 15 ms): 61.8 against 44.5 ms in total
-        static int ncu = 0;
-        if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
-        static const int abl_env = getenv("BM355_BF3_ABL") ? atoi(getenv("BM355_BF3_ABL")) : 0;
-        Bf3Strip sp;
-        sp.tiles_i = (a.I + Bf3W::TI - 1) / Bf3W::TI; sp.tiles_j = (a.J + Bf3W::TJ - 1) / Bf3W::TJ;
-        sp.abl = abl_env;
-        sp.strips = ncu / sp.tiles_i;
-        if (sp.strips < 1) sp.strips = 1;
-        if (sp.strips > sp.tiles_j) sp.strips = sp.tiles_j;
-        const dim3 grid(sp.tiles_i * sp.strips), blk(256);
-        if (a.b3.K2 > 0) hipLaunchKernelGGL((act_bf3w_kernel<true>), grid, blk, 0, st, a, sp);
-        else             hipLaunchKernelGGL((act_bf3w_kernel<false>), grid, blk, 0, st, a, sp);
-        return;
-    }
     if (geo == 8)      launch_act_bf3_geo<GeoGrad8, 1>(a, st);
     else if (geo == 2) launch_act_bf3_geo<GeoBf3S, 2>(a, st);
     else               launch_act_bf3_geo<GeoAct, 1>(a, st);
@@ -1829,12 +1736,13 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     if (b >= 0) T.best = cand_geo[b];
     // second dimension: the XCD grid of the block -> tile map, with the chosen geometry (the traffic model's choice is
     // one of the four; which one is fastest also depends on how the panels fall onto the memory channels)
-    float xi_us[4] = {1e30f, 1e30f, 1e30f, 1e30f};
-    static const int cand_xi[4] = {8, 4, 2, 1};
+    float xi_us[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    static const int cand_xi[5] = {8, 4, 2, 1, -1};
     static const bool tune_xi = !(getenv("BM355_XCD_MAP") || (getenv("BM355_TUNE_XCD") && atoi(getenv("BM355_TUNE_XCD")) == 0));
+    T.xi = -1;                                   // the slab order unless a grid is measurably (>= 2 %) faster
     if (tune_xi) {
         for (int round = 0; round < TUNE_ROUNDS; ++round)
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 5; ++c) {
                 t.map_xi = cand_xi[c];
                 launch_act_as(T.best, t, st);
                 (void)hipEventRecord(e0, st);
@@ -1846,8 +1754,8 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
             }
         int bx = 0;
         for (int c = 1; c < 4; ++c) if (xi_us[c] < xi_us[bx]) bx = c;
-        if (xi_us[bx] < 1e29f) T.xi = cand_xi[bx];
-    }
+        if (xi_us[bx] < 0.98f * xi_us[4]) T.xi = cand_xi[bx];
+    } else T.xi = 0;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
@@ -1857,13 +1765,13 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
                 T.t_us[4], T.t_us[5] > 1e29f ? -1.f : T.t_us[5], T.t_us[6], T.t_us[7], T.t_us[8] > 1e29f ? -1.f : T.t_us[8],
                 T.t_us[9] > 1e29f ? -1.f : T.t_us[9], T.t_us[10] > 1e29f ? -1.f : T.t_us[10], T.t_us[11] > 1e29f ? -1.f : T.t_us[11]);
     if (log && tune_xi)
-        fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> XCD grid %d x %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
-                a.I, a.J, a.K1, a.K2, flags, T.xi, T.xi ? 8 / T.xi : 0, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
+        fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> tile map %d (-1 slab, else XCD grid xi; us: slab %.1f, 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
+                a.I, a.J, a.K1, a.K2, flags, T.xi, xi_us[4], xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
 }
 // fast-binary launches: three tile geometries (2: 64 x 32 tiles, two workgroups per CU; 4: 64 x 64, one; 8: 128 x 32
 // with 8 waves), measured once per shape like the fp32 ones.  Which one wins follows the tile count and K, not one
 // rule: 20000 AIS chains take 2, the 3072 x 256 x 5000 top-down pass of BASELINE configs[2] takes 8 or 2 (68 / 71 us)
-// where 4 needs 117 us (192 tiles on 256 CUs).  BM355_BF3_GEO=8|4|2|16 forces one.
+// where 4 needs 117 us (192 tiles on 256 CUs).  BM355_BF3_GEO=8|4|2 forces one.
 static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
     static int geo_env = -1;
     if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
@@ -1907,8 +1815,16 @@ static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
     }
     launch_act_bf3_as(geo, a, st);
 }
+static inline void launch_act_f32(const ActArgs &a, hipStream_t st);
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     if (a.b3.K1 > 0) { launch_act_bf3(a, st); return; }
+    launch_act_f32(a, st);
+    // fast-binary mode, an fp32 launch whose sampled states the NEXT launches read as a bf16 shadow: converted here (the
+    // strip kernel writes its shadow itself; keeping the branch out of the fp32 epilogue is worth ~0.2 us per launch)
+    if (a.states16 && a.states)
+        hipLaunchKernelGGL(shadow16_kernel, dim3(256), dim3(256), 0, st, (const float *)a.states, a.ldo, a.J, a.I, a.states16, a.ld16);
+}
+static inline void launch_act_f32(const ActArgs &a, hipStream_t st) {
     const int ov = act_geo_override();
     if (ov) { launch_act_as(ov, a, st); return; }
     static std::mutex mu;
@@ -1940,16 +1856,17 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
 // BM355_GRAD_GEO=4|8 forces one.
 template <class G, int STG, int MINB = 1>
 static inline void launch_grad_geo(const GradArgs &g_in, hipStream_t st) {
-    GradArgs g = g_in;
+    const GradArgs &g = g_in;
+    TileMap tmap;
     {
         const double kt = (double)g.Kpos + (double)g.Kneg;
-        g.tmap = make_tile_map((g.I + G::TI - 1) / G::TI, (g.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, g.map_xi);
+        tmap = make_tile_map((g.I + G::TI - 1) / G::TI, (g.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, g.map_xi);
     }
     const bool fast = operand_fast(g.Ppos, KM, g.Kpos) && operand_fast(g.Qpos, KM, g.Kpos) &&
                       operand_fast(g.Pneg, KM, g.Kneg) && operand_fast(g.Qneg, KM, g.Kneg);
     const dim3 grid(tile_grid<G>(g.I, g.J) + g.nbias), blk(G::NT);
-    if (fast) hipLaunchKernelGGL((grad_kernel<G, true, 0, STG, MINB>), grid, blk, 0, st, g);
-    else      hipLaunchKernelGGL((grad_kernel<G, false, 0, STG_DMA, MINB>), grid, blk, 0, st, g);
+    if (fast) hipLaunchKernelGGL((grad_kernel<G, true, 0, STG, MINB>), grid, blk, 0, st, g, tmap);
+    else      hipLaunchKernelGGL((grad_kernel<G, false, 0, STG_DMA, MINB>), grid, blk, 0, st, g, tmap);
 }
 // geo: 4 | 8 waves, + 100 for register staging of the full chunks
 static inline void launch_grad_as(int geo, const GradArgs &g, hipStream_t st) {
@@ -1995,13 +1912,13 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
     for (int c = 1; c < NC; ++c) if (best_us[c] < best_us[b]) b = c;
     const int best = cand[b];
     // the XCD grid of the block -> tile map with that geometry (see tune_act_shape)
-    float xi_us[4] = {1e30f, 1e30f, 1e30f, 1e30f};
-    static const int cand_xi[4] = {8, 4, 2, 1};
+    float xi_us[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    static const int cand_xi[5] = {8, 4, 2, 1, -1};
     static const bool tune_xi = !(getenv("BM355_XCD_MAP") || (getenv("BM355_TUNE_XCD") && atoi(getenv("BM355_TUNE_XCD")) == 0));
-    int xi = 0;
+    int xi = 9;                                  // 9 = the slab order (map_xi -1), unless a grid is >= 2 % faster
     if (tune_xi) {
         for (int round = 0; round < 3; ++round)
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 5; ++c) {
                 t.map_xi = cand_xi[c];
                 launch_grad_as(best, t, st);
                 (void)hipEventRecord(e0, st);
@@ -2013,14 +1930,14 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
             }
         int bx = 0;
         for (int c = 1; c < 4; ++c) if (xi_us[c] < xi_us[bx]) bx = c;
-        if (xi_us[bx] < 1e29f) xi = cand_xi[bx];
-    }
+        if (xi_us[bx] < 0.98f * xi_us[4]) xi = cand_xi[bx];
+    } else xi = 0;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f; 8w bk32 x2: %.1f), "
-                        "XCD grid %d (us: 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
-                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3], best_us[4], xi, xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
+                        "tile map %d (9 slab, else XCD grid xi; us: slab %.1f, 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
+                g.I, g.J, g.Kpos, g.Kneg, g.form, g.fused, best, best_us[0], best_us[1], best_us[2], best_us[3], best_us[4], xi, xi_us[4], xi_us[0], xi_us[1], xi_us[2], xi_us[3]);
     return best + 1000 * xi;
 }
 static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
@@ -2035,13 +1952,13 @@ static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
         static std::map<std::array<long long, 7>, int> table;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1) | (g.split << 2)), (long long)g.ldw, (long long)dev};
+        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1)), (long long)g.ldw, (long long)dev};
         std::lock_guard<std::mutex> lk(mu);
         int &b = table[key];
         if (!b) b = tune_grad_shape(g, st);
         geo = b;
     }
-    if (geo >= 1000) { if (!g.map_xi) g.map_xi = geo / 1000; geo %= 1000; }
+    if (geo >= 1000) { if (!g.map_xi) g.map_xi = (geo / 1000 == 9) ? -1 : geo / 1000; geo %= 1000; }
     launch_grad_as(geo, g, st);
 }
 

@@ -27,8 +27,14 @@ enum : uint32_t { SITE_DROPOUT = 1, SITE_H0 = 2, SITE_V = 3, SITE_H = 4, SITE_PL
 
 using namespace bm;
 
+struct bm_xchg;
+// (bm_xchg.hip, later in this translation unit)
+static int xchg_check_status(bm_xchg *x);                    // error when a wait of the exchange ever expired
+static void xchg_bind_user(bm_xchg *x, bm_xchg **slot);      // the engine field that points at x (cleared by bm_xchg_destroy)
+
 struct bm_rbm {
     bm_rbm_config cfg;
+    bm_xchg *xchg_used = nullptr;     // the direct exchange this engine's gradients last went through (bm_rbm_sync checks it)
     int V, H, maxB;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -66,24 +72,6 @@ struct bm_rbm {
     bool fast_now = false;
     Mat16 W3, W3t, hs16, vs16;
     int *nonbinary = nullptr;  // device flag: a state handed to the fast path was not a {0,1} bitmap
-    // bm_rbm_train_epoch as a HIP graph: runs of updates that recur with the same arguments (the minibatches of an
-    // epoch, epoch after epoch) are captured once and replayed.  The RNG call counter of a replayed launch is
-    // (baked step index) + (*call_dev); the last node of the graph adds the number of steps to *call_dev.
-    struct EpochGraph { const float *X; long long N; int batch, k; float lr, mom; uint64_t seed; int64_t row0; int steps, seen; hipGraphExec_t exec; };
-    std::vector<EpochGraph> graphs;
-    unsigned *call_dev = nullptr;    // device word; its value is tracked in call_dev_val
-    uint32_t call_dev_val = 0;
-    bool capturing = false;
-    uint32_t capture_call0 = 0;
-    int epoch_graph = -1;            // bm_rbm_set_epoch_graph: 1 on, 0 off, -1: BM355_EPOCH_GRAPH (default off)
-    // the positive outer products of a fused update on a second stream, under the Gibbs chain (bm_rbm_set_grad_overlap):
-    // the chain of the raw gradient is cut at its segment boundary (GradArgs::split), the accumulators cross in pos_acc
-    int grad_overlap = -1;           // 1 on, 0 off, -1: BM355_GRAD_OVERLAP (default off)
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    Mat pos_acc;                     // [V][H] like W
-    bool pos_pending = false;
-    bool graph_mode = false;         // bm_rbm_train_epoch is on its graph path (eager pass included: it tunes the captured launches)
     // bm_rbm_stage / bm_rbm_get_staged: device-side copies of every variable taken in stream order (a checkpoint
     // snapshot that does not stop the stream), read back on their own stream by whoever writes the checkpoint
     struct Stage { Mat W, dW; DevBuf vb, hb, dvb, dhb, q, sigma; hipEvent_t ev = nullptr; bool ready = false; } stage[2];
@@ -117,7 +105,7 @@ static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
     k.k0 = (uint32_t)h->seed;
     k.k1 = (uint32_t)(h->seed >> 32);
     k.site = site + 16u * (uint32_t)t;
-    k.call = h->capturing ? h->call - h->capture_call0 : h->call;     // graph capture: the step index; *call_dev adds the rest
+    k.call = h->call;
     return k;
 }
 
@@ -138,7 +126,6 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.sample = states ? sample : 0;               // no consumer of the states: no draw
     a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
-    a.call_dev = h->capturing ? h->call_dev : nullptr;
     a.row0 = h->row0;
     if (h->fast_now && v == h->vs.p) {           // fast-binary: W^T planes x the bf16 shadow of the visible bitmap
         a.b3.P1 = Bf3Operand{h->W3t.p, h->W3t.plane_stride(), h->W3t.ld, h->H};
@@ -180,7 +167,6 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
     a.sample = sample;
     a.means = means; a.states = states; a.ldo = ldo;
     a.key = make_key(h, site, t);
-    a.call_dev = h->capturing ? h->call_dev : nullptr;
     a.row0 = h->row0;
     if (h->fast_now && hs == h->hs.p) {          // fast-binary: W planes x the bf16 shadow of the hidden bitmap
         a.b3.P1 = Bf3Operand{h->W3.p, h->W3.plane_stride(), h->W3.ld, h->V};
@@ -197,29 +183,6 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
 // need_vm: the last step's visible MEANS are wanted (msre metric); a plain update only consumes the
 // visible states, and nothing consumes the hidden STATES of the last step: those stores (and their
 // share of the kernel-boundary L2 writeback) are skipped.
-static void fill_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, GradArgs &g);
-static bool grad_overlap_on(bm_rbm *h) {
-    if (h->grad_overlap < 0) { const char *e = getenv("BM355_GRAD_OVERLAP"); h->grad_overlap = (e && atoi(e)) ? 1 : 0; }
-    return h->grad_overlap == 1 && !h->capturing && !h->prof && !h->graph_mode;
-}
-// fork: the positive rows of the raw gradient (X^T h0) on the side stream, as soon as h0 exists
-static int launch_grad_pos(bm_rbm *h, int B) {
-    if (!h->side_stream) {
-        BM_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
-        BM_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        BM_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-        BM_TRY(h->pos_acc.alloc(h->V, h->H));
-    }
-    BM_HIP(hipEventRecord(h->ev_fork, h->stream));
-    BM_HIP(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-    GradArgs g;
-    fill_grad(h, B, 0, (float)B, 0.f, 0.f, g);
-    g.split = 1; g.Kneg = 0; g.raw = h->pos_acc.p; g.ldw = h->pos_acc.ld;
-    bm::launch_grad(g, h->side_stream);
-    BM_HIP(hipEventRecord(h->ev_join, h->side_stream));
-    h->pos_pending = true;
-    return 0;
-}
 static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true, bool for_update = false) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
@@ -238,7 +201,6 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out,
     }
     h->Xin = Xin; h->Xin_ld = ldx;
     launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0);      // :421-422
-    if (for_update && grad_overlap_on(h)) BM_TRY(launch_grad_pos(h, B));
     const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
     for (int t = 0; t < k; ++t) {                                                 // :367-378
         const bool last = t == k - 1;
@@ -323,11 +285,6 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
     if (with_bias) {
         g.nbias = fill_bias_fused(h, B, lr, mom, g.bias);
         g.bias.raw_only = fused ? 0 : 1;      // split (data-parallel) step: raw column sums only
-    }
-    if (h->pos_pending) {                     // join: the chain continues from the side stream's accumulators
-        h->pos_pending = false;
-        (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
-        if (fused && h->pos_acc.ld == h->W.ld) { g.split = 2; g.acc_in = h->pos_acc.p; }
     }
     bm::launch_grad(g, h->stream);
 }
@@ -478,6 +435,7 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
 int bm_rbm_destroy(bm_rbm *h) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->stream);
+    if (h->xchg_used) xchg_bind_user(h->xchg_used, nullptr);
     Mat *mats[] = {&h->W, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
     DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->grad_alt, &h->pen, &h->rowacc, &h->hhat};
@@ -486,7 +444,6 @@ int bm_rbm_destroy(bm_rbm *h) {
         if (h->ev_reduced[i]) (void)hipEventDestroy(h->ev_reduced[i]);
     }
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
-    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
     if (h->stage_stream) { (void)hipStreamSynchronize(h->stage_stream); (void)hipStreamDestroy(h->stage_stream); }
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     for (auto &sg : h->stage) {
@@ -495,14 +452,9 @@ int bm_rbm_destroy(bm_rbm *h) {
         for (DevBuf *b : sv) b->release();
         if (sg.ev) (void)hipEventDestroy(sg.ev);
     }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    h->pos_acc.release();
     for (DevBuf *b : all) b->release();
     h->W3.release(); h->W3t.release(); h->hs16.release(); h->vs16.release();
     if (h->nonbinary) (void)hipFree(h->nonbinary);
-    for (auto &e : h->graphs) if (e.exec) (void)hipGraphExecDestroy(e.exec);
-    if (h->call_dev) (void)hipFree(h->call_dev);
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -515,6 +467,7 @@ int bm_rbm_destroy(bm_rbm *h) {
 
 int bm_rbm_sync(bm_rbm *h) {
     BM_HIP(hipStreamSynchronize(h->stream));
+    if (h->xchg_used) BM_TRY(xchg_check_status(h->xchg_used));      // a lost rank is an ERROR here, never a silent wrong sum
     if (h->nonbinary) {
         int bad = 0;
         BM_HIP(hipMemcpy(&bad, h->nonbinary, sizeof(int), hipMemcpyDeviceToHost));
@@ -686,92 +639,16 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr
     return 0;
 }
 
-__global__ void bump_call_kernel(unsigned *p, unsigned n) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += n; }
-
-static int train_epoch_eager(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
+// N rows of X_dev as consecutive minibatches of `batch` rows, driven from C: the same launches and RNG call counters
+// as the caller's own loop over bm_rbm_train_step, without a host round trip per batch.  (Round 3 could replay recurring
+// runs of updates from a HIP graph, bit-exactly, and measured it SLOWER on MI355X / ROCm 7.2 - 66.3 against 65.4 us per
+// update over 2000 updates, 75 - 77 against 69 us for a single 20-update replay; removed in round 4)
+int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
+    BM_CHECK(batch >= 1 && N >= 1, "bad N=%lld batch=%d", (long long)N, batch);
     for (int64_t s = 0; s < N; s += batch) {
         const int B = (int)((N - s < batch) ? (N - s) : batch);
         BM_TRY(bm_rbm_train_step(h, X_dev + (size_t)s * h->V, B, lr, mom, k));
     }
-    return 0;
-}
-
-// OPT-IN (bm_rbm_set_epoch_graph / BM355_EPOCH_GRAPH=1): runs of >= 4 plain updates (Bernoulli units, no dropout: no
-// host-dependent side kernels) that recur with the same arguments are replayed from a HIP graph: captured at the second
-// occurrence (the first one ran eagerly and tuned every launch), kept in a small cache; the RNG call counter of a
-// replayed launch is its baked step index plus a device word.  Same kernels, same arguments, same counters: same bits
-// (tests/test_rbm_parity_gpu.py).  MEASURED SLOWER on MI355X / ROCm 7.2 at the north-star shape, so it is off by
-// default: 66.3 against 65.4 us per update in 20-update replays over 2000 updates, and 75 - 77 against 69 us when the
-// timed region is a single 20-update replay (the replay's start-up costs more than the 0.35 us per kernel boundary
-// that tools/probe_act measured for a graph of identical launches gives back).
-int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
-    BM_CHECK(batch >= 1 && N >= 1, "bad N=%lld batch=%d", (long long)N, batch);
-    static const bool env_on = getenv("BM355_EPOCH_GRAPH") && atoi(getenv("BM355_EPOCH_GRAPH")) == 1;
-    const bool off = h->epoch_graph < 0 ? !env_on : h->epoch_graph == 0;
-    const int steps = (int)((N + batch - 1) / batch);
-    const bool plain = h->cfg.v_unit == BM_UNIT_BERNOULLI && !h->multinomial() && h->cfg.dropout < 0.f && !h->prof;
-    if (off || !plain || steps < 4 || steps > 4096 || batch > h->maxB) return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
-    struct GraphMode { bm_rbm *h; ~GraphMode() { h->graph_mode = false; } } gm{h};
-    h->graph_mode = true;
-    bm_rbm::EpochGraph *g = nullptr;
-    for (auto &e : h->graphs)
-        if (e.X == X_dev && e.N == N && e.batch == batch && e.k == k && e.lr == lr && e.mom == mom && e.seed == h->seed &&
-            e.row0 == h->row0) { g = &e; break; }        // (the seed and the row offset are baked into the launches)
-    if (!g) {                                   // first occurrence: remember it, run eagerly (this also tunes the launches)
-        if (h->graphs.size() >= 64) {           // cache full: drop the oldest entry
-            if (h->graphs.front().exec) (void)hipGraphExecDestroy(h->graphs.front().exec);
-            h->graphs.erase(h->graphs.begin());
-        }
-        h->graphs.push_back(bm_rbm::EpochGraph{X_dev, (long long)N, batch, k, lr, mom, h->seed, h->row0, steps, 1, nullptr});
-        return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
-    }
-    if (!h->call_dev) {
-        BM_HIP(hipMalloc((void **)&h->call_dev, sizeof(unsigned)));
-        BM_HIP(hipMemsetAsync(h->call_dev, 0, sizeof(unsigned), h->stream));
-        h->call_dev_val = 0;
-    }
-    if (!g->exec) {                             // second occurrence: capture
-        hipGraph_t graph = nullptr;
-        const uint32_t call0 = h->call;
-        BM_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        h->capturing = true; h->capture_call0 = call0;
-        int rc = train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
-        hipLaunchKernelGGL(bump_call_kernel, dim3(1), dim3(64), 0, h->stream, h->call_dev, (unsigned)steps);
-        h->capturing = false;
-        h->call = call0;                        // nothing ran: the counter moves when the graph does
-        const hipError_t e = hipStreamEndCapture(h->stream, &graph);
-        if (rc || e != hipSuccess || !graph || hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            if (graph) (void)hipGraphDestroy(graph);
-            g->exec = nullptr;
-            g->seen = -1000000;                 // this run is not capturable here: stay eager
-            return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
-        }
-        (void)hipGraphDestroy(graph);
-    }
-    if (g->seen < 0) return train_epoch_eager(h, X_dev, N, batch, lr, mom, k);
-    if (h->call_dev_val != h->call) {           // eager calls moved the host counter since the last replay
-        BM_HIP(hipMemsetD32Async((hipDeviceptr_t)h->call_dev, (int)h->call, 1, h->stream));
-        h->call_dev_val = h->call;
-    }
-    BM_HIP(hipGraphLaunch(g->exec, h->stream));
-    h->call += (uint32_t)steps;
-    h->call_dev_val += (uint32_t)steps;
-    g->seen++;
-    // what the eager path leaves in the handle
-    h->hm_is_neg = true;
-    h->Xin = X_dev + (size_t)(steps - 1) * batch * h->V; h->Xin_ld = h->V;
-    return 0;
-}
-
-int bm_rbm_set_grad_overlap(bm_rbm *h, int32_t on) {
-    BM_CHECK(h, "null handle");
-    h->grad_overlap = on ? 1 : 0;
-    return 0;
-}
-int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on) {
-    BM_CHECK(h, "null argument");
-    h->epoch_graph = on ? 1 : 0;
     return 0;
 }
 

@@ -103,15 +103,67 @@ __device__ __forceinline__ float philox_uniform_at(const PhiloxKey &key, uint64_
     return u32_to_uniform(w[idx & 3]);
 }
 
-// TF BoxMullerFloat on a word pair -> two standard normals (sin first, cos second)
+// ln(u) for u in [2^-24, 1) and (sin, cos)(2 pi u) for u in [0, 1), specified operation by operation like the
+// sigmoid (bm_numerics.h): correctly rounded fp32 mul / add / fma / div and integer bit operations only, so that
+// oracle/bm_oracle.c (`pin_log_unit`, `pin_sincos_2pi`) reproduces every Normal draw BIT FOR BIT (round 3 used the
+// device's logf / sincosf against glibc's: the Gaussian visible samples agreed to 1e-5 only and could flip a hidden
+// bit downstream).  Absolute error < 1.2e-7 (log: relative), i.e. what a float32 libm gives.
+//   log:    u = m 2^e with m in [1/sqrt2, sqrt2];  s = (m - 1) / (m + 1);  ln m = 2 s (1 + s^2/3 + ... + s^10/11);
+//           ln u = e ln2_hi + (e ln2_lo + ln m)
+//   sincos: t = 4 u, quadrant q = floor(t), f = t - q (exact), folded to [-1/2, 1/2]; x = f pi/2 in [-pi/4, pi/4];
+//           Taylor to x^9 (sin) / x^10 (cos) in Horner form; the quadrant permutes / negates
+__device__ __forceinline__ float pin_log_unit(float u) {
+    const uint32_t b = __float_as_uint(u);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);          // [1, 2)
+    if (m > 1.41421356237309504880f) { m = m * 0.5f; e = e + 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float t = s * s;
+    float p = 1.0f / 11.0f;
+    p = fmaf(p, t, 1.0f / 9.0f);
+    p = fmaf(p, t, 1.0f / 7.0f);
+    p = fmaf(p, t, 1.0f / 5.0f);
+    p = fmaf(p, t, 1.0f / 3.0f);
+    p = fmaf(p, t, 1.0f);
+    const float lm = (2.0f * s) * p;
+    const float ef = (float)e;
+    return fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723212e-6f, lm));
+}
+__device__ __forceinline__ void pin_sincos_2pi(float u, float &sn, float &cs) {
+    const float t = u * 4.0f;
+    int q = (int)t;                                   // t >= 0: floor
+    float f = t - (float)q;
+    if (f > 0.5f) { f = f - 1.0f; q = q + 1; }
+    const float x = f * 1.57079632679489661923f;
+    const float x2 = x * x;
+    float ps = 2.75573192239858906526e-6f;            // 1/9!
+    ps = fmaf(ps, x2, -1.98412698412698412698e-4f);   // -1/7!
+    ps = fmaf(ps, x2, 8.33333333333333333333e-3f);    // 1/5!
+    ps = fmaf(ps, x2, -1.66666666666666666667e-1f);   // -1/3!
+    const float sx = fmaf(x * x2, ps, x);
+    float pc = -2.75573192239858906526e-7f;           // -1/10!
+    pc = fmaf(pc, x2, 2.48015873015873015873e-5f);    // 1/8!
+    pc = fmaf(pc, x2, -1.38888888888888888889e-3f);   // -1/6!
+    pc = fmaf(pc, x2, 4.16666666666666666667e-2f);    // 1/4!
+    pc = fmaf(pc, x2, -0.5f);
+    const float cx = fmaf(pc, x2, 1.0f);
+    switch (q & 3) {
+        case 0: sn = sx; cs = cx; break;
+        case 1: sn = cx; cs = -sx; break;
+        case 2: sn = -sx; cs = -cx; break;
+        default: sn = -cx; cs = sx; break;
+    }
+}
+
+// TF BoxMullerFloat on a word pair -> two standard normals (sin first, cos second):
+// u1 = max(U(x0), 1e-7), r = sqrt(-2 ln u1), (sin, cos)(2 pi U(x1)) r
 __device__ __forceinline__ void box_muller(uint32_t x0, uint32_t x1, float &n0, float &n1) {
     const float eps = 1.0e-7f;
     float u1 = u32_to_uniform(x0);
     if (u1 < eps) u1 = eps;
-    const float v1 = 6.2831853071795864769f * u32_to_uniform(x1);
-    const float r = sqrtf(-2.0f * logf(u1));
+    const float r = sqrtf(-2.0f * pin_log_unit(u1));
     float s, c;
-    sincosf(v1, &s, &c);
+    pin_sincos_2pi(u32_to_uniform(x1), s, c);
     n0 = s * r;
     n1 = c * r;
 }

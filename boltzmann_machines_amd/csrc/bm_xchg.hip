@@ -74,20 +74,25 @@ __device__ __forceinline__ void store_sys(__amdgpu_buffer_rsrc_t r, unsigned byt
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 17);
 }
 
-// wait until flags[base + r] >= epoch for every r < n (one lane per rank), bounded
-__device__ __forceinline__ void wait_all(const Args &a, int base, int code) {
+// wait until flags[base + r] >= epoch for every r < n (one lane per rank), bounded.  Returns false - for the WHOLE
+// workgroup - when a wait expired: the status word then names the phase and the rank, it is STICKY (never cleared; the
+// engines' sync entry points report it as an error, round-3 advisor), and the caller writes NaN instead of sums so
+// that a lost rank can never pass for a result.
+__device__ __forceinline__ bool wait_all(const Args &a, int base, int code) {
     const int tid = threadIdx.x;
+    int bad = 0;
     if (tid < a.n) {
         const long long t0 = wall_clock64();
-        bool ok = true;
         while ((int)(__hip_atomic_load(a.flags + base + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.epoch) < 0) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > a.timeout_ticks) { ok = false; break; }
+            if (wall_clock64() - t0 > a.timeout_ticks) { bad = 1; break; }
         }
-        if (!ok) __hip_atomic_store(a.flags + F_STATUS, (unsigned)(code * 16 + tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (bad) __hip_atomic_store(a.flags + F_STATUS, (unsigned)(code * 16 + tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();
+    bad = __syncthreads_or(bad);
+    if (!bad && __hip_atomic_load(a.flags + F_STATUS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) bad = 1;   // an earlier launch failed
     __atomic_thread_fence(__ATOMIC_ACQUIRE);                 // system scope: nothing cached from before the wait
+    return !bad;
 }
 
 __global__ __launch_bounds__(NTX) void allreduce_kernel(Args a) {
@@ -95,7 +100,8 @@ __global__ __launch_bounds__(NTX) void allreduce_kernel(Args a) {
     // READY(e): my buffer is complete (stream order) - tell every rank, myself included
     if (blockIdx.x == 0 && tid < n)
         __hip_atomic_store(a.pflags[tid] + F_READY + me, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    wait_all(a, F_READY, 1);
+    const bool ok1 = wait_all(a, F_READY, 1);
+    const float qnan = __builtin_nanf("");
     // ---- reduce slice `me`
     const unsigned long long base = (unsigned long long)me * a.chunk;
     const unsigned long long len = base < a.count ? (a.count - base < a.chunk ? a.count - base : a.chunk) : 0ull;
@@ -113,6 +119,7 @@ __global__ __launch_bounds__(NTX) void allreduce_kernel(Args a) {
             f32x4 s = v[0];
 #pragma unroll
             for (int r = 1; r < MAXR; ++r) if (r < n) s = s + v[r];          // rank order
+            if (!ok1) s = (f32x4){qnan, qnan, qnan, qnan};                  // a failed wait never passes for a sum
             *reinterpret_cast<f32x4 *>(a.buf + base + e * 4) = s;
             store_sys(rred, off, s);
         }
@@ -129,9 +136,16 @@ __global__ __launch_bounds__(NTX) void allreduce_kernel(Args a) {
         }
     }
     if (n == 1) return;
-    wait_all(a, F_DONE, 2);
+    const bool ok2 = wait_all(a, F_DONE, 2);
     // ---- gather the other ranks' reduced slices (rotated start: the pulls spread over the links)
     for (int d = 1; d < n; ++d) {
+        if (!ok2) {                                         // the owner never answered: its slice is NaN here, not stale
+            const unsigned long long bq = (unsigned long long)((me + d) % n) * a.chunk;
+            const unsigned long long lq = bq < a.count ? (a.count - bq < a.chunk ? a.count - bq : a.chunk) : 0ull;
+            for (unsigned long long e = (unsigned long long)blockIdx.x * NTX + tid; e < (lq + 3) / 4; e += (unsigned long long)a.grid * NTX)
+                *reinterpret_cast<f32x4 *>(a.buf + bq + e * 4) = (f32x4){qnan, qnan, qnan, qnan};
+            continue;
+        }
         const int q = (me + d) % n;
         const unsigned long long bq = (unsigned long long)q * a.chunk;
         const unsigned long long lq = bq < a.count ? (a.count - bq < a.chunk ? a.count - bq : a.chunk) : 0ull;
@@ -145,6 +159,168 @@ __global__ __launch_bounds__(NTX) void allreduce_kernel(Args a) {
             *reinterpret_cast<f32x4 *>(a.buf + bq + (e + st) * 4) = v1;
         }
         if (e < lq4) *reinterpret_cast<f32x4 *>(a.buf + bq + e * 4) = load_sys(rq, (unsigned)(e * 16));
+    }
+}
+
+// ---- fused exchange of data-parallel CD-k (round-3 verdict): reduce-scatter -> parameter update on the owned slice
+// -> all-gather of the UPDATED WEIGHTS, one launch.  The buffer is the RBM's fused gradient [V * ldw | V | H | H]:
+//   * the W part is cut into N slices; rank r sums slice r of all ranks in rank order (as allreduce_kernel), applies
+//     g = raw / N - l2 W - pen, dW = lr (mom dW + g), W += dW to ITS slice of W / dW (apply_w_update's arithmetic:
+//     the replicas' bits are those of allreduce + bm_rbm_apply_step) and leaves the new weights in its staging slice;
+//     the momentum buffer of a slice is only ever read by its owner (bm_rbm_exchange_gather_dw refreshes the rest
+//     when the host asks for dW);
+//   * the 2.8 K floats of the tail are reduced by EVERY rank itself (rank order: same bits everywhere) and the bias /
+//     q_means update is applied to every replica - by the LAST workgroup, which then publishes the sparsity penalty
+//     the W update needs (an agent-scope flag; only waited for when sparsity_cost != 0);
+//   * gather: every rank pulls the other N - 1 updated slices of W.
+// One launch and 7/8 of the apply work less on every rank's critical path than allreduce + apply_step.
+struct RbmApply {
+    float *W, *dW;                                  // local [V][ldw]
+    unsigned long long countW, chunkW;              // floats of the W part; slice length (% 4 == 0)
+    int I, ldw, V, H;
+    float N, l2, lr, mom, damping, cost, target;
+    float *vb, *dvb, *hb, *dhb, *q, *pen;           // local vectors
+    float *tail_red;                                // local [V + 2 H (+3)]: the reduced tail
+    unsigned *tail_flag;                            // local word: epoch for which tail_red / pen are valid
+    int dw_only;                                    // 1: no update - gather the owners' dW slices (bm_rbm_exchange_gather_dw)
+};
+
+__global__ __launch_bounds__(NTX) void exchange_apply_kernel(Args a, RbmApply p) {
+    const int tid = threadIdx.x, me = a.rank, n = a.n;
+    const float qnan = __builtin_nanf("");
+    if (blockIdx.x == 0 && tid < n)
+        __hip_atomic_store(a.pflags[tid] + F_READY + me, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool ok1 = wait_all(a, F_READY, 1);
+    const unsigned long long base = (unsigned long long)me * p.chunkW;
+    const unsigned long long len = base < p.countW ? (p.countW - base < p.chunkW ? p.countW - base : p.chunkW) : 0ull;
+    const unsigned long long len4 = len / 4;                 // countW % 4 == 0, chunkW % 4 == 0
+    __amdgpu_buffer_rsrc_t rred = rsrc(a.red, len4 * 16);
+    if (!p.dw_only) {
+        // ---- tail (last workgroup): reduce, update the biases / q_means of this replica, publish the penalty
+        if (blockIdx.x == gridDim.x - 1) {
+            const int T = p.V + 2 * p.H, T4 = (T + 3) / 4;
+            __amdgpu_buffer_rsrc_t rt[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) rt[r] = rsrc(r < n ? a.pbuf[r] + p.countW : a.buf, r < n ? (unsigned long long)T4 * 16 : 0);
+            for (int c4 = tid; c4 < T4; c4 += NTX) {
+                f32x4 v[MAXR];
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) if (r < n) v[r] = load_sys(rt[r], (unsigned)c4 * 16u);
+                f32x4 s = v[0];
+#pragma unroll
+                for (int r = 1; r < MAXR; ++r) if (r < n) s = s + v[r];      // rank order
+                if (!ok1) s = (f32x4){qnan, qnan, qnan, qnan};
+                *reinterpret_cast<f32x4 *>(p.tail_red + 4 * c4) = s;
+            }
+            __syncthreads();
+            const float *sv = p.tail_red, *sh = p.tail_red + p.V, *sq = p.tail_red + p.V + p.H;
+            for (int c = tid; c < p.V + p.H; c += NTX) {          // rbm_bias_update (bm_kernels.h), same operations
+                if (c < p.V) {
+                    const float g = sv[c] / p.N;
+                    const float d = p.lr * (p.mom * p.dvb[c] + g);
+                    p.dvb[c] = d;
+                    p.vb[c] = p.vb[c] + d;
+                } else {
+                    const int h = c - p.V;
+                    const float qn = p.damping * p.q[h] + (1.0f - p.damping) * sq[h];
+                    p.q[h] = qn;
+                    const float pen = p.cost * (qn - p.target);
+                    p.pen[h] = pen;
+                    float g = sh[h] / p.N;
+                    g = g - pen;
+                    const float d = p.lr * (p.mom * p.dhb[h] + g);
+                    p.dhb[h] = d;
+                    p.hb[h] = p.hb[h] + d;
+                }
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(p.tail_flag, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---- W slice `me`: sum over the ranks, update, stage the new weights
+        bool okp = true;
+        if (p.cost != 0.f) {                                 // the penalty of this step (wave-uniform branch)
+            int bad = 0;
+            if (tid == 0) {
+                const long long t0 = wall_clock64();
+                while ((int)(__hip_atomic_load(p.tail_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.epoch) < 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > a.timeout_ticks) { bad = 1; break; }
+                }
+                if (bad) __hip_atomic_store(a.flags + F_STATUS, (unsigned)(4 * 16 + me + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            okp = !__syncthreads_or(bad);
+        }
+        const bool pow2 = ((__float_as_uint(p.N) & 0x007fffffu) == 0u) && p.N >= 1.0f;
+        const float invN = 1.0f / p.N;
+        __amdgpu_buffer_rsrc_t rs[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) rs[r] = rsrc(r < n ? a.pbuf[r] + base : a.buf, r < n ? len4 * 16 : 0);
+        for (unsigned long long e = (unsigned long long)blockIdx.x * NTX + tid; e < len4; e += (unsigned long long)a.grid * NTX) {
+            const unsigned off = (unsigned)(e * 16);
+            f32x4 v[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) if (r < n) v[r] = load_sys(rs[r], off);
+            f32x4 s = v[0];
+#pragma unroll
+            for (int r = 1; r < MAXR; ++r) if (r < n) s = s + v[r];          // rank order
+            const unsigned long long flat = base + e * 4;
+            const int i = (int)(flat % (unsigned long long)p.ldw);
+            f32x4 wv = *reinterpret_cast<const f32x4 *>(p.W + flat), dv = *reinterpret_cast<const f32x4 *>(p.dW + flat);
+            if (i < p.I) {                                       // I % 4 == 0: the whole group is inside the row
+                f32x4 pe = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.cost != 0.f) pe = *reinterpret_cast<const f32x4 *>(p.pen + i);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float g = pow2 ? s[c] * invN : s[c] / p.N;
+                    float w = wv[c], d = dv[c];
+                    bm::apply_w_update(g, pe[c], p.l2, p.lr, p.mom, w, d);
+                    wv[c] = w; dv[c] = d;
+                }
+                if (!ok1 || !okp) wv = dv = (f32x4){qnan, qnan, qnan, qnan};
+                *reinterpret_cast<f32x4 *>(p.W + flat) = wv;
+                *reinterpret_cast<f32x4 *>(p.dW + flat) = dv;
+            }
+            store_sys(rred, off, wv);
+        }
+    } else {
+        // ---- dW gather: stage this rank's slice of dW
+        for (unsigned long long e = (unsigned long long)blockIdx.x * NTX + tid; e < len4; e += (unsigned long long)a.grid * NTX)
+            store_sys(rred, (unsigned)(e * 16), *reinterpret_cast<const f32x4 *>(p.dW + base + e * 4));
+    }
+    // DONE(e)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)a.grid * a.epoch) {
+            __threadfence_system();
+            for (int r = 0; r < n; ++r)
+                __hip_atomic_store(a.pflags[r] + F_DONE + me, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (n == 1) return;
+    const bool ok2 = wait_all(a, F_DONE, 2);
+    // ---- gather the other ranks' slices of the new W (or of dW) into this replica
+    float *dst = p.dw_only ? p.dW : p.W;
+    for (int d = 1; d < n; ++d) {
+        const int q = (me + d) % n;
+        const unsigned long long bq = (unsigned long long)q * p.chunkW;
+        const unsigned long long lq = bq < p.countW ? (p.countW - bq < p.chunkW ? p.countW - bq : p.chunkW) : 0ull;
+        const unsigned long long lq4 = lq / 4;
+        __amdgpu_buffer_rsrc_t rq = rsrc(a.pred[q], lq4 * 16);
+        const unsigned long long st = (unsigned long long)a.grid * NTX;
+        unsigned long long e = (unsigned long long)blockIdx.x * NTX + tid;
+        if (!ok2) {
+            for (; e < lq4; e += st) *reinterpret_cast<f32x4 *>(dst + bq + e * 4) = (f32x4){qnan, qnan, qnan, qnan};
+            continue;
+        }
+        for (; e + st < lq4; e += 2 * st) {                  // two loads in flight per lane
+            const f32x4 v0 = load_sys(rq, (unsigned)(e * 16)), v1 = load_sys(rq, (unsigned)((e + st) * 16));
+            *reinterpret_cast<f32x4 *>(dst + bq + e * 4) = v0;
+            *reinterpret_cast<f32x4 *>(dst + bq + (e + st) * 4) = v1;
+        }
+        if (e < lq4) *reinterpret_cast<f32x4 *>(dst + bq + e * 4) = load_sys(rq, (unsigned)(e * 16));
     }
 }
 
@@ -197,6 +373,12 @@ struct bm_xchg {
     unsigned epoch = 0, epoch_max = 0;
     int grid = 1;
     long long timeout_ticks = 0;
+    // fused exchange + update (bm_rbm_exchange_apply_direct): the reduced tail and the flag that publishes the penalty
+    float *tail_red = nullptr;
+    unsigned *tail_flag = nullptr;
+    size_t tail_n = 0;
+    bool dw_stale = false;          // the owners' slices of dW moved since the replicas were last refreshed
+    bm_xchg **user = nullptr;       // the engine field that points at this exchange (cleared when it is destroyed)
 };
 
 static int xchg_alloc_flags(bm_xchg *x) {
@@ -211,6 +393,19 @@ static int xchg_alloc_flags(bm_xchg *x) {
     x->slots = (unsigned long long *)((char *)p + bmx::F_WORDS * sizeof(unsigned));
     return 0;
 }
+
+// 0 when no wait of this exchange has ever expired; otherwise an error (the status word is sticky).  Reads 4 bytes
+// of fine-grained memory; the caller has synchronised the stream.
+static int xchg_check_status(bm_xchg *x) {
+    if (!x) return 0;
+    unsigned s = 0;
+    BM_HIP(hipMemcpy(&s, x->flags + bmx::F_STATUS, sizeof(s), hipMemcpyDeviceToHost));
+    BM_CHECK(s == 0, "bm_xchg: a wait for rank %u expired in phase %u (1 READY, 2 DONE, 3 max, 4 penalty): the results of "
+                     "this exchange are NaN-poisoned, the job is lost", (s & 15u) - 1u, s >> 4);
+    return 0;
+}
+
+static void xchg_bind_user(bm_xchg *x, bm_xchg **slot) { if (x) x->user = slot; }
 
 extern "C" {
 
@@ -283,8 +478,11 @@ int bm_xchg_attach(bm_xchg *x, const void *all_blobs) {
 int bm_xchg_destroy(bm_xchg *x) {
     if (!x) return 0;
     (void)hipDeviceSynchronize();
+    if (x->user) *x->user = nullptr;
     for (int i = 0; i < x->n_opened; ++i) (void)hipIpcCloseMemHandle(x->opened[i]);
     if (x->red) (void)hipFree(x->red);
+    if (x->tail_red) (void)hipFree(x->tail_red);
+    if (x->tail_flag) (void)hipFree(x->tail_flag);
     if (x->ctr) (void)hipFree(x->ctr);
     if (x->flags) (void)hipFree(x->flags);
     delete x;
@@ -331,11 +529,73 @@ int bm_xchg_status(bm_xchg *x, int32_t *out_status) {
     return 0;
 }
 
+// bound of every in-kernel wait of later launches (seconds; the default is BM_XCHG_TIMEOUT_S or 20 s)
+int bm_xchg_set_timeout(bm_xchg *x, double seconds) {
+    BM_CHECK(x && seconds > 0.0, "bad argument");
+    x->timeout_ticks = (long long)(seconds * 1e8);
+    return 0;
+}
+
 int bm_xchg_info(bm_xchg *x, int32_t *out_rank, int32_t *out_nranks, size_t *out_count) {
     BM_CHECK(x, "null argument");
     if (out_rank) *out_rank = x->rank;
     if (out_nranks) *out_nranks = x->nranks;
     if (out_count) *out_count = x->count;
+    return 0;
+}
+
+static int xchg_launch_apply(bm_rbm *h, bm_xchg *x, float N_global, float lr, float mom, int dw_only) {
+    void *p = nullptr; size_t n = 0;
+    BM_TRY(bm_rbm_dev_ptr(h, "grad", &p, &n));
+    BM_CHECK(x->attached && p == (void *)x->buf && n == x->count, "the exchange was created for another buffer (gradient slots are not supported)");
+    BM_CHECK(h->H % 4 == 0 && h->W.ld % 4 == 0 && h->W.ld == h->dW.ld, "the fused exchange needs n_hidden % 4 == 0");
+    const size_t tail = (size_t)h->V + 2 * (size_t)h->H;
+    if (!x->tail_red || x->tail_n < tail) {
+        if (x->tail_red) (void)hipFree(x->tail_red);
+        BM_HIP(hipMalloc((void **)&x->tail_red, (tail + 4) * sizeof(float)));
+        x->tail_n = tail;
+    }
+    if (!x->tail_flag) {
+        BM_HIP(hipMalloc((void **)&x->tail_flag, 64));
+        BM_HIP(hipMemsetAsync(x->tail_flag, 0, 64, h->stream));
+    }
+    bmx::Args a;
+    memset(&a, 0, sizeof(a));
+    a.buf = x->buf; a.red = x->red; a.count = x->count; a.chunk = x->chunk;
+    a.rank = x->rank; a.n = x->nranks; a.epoch = ++x->epoch;
+    for (int r = 0; r < bmx::MAXR; ++r) { a.pbuf[r] = x->pbuf[r]; a.pred[r] = x->pred[r]; a.pflags[r] = x->pflags[r]; }
+    a.flags = x->flags; a.ctr = x->ctr; a.grid = x->grid; a.timeout_ticks = x->timeout_ticks;
+    bmx::RbmApply q;
+    memset(&q, 0, sizeof(q));
+    q.W = h->W.p; q.dW = h->dW.p;
+    q.countW = (unsigned long long)h->V * h->W.ld;
+    q.chunkW = (((q.countW + x->nranks - 1) / x->nranks) + 3) & ~3ull;
+    BM_CHECK(q.chunkW <= x->chunk, "staging slice too small");       // chunk covers count / N >= countW / N
+    q.I = h->H; q.ldw = h->W.ld; q.V = h->V; q.H = h->H;
+    q.N = N_global; q.l2 = h->cfg.l2; q.lr = lr; q.mom = mom;
+    q.damping = h->cfg.sparsity_damping; q.cost = h->cfg.sparsity_cost; q.target = h->cfg.sparsity_target;
+    q.vb = h->vb.p; q.dvb = h->dvb.p; q.hb = h->hb.p; q.dhb = h->dhb.p; q.q = h->q.p; q.pen = h->pen.p;
+    q.tail_red = x->tail_red; q.tail_flag = x->tail_flag; q.dw_only = dw_only;
+    hipLaunchKernelGGL(bmx::exchange_apply_kernel, dim3(x->grid), dim3(bmx::NTX), 0, h->stream, a, q);
+    BM_HIP(hipGetLastError());
+    h->xchg_used = x; x->user = &h->xchg_used;
+    return 0;
+}
+
+// data-parallel CD-k, the exchange and the update in ONE launch: replaces bm_rbm_allreduce_grads_direct +
+// bm_rbm_apply_step (same bits).  After it every replica holds the new W, vb, hb, dvb, dhb, q_means; of dW every rank
+// holds ITS slice (bm_rbm_exchange_gather_dw completes the replicas, e.g. before a checkpoint).
+int bm_rbm_exchange_apply_direct(bm_rbm *h, bm_xchg *x, int32_t B_global, float lr, float mom) {
+    BM_CHECK(h && x, "null argument");
+    BM_TRY(xchg_launch_apply(h, x, (float)B_global, lr, mom, 0));
+    x->dw_stale = x->nranks > 1;
+    return 0;
+}
+int bm_rbm_exchange_gather_dw(bm_rbm *h, bm_xchg *x) {
+    BM_CHECK(h && x, "null argument");
+    if (!x->dw_stale) return 0;
+    BM_TRY(xchg_launch_apply(h, x, 1.f, 0.f, 0.f, 1));
+    x->dw_stale = false;
     return 0;
 }
 
@@ -358,6 +618,7 @@ int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x) {
     BM_TRY(bm_rbm_dev_ptr(h, "grad", &p, &n));
     BM_CHECK(p == (void *)x->buf && n == x->count, "the exchange was created for another buffer (gradient slots are not supported)");
     BM_TRY(bm_rbm_stream(h, &st));
+    h->xchg_used = x; x->user = &h->xchg_used;
     return bm_xchg_allreduce_sum(x, st);
 }
 int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x) {
@@ -366,6 +627,7 @@ int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x) {
     BM_TRY(bm_dbm_dev_ptr(h, "grad", &p, &n));
     BM_CHECK(p == (void *)x->buf && n == x->count, "the exchange was created for another buffer");
     BM_TRY(bm_dbm_stream(h, &st));
+    h->xchg_used = x; x->user = &h->xchg_used;
     return bm_xchg_allreduce_sum(x, st);
 }
 

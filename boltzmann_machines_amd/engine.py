@@ -115,14 +115,6 @@ class RbmEngine(object):
         """N rows starting at `row`, consecutive batches of `batch` rows, driven from C (no Python per batch)"""
         check(self.lib.bm_rbm_train_epoch(self._h, Xd.offset_ptr(row * self.V), N, batch, lr, momentum, k))
 
-    def set_epoch_graph(self, on):
-        """train_epoch replays recurring runs of updates from a HIP graph (opt-in; measured slower, bm_rbm.hip)"""
-        check(self.lib.bm_rbm_set_epoch_graph(self._h, int(bool(on))))
-
-    def set_grad_overlap(self, on=True):
-        """positive outer products on a second stream under the Gibbs chain (bit-identical; bm355.h)"""
-        check(self.lib.bm_rbm_set_grad_overlap(self._h, int(bool(on))))
-
     def grad_step(self, Xd, B, k, row=0):
         check(self.lib.bm_rbm_grad_step(self._h, Xd.offset_ptr(row * self.V), B, k))
 
@@ -376,9 +368,9 @@ class DbmEngine(object):
         """opt-in exact-product bf16 x 3 mode of AIS (bm_dbm_set_fast_binary)"""
         check(self.lib.bm_dbm_set_fast_binary(self._h, int(bool(on))))
 
-    def set_mf_persistent(self, on):
-        """0 (default): the mean-field loop as one launch per layer and sweep; 1: the persistent kernel where it applies"""
-        check(self.lib.bm_dbm_set_mf_persistent(self._h, int(bool(on))))
+    def set_ais_literal(self, on):
+        """AIS log-weights accumulated in float32 in the reference graph's order (bm_dbm_set_ais_literal)"""
+        check(self.lib.bm_dbm_set_ais_literal(self._h, int(bool(on))))
 
     def set_xchg(self, xchg):
         """like set_comm, with the per-sweep residual max over the direct peer-memory exchange (bm_dbm_set_xchg)"""

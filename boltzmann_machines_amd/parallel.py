@@ -44,13 +44,19 @@ class DataParallelRBM(object):
     """Drives one rank's engine (RbmEngine, or any object with grad_step / apply_step /
     set_row_offset) through data-parallel CD-k updates."""
 
-    def __init__(self, engine, rank, world, local_batch, allreduce_):
+    def __init__(self, engine, rank, world, local_batch, allreduce_, fused=None):
         self.engine, self.rank, self.world, self.local_batch = engine, rank, world, local_batch
         self.allreduce_ = allreduce_            # in-place sum over ranks of this rank's grad buffer
+        # fused: a DirectExchange whose exchange_apply() does the all-reduce AND the update in one kernel (the momentum
+        # buffer dW then lives slice-wise on its owners: call fused.gather_dw() before reading it)
+        self.fused = fused if (fused is not None and engine.H % 4 == 0) else None
         engine.set_row_offset(rank * local_batch)
 
     def train_step(self, X_local, lr, momentum, k, **kw):
         self.engine.grad_step(X_local, self.local_batch, k, **kw)
+        if self.fused is not None:          # exchange + update in one launch (DirectExchange.exchange_apply)
+            self.fused.exchange_apply(self.local_batch * self.world, lr, momentum)
+            return
         self.allreduce_()
         self.engine.apply_step(self.local_batch * self.world, lr, momentum)
 
@@ -305,6 +311,20 @@ class DirectExchange(object):
         f = lib.bm_dbm_allreduce_grads_direct if self._dbm else lib.bm_rbm_allreduce_grads_direct
         self._ffi.check(f(self.engine._h, self._c))
 
+    def exchange_apply(self, B_global, lr, momentum):
+        """RBM: reduce-scatter + parameter update on the owned slice + all-gather of W, ONE kernel on the engine's
+        stream (bm_rbm_exchange_apply_direct): replaces allreduce_grads() + engine.apply_step(), same bits"""
+        self._ffi.check(self._ffi.load().bm_rbm_exchange_apply_direct(self.engine._h, self._c, int(B_global), lr, momentum))
+
+    def gather_dw(self):
+        """complete every replica's momentum buffer dW (owners hold their slices between updates); a no-op when fresh"""
+        self._ffi.check(self._ffi.load().bm_rbm_exchange_gather_dw(self.engine._h, self._c))
+
+    def set_timeout(self, seconds):
+        """bound of every in-kernel wait of later launches (a wait that expires is FATAL: the status word is sticky, the
+        results are NaN-poisoned and the engine's sync() raises)"""
+        self._ffi.check(self._ffi.load().bm_xchg_set_timeout(self._c, float(seconds)))
+
     def status(self):
         """0 when no in-kernel wait has timed out (synchronises the device)"""
         import ctypes as C
@@ -347,9 +367,69 @@ def direct_allreduce_on_engine_stream(engine, xchg):
 _SOCKET_CALLS = [0]
 
 
+_MAX_MSG = 1 << 20
+
+
+def _wire_encode(x):
+    """bytes / str / None / int and tuples or lists of them -> JSON text (bytes as base64): the rendezvous payloads are
+    a 256-byte blob and an error string; nothing that arrives over the socket is ever unpickled or evaluated"""
+    import base64
+    import json
+
+    def enc(v):
+        if isinstance(v, (bytes, bytearray)):
+            return {'b': base64.b64encode(bytes(v)).decode('ascii')}
+        if isinstance(v, (list, tuple)):
+            return {'l': [enc(y) for y in v]}
+        if v is None or isinstance(v, (str, int)):
+            return {'v': v}
+        raise TypeError('socket rendezvous carries bytes, str, int, None and tuples of them, not %s' % type(v).__name__)
+    return json.dumps(enc(x)).encode('ascii')
+
+
+def _wire_decode(raw):
+    import base64
+    import json
+
+    def dec(d):
+        if not isinstance(d, dict) or len(d) != 1:
+            raise ValueError('malformed rendezvous message')
+        (k, v), = d.items()
+        if k == 'b' and isinstance(v, str):
+            return base64.b64decode(v.encode('ascii'), validate=True)
+        if k == 'l' and isinstance(v, list):
+            return tuple(dec(y) for y in v)
+        if k == 'v' and (v is None or isinstance(v, (str, int))):
+            return v
+        raise ValueError('malformed rendezvous message')
+    return dec(json.loads(raw.decode('ascii')))
+
+
+def _recv_msg(c):
+    """one length-prefixed message (4-byte little-endian length, at most _MAX_MSG bytes) from a socket with a timeout"""
+    buf = b''
+    while len(buf) < 4:
+        chunk = c.recv(4 - len(buf))
+        if not chunk:
+            raise ConnectionError('rendezvous peer closed the connection')
+        buf += chunk
+    n = int.from_bytes(buf, 'little')
+    if n > _MAX_MSG:
+        raise ValueError('rendezvous message of %d bytes refused' % n)
+    out = b''
+    while len(out) < n:
+        chunk = c.recv(min(65536, n - len(out)))
+        if not chunk:
+            raise ConnectionError('rendezvous peer closed the connection')
+        out += chunk
+    return out
+
+
 def socket_allgather(payload, rank, world, addr=None, port=None, timeout=120.0):
-    """every rank sends `payload` (anything picklable) to rank 0 over TCP and receives the list of all payloads (rank order)"""
-    import pickle
+    """every rank sends `payload` (bytes / str / None / tuples of them) to rank 0 over TCP and receives the tuple of
+    all payloads in rank order.  Messages are length-prefixed JSON (no pickle: a peer that can reach the port can
+    make the set-up FAIL, not run code); rank 0 checks the sender's rank, refuses duplicates and oversized messages,
+    and every accepted connection carries the call's timeout."""
     import socket
     import time
     addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
@@ -359,50 +439,56 @@ def socket_allgather(payload, rank, world, addr=None, port=None, timeout=120.0):
         port = int(os.environ.get('MASTER_PORT', '29533')) + 2 + _SOCKET_CALLS[0]
         _SOCKET_CALLS[0] += 1
     port = int(port)
-
-    def recv_msg(c):
-        buf = b''
-        while len(buf) < 4 or len(buf) < 4 + int.from_bytes(buf[:4], 'little'):
-            chunk = c.recv(65536)
-            if not chunk:
-                break
-            buf += chunk
-        return buf[4:4 + int.from_bytes(buf[:4], 'little')]
+    deadline = time.time() + timeout
 
     if rank == 0:
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((addr, port))
         srv.listen(world)
-        srv.settimeout(timeout)
         parts, conns = {0: payload}, []
-        for _ in range(world - 1):
-            c, _a = srv.accept()
-            r, b = pickle.loads(recv_msg(c))
-            parts[r] = b
-            conns.append(c)
-        out = [parts[r] for r in range(world)]
-        msg = pickle.dumps(out)
-        for c in conns:
-            c.sendall(len(msg).to_bytes(4, 'little') + msg)
-            c.close()
-        srv.close()
-        return out
-    t0 = time.time()
+        try:
+            while len(parts) < world:
+                srv.settimeout(max(0.01, deadline - time.time()))
+                c, _a = srv.accept()
+                c.settimeout(max(0.01, deadline - time.time()))
+                try:
+                    msg = _wire_decode(_recv_msg(c))
+                    if not (isinstance(msg, tuple) and len(msg) == 2 and isinstance(msg[0], int)
+                            and 0 < msg[0] < world and msg[0] not in parts):
+                        raise ValueError('unexpected sender')
+                except (ValueError, ConnectionError, OSError):
+                    c.close()               # not one of this job's ranks: drop it and keep waiting for them
+                    continue
+                parts[msg[0]] = msg[1]
+                conns.append(c)
+            out = tuple(parts[r] for r in range(world))
+            wire = _wire_encode(out)
+            for c in conns:
+                c.sendall(len(wire).to_bytes(4, 'little') + wire)
+        finally:
+            for c in conns:
+                c.close()
+            srv.close()
+        return list(out)
     while True:
         try:
             c = socket.create_connection((addr, port), timeout=5.0)
             break
         except OSError:
-            if time.time() - t0 > timeout:
+            if time.time() > deadline:
                 raise
             time.sleep(0.05)
-    c.settimeout(timeout)
-    msg = pickle.dumps((rank, payload))
-    c.sendall(len(msg).to_bytes(4, 'little') + msg)
-    out = pickle.loads(recv_msg(c))
-    c.close()
-    return out
+    try:
+        c.settimeout(max(0.01, deadline - time.time()))
+        wire = _wire_encode((int(rank), payload))
+        c.sendall(len(wire).to_bytes(4, 'little') + wire)
+        out = _wire_decode(_recv_msg(c))
+    finally:
+        c.close()
+    if not (isinstance(out, tuple) and len(out) == world):
+        raise ValueError('malformed rendezvous reply')
+    return list(out)
 
 
 def socket_broadcast(payload, rank, world, addr=None, port=None, timeout=120.0):

@@ -117,19 +117,12 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B,
 int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch,
                        float learning_rate, float momentum, int32_t n_gibbs_steps);
 
-/* bm_rbm_train_epoch may replay recurring runs of updates from a HIP graph (1) instead of launching them one by one
- * (0, the default: the replay measured slower on MI355X / ROCm 7.2, csrc/bm_rbm.hip); same bits either way */
 /* A snapshot of every variable that does not stop the stream (the per-epoch checkpoint of base_rbm.py:665-666 while
  * the next epoch already runs): bm_rbm_stage copies them device-to-device into slot 0 | 1 in stream order and returns;
  * bm_rbm_get_staged reads one variable of that snapshot (dense, like bm_rbm_get_param) on its own stream - it waits
  * for the staged copies only - and may be called from another host thread.  Do not re-stage a slot being read. */
 int bm_rbm_stage(bm_rbm *h, int32_t slot);
 int bm_rbm_get_staged(bm_rbm *h, int32_t slot, const char *name, float *host, size_t n);
-int bm_rbm_set_epoch_graph(bm_rbm *h, int32_t on);
-/* bm_rbm_train_step / _train_epoch: run the positive outer products X^T h0 (base_rbm.py:447) on a second stream under
- * the Gibbs chain; the chain of the raw gradient is cut at its segment boundary and continues from the stored fp32
- * accumulators, so the update is bit-identical.  Default: BM355_GRAD_OVERLAP (off). */
-int bm_rbm_set_grad_overlap(bm_rbm *h, int32_t on);
 
 /* Data-parallel split of a train step: phase 1 runs the chain and
  * leaves the raw un-normalised sums in the "grad" buffer
@@ -359,6 +352,7 @@ int bm_xchg_allreduce_sum(bm_xchg *x, void *stream);
  * every peer's slot, one fabric hop (the mean-field residual of a data-parallel DBM, dbm.py:449-452) */
 int bm_xchg_allreduce_max1(bm_xchg *x, float *val_dev, void *stream);
 int bm_xchg_status(bm_xchg *x, int32_t *out_status);                     /* synchronises; 0 = no wait timed out */
+int bm_xchg_set_timeout(bm_xchg *x, double seconds);                     /* bound of the in-kernel waits of later launches */
 int bm_xchg_info(bm_xchg *x, int32_t *out_rank, int32_t *out_nranks, size_t *out_count);
 /* the handle's fused "grad" buffer as the exchanged buffer; bm_*_allreduce_grads_direct is the drop-in for
  * bm_*_allreduce_grads between bm_*_grad_step and bm_*_apply_step */
@@ -366,6 +360,15 @@ int bm_rbm_xchg_create(bm_rbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
 int bm_dbm_xchg_create(bm_dbm *h, int32_t rank, int32_t nranks, bm_xchg **out);
 int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x);
 int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
+/* Data-parallel CD-k, the exchange AND the parameter update in ONE launch (replaces bm_rbm_allreduce_grads_direct +
+ * bm_rbm_apply_step; same bits): rank r sums slice r of the W part of every rank's gradient buffer in rank order,
+ * applies g = raw / N - l2 W - pen, dW = lr (mom dW + g), W += dW (base_rbm.py:446-468) to ITS slice of W / dW and
+ * every rank gathers the updated slices of W; the [V | H | H] tail is reduced by every rank itself (rank order) and
+ * the bias / q_means update applied to every replica.  After it all replicas hold the same W, vb, hb, dvb, dhb,
+ * q_means; of the momentum buffer dW a rank holds its own slice - bm_rbm_exchange_gather_dw completes the replicas
+ * (call it before dW is read: checkpoints, get_param("dW")).  Needs n_hidden % 4 == 0. */
+int bm_rbm_exchange_apply_direct(bm_rbm *h, bm_xchg *x, int32_t B_global, float learning_rate, float momentum);
+int bm_rbm_exchange_gather_dw(bm_rbm *h, bm_xchg *x);
 /* Opt-in "fast-binary" mode (SURVEY §7 hard part 4; csrc/bm_bf3.h): contractions whose input states are {0,1}
  * bitmaps (AIS with all layers sampled; the RBM sampling sweep with both layers sampled; in the PCD particle sweeps of
  * bm_dbm_train_step / bm_dbm_sample_v every contraction over a Bernoulli layer sampled earlier in the same call - a
@@ -375,10 +378,11 @@ int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
  * identical except where |u - p| is at round-off distance), NOT bit for bit.  Never the default. */
 int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on);
 int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on);
-/* The mean-field loop of a 2-layer DBM can run as ONE persistent kernel where the shape tiles the chip (512 / 1024
- * hidden units, N in {128, 256, 384, 512}; csrc/bm_mf.h) instead of one launch per layer and sweep; same bits either
- * way.  Opt-in (1): on MI355X it measured no faster than the launches it replaces (bm_mf.h); 0 = default. */
-int bm_dbm_set_mf_persistent(bm_dbm *h, int32_t on);
+/* bm_dbm_ais accumulation.  0 (default): per chain the DIFFERENCE log p*_b(x) - log p*_a(x) of consecutive betas, its
+ * row sums and the running log-weight in double, in a fixed order.  1: LITERALLY the reference's float32 arithmetic
+ * (dbm.py:650-660, :708-728): each log p*_beta(x) formed in float32 and added to / subtracted from a float32
+ * log-weight in the graph's order; two extra score-only passes per beta. */
+int bm_dbm_set_ais_literal(bm_dbm *h, int32_t on);
 /* like bm_dbm_set_comm, with the per-sweep residual max going through bm_xchg_allreduce_max1; NULL removes it */
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x);
 

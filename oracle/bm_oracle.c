@@ -81,15 +81,67 @@ static float uniform_at(orc_key key, uint64_t idx) {
 }
 
 /* TF BoxMullerFloat */
+/* ln(u), u in [2^-24, 1), and (sin, cos)(2 pi u), u in [0, 1): the operation-by-operation definitions of
+ * csrc/bm_rng.h (`pin_log_unit`, `pin_sincos_2pi`) - correctly rounded fp32 operations only, so that every Normal
+ * draw of the engine is reproduced bit for bit.  TF's own BoxMullerFloat calls the platform's logf / sinf / cosf:
+ * unknowable in the last bit, this definition is within 1.2e-7 of them. */
+static float pin_log_unit(float u) {
+    union { uint32_t u; float f; } v;
+    v.f = u;
+    int e = (int)(v.u >> 23) - 127;
+    v.u = (v.u & 0x007fffffu) | 0x3f800000u;
+    float m = v.f;
+    if (m > 1.41421356237309504880f) { m = m * 0.5f; e = e + 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float t = s * s;
+    float p = 1.0f / 11.0f;
+    p = fmaf(p, t, 1.0f / 9.0f);
+    p = fmaf(p, t, 1.0f / 7.0f);
+    p = fmaf(p, t, 1.0f / 5.0f);
+    p = fmaf(p, t, 1.0f / 3.0f);
+    p = fmaf(p, t, 1.0f);
+    const float lm = (2.0f * s) * p;
+    const float ef = (float)e;
+    return fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860682030941723212e-6f, lm));
+}
+static void pin_sincos_2pi(float u, float *sn, float *cs) {
+    const float t = u * 4.0f;
+    int q = (int)t;
+    float f = t - (float)q;
+    if (f > 0.5f) { f = f - 1.0f; q = q + 1; }
+    const float x = f * 1.57079632679489661923f;
+    const float x2 = x * x;
+    float ps = 2.75573192239858906526e-6f;
+    ps = fmaf(ps, x2, -1.98412698412698412698e-4f);
+    ps = fmaf(ps, x2, 8.33333333333333333333e-3f);
+    ps = fmaf(ps, x2, -1.66666666666666666667e-1f);
+    const float sx = fmaf(x * x2, ps, x);
+    float pc = -2.75573192239858906526e-7f;
+    pc = fmaf(pc, x2, 2.48015873015873015873e-5f);
+    pc = fmaf(pc, x2, -1.38888888888888888889e-3f);
+    pc = fmaf(pc, x2, 4.16666666666666666667e-2f);
+    pc = fmaf(pc, x2, -0.5f);
+    const float cx = fmaf(pc, x2, 1.0f);
+    switch (q & 3) {
+        case 0: *sn = sx; *cs = cx; break;
+        case 1: *sn = cx; *cs = -sx; break;
+        case 2: *sn = -sx; *cs = -cx; break;
+        default: *sn = -cx; *cs = sx; break;
+    }
+}
+float orc_pin_log_unit(float u) { return pin_log_unit(u); }
+void orc_pin_sincos_2pi(float u, float *sn, float *cs) { pin_sincos_2pi(u, sn, cs); }
+
 static float normal_at(orc_key key, uint64_t idx) {
     uint32_t w[4];
     philox_block(key, idx >> 2, w);
     const int pr = (int)((idx & 3) >> 1);
     float u1 = u32_to_uniform(w[2 * pr]);
     if (u1 < 1.0e-7f) u1 = 1.0e-7f;
-    const float v1 = 6.2831853071795864769f * u32_to_uniform(w[2 * pr + 1]);
-    const float r = sqrtf(-2.0f * logf(u1));
-    return ((idx & 1) ? cosf(v1) : sinf(v1)) * r;
+    const float r = sqrtf(-2.0f * pin_log_unit(u1));
+    float sn, cs;
+    pin_sincos_2pi(u32_to_uniform(w[2 * pr + 1]), &sn, &cs);
+    return ((idx & 1) ? cs : sn) * r;
 }
 
 /* exported for tests: raw words, uniforms and normals of a stream */

@@ -96,27 +96,6 @@ def test_ais_short_runs_match_the_default_path(gpu_lib, V, nh, R):
     eng.close()
 
 
-def test_wide_tile_kernel_equals_the_narrow_one(gpu_lib):
-    """BM355_BF3_GEO=16 (64 x 128 tiles, 4 row blocks per wave; forceable only, it measured slower): same values as
-    the default fast-binary tile to fp32 round-off, in a subprocess because the choice is read once per process"""
-    import os
-    import subprocess
-    import sys
-    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
-            "from tests import test_dbm_parity_gpu as D\n"
-            "eng, _ = D.make_pair(784, [512, 1024], 8, 8); eng.set_fast_binary(True)\n"
-            "v = eng.ais(n_betas=4, n_runs=2304, k=1, seed=2222); print('SUM', repr(float(v.astype(np.float64).sum())))\n"
-            "np.save(sys.argv[1], v)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {}
-    for geo in ('2', '16'):
-        f = '/tmp/bm355_bf3_geo%s.npy' % geo
-        r = subprocess.run([sys.executable, '-c', code, f], env=dict(os.environ, BM355_BF3_GEO=geo), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out[geo] = np.load(f)
-    close = np.isclose(out['2'], out['16'], rtol=1e-5, atol=1e-4)
-    assert (~close).sum() <= 2304 // 50
-
-
 def test_ais_fast_brackets_exact_log_Z(gpu_lib):
     """ground truth (tests/np_reference.dbm_exact_log_Z): 6-4-3 DBM, 2^13 states summed exactly"""
     from boltzmann_machines_amd.utils import log_mean_exp, log_std_exp

@@ -26,8 +26,9 @@ def _inputs(world=2):
     return W, Xg
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, fused=False, cost=1e-2):
     sys.path.insert(0, ROOT)
+    KW = dict(sample_v_states=True, l2=1e-3, sparsity_cost=cost)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from boltzmann_machines_amd import parallel
     from boltzmann_machines_amd.engine import RbmEngine, as_device
@@ -37,10 +38,18 @@ def _worker(rank, world, port, out):
     eng.seed(99)
     # the blobs travel over a plain TCP socket (no process group): the library's exchange needs nothing else
     xchg = parallel.DirectExchange(eng, rank, world, gather=lambda b: parallel.socket_allgather(b, rank, world))
-    dp = parallel.DataParallelRBM(eng, rank, world, BL, parallel.direct_allreduce_on_engine_stream(eng, xchg))
+    # fused: the all-reduce AND the update in one kernel per rank (bm_rbm_exchange_apply_direct): reduce-scatter, update of
+    # the owned slice of W / dW, all-gather of the new W; every replica updates its own biases from the reduced tail
+    dp = parallel.DataParallelRBM(eng, rank, world, BL, parallel.direct_allreduce_on_engine_stream(eng, xchg),
+                                  fused=xchg if fused else None)
+    assert (dp.fused is not None) == bool(fused)
     Xd = as_device(Xg[rank * BL:(rank + 1) * BL])
     for step in range(3):
         dp.train_step(Xd, 0.05, 0.5, K)
+    if fused:
+        own = eng.get('dW')                 # between updates a rank holds ITS slice of the momentum buffer ...
+        xchg.gather_dw()                    # ... the replicas are completed on demand
+        xchg.gather_dw()                    # (a no-op the second time)
     eng.sync()
     assert xchg.status() == 0
     np.savez(out + '.r%d' % rank, **{n: eng.get(n) for n in ('W', 'vb', 'hb', 'dW', 'q_means')})
@@ -55,12 +64,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_dp_direct_exchange_on_gpu(gpu_lib, tmp_path, world):
+@pytest.mark.parametrize('world,fused,cost', [(2, False, 1e-2), (3, False, 1e-2), (2, True, 1e-2), (3, True, 1e-2), (2, True, 0.0)])
+def test_dp_direct_exchange_on_gpu(gpu_lib, tmp_path, world, fused, cost):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
+    KW = dict(sample_v_states=True, l2=1e-3, sparsity_cost=cost)
     out = str(tmp_path / 'dp')
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, fused, cost), nprocs=world, join=True)
     rs = [np.load(out + '.r%d.npz' % r) for r in range(world)]
     for r in rs[1:]:
         for n in rs[0].files:                                  # replicas identical
