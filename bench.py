@@ -50,6 +50,8 @@ V, H, B = 784, 1024, 512
 LR, MOM, L2 = 0.05, 0.9, 1e-5            # examples/rbm_mnist.py:160,166,55
 PEAK_FP32_MFMA = 157.3                    # TFLOP/s, MI355X_MICROARCH.md
 PEAK_HBM = 8000.0                         # GB/s (spec), MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2500.0                   # TFLOP/s dense, MI355X_MICROARCH.md
+PEAK_BF16X3 = PEAK_BF16_MFMA / 3.0        # an exact-product fp32 weight = three bf16 planes = three MFMA passes per flop
 N_BATCHES = 20                            # synthetic batches resident in HBM, cycled
 
 
@@ -360,6 +362,7 @@ class RbmGibbs(Workload):
                        'parallelism': 'replicas%d' % world, 'fast_binary': FAST_NOTE if self.fast else False},
             'flops_per_step': flops,
             'roofline_extra': {
+                'bf16x3_flop_fraction': 1.0 if self.fast else 0.0,
                 'scope': '%d sweeps per call, 2*2*B*V*H = %.3f GFLOP per sweep; the sweep is MFMA-bound (the 6.4 MB of W '
                          'and the 3.7 MB of states are L2 / Infinity-Cache resident), the HBM figure is the secondary '
                          'number north_star asks for' % (k, 2 * F / 1e9),
@@ -449,7 +452,8 @@ class Grbm(_DbmBase):
                                        'bottom-up ones read real-valued visibles and stay fp32, as do the data pass and '
                                        'the outer products.') if self.fast else False},
             'flops_per_step': flops,
-            'roofline_extra': {'scope': 'whole PCD-5 update = (2*5+3)*2*B*V*H = %.1f GFLOP (SURVEY 8d)' % (flops / 1e9),
+            'roofline_extra': {'bf16x3_flop_fraction': (self.GK / (2.0 * self.GK + 3.0)) if self.fast else 0.0,
+                               'scope': 'whole PCD-5 update = (2*5+3)*2*B*V*H = %.1f GFLOP (SURVEY 8d)' % (flops / 1e9),
                                'traffic': pmc_traffic('grbm')},
         }
 
@@ -509,7 +513,8 @@ class Dbm(_DbmBase):
                        'fast_binary': (FAST_NOTE + ' Here: the PCD particle sweeps; mean-field (real-valued mu) and the '
                                        'outer products stay fp32.') if self.fast else False},
             'flops_per_step': flops,
-            'roofline_extra': {'scope': 'whole update, SURVEY 8d formula with T = %.1f executed mean-field sweeps = %.2f GFLOP'
+            'roofline_extra': {'bf16x3_flop_fraction': (k * N_ * (4.0 * V_ * H1 + 4.0 * H1 * H2) / flops) if self.fast else 0.0,
+                               'scope': 'whole update, SURVEY 8d formula with T = %.1f executed mean-field sweeps = %.2f GFLOP'
                                         % (T, flops / 1e9), 'traffic': pmc_traffic('dbm')},
         }
 
@@ -555,7 +560,8 @@ class Ais(_DbmBase):
                        'collective': 'bm_comm all-gather of the per-chain log-weights (once per run)' if self.comm else None,
                        'log_Z_estimate': float(log_mean_exp(self.last.astype(np.float64))) if self.last is not None else None},
             'flops_per_step': flops,
-            'roofline_extra': {'scope': 'one run = n_betas * 4*M*H1*(V+H2) = %.2f TFLOP per GPU (SURVEY 8d, shared pre-activations)'
+            'roofline_extra': {'bf16x3_flop_fraction': 1.0 if self.fast else 0.0,
+                               'scope': 'one run = n_betas * 4*M*H1*(V+H2) = %.2f TFLOP per GPU (SURVEY 8d, shared pre-activations)'
                                         % (flops / 1e12), 'traffic': pmc_traffic('ais')},
         }
 
@@ -567,8 +573,8 @@ OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 20, 5, 0.2), ('
           ('gibbs+fast_binary', 100, 10, 0.2), ('ais+fast_binary', 1, 1, 0.0), ('grbm+fast_binary', 12, 3, 0.2),
           ('dbm+fast_binary', 20, 5, 0.2))
 FAST_NOTE = ('NON-DEFAULT opt-in mode: exact-product bf16 x 3 on the bf16 matrix cores (csrc/bm_bf3.h); results agree with '
-             'the f32 chain to fp32 round-off, not bit for bit; the roofline block still prices the algorithmic flops '
-             'against the fp32-MFMA peak, so frac may exceed what an f32 kernel can reach')
+             'the f32 chain to fp32 round-off, not bit for bit; the roofline block prices the flops that run as bf16 x 3 '
+             'against the bf16 peak / 3 and the rest against the fp32-MFMA peak (`bf16x3_flop_fraction`)')
 COLLECTIVE_NAMES = {
     'direct': 'bm_xchg (in-library one-shot reduce-scatter + all-gather over peer-mapped memory / xGMI)',
     'rccl': 'bm_comm (in-library RCCL all-reduce)',
@@ -780,10 +786,16 @@ def make_record(wl, rep, world, steps, warmup, precondition_s, dt, ev_ms):
     src = None
     if isinstance(traffic, tuple):
         traffic, src = traffic
-    roof = dict({'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MFMA, 'unit': 'TFLOP/s',
-                 'frac': round(achieved / PEAK_FP32_MFMA, 4),
+    # the roof that binds: fp32 MFMA for the default path; for the opt-in fast-binary mode the fraction f of the flops
+    # that runs as three bf16 passes is priced at the bf16 peak / 3, the rest at the fp32 peak (harmonic blend) -
+    # never a frac above 1
+    f16 = float(extra.get('bf16x3_flop_fraction', 0.0) or 0.0)
+    peak = 1.0 / (f16 / PEAK_BF16X3 + (1.0 - f16) / PEAK_FP32_MFMA)
+    bound = 'mfma' if f16 == 0.0 else ('mfma-bf16x3' if f16 == 1.0 else 'mfma (bf16x3 / fp32 blend)')
+    roof = dict({'bound': bound, 'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                 'frac': round(achieved / peak, 4),
                  # the same flops over the WALL clock of the timed region (ms_per_step): what the driver's own clock sees
-                 'frac_wall': round(achieved_wall / PEAK_FP32_MFMA, 4),
+                 'frac_wall': round(achieved_wall / peak, 4),
                  'timebase': 'frac: HIP events on the engine stream around the timed steps; frac_wall: ms_per_step',
                  'traffic': traffic,
                  # HBM-side bytes come from a committed rocprofv3 PMC pass of this same command, not from this run

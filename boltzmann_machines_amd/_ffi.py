@@ -108,6 +108,8 @@ SIGNATURES = {
     'bm_rbm_set_row_offset': [_vp, _i64],
     'bm_rbm_train_step': [_vp, _vp, _i32, _f32, _f32, _i32],
     'bm_rbm_train_step_metrics': [_vp, _vp, _i32, _f32, _f32, _i32, _fp],
+    'bm_rbm_train_step_metrics_async': [_vp, _vp, _i32, _f32, _f32, _i32],
+    'bm_rbm_collect_metrics': [_vp, _fp, _i32, C.POINTER(C.c_int32)],
     'bm_rbm_train_epoch': [_vp, _vp, _i64, _i32, _f32, _f32, _i32],
     'bm_rbm_stage': [_vp, _i32],
     'bm_rbm_get_staged': [_vp, _i32, C.c_char_p, _vp, _sz],

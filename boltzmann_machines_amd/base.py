@@ -272,8 +272,12 @@ class EngineModel(BaseModel, DtypeMixin):
                 return
             self._save_busy = True
             self._save_inflight_slot = slot if slot is not None else 1
-        self._save_thread = threading.Thread(target=self._save_writer, args=(job, lock), daemon=False)
-        self._save_thread.start()
+        try:
+            self._save_thread = threading.Thread(target=self._save_writer, args=(job, lock), daemon=False)
+            self._save_thread.start()
+        except BaseException:               # e.g. the process is out of threads: write this checkpoint synchronously
+            self._save_thread = None
+            self._save_writer(job, lock)    # (drains a waiting snapshot and clears _save_busy like the thread would)
 
     def _stage_variables(self, slot):
         """engines with device-side snapshot slots: stage the variables into `slot` and return a callable that reads
@@ -287,6 +291,9 @@ class EngineModel(BaseModel, DtypeMixin):
         try:
             va, vb = a[2], b[2]
             if sorted(va.keys()) != sorted(vb.keys()):
+                return False
+            # ... and the files are still there (deleted or replaced from outside: the reference always rewrites)
+            if not all(os.path.isfile(f) for f in (a[3][0], a[3][2])) or (a[1] is not None and not os.path.isfile(a[3][1])):
                 return False
             return all(np.array_equal(va[k], vb[k]) for k in va.keys())
         except Exception:       # noqa: BLE001 - anything unusual about the snapshot: write it

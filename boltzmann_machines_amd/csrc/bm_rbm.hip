@@ -9,6 +9,7 @@
 #include "bm_kernels.h"
 
 #include <math.h>
+#include <atomic>
 
 namespace bm {
 
@@ -74,11 +75,17 @@ struct bm_rbm {
     int *nonbinary = nullptr;  // device flag: a state handed to the fast path was not a {0,1} bitmap
     // bm_rbm_stage / bm_rbm_get_staged: device-side copies of every variable taken in stream order (a checkpoint
     // snapshot that does not stop the stream), read back on their own stream by whoever writes the checkpoint
-    struct Stage { Mat W, dW; DevBuf vb, hb, dvb, dhb, q, sigma; hipEvent_t ev = nullptr; bool ready = false; } stage[2];
+    struct Stage { Mat W, dW; DevBuf vb, hb, dvb, dhb, q, sigma; hipEvent_t ev = nullptr; bool ready = false;
+                   std::atomic<int> readers{0}; } stage[2];
     hipStream_t stage_stream = nullptr;
     int last_stage = -1;
     float *stage_host = nullptr;     // pinned bounce buffer of bm_rbm_get_staged ([V][H])
     int device = 0;
+    // bm_rbm_train_step_metrics_async: pinned ring of the six device sums of every pending metrics fetch
+    static constexpr int MRING = 4096;
+    double *mring = nullptr;
+    std::vector<int> mring_B;
+    int mring_n = 0;
     // optional per-kernel-class event timing
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; };
@@ -323,6 +330,7 @@ static double mn_fe_const(const bm_rbm *h) {
 }
 
 // metrics from the chain currently in the handle (base_rbm.py:482-517)
+static void metrics_to_out4(const bm_rbm *h, const double *host, int B, float *out4);
 static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
     BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
     BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 3 * (size_t)h->maxB * sizeof(float), h->stream));
@@ -333,9 +341,14 @@ static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
     hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
                        make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
     launch_fe(h, h->Xin, h->Xin_ld, B, true);
+    if (!out4) return 0;                                    // asynchronous caller: the sums stay in h->scal
     double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
     BM_HIP(hipStreamSynchronize(h->stream));
+    metrics_to_out4(h, host, B, out4);
+    return 0;
+}
+static void metrics_to_out4(const bm_rbm *h, const double *host, int B, float *out4) {
     // MultinomialRBM: every _free_energy() call draws its own h_hat (host[4] = F(x) of the PLL pair)
     // and carries the constant of rbm.py:61 (it cancels in the PLL difference)
     const double fe = host[2] / B + mn_fe_const(h), fe1 = h->multinomial() ? host[4] / B + mn_fe_const(h) : fe;
@@ -346,7 +359,6 @@ static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
     out4[1] = (float)h->V * ls;
     out4[2] = h->cfg.l2 * (float)(0.5 * host[1]);               // l2_loss       :483
     out4[3] = (float)fe;                                        // free energy   :516
-    return 0;
 }
 
 extern "C" {
@@ -446,6 +458,7 @@ int bm_rbm_destroy(bm_rbm *h) {
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->stage_stream) { (void)hipStreamSynchronize(h->stage_stream); (void)hipStreamDestroy(h->stage_stream); }
     if (h->stage_host) (void)hipHostFree(h->stage_host);
+    if (h->mring) (void)hipHostFree(h->mring);
     for (auto &sg : h->stage) {
         sg.W.release(); sg.dW.release();
         DevBuf *sv[] = {&sg.vb, &sg.hb, &sg.dvb, &sg.dhb, &sg.q, &sg.sigma};
@@ -555,6 +568,9 @@ int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n) {
 int bm_rbm_stage(bm_rbm *h, int32_t slot) {
     BM_CHECK(h && (slot == 0 || slot == 1), "bad stage slot %d", (int)slot);
     bm_rbm::Stage &sg = h->stage[slot];
+    // a slot that another thread is reading back must not be overwritten under it (any caller of the C API, not
+    // only the Python bookkeeping of base.py: round-3 advisor)
+    BM_CHECK(sg.readers.load() == 0, "stage slot %d is being read by bm_rbm_get_staged: use the other slot", (int)slot);
     if (!sg.ev) {
         BM_TRY(sg.W.alloc(h->V, h->H)); BM_TRY(sg.dW.alloc(h->V, h->H));
         BM_TRY(sg.vb.alloc(h->V)); BM_TRY(sg.dvb.alloc(h->V)); BM_TRY(sg.sigma.alloc(h->V));
@@ -582,6 +598,7 @@ int bm_rbm_get_staged(bm_rbm *h, int32_t slot, const char *name, float *host, si
     BM_CHECK(h && (slot == 0 || slot == 1) && h->stage[slot].ready, "stage slot %d holds no snapshot", (int)slot);
     BM_HIP(hipSetDevice(h->device));                 // (the calling thread may be a fresh one)
     bm_rbm::Stage &sg = h->stage[slot];
+    struct Reading { std::atomic<int> &n; Reading(std::atomic<int> &r) : n(r) { ++n; } ~Reading() { --n; } } reading(sg.readers);
     const std::string nm(name ? name : "");
     // Wait for the staged copies on the HOST first, then copy through a pinned bounce buffer: a pageable
     // device-to-host copy that has to wait for an event parks inside the runtime (measured: the training thread's
@@ -636,6 +653,37 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr
     launch_update_fused(h, B, lr, mom);
     h->call++;
     BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// The same fetch WITHOUT the host wait: the reference reads the train metrics every `train_metrics_every_iter`-th
+// iteration but only uses their mean at the end of the epoch (base_rbm.py:549-571), so the six device sums of a metrics
+// iteration are copied into a pinned ring in stream order and converted when bm_rbm_collect_metrics is called (one
+// synchronisation per epoch instead of one per fetch: fit() with the reference's default cadence ran 81 - 98 us per
+// update against 68 without metrics, almost all of it the GPU idling behind the host round trips).
+int bm_rbm_train_step_metrics_async(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
+    if (!h->mring) {
+        BM_HIP(hipHostMalloc((void **)&h->mring, (size_t)bm_rbm::MRING * 6 * sizeof(double), hipHostMallocDefault));
+        h->mring_B.resize(bm_rbm::MRING);
+    }
+    BM_CHECK(h->mring_n < bm_rbm::MRING, "%d metric fetches are pending: call bm_rbm_collect_metrics", h->mring_n);
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(metrics_from_chain(h, B, nullptr));
+    BM_HIP(hipMemcpyAsync(h->mring + (size_t)h->mring_n * 6, h->scal, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    h->mring_B[h->mring_n++] = B;
+    launch_update_fused(h, B, lr, mom);
+    h->call++;
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+// out4n [max_n][4] <- the pending fetches in order (msre, pll, l2_loss, free energy each); *out_n their number
+int bm_rbm_collect_metrics(bm_rbm *h, float *out4n, int32_t max_n, int32_t *out_n) {
+    BM_CHECK(h && out_n && (out4n || max_n == 0), "null argument");
+    BM_CHECK(h->mring_n <= max_n, "%d fetches pending, room for %d", h->mring_n, (int)max_n);
+    BM_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < h->mring_n; ++i) metrics_to_out4(h, h->mring + (size_t)i * 6, h->mring_B[i], out4n + 4 * (size_t)i);
+    *out_n = h->mring_n;
+    h->mring_n = 0;
     return 0;
 }
 
@@ -768,11 +816,27 @@ int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_ste
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(H_dev && V_dev, "null state pointer");
     BM_CHECK(n_steps >= 1, "n_steps must be >= 1");
-    // dense user buffers <-> pitched workspaces (hs / vs)
-    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)H_dev, h->H, h->hs.p, h->hs.ld, B, h->H);
     struct FastScope { bm_rbm *h; ~FastScope() { h->fast_now = false; } } fast_scope{h};
-    if (h->fast && h->cfg.v_unit == BM_UNIT_BERNOULLI && !h->multinomial() && h->cfg.sample_v_states && h->cfg.sample_h_states &&
-        h->cfg.dropout < 0.f) {
+    const bool fast = h->fast && h->cfg.v_unit == BM_UNIT_BERNOULLI && !h->multinomial() && h->cfg.sample_v_states &&
+                      h->cfg.sample_h_states && h->cfg.dropout < 0.f;
+    if (!fast && !h->multinomial()) {
+        // The sweeps read and write the caller's dense buffers IN PLACE: the first prop-down takes H_dev (pitch H) as its
+        // operand, the last sweep's launches store straight into V_dev / H_dev - no copy kernels (round 3 moved the
+        // states through the pitched workspaces with three copy2d launches per call: 5 % of the sweep benchmark).
+        for (int t = 0; t < n_steps; ++t) {
+            const bool first = t == 0, last = t == n_steps - 1;
+            launch_down(h, first ? H_dev : h->hs.p, first ? h->H : h->hs.ld, B, nullptr, last ? V_dev : h->vs.p,
+                        last ? h->V : h->vs.ld, h->cfg.sample_v_states, SITE_V, t);
+            launch_up(h, last ? V_dev : h->vs.p, last ? h->V : h->vs.ld, B, nullptr, last ? H_dev : h->hs.p,
+                      last ? h->H : h->hs.ld, h->cfg.sample_h_states, SITE_H, t);
+        }
+        h->call++;
+        BM_HIP(hipGetLastError());
+        return 0;
+    }
+    // fast-binary / Multinomial sweeps: dense user buffers <-> pitched workspaces (hs / vs, which carry the bf16 shadows)
+    hipLaunchKernelGGL(copy2d_kernel, dim3(256), dim3(256), 0, h->stream, (const float *)H_dev, h->H, h->hs.p, h->hs.ld, B, h->H);
+    if (fast) {
         // fast-binary sweep: both layers are sampled, so every contraction has a {0,1} operand (the caller's hidden
         // states must be a bitmap as well: checked on the device, reported by bm_rbm_sync)
         if (h->W3.rows != h->V) {

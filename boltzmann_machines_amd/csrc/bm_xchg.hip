@@ -415,12 +415,16 @@ int bm_xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t count, b
     BM_CHECK(((uintptr_t)buf_dev & 15u) == 0, "the exchanged buffer must be 16-byte aligned");
     bm_xchg *x = new bm_xchg();
     x->rank = rank; x->nranks = nranks; x->buf = buf_dev; x->count = count;
-    BM_HIP(hipGetDevice(&x->device));
     x->chunk = (((count + nranks - 1) / nranks) + 3) & ~(size_t)3;
-    BM_HIP(hipMalloc((void **)&x->red, (x->chunk ? x->chunk : 4) * sizeof(float)));
-    BM_HIP(hipMalloc((void **)&x->ctr, 64));
-    BM_HIP(hipMemset(x->ctr, 0, 64));
-    BM_TRY(xchg_alloc_flags(x));
+    // (an early return below must not leak what was allocated so far: round-3 advisor)
+    auto fail = [&]() { if (x->red) (void)hipFree(x->red); if (x->ctr) (void)hipFree(x->ctr); if (x->flags) (void)hipFree(x->flags); delete x; return 1; };
+    if (hipGetDevice(&x->device) != hipSuccess ||
+        hipMalloc((void **)&x->red, (x->chunk ? x->chunk : 4) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&x->ctr, 64) != hipSuccess || hipMemset(x->ctr, 0, 64) != hipSuccess) {
+        bm::set_error("bm_xchg_create: device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail();
+    }
+    if (xchg_alloc_flags(x)) return fail();
     const size_t f4 = (x->chunk / 4 + bmx::NTX - 1) / bmx::NTX;
     x->grid = (int)(f4 < 1 ? 1 : (f4 > 256 ? 256 : f4));
     const char *t = getenv("BM_XCHG_TIMEOUT_S");
@@ -475,6 +479,11 @@ int bm_xchg_attach(bm_xchg *x, const void *all_blobs) {
     return 0;
 }
 
+// Teardown is COLLECTIVE in one respect: a rank's kernel ends when every peer has published DONE, not when every peer
+// has finished pulling this rank's staging slice - so a rank must not free `red` / `flags` while a slower peer may still
+// be reading them.  The caller therefore places a host barrier over all ranks between the last exchange and
+// bm_xchg_destroy (parallel.DirectExchange.close() does: one more gather of the rendezvous channel); the library
+// cannot do it itself without a host channel.
 int bm_xchg_destroy(bm_xchg *x) {
     if (!x) return 0;
     (void)hipDeviceSynchronize();

@@ -94,6 +94,8 @@ class DBM(EngineModel):
         self.epoch_ = 0
         self.iter_ = 0
         self.n_samples_generated_ = 0
+        # log_Z accumulation (not a constructor keyword of the reference: set_ais_accumulation / BM355_AIS_LITERAL=1)
+        self._ais_literal = os.environ.get('BM355_AIS_LITERAL', '0') == '1'
 
     # ---- composition from pre-trained RBMs (reference dbm.py:207-231) ------------------
     def load_rbms(self, rbms):
@@ -420,12 +422,24 @@ class DBM(EngineModel):
             self._restore(snap)
         return v
 
+    def set_ais_accumulation(self, dtype='float64'):
+        """How `log_Z` accumulates the AIS log-weights.  'float64' (default): per chain the difference of consecutive
+        log p*, row sums and running sum in double, fixed order - deterministic and closer to the exactly enumerable
+        log Z.  'float32': LITERALLY the reference graph (dbm.py:650-660, :708-728) - every log p*_beta(x) formed and
+        added / subtracted in float32 in the graph's order (the reference's README notes the nats this loses at many
+        betas).  Both agree with the reference to the 1e-5 the parity bar asks for at the beta counts tested."""
+        if dtype not in ('float32', 'float64'):
+            raise ValueError("dtype must be 'float32' or 'float64'")
+        self._ais_literal = dtype == 'float32'
+        return self
+
     @run_on_engine(update_seed=True)
     def log_Z(self, n_betas=100, n_runs=100, n_gibbs_steps=5):
         """AIS estimate of the log partition function of the 2-layer binary DBM
         (reference dbm.py:899-939).  Returns log_mean, (log_low, log_high), values."""
         assert self.n_layers_ == 2
         assert self._all_bernoulli()           # reference dbm.py:926-927: every layer is a BernoulliLayer
+        self._engine.set_ais_literal(self._ais_literal)
         if getattr(self, '_comm', None) is not None:
             # multi-GPU job: the independent chains are sharded over the ranks (their index in the RNG stream is
             # global), ONE all-gather of the per-chain values at the end; every rank returns all of them

@@ -111,6 +111,20 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_train_step_metrics(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k, out))
         return np.array(out[:], dtype=np.float32)
 
+    MAX_PENDING_METRICS = 4096
+
+    def train_step_metrics_async(self, Xd, B, lr, momentum, k, row=0):
+        """train_step_metrics without the host wait: the values arrive with the next collect_metrics()"""
+        check(self.lib.bm_rbm_train_step_metrics_async(self._h, Xd.offset_ptr(row * self.V), B, lr, momentum, k))
+
+    def collect_metrics(self):
+        """[n, 4] float32: the pending asynchronous fetches, oldest first (ONE stream synchronisation)"""
+        out = np.empty((self.MAX_PENDING_METRICS, 4), dtype=np.float32)
+        n = C.c_int32(0)
+        check(self.lib.bm_rbm_collect_metrics(self._h, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                              self.MAX_PENDING_METRICS, C.byref(n)))
+        return out[:n.value].copy()
+
     def train_epoch(self, Xd, N, batch, lr, momentum, k, row=0):
         """N rows starting at `row`, consecutive batches of `batch` rows, driven from C (no Python per batch)"""
         check(self.lib.bm_rbm_train_epoch(self._h, Xd.offset_ptr(row * self.V), N, batch, lr, momentum, k))

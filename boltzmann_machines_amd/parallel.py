@@ -285,8 +285,10 @@ class DirectExchange(object):
                 blob = bytes(buf)
         except Exception as e:      # noqa: BLE001
             err = '%s: %s' % (type(e).__name__, e)
+        self._gather = None
         if world > 1:
             gather = gather or default_gather(rank, world)
+            self._gather = gather
             got = gather((err, blob))
             if err is None and not any(g[0] for g in got):
                 try:
@@ -332,14 +334,23 @@ class DirectExchange(object):
         self._ffi.check(self._ffi.load().bm_xchg_status(self._c, C.byref(st)))
         return int(st.value)
 
-    def close(self):
+    def close(self, barrier=True):
+        """Frees the exchange.  COLLECTIVE when world > 1 and a gather channel is known: every rank synchronises its
+        device and meets the others once more before anything is unmapped - a rank's last kernel ends when its peers have
+        published DONE, not when they have finished pulling its staging slice (round-3 advisor)."""
         if getattr(self, '_c', None) is not None and self._c:
+            if barrier and self.world > 1 and getattr(self, '_gather', None) is not None:
+                try:
+                    self.engine.sync()
+                    self._gather((None, None))
+                except Exception:       # noqa: BLE001 - a lost peer must not keep this rank from freeing its side
+                    pass
             self._ffi.load().bm_xchg_destroy(self._c)
             self._c = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(barrier=False)       # garbage collection is not a collective moment
         except Exception:
             pass
 

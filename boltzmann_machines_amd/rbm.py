@@ -8,7 +8,7 @@ base_rbm.py:535-541), metric cadence (:549-571), validation metrics (:573-590),
 free-energy gap (:592-621) and per-epoch checkpoint (:665-666).  The TF graph
 of `_make_train_op` (:415-525) is executed by libbm355 (csrc/bm_rbm.hip).
 
-MultinomialRBM is out of scope of the hot path.
+BernoulliRBM, MultinomialRBM (rbm.py:25-65) and GaussianRBM (rbm.py:68-116) in float32 and float64.
 """
 import os
 
@@ -31,23 +31,6 @@ def assert_len(obj, name, desired_len):
     actual_len = len(getattr(obj, name))
     if actual_len != desired_len:
         raise ValueError('`{0}` has invalid len {1} != {2}'.format(name, actual_len, desired_len))
-
-
-class _HostVars(object):
-    """models without a device path for their dtype (none of the RBMs any more; kept for dtypes other than
-    float32 / float64): variables on the host only."""
-
-    def __init__(self, variables):
-        self.vars = variables
-
-    def get(self, name):
-        return self.vars[name]
-
-    def set(self, name, value):
-        self.vars[name] = np.asarray(value, dtype=self.vars[name].dtype).reshape(self.vars[name].shape)
-
-    def close(self):
-        pass
 
 
 class BaseRBM(EngineModel):
@@ -193,7 +176,7 @@ class BaseRBM(EngineModel):
                 self._dp = parallel.DataParallelRBM(self._engine, self._rank, self._world, self.batch_size,
                                                     parallel.native_allreduce_on_engine_stream(self._engine, self._comm))
         else:
-            self._engine = _HostVars(variables)
+            raise NotImplementedError("%s: dtype must be 'float32' or 'float64' (got %r)" % (self.__class__.__name__, self.dtype))
 
     def _needs_device(self):
         return False
@@ -281,7 +264,17 @@ class BaseRBM(EngineModel):
             return {m: None for m in names}
         # runs of batches without a metrics fetch go to the engine as ONE call (bm_rbm_train_epoch loops in
         # C: same launches, same RNG call counters, no Python per batch)
+        # ... and the metrics iterations leave their sums in a pinned ring (train_step_metrics_async): the reference
+        # only uses the epoch mean (base_rbm.py:571), so the host waits for the stream once per epoch
         run_start, fused = None, hasattr(eng, 'train_epoch')
+        deferred, pending = hasattr(eng, 'train_step_metrics_async'), 0
+
+        def collect():
+            for out in eng.collect_metrics():
+                vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
+                for m in names:
+                    results[m].append(vals[m])
+            return 0
         for start in range(0, N, self.batch_size):
             B = min(self.batch_size, N - start)
             self.iter_ += 1
@@ -289,10 +282,16 @@ class BaseRBM(EngineModel):
                 if run_start is not None:
                     eng.train_epoch(Xd, start - run_start, self.batch_size, lr, mom, k, row=run_start)
                     run_start = None
-                out = eng.train_step_metrics(Xd, B, lr, mom, k, row=start)
-                vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
-                for m in names:
-                    results[m].append(vals[m])
+                if deferred:
+                    if pending >= eng.MAX_PENDING_METRICS:
+                        pending = collect()
+                    eng.train_step_metrics_async(Xd, B, lr, mom, k, row=start)
+                    pending += 1
+                else:
+                    out = eng.train_step_metrics(Xd, B, lr, mom, k, row=start)
+                    vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
+                    for m in names:
+                        results[m].append(vals[m])
             elif fused:
                 if run_start is None:
                     run_start = start
@@ -300,6 +299,8 @@ class BaseRBM(EngineModel):
                 eng.train_step(Xd, B, lr, mom, k, row=start)
         if run_start is not None:
             eng.train_epoch(Xd, N - run_start, self.batch_size, lr, mom, k, row=run_start)
+        if pending:
+            collect()
         return {m: (np.mean(r) if r else None) for m, r in results.items()}
 
     def _run_val_metrics(self, Xvd, N):

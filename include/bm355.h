@@ -109,6 +109,13 @@ int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B,
 int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B,
                               float learning_rate, float momentum, int32_t n_gibbs_steps,
                               float *out4);
+/* The same fetch without the host wait.  The reference only uses the MEAN of the train metrics at the end
+ * of the epoch (base_rbm.py:571), so the sums of a metrics iteration are copied to a pinned ring in stream
+ * order; bm_rbm_collect_metrics synchronises once and returns the pending fetches in order
+ * (out4n [max_n][4], *out_n their number; at most 4096 may be pending). */
+int bm_rbm_train_step_metrics_async(bm_rbm *h, const float *X_dev, int32_t B,
+                                    float learning_rate, float momentum, int32_t n_gibbs_steps);
+int bm_rbm_collect_metrics(bm_rbm *h, float *out4n, int32_t max_n, int32_t *out_n);
 /* The `for X_batch in batch_iter(X, batch_size)` loop of _train_epoch
  * (base_rbm.py:549-571) behind ONE call: N rows, consecutive batches of `batch` rows (last one may be
  * short).  The library enqueues every update's four launches from a native loop, asynchronously on the

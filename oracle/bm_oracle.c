@@ -845,6 +845,79 @@ void orc_dbm_ais(const orc_dbm_cfg *c, const orc_dbm_state *s, int n_betas, int 
 #undef AIS_TRANSIT
 }
 
+/* log p*_beta(x) with the reference graph's float32 STRUCTURE (dbm.py:650-660): T1 = x.hb0; T1 *= beta; log_p = T1;
+ * log_p += reduce_sum(softplus(beta (x W0^T + vb))); log_p += reduce_sum(softplus(beta (x W1 + hb1))) - three float32
+ * values combined in float32 (each row sum itself is taken in double and rounded once: the order inside tf.reduce_sum
+ * is the backend's). */
+static void ais_log_p_f32(const orc_dbm_cfg *c, const orc_dbm_state *s, const float *x, int R, float beta, float *out) {
+    const int V = c->V, H1 = c->n[0], H2 = c->n[1];
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < R; ++r) {
+        const float *xr = x + (size_t)r * H1;
+        double t1 = 0.0, sv = 0.0, sh = 0.0;
+        for (int h = 0; h < H1; ++h) t1 += (double)xr[h] * (double)s->hb[0][h];
+        for (int v = 0; v < V; ++v) {
+            double z = s->vb[v];
+            for (int h = 0; h < H1; ++h) z += (double)xr[h] * (double)s->W[0][(size_t)v * H1 + h];
+            sv += softplus_d(z * (double)beta);
+        }
+        for (int k2 = 0; k2 < H2; ++k2) {
+            double z = s->hb[1][k2];
+            for (int h = 0; h < H1; ++h) z += (double)xr[h] * (double)s->W[1][(size_t)h * H2 + k2];
+            sh += softplus_d(z * (double)beta);
+        }
+        float lp = (float)t1 * beta;
+        lp = lp + (float)sv;
+        lp = lp + (float)sh;
+        out[r] = lp;
+    }
+}
+
+/* AIS with the reference's LITERAL float32 accumulation (dbm.py:708-728): log_Z = -log p_0(x_1); per beta:
+ * log_Z += log p_beta(x); x' ~ T(x); log_Z -= log p_beta(x'); finally += log p_1(x_M), += log Z_0 - every operation
+ * in float32, in that order.  Same chains (same RNG addressing) as orc_dbm_ais. */
+void orc_dbm_ais_literal(const orc_dbm_cfg *c, const orc_dbm_state *s, int n_betas, int R, int k,
+                         uint64_t seed, int64_t chain0, float *values) {
+    const int V = c->V, H1 = c->n[0], H2 = c->n[1];
+    float *x = (float *)malloc((size_t)R * H1 * sizeof(float)), *xn = (float *)malloc((size_t)R * H1 * sizeof(float));
+    float *v = (float *)malloc((size_t)R * V * sizeof(float)), *h2 = (float *)malloc((size_t)R * H2 * sizeof(float));
+    float *lz = (float *)calloc(R, sizeof(float)), *lp = (float *)malloc(R * sizeof(float));
+    float *Wt0 = transpose(s->W[0], V, H1), *Wt1 = transpose(s->W[1], H1, H2);
+    const orc_key k0 = make_key(seed, SITE_AIS_X0, 0);
+    for (int r = 0; r < R; ++r)
+        for (int h = 0; h < H1; ++h)
+            x[(size_t)r * H1 + h] = (uniform_at(k0, (uint64_t)(chain0 + r) * (uint64_t)H1 + h) < 0.5f) ? 1.0f : 0.0f;
+    const float db = 1.0f / (float)n_betas;
+#define AIS_TRANSIT_L(BETA, STEP)                                                                           \
+    for (int t = 0; t < k; ++t) {                                                                           \
+        orc_act2(x, H1, Wt0, NULL, 0, NULL, V, R, s->vb, s->sigma, (BETA), (BETA), UNIT_BERNOULLI,         \
+                 c->sample_v, NULL, v, seed, SITE_DBM_V + 16u * (uint32_t)t, (STEP), chain0);               \
+        orc_act2(x, H1, s->W[1], NULL, 0, NULL, H2, R, s->hb[1], NULL, (BETA), (BETA), UNIT_BERNOULLI,     \
+                 c->sample_h[1], NULL, h2, seed, SITE_DBM_H + 1 + 16u * (uint32_t)t, (STEP), chain0);       \
+        orc_act2(v, V, s->W[0], h2, H2, Wt1, H1, R, s->hb[0], NULL, (BETA), (BETA), UNIT_BERNOULLI,        \
+                 c->sample_h[0], NULL, xn, seed, SITE_DBM_H + 0 + 16u * (uint32_t)t, (STEP), chain0);       \
+        float *tx = x; x = xn; xn = tx;                                                                     \
+    }
+    AIS_TRANSIT_L(db, 0u)
+    ais_log_p_f32(c, s, x, R, 0.0f, lp);
+    for (int r = 0; r < R; ++r) lz[r] = lz[r] - lp[r];
+    float beta = db; uint32_t step = 1;
+    while (beta < 1.0f - db + 1e-5f) {
+        ais_log_p_f32(c, s, x, R, beta, lp);
+        for (int r = 0; r < R; ++r) lz[r] = lz[r] + lp[r];
+        AIS_TRANSIT_L(beta + db, step)
+        ++step;
+        ais_log_p_f32(c, s, x, R, beta, lp);
+        for (int r = 0; r < R; ++r) lz[r] = lz[r] - lp[r];
+        beta = beta + db;
+    }
+    ais_log_p_f32(c, s, x, R, 1.0f, lp);
+    const float logZ0 = (float)(V + H1 + H2) * logf(2.0f);
+    for (int r = 0; r < R; ++r) values[r] = (lz[r] + lp[r]) + logZ0;
+    free(x); free(xn); free(v); free(h2); free(lz); free(lp); free(Wt0); free(Wt1);
+#undef AIS_TRANSIT_L
+}
+
 /* variational lower bound terms per row (dbm.py:738-759) given mu from mean-field, double accumulation */
 void orc_dbm_log_proba(const orc_dbm_cfg *c, orc_dbm_state *s, const float *X, float *out) {
     orc_dbm_mean_field(c, s, X);

@@ -346,6 +346,7 @@ def _dbm_lib():
                                          C.c_int64, C.POINTER(C.c_float)]
         L.orc_dbm_sample_v.argtypes = [cp, sp, C.c_int, C.c_uint64, C.c_uint32, C.c_int64]
         L.orc_dbm_ais.argtypes = [cp, sp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, f32p]
+        L.orc_dbm_ais_literal.argtypes = [cp, sp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, f32p]
         L.orc_dbm_log_proba.argtypes = [cp, sp, f32p, f32p]
         L._dbm_ready = True
     return L
@@ -457,10 +458,12 @@ class OracleDBM(object):
         self.call += 1
         return self.p['v'].copy()
 
-    def ais(self, n_betas, n_runs, k, seed, chain0=0):
+    def ais(self, n_betas, n_runs, k, seed, chain0=0, literal=False):
+        """literal: the reference's float32 accumulation order (dbm.py:708-728); default: double, difference form"""
         s = self._state()
         out = np.zeros(n_runs, dtype=np.float32)
-        _dbm_lib().orc_dbm_ais(C.byref(self.cfg), C.byref(s), n_betas, n_runs, k, int(seed), int(chain0), out)
+        f = _dbm_lib().orc_dbm_ais_literal if literal else _dbm_lib().orc_dbm_ais
+        f(C.byref(self.cfg), C.byref(s), n_betas, n_runs, k, int(seed), int(chain0), out)
         return out
 
     def log_proba(self, X):

@@ -104,6 +104,15 @@ class OracleRbmEngine(_OracleRbmBase):
         self.twin.train_step(X, lr, momentum, k)
         return out
 
+    MAX_PENDING_METRICS = 4096
+
+    def train_step_metrics_async(self, Xd, B, lr, momentum, k, row=0):
+        self.__dict__.setdefault('_pending', []).append(self.train_step_metrics(Xd, B, lr, momentum, k, row=row))
+
+    def collect_metrics(self):
+        out, self._pending = np.array(self.__dict__.get('_pending', []), dtype=np.float32).reshape(-1, 4), []
+        return out
+
 
 class OracleRbmEngine64(_OracleRbmBase):
     dtype = np.float64
@@ -160,6 +169,9 @@ class OracleDbmEngine(object):
     def set_fast_binary(self, on):
         raise RuntimeError('the oracle has no fast-binary mode')
 
+    def set_ais_literal(self, on):
+        self._ais_literal = bool(on)
+
     def _rows(self, Xd, row):
         return Xd.a[row:row + self.N]
 
@@ -185,7 +197,7 @@ class OracleDbmEngine(object):
             Vd.a[...] = v
 
     def ais(self, n_betas, n_runs, k, seed, chain0=0):
-        return self.twin.ais(n_betas, n_runs, k, seed, chain0)
+        return self.twin.ais(n_betas, n_runs, k, seed, chain0, literal=getattr(self, '_ais_literal', False))
 
     def log_proba(self, Xd, row=0):
         return self.twin.log_proba(self._rows(Xd, row))

@@ -107,6 +107,26 @@ def test_config4_ais_1000_betas_vs_oracle(gpu_lib):
     eng.close()
 
 
+def test_config4_ais_literal_float32_accumulation(gpu_lib):
+    """bm_dbm_set_ais_literal: the reference's own arithmetic (dbm.py:650-660, :708-728) - every log p*_beta(x) formed
+    and added / subtracted in float32, in the graph's order - at the full 1000 betas against the oracle's literal
+    twin (rtol 1e-5), deterministic, and within float32 accumulation noise of the default (double) mode."""
+    V, nh, N = 784, [512, 1024], 64
+    eng, twin = D.make_pair(V, nh, N, N)
+    d64 = eng.ais(n_betas=1000, n_runs=64, k=1, seed=2222, chain0=12345)
+    eng.set_ais_literal(True)
+    g = eng.ais(n_betas=1000, n_runs=64, k=1, seed=2222, chain0=12345)
+    c = twin.ais(n_betas=1000, n_runs=64, k=1, seed=2222, chain0=12345, literal=True)
+    np.testing.assert_allclose(g, c, rtol=1e-5)
+    g2 = eng.ais(n_betas=1000, n_runs=64, k=1, seed=2222, chain0=12345)
+    assert np.array_equal(g.view(np.uint32), g2.view(np.uint32))
+    assert not np.array_equal(g, d64)                      # a different accumulation ...
+    np.testing.assert_allclose(g, d64, rtol=2e-5)          # ... of the same chains
+    eng.set_ais_literal(False)
+    assert np.array_equal(eng.ais(n_betas=1000, n_runs=64, k=1, seed=2222, chain0=12345).view(np.uint32), d64.view(np.uint32))
+    eng.close()
+
+
 def test_ais_on_gpu_brackets_exact_log_Z(gpu_lib):
     """Ground truth: 6-4-3 DBM, partition function summed exactly over all 2^13 states (tests/np_reference.py);
     the GPU's AIS (10 000 betas, 512 runs) estimates it within 0.02 nats / 4 standard errors."""

@@ -96,7 +96,9 @@ def test_host_philox_matches_oracle():
     from oracle import oracle as orc
     assert np.array_equal(philox.philox_blocks(123456789012, 7, 9, 5, 33), orc.philox_words(123456789012, 7, 9, 5, 33))
     assert np.array_equal(philox.uniform(5, 3, 7, 1001, idx0=3), orc.uniform(5, 3, 7, 1001, idx0=3))
-    np.testing.assert_allclose(philox.normal(5, 3, 7, 1001), orc.normal(5, 3, 7, 1001), atol=5e-7)
+    # the host initialiser calls numpy's log / sin / cos, the engine and the oracle the bit-pinned Box-Muller
+    # (csrc/bm_rng.h pin_log_unit / pin_sincos_2pi): a few ulp apart, as TF's own libm calls are
+    np.testing.assert_allclose(philox.normal(5, 3, 7, 1001), orc.normal(5, 3, 7, 1001), rtol=1e-6, atol=5e-7)
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -359,3 +359,33 @@ def test_train_epoch_equals_the_loop_over_train_step(gpu_lib):
         twin.train_step(X[B:2 * B], 0.02, 0.9, 2)
     assert_state_equal(eng, twin)
     eng.close()
+
+
+def test_deferred_metrics_equal_the_synchronous_fetch(gpu_lib):
+    """bm_rbm_train_step_metrics_async + bm_rbm_collect_metrics: the same values, in order, as the synchronous fetch
+    (base_rbm.py:554-571), the same parameters afterwards; updates in between do not disturb pending fetches"""
+    from boltzmann_machines_amd.engine import as_device
+    V, H, B = 96, 64, 16
+    kw = dict(max_batch=B, sample_v_states=True, l2=1e-4)
+    a, twin = make_pair(V, H, **kw)
+    b, _ = make_pair(V, H, **kw)
+    X = synth_data(6 * B, V, 9)
+    Xd = as_device(X)
+    for e in (a, b):
+        e.seed(33)
+    want = []
+    for i in range(6):
+        row = i * B
+        if i % 2:
+            want.append(a.train_step_metrics(Xd, B if i != 5 else B - 3, 0.05, 0.5, 1, row=row))
+            b.train_step_metrics_async(Xd, B if i != 5 else B - 3, 0.05, 0.5, 1, row=row)
+        else:
+            a.train_step(Xd, B, 0.05, 0.5, 1, row=row)
+            b.train_step(Xd, B, 0.05, 0.5, 1, row=row)
+    got = b.collect_metrics()
+    assert got.shape == (3, 4)
+    assert np.array_equal(got, np.array(want, dtype=np.float32))
+    assert b.collect_metrics().shape == (0, 4)
+    for name in ('W', 'vb', 'hb', 'dW', 'dvb', 'dhb'):
+        assert np.array_equal(a.get(name), b.get(name)), name
+    a.close(); b.close()

@@ -52,3 +52,32 @@ def test_reference_path_table(monkeypatch):
             getattr(t, name)()
             ran += 1
     assert ran >= 3
+
+
+def test_reference_ais_is_the_literal_float32_accumulation(tmp_path, monkeypatch):
+    """The reference's AIS graph (dbm.py:696-736) run on the stand-in - float32 `log_Z +=` / `-=` by construction -
+    against the oracle on the same parameters and chains: the oracle's LITERAL mode follows it to float32 round-off;
+    the default double accumulation stays within the 1e-5 parity bar at this length."""
+    import numpy as np
+    from tests.golden import make_golden_from_reference as gen, scenarios
+    from oracle import oracle as orc
+    monkeypatch.chdir(tmp_path)
+    pkg = gen.ReferencePackage()
+    V = 20
+    X = (pkg.RNG(seed=5).rand(40, V) < 0.3).astype(np.float32)
+    rbms, _ = scenarios._pretrain(pkg, str(tmp_path), X, (V, 12, 16))
+    dbm = pkg.DBM(rbms=rbms, n_particles=10, batch_size=10, max_epoch=1, random_seed=13, verbose=False,
+                  model_path=str(tmp_path / 'dbm') + '/')
+    dbm.init()
+    seeds = []
+    orig = pkg.tf.set_random_seed
+    monkeypatch.setattr(pkg.tf, 'set_random_seed', lambda s: (seeds.append(s), orig(s))[1])
+    _, _, values = dbm.log_Z(n_betas=600, n_runs=12, n_gibbs_steps=1)
+    p = dbm.get_tf_params(scope='weights')
+    twin = orc.OracleDBM(V, [12, 16], n_particles=10, batch_size=10)
+    for k in ('W', 'W_1', 'vb', 'hb', 'hb_1'):
+        twin.p[k][...] = p[k]
+    lit = twin.ais(600, 12, 1, seeds[-1], literal=True)
+    dbl = twin.ais(600, 12, 1, seeds[-1])
+    np.testing.assert_allclose(lit, values, rtol=2e-6)
+    np.testing.assert_allclose(dbl, values, rtol=1e-5)

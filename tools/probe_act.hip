@@ -36,6 +36,7 @@ int main(int argc, char **argv) {
     float *hb; CK(hipMalloc((void **)&hb, H * 4)); CK(hipMemset(hb, 0, H * 4));
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    TileMap tm_slab = make_tile_map(1, 1, 1.0, 1.0, -1);      // the slab order (block_to_tile): no table
     ActArgs a; memset(&a, 0, sizeof(a));
     a.P1 = make_operand(W.p, W.ld, H); a.Q1 = make_operand(X.p, X.ld, B); a.K1 = V;
     a.I = H; a.J = B; a.bias = hb; a.mult = 1.f; a.kind = 0; a.sample = 1;
@@ -61,16 +62,16 @@ int main(int argc, char **argv) {
             (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(gr);
         };
         graph_time([&] { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, Hs.p); }, "k_empty (graph)");
-        graph_time([&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a); }, "8w full (graph)");
+        graph_time([&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a, tm_slab); }, "8w full (graph)");
         printf("%-34s %6.2f us per kernel, stream launches\n", "8w full (stream)",
-               time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a); }));
+               time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a, tm_slab); }));
     }
     long long *dbg; CK(hipMalloc((void **)&dbg, 8192 * 8)); CK(hipMemset(dbg, 0, 8192 * 8));
     a.dbg = dbg;
 #define RUNG(GEO, MINB, MASK, NAME) { \
         const int nblk = tile_grid<GEO>(a.I, a.J); \
         const dim3 grid(nblk), blk(GEO::NT); \
-        float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, MASK>), grid, blk, 0, st, a); }); \
+        float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, MASK>), grid, blk, 0, st, a, tm_slab); }); \
         std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
         double d[4] = {0, 0, 0, 0}, s1 = 0, s2 = 0; \
         for (int b = 0; b < nblk; ++b) { for (int q = 0; q < 4; ++q) d[q] += hd[2048 + b * 8 + q + 1] - hd[2048 + b * 8 + q]; s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
@@ -141,8 +142,8 @@ int main(int argc, char **argv) {
             auto once = [&] { \
                 (void)hipEventRecord(f0, st); (void)hipStreamWaitEvent(st2, f0, 0); \
                 for (int c = 0; c < CHAIN; ++c) { \
-                    hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, 0>), grid, blk, 0, st, h1); \
-                    hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, 0>), grid, blk, 0, st2, h2); } \
+                    hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, 0>), grid, blk, 0, st, h1, tm_slab); \
+                    hipLaunchKernelGGL((act_kernel<GEO, MINB, false, true, 0>), grid, blk, 0, st2, h2, tm_slab); } \
                 (void)hipEventRecord(f1, st2); (void)hipStreamWaitEvent(st, f1, 0); }; \
             float us = time_it(st, e0, e1, once); \
             printf("%-34s %6.2f us per fork-join of %d kernels per stream = %6.2f us per full-batch kernel\n", NAME, us, CHAIN, us / CHAIN); }
@@ -177,7 +178,7 @@ int main(int argc, char **argv) {
         }
 #define GRUN(MASK, NAME) { \
             const dim3 gg(tile_grid<GeoGrad>(g.I, g.J)); \
-            float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad, true, MASK>), gg, dim3(NT), 0, st, g); }); \
+            float us = time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad, true, MASK>), gg, dim3(NT), 0, st, g, tm_slab); }); \
             std::vector<long long> hd(8192); CK(hipMemcpy(hd.data(), dbg, 8192 * 8, hipMemcpyDeviceToHost)); \
             double s1 = 0, s2 = 0; for (int b = 0; b < 208; ++b) { s1 += hd[b*4+1]-hd[b*4]; s2 += hd[b*4+2]-hd[b*4+1]; } \
             printf("grad %-26s %6.2f us | mainloop %6.0f epilogue %5.0f\n", NAME, us, s1/208, s2/208); }
@@ -190,15 +191,15 @@ int main(int argc, char **argv) {
         GRUN(32, "no-barrier")
         GRUN(45, "only mfma")
         {   const dim3 gg4(tile_grid<GeoGrad>(g.I, g.J));
-            printf("grad 4w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad, true, 0, STG_REG>), gg4, dim3(256), 0, st, g); }));
-            printf("grad 8w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 0, STG_REG>), gg4, dim3(512), 0, st, g); }));
-            printf("act  8w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0, KM, STG_REG>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a); }));
+            printf("grad 4w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad, true, 0, STG_REG>), gg4, dim3(256), 0, st, g, tm_slab); }));
+            printf("grad 8w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 0, STG_REG>), gg4, dim3(512), 0, st, g, tm_slab); }));
+            printf("act  8w REG staging              %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0, KM, STG_REG>), dim3(tile_grid<GeoAct8>(a.I, a.J)), dim3(512), 0, st, a, tm_slab); }));
         }
         {   const dim3 gg(tile_grid<GeoGrad8>(g.I, g.J));
-            printf("grad 8w ping-pong                %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 0>), gg, dim3(512), 0, st, g); }));
-            printf("grad 8w lock-step                %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 128>), gg, dim3(512), 0, st, g); }));
-            printf("grad 8w ping-pong no-gload       %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 1>), gg, dim3(512), 0, st, g); }));
-            printf("grad 8w ping-pong only-mfma      %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 45>), gg, dim3(512), 0, st, g); }));
+            printf("grad 8w ping-pong                %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 0>), gg, dim3(512), 0, st, g, tm_slab); }));
+            printf("grad 8w lock-step                %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 128>), gg, dim3(512), 0, st, g, tm_slab); }));
+            printf("grad 8w ping-pong no-gload       %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 1>), gg, dim3(512), 0, st, g, tm_slab); }));
+            printf("grad 8w ping-pong only-mfma      %6.2f us\n", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((grad_kernel<GeoGrad8, true, 45>), gg, dim3(512), 0, st, g, tm_slab); }));
         }
         for (int variant = 0; variant < 1; ++variant) {
             g.Wt = (variant == 2) ? nullptr : Wt.p;
