@@ -122,6 +122,7 @@ SIGNATURES = {
     'bm_rbm_stream': [_vp, C.POINTER(_vp)],
     'bm_rbm_profile': [_vp, _i32],
     'bm_rbm_kernel_times': [_vp, _fp, _ip],
+    'bm_rbm_chain_stats': [_vp, C.POINTER(C.c_int64)],
     'bm_rbm_timer_start': [_vp],
     'bm_rbm_timer_stop': [_vp, _fp],
     'bm_rbm_timer_mark': [_vp],

@@ -69,6 +69,11 @@ namespace bm {
 // epilogue needs).  Default: none.
 struct NoSide {
     static constexpr bool kFinalSync = true;     // a following pipeline may refill the LDS ring
+    // chained launches (bm_chain.h): the Q operand was written by OTHER workgroups of the same launch.  kSplitFill: the
+    // pipeline fill requests the P pieces first, calls wait_inputs() (spin on the producers' flags), then the Q pieces;
+    // kCohQ: every Q load bypasses the CU's vector L1 (sc1), which may hold the previous contents of those lines.
+    static constexpr bool kSplitFill = false, kCohQ = false;
+    __device__ __forceinline__ void wait_inputs() {}
     __device__ __forceinline__ void fill() {}
     __device__ __forceinline__ void drain() {}
 };
@@ -183,9 +188,19 @@ __device__ __forceinline__ float4 load4_guard(const float *p, bool row_ok, int c
 // f / (row float4s), chunk f % (row float4s).  FAST: every float4 is either fully inside or fully outside
 // the operand, so the load is unconditional with clamped indices; the K tail is zeroed at the LDS store,
 // x-tail garbage only reaches outputs i >= I / j >= J, which are never stored.
-template <int L, int TX, int BK, int NTH, bool FAST>
+// 16 bytes through the L2, past the CU's vector L1: two relaxed agent-scope loads (global_load_dwordx2 ... sc1)
+__device__ __forceinline__ float4 load4_coh(const float *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)),
+                       __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
+
+template <int L, int TX, int BK, int NTH, bool FAST, bool COH = false>
 __device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NTH)], const float *ptr, int ld, int nx, int vec,
                                     int x0, int k0, int K, int tid) {
+    static_assert(!COH || FAST, "coherent register path: 16-byte-legal operands only");
     constexpr int NV = TX * BK / (4 * NTH);
     constexpr int RC = (L == KM) ? TX / 4 : BK / 4;      // float4 per tile row
 #pragma unroll
@@ -198,7 +213,7 @@ __device__ __forceinline__ void g2r(float4 (&reg)[TX * BK / (4 * NTH)], const fl
             const int kc = (L == KM) ? min(k, K - 1) : min(k, K - 4);
             const int xc = (L == KM) ? min(x, nx - 4) : min(x, nx - 1);
             const float *pc = (L == KM) ? ptr + (size_t)kc * ld + xc : ptr + (size_t)xc * ld + kc;
-            reg[n] = *reinterpret_cast<const float4 *>(pc);
+            reg[n] = COH ? load4_coh(pc) : *reinterpret_cast<const float4 *>(pc);
         } else if (L == KM) {
             reg[n] = load4_guard(ptr + (size_t)k * ld + x, k < K, x, nx, vec);
         } else {
@@ -423,14 +438,23 @@ __device__ __forceinline__ void dma16s(const void *sbase, uint32_t voff, unsigne
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
                  :: "s"(sbase), "v"(voff), "s"(lds_byte) : "memory");
 }
+// the same with sc1: the load bypasses the CU's vector L1 and is served by the XCD's L2 (operands written by another
+// workgroup of the SAME launch on the same XCD, bm_chain.h)
+__device__ __forceinline__ void dma16s_coh(const void *sbase, uint32_t voff, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 sc1"
+                 :: "s"(sbase), "v"(voff), "s"(lds_byte) : "memory");
+}
 // chunk `kc` of ONE segment (full chunk): scalar chunk bases pb / qb, plan of that segment, LDS byte addresses of
 // this wave's first piece in the destination slot images
-template <class G, int DW>
+template <class G, int DW, bool QSC = false>
 __device__ __forceinline__ void dma_chunk_s(const DmaPlan<G, DW> &pl, const char *pb, const char *qb, unsigned ldsP, unsigned ldsQ) {
 #pragma unroll
     for (int n = 0; n < DmaPlan<G, DW>::NPP; ++n) dma16s(pb, pl.p[n], ldsP + (unsigned)(n * DW * 1024));
 #pragma unroll
-    for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) dma16s(qb, pl.q[n], ldsQ + (unsigned)(n * DW * 1024));
+    for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) {
+        if (QSC) dma16s_coh(qb, pl.q[n], ldsQ + (unsigned)(n * DW * 1024));
+        else     dma16s(qb, pl.q[n], ldsQ + (unsigned)(n * DW * 1024));
+    }
 }
 
 // chunk c (a FULL chunk of its segment) -> LDS slot images sP / sQ, all pieces of this wave
@@ -461,12 +485,13 @@ __device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G, DW>
 }
 
 // register path: load chunk c (any chunk) / store it into the slot images with the K-tail zero fill
-template <int QL, class G, bool FAST, bool SEG2, int PL = KM>
+template <int QL, class G, bool FAST, bool SEG2, int PL = KM, bool COHQ = false>
 __device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, int nch1, int i0, int j0, int c, int tid) {
     constexpr int BK = G::BK;
+    static_assert(!COHQ || !SEG2, "coherent Q loads: single segment");
     if (!SEG2) {
         g2r<PL, G::TI, BK, G::NT, FAST>(r.p, kr.P1.ptr, kr.P1.ld, kr.P1.nx, kr.P1.vec, i0, c * BK, kr.K1, tid);
-        g2r<QL, G::TJ, BK, G::NT, FAST>(r.q, kr.Q1.ptr, kr.Q1.ld, kr.Q1.nx, kr.Q1.vec, j0, c * BK, kr.K1, tid);
+        g2r<QL, G::TJ, BK, G::NT, FAST, COHQ>(r.q, kr.Q1.ptr, kr.Q1.ld, kr.Q1.nx, kr.Q1.vec, j0, c * BK, kr.K1, tid);
     } else {
         const int m = -(int)((c >= nch1) & (kr.K2 > 0));   // all-ones in segment 2 (wave-uniform)
         const int kc = c - (nch1 & m);
@@ -641,6 +666,32 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         __builtin_amdgcn_sched_barrier(0);
         store_chunk_slim<QL, G, PL>(ga, sP, sQ, tid);
         store_chunk_slim<QL, G, PL>(gb, sP + P_BUF, sQ + Q_BUF, tid);
+    } else if constexpr (Side::kSplitFill) {
+        // ---- pipeline fill of a chained launch (bm_chain.h; the host guarantees FAST, DMA staging, one segment and
+        // K1 >= PF * BK: chunks 0 .. PF-1 are full DMA chunks).  The P pieces (weights: constant during the launch) go
+        // out first, then the wave waits for the producers of its Q rows, then the Q pieces.  The vector-memory queue
+        // completes in order: with only the Q pieces of chunk PF-1 .. 2 still in flight, chunks 0 and 1 are complete.
+        static_assert(FAST && !SEG2 && STG == STG_DMA && DW == G::NW, "chained fill");
+        const unsigned l0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+        const unsigned lP = l0 + (unsigned)w * 1024u, lQ = l0 + (unsigned)(NBUF * P_BUF * 4) + (unsigned)w * 1024u;
+#pragma unroll
+        for (int c = 0; c < PF; ++c) {
+            const char *pb = (const char *)kr.P1.ptr + (size_t)c * ((PL == KM) ? (size_t)BK * kr.P1.ld * 4 : (size_t)BK * 4);
+#pragma unroll
+            for (int n = 0; n < DmaPlan<G, DW>::NPP; ++n) dma16s(pb, pl1.p[n], lP + (unsigned)(c * P_BUF * 4 + n * DW * 1024));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        side.fill();
+        __builtin_amdgcn_sched_barrier(0);
+        side.wait_inputs();
+#pragma unroll
+        for (int c = 0; c < PF; ++c) {
+            const char *qb = (const char *)kr.Q1.ptr + (size_t)c * ((QL == KM) ? (size_t)BK * kr.Q1.ld * 4 : (size_t)BK * 4);
+#pragma unroll
+            for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) dma16s_coh(qb, pl1.q[n], lQ + (unsigned)(c * Q_BUF * 4 + n * DW * 1024));
+        }
+        constexpr int NQ_LEFT = (PF - 2) * DmaPlan<G, DW>::NPQ;
+        BM_WAIT_VM(NQ_LEFT);
     } else {
         // ---- pipeline fill: chunks 0 .. PF-1
 #pragma unroll
@@ -715,7 +766,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         if (SEG2 && !in2 && (CD) >= nch1) { in2 = true; pl1 = pl2; }                              \
         const char *pb_, *qb_;                                                                    \
         chunk_bases((CD), pb_, qb_);                                                              \
-        if (dmaw) dma_chunk_s<G, DW>(pl1, pb_, qb_, ldsPw + (unsigned)((SD) * P_BUF * 4),         \
+        if (dmaw) dma_chunk_s<G, DW, Side::kCohQ>(pl1, pb_, qb_, ldsPw + (unsigned)((SD) * P_BUF * 4), \
                                      ldsQw + (unsigned)((SD) * Q_BUF * 4));                       \
     }
     // steady step: chunk cc+3 by DMA, chunk cc+2 a DMA chunk as well (nothing passes through registers)
@@ -737,7 +788,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         const bool do_dma = cd < nch && is_dma(cd) && !BM_ABL(0);                                 \
         const bool do_reg = cr < nch && !is_dma(cr) && !BM_ABL(0);                                \
         if (cc == last - 1) side.drain();      /* step nch-2: every operand load has landed (waited in step nch-3) */ \
-        if (do_reg) load_chunk<QL, G, FAST, SEG2, PL>(gr, kr, nch1, i0, j0, cr, tid);             \
+        if (do_reg) load_chunk<QL, G, FAST, SEG2, PL, Side::kCohQ>(gr, kr, nch1, i0, j0, cr, tid); \
         if (do_dma) BM_DMA_AT(cd, S3)                                                             \
         read_frags<QL, G, ABL, PL>(FN, sP + (S1) * P_BUF, sQ + (S1) * Q_BUF, wi, wj, lane);       \
         mfma_frags<G, ABL>(acc, FC);                                                              \

@@ -164,6 +164,7 @@ template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
 // act_kernel's side work for the main loop's pipeline fill
 template <int E, class Rng> struct ActSide {
     static constexpr bool kFinalSync = false;    // one pipeline per kernel: waves enter the epilogue as they finish
+    static constexpr bool kSplitFill = false, kCohQ = false;
     const float *bias, *sigma;
     const float *prev_row;       // mean-field: &prev[j][ib0] when the row is valid, else null
     int ib0, I, with_rng;
@@ -736,6 +737,7 @@ struct DivBy {
 // the pipeline drain, so the read-modify-write epilogue does not start with a memory round trip
 template <int NJ> struct GradSide {
     static constexpr bool kFinalSync = true;     // form 1 runs two pipelines through the same LDS ring
+    static constexpr bool kSplitFill = false, kCohQ = false;
     const float *W, *dW; int ldw, I, J, ib0, jb[NJ]; bool on, vec8;
     float4 w[NJ][2], d[NJ][2];
     bool at_fill;

@@ -7,6 +7,7 @@
 #include "../../include/bm355.h"
 #include "bm_common.h"
 #include "bm_kernels.h"
+#include "bm_chain.h"
 
 #include <math.h>
 #include <atomic>
@@ -91,6 +92,8 @@ struct bm_rbm {
     struct Rec { int cls; hipEvent_t a, b; };
     std::vector<Rec> recs;
     size_t grad_tail() const { return (size_t)V * W.ld; }
+    // a run of dependent propagation passes recorded by launch_up / launch_down and issued as ONE launch (bm_chain.h)
+    ChainState chain;
 };
 
 enum { KC_UP = 0, KC_DOWN = 1, KC_GRAD = 2, KC_COLSUM = 3, KC_BIAS = 4, KC_OTHER = 5 };
@@ -114,6 +117,21 @@ static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
     k.site = site + 16u * (uint32_t)t;
     k.call = h->call;
     return k;
+}
+
+// a propagation pass: launched now, or recorded while a chained run is open (chain_begin .. chain_end)
+static void act_pass(bm_rbm *h, const ActArgs &a) {
+    if (h->chain.on) h->chain.rec.push_back(a);
+    else launch_act(a, h->stream);
+}
+static void chain_begin(bm_rbm *h) {
+    // per-class event timing, Multinomial hidden units (a softmax launch between the passes) and the fast-binary sweep
+    // keep their per-pass launches
+    h->chain.on = !h->prof && !h->multinomial() && !h->fast_now && chain_mode(h->chain) > 0;
+}
+static int chain_end(bm_rbm *h) {
+    BM_CHECK(chain_flush(h->chain, h->stream, h->maxB) == 0, "chained launch: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
 }
 
 // E[h|v] (+ sample): base_rbm.py:339-351.  v [B][V] pitch ldv
@@ -153,7 +171,7 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
         hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(B), dim3(64), 2 * (size_t)h->H * sizeof(float), h->stream, m);
         return;
     }
-    launch_act(a, h->stream);
+    act_pass(h, a);
 }
 
 // E[v|h] (+ sample): base_rbm.py:353-365.  hs [B][H] pitch ldh
@@ -181,7 +199,7 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
         a.b3.K1 = h->hs16.ld;
         if (states == h->vs.p) { a.states16 = h->vs16.p; a.ld16 = h->vs16.ld; }
     }
-    launch_act(a, h->stream);
+    act_pass(h, a);
 }
 
 // input preprocessing + h0 + k Gibbs steps (base_rbm.py:417-426). Leaves
@@ -207,6 +225,7 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out,
         Xin = h->Xd.p; ldx = h->Xd.ld;
     }
     h->Xin = Xin; h->Xin_ld = ldx;
+    chain_begin(h);               // h0 and the k Gibbs steps: one launch where the shape allows it (bm_chain.h)
     launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0);      // :421-422
     const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
     for (int t = 0; t < k; ++t) {                                                 // :367-378
@@ -221,6 +240,7 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out,
                   last_out ? h->H : h->hm.ld, h->cfg.sample_h_states, SITE_H, t, (!hm_out && last) ? h->hneg.p : nullptr);
         hstate = h->hs.p;
     }
+    BM_TRY(chain_end(h));
     return 0;
 }
 
@@ -470,6 +490,7 @@ int bm_rbm_destroy(bm_rbm *h) {
     if (h->nonbinary) (void)hipFree(h->nonbinary);
     if (h->flip) (void)hipFree(h->flip);
     if (h->scal) (void)hipFree(h->scal);
+    h->chain.release();
     for (auto &r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
@@ -488,6 +509,15 @@ int bm_rbm_sync(bm_rbm *h) {
             BM_HIP(hipMemset(h->nonbinary, 0, sizeof(int)));
             BM_CHECK(false, "fast-binary mode: bm_rbm_gibbs was given hidden states that are not a {0,1} bitmap");
         }
+    }
+    if (h->chain.status) {      // chained launches (bm_chain.h): an expired wait or a tile nobody computed is an ERROR
+        int st[2] = {0, 0};
+        BM_HIP(hipMemcpy(st, h->chain.status, sizeof(st), hipMemcpyDeviceToHost));
+        BM_CHECK(st[0] == 0, "chained propagation launch failed (status %d: %s); results are invalid", st[0],
+                 st[0] == CHAIN_ERR_TIMEOUT ? "a wait for a producing tile expired" : "not an 8-XCD device");
+        BM_CHECK((long long)(unsigned)st[1] == (h->chain.tiles_expected & 0xffffffffLL),
+                 "chained propagation launches computed %u tiles, expected %lld; results are invalid", (unsigned)st[1],
+                 h->chain.tiles_expected & 0xffffffffLL);
     }
     return 0;
 }
@@ -823,6 +853,7 @@ int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_ste
         // The sweeps read and write the caller's dense buffers IN PLACE: the first prop-down takes H_dev (pitch H) as its
         // operand, the last sweep's launches store straight into V_dev / H_dev - no copy kernels (round 3 moved the
         // states through the pitched workspaces with three copy2d launches per call: 5 % of the sweep benchmark).
+        chain_begin(h);
         for (int t = 0; t < n_steps; ++t) {
             const bool first = t == 0, last = t == n_steps - 1;
             launch_down(h, first ? H_dev : h->hs.p, first ? h->H : h->hs.ld, B, nullptr, last ? V_dev : h->vs.p,
@@ -830,6 +861,7 @@ int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_ste
             launch_up(h, last ? V_dev : h->vs.p, last ? h->V : h->vs.ld, B, nullptr, last ? H_dev : h->hs.p,
                       last ? h->H : h->hs.ld, h->cfg.sample_h_states, SITE_H, t);
         }
+        BM_TRY(chain_end(h));
         h->call++;
         BM_HIP(hipGetLastError());
         return 0;
@@ -895,6 +927,12 @@ int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6) {
         ms6[r.cls] += ms;
         n6[r.cls] += 1;
     }
+    return 0;
+}
+
+int bm_rbm_chain_stats(bm_rbm *h, int64_t *out3) {
+    BM_CHECK(h && out3, "null argument");
+    out3[0] = (int64_t)h->chain.launches; out3[1] = (int64_t)h->chain.tiles_expected; out3[2] = (int64_t)chain_mode(h->chain);
     return 0;
 }
 

@@ -166,6 +166,12 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_stream(self._h, C.byref(p)))
         return p.value
 
+    def chain_stats(self):
+        """(chained launches issued, tiles they must compute, BM355_CHAIN mode) - csrc/bm_chain.h"""
+        out = (C.c_int64 * 3)()
+        check(self.lib.bm_rbm_chain_stats(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def profile(self, enable):
         check(self.lib.bm_rbm_profile(self._h, int(bool(enable))))
 

@@ -171,6 +171,11 @@ int bm_rbm_stream(bm_rbm *h, void **out_stream);
 int bm_rbm_profile(bm_rbm *h, int32_t enable);
 int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6);
 
+/* Chained launches (csrc/bm_chain.h): h0 and the k Gibbs steps of base_rbm.py:417-426 / the sweeps of bm_rbm_gibbs run as
+ * ONE launch where the shape allows it (BM355_CHAIN=0: never, 1: default rule, 2: wherever legal).  out3 = {chained
+ * launches issued so far, tiles they must compute, mode}; bm_rbm_sync reports a launch that did not complete as an error. */
+int bm_rbm_chain_stats(bm_rbm *h, int64_t *out3);
+
 /* HIP-event timer on the handle's stream (bench.py roofline leg). */
 int bm_rbm_timer_start(bm_rbm *h);
 int bm_rbm_timer_stop(bm_rbm *h, float *out_ms);
