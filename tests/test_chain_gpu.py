@@ -58,8 +58,8 @@ for V, H, B, k, kw in cases:
         assert st[0] == 0, st
     eng.close()
 
-# sampling sweeps: 10 sweeps = 20 passes = three launches (8 + 8 + 4), in place in the caller's buffers
-for V, H, B, n in ((784, 1024, 512, 10), (784, 128, 64, 4), (256, 192, 700, 5)):
+# sampling sweeps, in place in the caller's buffers: 15 sweeps = 30 passes = two launches (24 + 6)
+for V, H, B, n in ((784, 1024, 512, 15), (784, 128, 64, 4), (256, 192, 700, 5)):
     eng, twin = make_pair(V, H, max_batch=B, sample_v_states=True)
     eng.seed(5); twin.set_seed(5)
     H0 = synth_data(B, H, 9)
