@@ -257,10 +257,12 @@ static inline int chain_flush(ChainState &cs, hipStream_t st, int maxB) {
     rec.swap(cs.rec);
     if (rec.empty()) return 0;
     using G = GeoChain;
-    // default rule: four passes or more (CD-k with k >= 2, sampling sweeps).  A CD-1 update has three: its two hand-overs
-    // save ~1.2 us each against a kernel boundary, and the first pass pays that back - every XCD pulls ALL of W through
-    // the fabric instead of an eighth (measured: 65.8 against 66.0 us per update on the same box, a tie).
-    bool ok = chain_mode(cs) > 0 && rec.size() >= (cs.mode == 1 ? 4u : 2u);
+    // default rule: six passes or more (CD-k with k >= 3, three sampling sweeps).  A chained pass costs ~12.3 us against
+    // 12.9 / 14.1 us for the per-pass kernels, but the launch pays ~3 us up front and its first pass runs with every XCD
+    // pulling ALL of W through the fabric instead of an eighth: the three passes of a CD-1 update take 42.9 us chained
+    // against 39.9 us as three launches (same box, rocprofv3 kernel trace; 67.4 against 64.0 us per update), twenty
+    // passes 253 against 283 us.
+    bool ok = chain_mode(cs) > 0 && rec.size() >= (cs.mode == 1 ? 6u : 2u);
     const int J = rec[0].J, tiles_j = (J + G::TJ - 1) / G::TJ;
     for (const ActArgs &a : rec) ok = ok && chain_phase_ok(a) && a.J == J;
     // auto mode: every XCD must own a row block, and a pass should be about one tile per CU (larger outputs keep their
