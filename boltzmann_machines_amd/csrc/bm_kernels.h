@@ -1173,6 +1173,53 @@ __global__ void sqdiff_kernel(const float *A, int lda, const float *B, int ldb, 
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
+// The metric fetch of a training iteration (base_rbm.py:482-517) as few launches as its dependences allow (round 4: it
+// was two memsets, two sqdiff launches and the index kernel, then the two free-energy kernels and a device-to-host copy -
+// eight stream operations, ~120 us next to a 64 us update):
+//   metrics_prep_kernel  zeroes the six double sums and the row accumulators and draws the PLL flip column of every row;
+//   sqdiff2_kernel       both squared sums (msre over [B][V], l2 over W) in one grid, row-wise (no 64-bit divisions);
+//   scal_to_host_kernel  writes the six sums into the caller's pinned ring (a 48-byte store over PCIe instead of a copy
+//                        engine operation that the compute queue waits for).
+struct MetricsPrepArgs {
+    double *scal; float *rowacc; int n_rowacc; int *flip; int B, V; PhiloxKey key; unsigned long long row0;
+};
+__global__ __launch_bounds__(256) void metrics_prep_kernel(MetricsPrepArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (t < 6) a.scal[t] = 0.0;
+    for (int e = t; e < a.n_rowacc; e += nt) a.rowacc[e] = 0.f;
+    for (int b = t; b < a.B; b += nt) {                 // pll_rand = tf.random_uniform([B], 0, V, int32) (base_rbm.py:500-501)
+        const unsigned long long idx = a.row0 + b;
+        uint32_t w[4];
+        philox_block(a.key, idx >> 2, w);
+        a.flip[b] = (int)(w[idx & 3] % (uint32_t)a.V);
+    }
+}
+struct SqJob { const float *A; int lda; const float *B; int ldb; int rows, cols; double *out; };
+__global__ __launch_bounds__(256) void sqdiff2_kernel(SqJob j0, SqJob j1) {
+    const int half = gridDim.x >> 1;
+    const bool second = (int)blockIdx.x >= half;
+    const SqJob &j = second ? j1 : j0;
+    const int nb = second ? (int)gridDim.x - half : half, b = second ? (int)blockIdx.x - half : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = b * (blockDim.x >> 6) + (threadIdx.x >> 6), nwv = nb * (blockDim.x >> 6);
+    double s = 0.0;
+    for (int r = wv; r < j.rows; r += nwv) {
+        const float *pa = j.A + (size_t)r * j.lda, *pb = j.B ? j.B + (size_t)r * j.ldb : nullptr;
+        for (int c = lane; c < j.cols; c += 64) {
+            const float d = pb ? (pa[c] - pb[c]) : pa[c];
+            s += (double)d * (double)d;
+        }
+    }
+    // ONE atomic per workgroup: same-address double atomics cost ~16 ns each (a wave-level version spent 17 us on 1024)
+    __shared__ double s_part[4];
+    s = wave_sum(s);
+    if (lane == 0) s_part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(j.out, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+__global__ void scal_to_host_kernel(const double *scal, double *dst) {
+    if (threadIdx.x < 6) dst[threadIdx.x] = scal[threadIdx.x];
+}
+
 // ------------------------------------------------ free-energy hidden term (K5/K6)
 // rowacc[j]  += sum_i softplus(z[j][i] + hb[i])           over this block's i-range
 // rowacc2[j] += the same for the PLL-corrupted row x~ (one flipped column per row,
@@ -1253,30 +1300,40 @@ struct FeRowArgs {
     const int *flip_col;
     double *out;
 };
+constexpr int FE_ROWS_PER_WG = 16;      // 4 waves x 4 rows: one atomic per target and workgroup (see sqdiff2_kernel)
 __global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= a.B) return;
-    const float *x = a.X + (size_t)row * a.ld;
-    const int fc = a.flip_col ? a.flip_col[row] : -1;
-    double t = 0.0, t2 = 0.0;
-    for (int c = lane; c < a.V; c += 64) {
-        const float xv = x[c];
-        const float xf = (c == fc) ? 1.0f - xv : xv;
-        if (a.sigma) {
-            const float mu = a.vb[c] / a.sigma[c];
-            t += 0.5 * (double)((xv - mu) * (xv - mu));
-            t2 += 0.5 * (double)((xf - mu) * (xf - mu));
-        } else {
-            t -= (double)(xv * a.vb[c]);
-            t2 -= (double)(xf * a.vb[c]);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < FE_ROWS_PER_WG / 4; ++q) {
+        const int row = blockIdx.x * FE_ROWS_PER_WG + q * 4 + wv;
+        if (row >= a.B) break;                       // wave-uniform
+        const float *x = a.X + (size_t)row * a.ld;
+        const int fc = a.flip_col ? a.flip_col[row] : -1;
+        double t = 0.0, t2 = 0.0;
+        for (int c = lane; c < a.V; c += 64) {
+            const float xv = x[c];
+            const float xf = (c == fc) ? 1.0f - xv : xv;
+            if (a.sigma) {
+                const float mu = a.vb[c] / a.sigma[c];
+                t += 0.5 * (double)((xv - mu) * (xv - mu));
+                t2 += 0.5 * (double)((xf - mu) * (xf - mu));
+            } else {
+                t -= (double)(xv * a.vb[c]);
+                t2 -= (double)(xf * a.vb[c]);
+            }
         }
+        t = wave_sum(t);
+        t2 = wave_sum(t2);
+        s0 += t - (double)a.rowacc[row];
+        if (a.rowacc2) s1 += t2 - (double)a.rowacc2[row];
+        if (a.rowacc3) s2 += t - (double)a.rowacc3[row];
     }
-    t = wave_sum(t);
-    t2 = wave_sum(t2);
-    if (lane == 0) {
-        atomicAdd(a.out + 0, t - (double)a.rowacc[row]);
-        if (a.rowacc2) atomicAdd(a.out + 1, t2 - (double)a.rowacc2[row]);
-        if (a.rowacc3) atomicAdd(a.out + 2, t - (double)a.rowacc3[row]);
+    __shared__ double s_part[3][4];
+    if (lane == 0) { s_part[0][wv] = s0; s_part[1][wv] = s1; s_part[2][wv] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double v = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]);
+        if (threadIdx.x == 0 || (threadIdx.x == 1 && a.rowacc2) || (threadIdx.x == 2 && a.rowacc3)) atomicAdd(a.out + threadIdx.x, v);
     }
 }
 

@@ -84,7 +84,7 @@ struct bm_rbm {
     int device = 0;
     // bm_rbm_train_step_metrics_async: pinned ring of the six device sums of every pending metrics fetch
     static constexpr int MRING = 4096;
-    double *mring = nullptr;
+    double *mring = nullptr, *mring_dev = nullptr;    // pinned host ring and its device-side address
     std::vector<int> mring_B;
     int mring_n = 0;
     // optional per-kernel-class event timing
@@ -339,7 +339,7 @@ static void launch_fe(bm_rbm *h, const float *Xin, int ldx, int B, bool with_fli
     r.X = Xin; r.ld = ldx; r.V = h->V; r.B = B;
     r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
     r.rowacc = f.rowacc; r.rowacc2 = f.rowacc2; r.rowacc3 = f.rowacc3; r.flip_col = f.flip_col; r.out = h->scal + 2;
-    hipLaunchKernelGGL(fe_row_kernel, dim3((B + 3) / 4), dim3(256), 0, h->stream, r);
+    hipLaunchKernelGGL(fe_row_kernel, dim3((B + FE_ROWS_PER_WG - 1) / FE_ROWS_PER_WG), dim3(256), 0, h->stream, r);
 }
 
 // -lgamma(M + K) + lgamma(M + 1) + lgamma(K)  (rbm.py:61); 0 for the other RBMs
@@ -352,14 +352,13 @@ static double mn_fe_const(const bm_rbm *h) {
 // metrics from the chain currently in the handle (base_rbm.py:482-517)
 static void metrics_to_out4(const bm_rbm *h, const double *host, int B, float *out4);
 static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
-    BM_HIP(hipMemsetAsync(h->scal, 0, 6 * sizeof(double), h->stream));
-    BM_HIP(hipMemsetAsync(h->rowacc.p, 0, 3 * (size_t)h->maxB * sizeof(float), h->stream));
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->Xin, h->Xin_ld, h->vm.p, h->vm.ld,
-                       B, h->V, h->scal + 0);                                                             // msre
-    hipLaunchKernelGGL(sqdiff_kernel, dim3(128), dim3(256), 0, h->stream, h->W.p, h->W.ld, (const float *)nullptr, 0,
-                       h->V, h->H, h->scal + 1);                                                          // l2
-    hipLaunchKernelGGL(pll_index_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, h->flip, B, h->V,
-                       make_key(h, SITE_PLL, 0), (unsigned long long)h->row0);
+    MetricsPrepArgs mp;
+    mp.scal = h->scal; mp.rowacc = h->rowacc.p; mp.n_rowacc = 3 * h->maxB; mp.flip = h->flip; mp.B = B; mp.V = h->V;
+    mp.key = make_key(h, SITE_PLL, 0); mp.row0 = (unsigned long long)h->row0;
+    hipLaunchKernelGGL(metrics_prep_kernel, dim3(8), dim3(256), 0, h->stream, mp);
+    const SqJob msre{h->Xin, h->Xin_ld, h->vm.p, h->vm.ld, B, h->V, h->scal + 0};                        // :486-488
+    const SqJob l2{h->W.p, h->W.ld, nullptr, 0, h->V, h->H, h->scal + 1};                                 // :482-484
+    hipLaunchKernelGGL(sqdiff2_kernel, dim3(128), dim3(256), 0, h->stream, msre, l2);
     launch_fe(h, h->Xin, h->Xin_ld, B, true);
     if (!out4) return 0;                                    // asynchronous caller: the sums stay in h->scal
     double host[6];
@@ -694,12 +693,14 @@ int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr
 int bm_rbm_train_step_metrics_async(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
     if (!h->mring) {
         BM_HIP(hipHostMalloc((void **)&h->mring, (size_t)bm_rbm::MRING * 6 * sizeof(double), hipHostMallocDefault));
+        BM_HIP(hipHostGetDevicePointer((void **)&h->mring_dev, h->mring, 0));
         h->mring_B.resize(bm_rbm::MRING);
     }
     BM_CHECK(h->mring_n < bm_rbm::MRING, "%d metric fetches are pending: call bm_rbm_collect_metrics", h->mring_n);
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
     BM_TRY(metrics_from_chain(h, B, nullptr));
-    BM_HIP(hipMemcpyAsync(h->mring + (size_t)h->mring_n * 6, h->scal, 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    hipLaunchKernelGGL(scal_to_host_kernel, dim3(1), dim3(64), 0, h->stream, (const double *)h->scal,
+                       h->mring_dev + (size_t)h->mring_n * 6);
     h->mring_B[h->mring_n++] = B;
     launch_update_fused(h, B, lr, mom);
     h->call++;
