@@ -69,8 +69,9 @@ for cfg in configs:
     if marker:
         per = {'dbm_bias_kernel': 3}.get(marker, 1)
         n_steps = max(1, sum(n for k, n in ndisp.items() if marker in k) // per)
-    else:       # gibbs: 2 act launches per sweep, 10 sweeps per step
-        n_steps = max(1, sum(n for k, n in ndisp.items() if 'act_kernel' in k) // 20)
+    else:       # gibbs: one chained launch per step (10 sweeps; csrc/bm_chain.h), or 2 act launches per sweep
+        n_steps = max(1, sum(n for k, n in ndisp.items() if 'act_chain_kernel' in k) +
+                      sum(n for k, n in ndisp.items() if 'act_kernel' in k) // 20)
     traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_steps
     lines = ['# rocprofv3 summary %s / %s - `python bench.py --config %s` on 1x MI355X' % (tag, cfg, cfg), '',
              '| kernel | calls | avg us (kernel-trace) | total % | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | issue-stalled % (WAIT_INST_ANY) | parked % (WAIT_ANY) | MFMA instr f32 / bf16 | LDS bank-conflict cycles |',
