@@ -346,6 +346,13 @@ class RbmGibbs(Workload):
     def precondition_steps(self, seconds):
         return int(seconds * 30000 / self.k)
 
+    def _launch_note(self):
+        n, _, mode = self.eng.chain_stats()
+        if n:
+            return ('chained: the %d passes of a call are workgroups of ONE launch that hand their rows over inside an '
+                    "XCD's L2 (csrc/bm_chain.h; BM355_CHAIN=%d; bit-identical to the per-pass launches)" % (2 * self.k, mode))
+        return 'one launch per pass'
+
     def report(self, args, world, dt, ev_ms):
         k = self.k
         F = 2.0 * B * V * H
@@ -359,16 +366,20 @@ class RbmGibbs(Workload):
             'unit': 'Gibbs-steps/s (512-row block sweeps h->v->h, sampling both ways, no update)',
             'config': {'workload': 'BernoulliRBM 784x1024 sampling sweep batch=512 fp32 (SURVEY 8d-ii, bm_rbm_gibbs)',
                        'n_visible': V, 'n_hidden': H, 'batch_per_gpu': B, 'sweeps_per_call': k,
-                       'parallelism': 'replicas%d' % world, 'fast_binary': FAST_NOTE if self.fast else False},
+                       'parallelism': 'replicas%d' % world, 'fast_binary': FAST_NOTE if self.fast else False,
+                       'launches': self._launch_note()},
             'flops_per_step': flops,
             'roofline_extra': {
                 'bf16x3_flop_fraction': 1.0 if self.fast else 0.0,
+                'traffic_per_sweep_over_algorithmic': (round(pmc_traffic('gibbs')[0] / k / bytes_sweep, 2)
+                                                       if pmc_traffic('gibbs') else None),
                 'scope': '%d sweeps per call, 2*2*B*V*H = %.3f GFLOP per sweep; the sweep is MFMA-bound (the 6.4 MB of W '
                          'and the 3.7 MB of states are L2 / Infinity-Cache resident), the HBM figure is the secondary '
                          'number north_star asks for' % (k, 2 * F / 1e9),
                 'hbm': {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': PEAK_HBM, 'unit': 'GB/s',
                         'frac': round(gbps / PEAK_HBM, 4),
-                        'algorithmic_bytes_per_sweep': bytes_sweep, 'traffic': (pmc_traffic('gibbs') or (None,))[0]}},
+                        'algorithmic_bytes_per_sweep': bytes_sweep,
+                        'traffic_per_sweep': (round(pmc_traffic('gibbs')[0] / k, 1) if pmc_traffic('gibbs') else None)}},
         }
 
 
