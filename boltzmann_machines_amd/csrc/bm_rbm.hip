@@ -40,9 +40,15 @@ struct bm_rbm {
     int V, H, maxB;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // variables (padded pitch, see pad_ld).  No transposed copy of W: the prop-down reads W itself as an
-    // x-major operand (ActArgs::p_xm), which saves 3.2 MB of writes per update at 784 x 1024
+    // variables (padded pitch, see pad_ld).  The prop-down reads W itself as an x-major operand (ActArgs::p_xm).
     Mat W, dW;                         // [V][H], [V][H]
+    // the transpose [H][V], written by the fused update next to W: the prop-up then reads its weights x-major as well
+    // (one ds_read_b128 per 16 k and lane instead of four ds_read_b32): 12.95 -> 12.5 us per prop-up, +0.45 us in the
+    // update's epilogue (3.2 MB more stores): 64.1 -> 63.7 us per CD-1 update, same box, alternating runs
+    // (tools/upxm_ab.sh; BM355_UP_XM=0 switches it off).  Valid only while every write of W went through that kernel
+    // (wt_valid: cleared by set_param, apply_step and the exchange); otherwise the prop-up reads W k-major as before.
+    Mat Wt;
+    bool use_wt = false, wt_valid = false;
     DevBuf vb, hb, dvb, dhb, q, sigma;
     // chain workspaces
     Mat h0m, h0s, hm, hs, hneg;        // [maxB][H]; hneg = -hm (negative-phase operand of the outer products)
@@ -141,6 +147,7 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     ActArgs a;
     memset(&a, 0, sizeof(a));
     a.P1 = make_operand(h->W.p, h->W.ld, h->H);   // W[k=v][i=h], KM
+    if (h->use_wt && h->wt_valid) { a.P1 = make_operand(h->Wt.p, h->Wt.ld, h->H); a.p_xm = 1; }   // W^T[i=h][k=v], XM
     a.Q1 = make_operand(v, ldv, B);               // v[j=b][k=v], XM
     a.K1 = h->V;
     a.I = h->H; a.J = B;
@@ -302,6 +309,7 @@ static void fill_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom,
     g.raw = h->grad.p; g.raw2 = nullptr;
     g.W = h->W.p; g.dW = h->dW.p; g.Wt = nullptr;
     g.ldw = h->W.ld; g.ldwt = 0;
+    if (h->use_wt && fused) { g.Wt = h->Wt.p; g.ldwt = h->Wt.ld; }
     g.N = N; g.M = N; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
 }
 static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, bool with_bias) {
@@ -314,6 +322,8 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
         g.bias.raw_only = fused ? 0 : 1;      // split (data-parallel) step: raw column sums only
     }
     bm::launch_grad(g, h->stream);
+    if (fused && h->use_wt) h->wt_valid = true;      // the fused update wrote W and W^T together (every other writer of W
+                                                     // clears the flag: set_param, apply_step, the exchange)
 }
 
 static void launch_fe(bm_rbm *h, const float *Xin, int ldx, int B, bool with_flip) {
@@ -446,6 +456,11 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     BM_HIP(hipEventCreate(&h->ev0));
     BM_HIP(hipEventCreate(&h->ev1));
     BM_TRY(h->W.alloc(V, H)); BM_TRY(h->dW.alloc(V, H));
+    {
+        const char *e = getenv("BM355_UP_XM");          // default on; 0 keeps the k-major prop-up
+        h->use_wt = !(e && atoi(e) == 0) && (V % 4 == 0) && !h->multinomial();
+        if (h->use_wt) BM_TRY(h->Wt.alloc(H, V));
+    }
     BM_TRY(h->vb.alloc(V)); BM_TRY(h->hb.alloc(H)); BM_TRY(h->dvb.alloc(V)); BM_TRY(h->dhb.alloc(H));
     BM_TRY(h->q.alloc(H)); BM_TRY(h->sigma.alloc(V));
     BM_TRY(h->h0m.alloc(B, H)); BM_TRY(h->h0s.alloc(B, H)); BM_TRY(h->hm.alloc(B, H)); BM_TRY(h->hs.alloc(B, H)); BM_TRY(h->hneg.alloc(B, H));
@@ -467,7 +482,7 @@ int bm_rbm_destroy(bm_rbm *h) {
     if (!h) return 0;
     (void)hipStreamSynchronize(h->stream);
     if (h->xchg_used) xchg_bind_user(h->xchg_used, nullptr);
-    Mat *mats[] = {&h->W, &h->dW, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
+    Mat *mats[] = {&h->W, &h->dW, &h->Wt, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
     DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->grad_alt, &h->pen, &h->rowacc, &h->hhat};
     for (int i = 0; i < 2; ++i) {
@@ -547,6 +562,7 @@ int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
     if (nm == "W" || nm == "dW") {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
         BM_TRY((nm == "W" ? h->W : h->dW).upload(host));
+        if (nm == "W") h->wt_valid = false;
         return 0;
     }
     DevBuf *b = find_vec(h, nm);
@@ -564,6 +580,7 @@ int bm_rbm_set_param_dev(bm_rbm *h, const char *name, const float *src_dev, size
     if (nm == "W" || nm == "dW") {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
         Mat &m = nm == "W" ? h->W : h->dW;
+        if (nm == "W") h->wt_valid = false;
         BM_HIP(hipMemcpy2DAsync(m.p, (size_t)m.ld * sizeof(float), src_dev, (size_t)m.cols * sizeof(float),
                                 (size_t)m.cols * sizeof(float), m.rows, hipMemcpyDeviceToDevice, h->stream));
         return 0;
@@ -784,6 +801,7 @@ int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float lr, float mom) {
     memset(&a, 0, sizeof(a));
     a.raw = h->grad.p; a.raw2 = nullptr;
     a.W = h->W.p; a.dW = h->dW.p; a.Wt = nullptr;
+    h->wt_valid = false;
     a.I = h->H; a.J = h->V; a.ldw = h->W.ld; a.ldwt = 0; a.form = 0;
     a.N = (float)B_global; a.M = a.N; a.l2 = h->cfg.l2; a.lr = lr; a.mom = mom;
     if (h->cfg.sparsity_cost != 0.f) {      // the W update needs the penalty: bias update first

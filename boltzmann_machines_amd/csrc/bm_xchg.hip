@@ -577,6 +577,7 @@ static int xchg_launch_apply(bm_rbm *h, bm_xchg *x, float N_global, float lr, fl
     bmx::RbmApply q;
     memset(&q, 0, sizeof(q));
     q.W = h->W.p; q.dW = h->dW.p;
+    h->wt_valid = false;
     q.countW = (unsigned long long)h->V * h->W.ld;
     q.chunkW = (((q.countW + x->nranks - 1) / x->nranks) + 3) & ~3ull;
     BM_CHECK(q.chunkW <= x->chunk, "staging slice too small");       // chunk covers count / N >= countW / N
