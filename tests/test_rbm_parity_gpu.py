@@ -389,3 +389,44 @@ def test_deferred_metrics_equal_the_synchronous_fetch(gpu_lib):
     for name in ('W', 'vb', 'hb', 'dW', 'dvb', 'dhb'):
         assert np.array_equal(a.get(name), b.get(name)), name
     a.close(); b.close()
+
+
+def test_every_writer_of_W_keeps_the_transposed_weights_in_step(gpu_lib):
+    """The fused update writes W and its transpose (the x-major prop-up operand, bm_rbm.hip `Wt`); every OTHER writer of
+    W - set_param, the split step's apply, set_from_device - must send the prop-up back to W itself until the next
+    fused update.  A stale transpose would show up as different hidden bitmaps: the mixed sequence below stays
+    bit-identical to the oracle (and to a handle that never uses the transpose: gradient steps only)."""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    from oracle import oracle as orc
+    V, H, B = 256, 192, 64
+    kw = dict(sample_v_states=True, l2=1e-4)
+    eng, twin = make_pair(V, H, max_batch=B, **kw)
+    eng.seed(21); twin.set_seed(21)
+    W2 = (orc.normal(5, 6, 0, V * H) * np.float32(0.02)).reshape(V, H)
+
+    def fused(s):
+        X = synth_data(B, V, s)
+        eng.train_step(as_device(X), B, 0.05, 0.9, 2)
+        twin.train_step(X, 0.05, 0.9, 2)
+
+    def split(s):
+        X = synth_data(B, V, s)
+        eng.grad_step(as_device(X), B, 2)
+        eng.apply_step(B, 0.05, 0.9)
+        raw = twin.raw_grads(X, 2)
+        twin.apply(raw, B, 0.05, 0.9)
+
+    fused(0); fused(1)                  # transpose valid from the first fused update on
+    split(2)                            # apply_step rewrites W without the transpose
+    fused(3)
+    assert_state_equal(eng, twin)
+    eng.set('W', W2); twin.p['W'][...] = W2
+    fused(4); fused(5)
+    assert_state_equal(eng, twin)
+    X = synth_data(B, V, 9)
+    Hd = DeviceArray((B, H))
+    eng.transform(as_device(X), B, 1, Hd)
+    eng.sync()
+    assert np.array_equal(Hd.numpy().view(np.uint32), twin.transform(X, 1).view(np.uint32))
+    eng.close()
