@@ -83,6 +83,7 @@ struct NoSide {
 //   bit 0: no global -> LDS traffic   bit 1: VALU instead of MFMA   bit 3: no fragment reads
 //   bit 4: no epilogue (act_kernel)   bit 5: no barriers             bit 6: register path for every chunk
 //   bit 8: no wait for the DMA in the steady steps (wrong results: prices the data-arrival stalls)
+//   bit 9: only every other Q piece is moved (wrong results: what would half the Q bytes - a 16-bit state operand - buy?)
 #define BM_ABL(bit) ((ABL >> (bit)) & 1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -446,19 +447,20 @@ __device__ __forceinline__ void dma16s_coh(const void *sbase, uint32_t voff, uns
 }
 // chunk `kc` of ONE segment (full chunk): scalar chunk bases pb / qb, plan of that segment, LDS byte addresses of
 // this wave's first piece in the destination slot images
-template <class G, int DW, bool QSC = false>
+template <class G, int DW, bool QSC = false, bool QHALF = false>
 __device__ __forceinline__ void dma_chunk_s(const DmaPlan<G, DW> &pl, const char *pb, const char *qb, unsigned ldsP, unsigned ldsQ) {
 #pragma unroll
     for (int n = 0; n < DmaPlan<G, DW>::NPP; ++n) dma16s(pb, pl.p[n], ldsP + (unsigned)(n * DW * 1024));
 #pragma unroll
     for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) {
+        if (QHALF && (n & 1)) continue;
         if (QSC) dma16s_coh(qb, pl.q[n], ldsQ + (unsigned)(n * DW * 1024));
         else     dma16s(qb, pl.q[n], ldsQ + (unsigned)(n * DW * 1024));
     }
 }
 
 // chunk c (a FULL chunk of its segment) -> LDS slot images sP / sQ, all pieces of this wave
-template <int QL, class G, bool SEG2, int PL = KM, int DW = G::NW>
+template <int QL, class G, bool SEG2, int PL = KM, int DW = G::NW, bool QHALF = false>
 __device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G, DW> &pl1, const DmaPlan<G, DW> &pl2, int nch1, int c,
                                           float *sP, float *sQ, int wave) {
     constexpr int BK = G::BK;
@@ -478,6 +480,7 @@ __device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G, DW>
     }
 #pragma unroll
     for (int n = 0; n < DmaPlan<G, DW>::NPQ; ++n) {
+        if (QHALF && (n & 1)) continue;
         const uint32_t o1 = pl1.q[n], o2 = SEG2 ? pl2.q[n] : 0u;
         const uint32_t o = SEG2 ? (o1 ^ ((o1 ^ o2) & (uint32_t)m)) : o1;
         dma16(qb + o, sQ + (wave + n * DW) * 256);
@@ -614,7 +617,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #endif
     constexpr int BK = G::BK, P_BUF = G::P_BUF, Q_BUF = G::Q_BUF, NBUF = G::NBUF, PF = G::PF;
     constexpr int DW = (STG == STG_DMAH && G::NW == 8) ? 4 : G::NW;       // waves that issue DMA instructions
-    constexpr int NPW = DmaPlan<G, DW>::NPP + DmaPlan<G, DW>::NPQ;         // DMA instructions per DMA wave and chunk
+    constexpr int NPW = DmaPlan<G, DW>::NPP + (BM_ABL(9) ? (DmaPlan<G, DW>::NPQ + 1) / 2 : DmaPlan<G, DW>::NPQ);   // DMA instructions per DMA wave and chunk
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (SGPR): LDS piece bases stay scalar
     const int wi = w % G::WI, wj = w / G::WI;
@@ -697,7 +700,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
 #pragma unroll
         for (int c = 0; c < PF; ++c)
             if (c < nch && is_dma(c) && dmaw && !BM_ABL(0))
-                dma_chunk<QL, G, SEG2, PL, DW>(kr, pl1, pl2, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, w);
+                dma_chunk<QL, G, SEG2, PL, DW, (BM_ABL(9) != 0)>(kr, pl1, pl2, nch1, c, sP + (c % NBUF) * P_BUF, sQ + (c % NBUF) * Q_BUF, w);
         __builtin_amdgcn_sched_barrier(0);
         side.fill();
         __builtin_amdgcn_sched_barrier(0);
@@ -766,7 +769,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         if (SEG2 && !in2 && (CD) >= nch1) { in2 = true; pl1 = pl2; }                              \
         const char *pb_, *qb_;                                                                    \
         chunk_bases((CD), pb_, qb_);                                                              \
-        if (dmaw) dma_chunk_s<G, DW, Side::kCohQ>(pl1, pb_, qb_, ldsPw + (unsigned)((SD) * P_BUF * 4), \
+        if (dmaw) dma_chunk_s<G, DW, Side::kCohQ, (BM_ABL(9) != 0)>(pl1, pb_, qb_, ldsPw + (unsigned)((SD) * P_BUF * 4), \
                                      ldsQw + (unsigned)((SD) * Q_BUF * 4));                       \
     }
     // steady step: chunk cc+3 by DMA, chunk cc+2 a DMA chunk as well (nothing passes through registers)

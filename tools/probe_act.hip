@@ -95,6 +95,15 @@ int main(int argc, char **argv) {
     printf("---- 8-wave geometry (the one the tuner picks at this shape)\n");
     RUNG(GeoAct8, 1, 0, "8w full")
     RUNG(GeoAct8, 1, 256, "8w no wait for the DMA")
+    RUNG(GeoAct8, 1, 512, "8w HALF the Q bytes moved")
+    {   // the same for the x-major-P instantiation (prop-down / prop-up from W^T): P = an [I][K] matrix
+        Mat Wx; Wx.alloc(H, V);
+        ActArgs ax = a; ax.P1 = make_operand(Wx.p, Wx.ld, H); ax.p_xm = 1;
+        const dim3 grid(tile_grid<GeoAct8>(ax.I, ax.J)), blk(512);
+        printf("%-34s %6.2f us\n", "8w x-major P full", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 0, XM>), grid, blk, 0, st, ax, tm_slab); }));
+        printf("%-34s %6.2f us\n", "8w x-major P, HALF the Q bytes", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 512, XM>), grid, blk, 0, st, ax, tm_slab); }));
+        printf("%-34s %6.2f us\n", "8w x-major P, no gload at all", time_it(st, e0, e1, [&] { hipLaunchKernelGGL((act_kernel<GeoAct8, 1, false, true, 1, XM>), grid, blk, 0, st, ax, tm_slab); }));
+    }
     RUNG(GeoAct8, 1, 129, "8w lock-step no-gload")
     RUNG(GeoAct8, 1, 136, "8w lock-step no-ldsread")
     RUNG(GeoAct8, 1, 16, "8w no-epilogue")
