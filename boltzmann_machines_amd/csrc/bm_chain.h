@@ -205,6 +205,10 @@ struct ChainState {
     int mode = -1;                                   // BM355_CHAIN: 0 off, 1 auto (default), 2 force where legal
     int ncu = 0;
     std::vector<ActArgs> rec;
+    // per recorded pass: an x-major P operand (W^T) the PER-PASS launch should use instead of rec[i].P1 (ptr null: none).
+    // A chained launch keeps the k-major W: with both W and W^T streaming through an XCD's 4 MiB L2 neither stays
+    // resident (measured: 26.0 against 25.2 us per sweep).
+    std::vector<Operand> alt_p;
     long long *stamps = nullptr;                     // BM355_CHAIN_STAMPS=file: timeline of the LAST chained launch, dumped at release
     static constexpr int CLAIM_SLOTS = 16;
     static constexpr size_t STAMP_WORDS = 256 * 16 * 8;
@@ -254,8 +258,11 @@ static inline bool chain_phase_ok(const ActArgs &a) {
 static inline int chain_flush(ChainState &cs, hipStream_t st, int maxB) {
     cs.on = false;
     std::vector<ActArgs> rec;
+    std::vector<Operand> alt;
     rec.swap(cs.rec);
+    alt.swap(cs.alt_p);
     if (rec.empty()) return 0;
+    alt.resize(rec.size(), Operand{nullptr, 0, 0, 0});
     using G = GeoChain;
     // default rule: six passes or more (CD-k with k >= 3, three sampling sweeps).  A chained pass costs ~12.3 us against
     // 12.9 / 14.1 us for the per-pass kernels, but the launch pays ~3 us up front and its first pass runs with every XCD
@@ -272,7 +279,10 @@ static inline int chain_flush(ChainState &cs, hipStream_t st, int maxB) {
         for (const ActArgs &a : rec) ok = ok && ((a.I + G::TI - 1) / G::TI) * ((tiles_j + 7) / 8) <= 2 * 32;
     }
     if (!ok) {
-        for (const ActArgs &a : rec) launch_act(a, st);
+        for (size_t i = 0; i < rec.size(); ++i) {
+            if (alt[i].ptr) { rec[i].P1 = alt[i]; rec[i].p_xm = 1; }
+            launch_act(rec[i], st);
+        }
         return 0;
     }
     const int rounds = (tiles_j + 7) / 8;

@@ -1153,6 +1153,19 @@ __global__ void copy2d_kernel(const float *X, int ldx, float *Y, int ldy, int ro
     }
 }
 
+// T[c][r] = A[r][c], 32 x 32 tiles through LDS (full-line reads and writes)
+__global__ __launch_bounds__(256) void transpose_kernel(const float *A, int lda, float *T, int ldt, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int tiles_c = (cols + 31) / 32;
+    const int r0 = ((int)blockIdx.x / tiles_c) * 32, c0 = ((int)blockIdx.x % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (r0 + r < rows && c0 + tx < cols) t[r][tx] = A[(size_t)(r0 + r) * lda + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) T[(size_t)(c0 + c) * ldt + r0 + tx] = t[tx][c];
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);

@@ -126,9 +126,16 @@ static PhiloxKey make_key(const bm_rbm *h, uint32_t site, int t) {
 }
 
 // a propagation pass: launched now, or recorded while a chained run is open (chain_begin .. chain_end)
-static void act_pass(bm_rbm *h, const ActArgs &a) {
-    if (h->chain.on) h->chain.rec.push_back(a);
-    else launch_act(a, h->stream);
+static void act_pass(bm_rbm *h, const ActArgs &a, const Operand *alt_p = nullptr) {
+    if (h->chain.on) {
+        h->chain.rec.push_back(a);
+        h->chain.alt_p.resize(h->chain.rec.size(), Operand{nullptr, 0, 0, 0});
+        if (alt_p) h->chain.alt_p.back() = *alt_p;
+    } else if (alt_p) {
+        ActArgs b = a;
+        b.P1 = *alt_p; b.p_xm = 1;
+        launch_act(b, h->stream);
+    } else launch_act(a, h->stream);
 }
 static void chain_begin(bm_rbm *h) {
     // per-class event timing, Multinomial hidden units (a softmax launch between the passes) and the fast-binary sweep
@@ -140,6 +147,16 @@ static int chain_end(bm_rbm *h) {
     return 0;
 }
 
+// W^T for the x-major prop-up when W was last written by something else than the fused update (set_param, a sampling-
+// only handle): one transpose, valid until the next such write.  NOT called on the split (data-parallel) step, whose
+// apply / exchange rewrites W every step.
+static void ensure_wt(bm_rbm *h) {
+    if (!h->use_wt || h->wt_valid) return;
+    const int nt = ((h->V + 31) / 32) * ((h->H + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, dim3(nt), dim3(256), 0, h->stream, (const float *)h->W.p, h->W.ld, h->Wt.p, h->Wt.ld, h->V, h->H);
+    h->wt_valid = true;
+}
+
 // E[h|v] (+ sample): base_rbm.py:339-351.  v [B][V] pitch ldv
 static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, float *states, int ldo,
                       int sample, uint32_t site, int t, float *negmeans = nullptr) {
@@ -147,7 +164,6 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     ActArgs a;
     memset(&a, 0, sizeof(a));
     a.P1 = make_operand(h->W.p, h->W.ld, h->H);   // W[k=v][i=h], KM
-    if (h->use_wt && h->wt_valid) { a.P1 = make_operand(h->Wt.p, h->Wt.ld, h->H); a.p_xm = 1; }   // W^T[i=h][k=v], XM
     a.Q1 = make_operand(v, ldv, B);               // v[j=b][k=v], XM
     a.K1 = h->V;
     a.I = h->H; a.J = B;
@@ -178,7 +194,10 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
         hipLaunchKernelGGL(softmax_multinomial_kernel, dim3(B), dim3(64), 2 * (size_t)h->H * sizeof(float), h->stream, m);
         return;
     }
-    act_pass(h, a);
+    if (h->use_wt && h->wt_valid && !(h->fast_now && v == h->vs.p)) {
+        const Operand wt = make_operand(h->Wt.p, h->Wt.ld, h->H);      // W^T[i=h][k=v], x-major: the per-pass launch's P
+        act_pass(h, a, &wt);
+    } else act_pass(h, a);
 }
 
 // E[v|h] (+ sample): base_rbm.py:353-365.  hs [B][H] pitch ldh
@@ -215,9 +234,11 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
 // need_vm: the last step's visible MEANS are wanted (msre metric); a plain update only consumes the
 // visible states, and nothing consumes the hidden STATES of the last step: those stores (and their
 // share of the kernel-boundary L2 writeback) are skipped.
-static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true, bool for_update = false) {
+static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true, bool for_update = false,
+                     bool split_step = false) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    if (!split_step) ensure_wt(h);
     const float *Xin = X_dev;
     int ldx = h->V;
     if (h->cfg.v_unit == BM_UNIT_GAUSSIAN) {   // rbm.py:107
@@ -749,7 +770,7 @@ int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, 
 }
 
 int bm_rbm_grad_step(bm_rbm *h, const float *X_dev, int32_t B, int32_t k) {
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr, false));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, false, false, true));
     rbm_grad(h, B, 0, (float)B, 0.f, 0.f, true);     // raw outer products + raw column sums, one launch
     h->call++;
     BM_HIP(hipGetLastError());
@@ -872,6 +893,7 @@ int bm_rbm_gibbs(bm_rbm *h, float *H_dev, float *V_dev, int32_t B, int32_t n_ste
         // The sweeps read and write the caller's dense buffers IN PLACE: the first prop-down takes H_dev (pitch H) as its
         // operand, the last sweep's launches store straight into V_dev / H_dev - no copy kernels (round 3 moved the
         // states through the pitched workspaces with three copy2d launches per call: 5 % of the sweep benchmark).
+        ensure_wt(h);
         chain_begin(h);
         for (int t = 0; t < n_steps; ++t) {
             const bool first = t == 0, last = t == n_steps - 1;
