@@ -5,9 +5,15 @@ API and writes tests/golden/ref_<scenario>.npz.
     python tests/golden/make_golden_from_reference.py [scenario ...]
 
 Runs in the build container only (the reference checkout does not travel to the GPU box; the .npz files do).
-Random streams of the reference's unseeded ops follow tests/golden/reference_rng_policy.py; a scenario whose Bernoulli
-draws come closer than 2e-6 to a tie (|u - p|) is rejected, so that float32 round-off of a different summation order
-cannot flip a sample of the recorded trajectory."""
+Random streams of the reference's unseeded ops follow tests/golden/reference_rng_policy.py.
+
+Near-ties (hard part 2).  A Bernoulli draw with |u - p| below the float32 round-off of p can come out the
+other way under another summation order of the same matrix product; from there the two trajectories differ.  Such
+draws are not avoidable at the BASELINE sizes (10^6 .. 10^8 draws per scenario), so they are RECORDED, not rejected:
+every draw with |u - p| < TIE_EPS goes into the fixture as a row of `near_ties` = (label, op execution, row, column,
+u - p), `label` being the public call the scenario announced with `pkg.mark()`; `near_tie_labels` / `near_tie_scopes`
+name the labels and the graph scope of each draw, `n_bernoulli_draws` counts all draws.  tests/reference_fixtures.py
+requires equality everywhere except on trajectories a recorded near-tie can have forked, and reports the counts."""
 import os
 import shutil
 import sys
@@ -20,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MIN_MARGIN = 2e-6
+TIE_EPS = 2e-6
 
 
 class ReferencePackage(object):
@@ -36,15 +42,33 @@ class ReferencePackage(object):
         from boltzmann_machines.utils import RNG
         self.BernoulliRBM, self.GaussianRBM, self.MultinomialRBM, self.DBM, self.RNG = \
             BernoulliRBM, GaussianRBM, MultinomialRBM, DBM, RNG
-        self.margins = []
+        self.reset()
         from tensorflow.contrib import distributions
-        distributions.set_margin_trace(lambda scope, m: self.margins.append((m, scope)))
+        distributions.set_margin_trace(self._trace, TIE_EPS)
+
+    def reset(self):
+        self.margin, self.n_draw_ops, self.labels, self.label = np.inf, 0, ['start'], 0
+        self.ties, self.tie_scopes, self.n_draws = [], [], 0
+
+    def mark(self, label):
+        """scenario hook: the draws that follow belong to the public call `label`"""
+        if label not in self.labels:
+            self.labels.append(label)
+        self.label = self.labels.index(label)
+
+    def _trace(self, scope, margin, ties, n):
+        self.margin = min(self.margin, margin)
+        self.n_draws += n
+        for row, col, d in ties:
+            self.ties.append((self.label, self.n_draw_ops, row, col, d))
+            self.tie_scopes.append(scope)
+        self.n_draw_ops += 1
 
 
 def generate(name, pkg=None):
     from tests.golden import scenarios
     pkg = pkg or ReferencePackage()
-    pkg.margins[:] = []
+    pkg.reset()
     d = tempfile.mkdtemp(prefix='bm_ref_%s_' % name)
     cwd = os.getcwd()
     try:
@@ -53,8 +77,11 @@ def generate(name, pkg=None):
     finally:
         os.chdir(cwd)
         shutil.rmtree(d, ignore_errors=True)
-    margin = min(pkg.margins)[0] if pkg.margins else np.inf
-    out['min_bernoulli_margin'] = np.array([margin])
+    out['min_bernoulli_margin'] = np.array([pkg.margin])
+    out['near_ties'] = np.asarray(pkg.ties, dtype=np.float64).reshape(-1, 5)
+    out['near_tie_labels'] = np.array(pkg.labels)
+    out['near_tie_scopes'] = np.array(pkg.tie_scopes, dtype=str) if pkg.tie_scopes else np.zeros(0, dtype='<U1')
+    out['n_bernoulli_draws'] = np.array([pkg.n_draws], dtype=np.int64)
     return out
 
 
@@ -62,19 +89,13 @@ def main(argv):
     from tests.golden import scenarios
     names = argv or sorted(scenarios.SCENARIOS)
     pkg = ReferencePackage()
-    bad = []
     for name in names:
         out = generate(name, pkg)
-        margin = float(out['min_bernoulli_margin'][0])
         path = os.path.join(HERE, 'ref_%s.npz' % name)
-        if margin < MIN_MARGIN:
-            print('%-40s REJECTED: a Bernoulli draw lies %.2e from a tie: pick other seeds for this scenario' % (name, margin))
-            bad.append(name)
-            continue
         np.savez_compressed(path, **out)
-        print('%-40s %3d arrays  %7.1f KiB  min |u - p| = %.2e' % (name, len(out), os.path.getsize(path) / 1024.0, margin))
-    if bad:
-        raise SystemExit('rejected: %s' % ', '.join(bad))
+        print('%-40s %3d arrays  %7.1f KiB  %.3g Bernoulli draws, %d within %.0e of a tie, min |u - p| = %.2e'
+              % (name, len(out), os.path.getsize(path) / 1024.0, float(out['n_bernoulli_draws'][0]),
+                 len(out['near_ties']), TIE_EPS, float(out['min_bernoulli_margin'][0])))
 
 
 if __name__ == '__main__':

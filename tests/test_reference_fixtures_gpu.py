@@ -12,18 +12,19 @@ from tests.golden import scenarios
 pytestmark = pytest.mark.gpu
 
 
-def _tols(name):
-    if name == 'rbm_float64':
-        return dict(rtol=1e-11, metrics_rtol=1e-7, atol=1e-15)
-    if name in scenarios.GAUSSIAN:
-        return dict(rtol=5e-5, metrics_rtol=5e-5)
-    if name == 'dbm_three_layers':
-        return dict(rtol=1e-5, metrics_rtol=1e-5, n_mf_atol=1.0)     # mf_tol at round-off level, see the CPU leg
-    return dict(rtol=1e-5, metrics_rtol=1e-5)
-
-
 @pytest.mark.parametrize('name', sorted(scenarios.SCENARIOS))
 def test_hip_path_reproduces_the_reference_fixture(gpu_lib, name, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     got = scenarios.SCENARIOS[name](rf.OursPackage(), str(tmp_path))
-    rf.compare(name, got, rf.load(name), **_tols(name))
+    report = rf.check(name, got)
+    print('\n'.join(['', name] + report))
+
+
+def test_ais_slice_in_the_reference_order_of_float32_accumulation(gpu_lib, tmp_path, monkeypatch):
+    """the same 64 chains x 1000 betas with every log p*_beta(x) formed, added and subtracted in float32 in the order of
+    the reference graph (dbm.py:650-660, :708-728; `DBM.set_ais_accumulation('float32')`) instead of the default
+    per-chain double accumulation: both must hold the fixture's 1e-5; the report line shows the gap of each"""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('BM355_AIS_LITERAL', '1')
+    got = scenarios.SCENARIOS['ais_config4_slice'](rf.OursPackage(), str(tmp_path))
+    print('\n'.join(['', 'ais_config4_slice, float32 accumulation'] + rf.check('ais_config4_slice', got)))

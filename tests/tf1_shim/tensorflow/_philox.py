@@ -54,11 +54,18 @@ def uniform(key, w2, w3, n, dtype=np.float32, idx0=0):
 def normal(key, w2, w3, n, dtype=np.float32):
     """Box-Muller on word pairs: (sin, cos)(2 pi u2) * sqrt(-2 ln u1); 4 float32 or 2 float64 normals per block"""
     if np.dtype(dtype) == np.float32:
+        # TF's BoxMullerFloat takes float32 log / sqrt / sincos from the platform's libm; which last bit those return
+        # is not part of TF's contract.  The stand-in evaluates each float32 operation of that function in float64 and
+        # rounds it ONCE (= a correctly rounded libm), so that it sits within half an ulp per operation of any
+        # implementation instead of adding NumPy's own float32 SIMD error (up to 1.4 ulp in exp / log / sin).
         w = blocks(key, w2, w3, 0, (n + 3) // 4)
         u1 = np.maximum(_f32(w[:, 0::2]), np.float32(1.0e-7))
         v1 = np.float32(2.0 * np.pi) * _f32(w[:, 1::2])
-        r = np.sqrt(np.float32(-2.0) * np.log(u1))
-        return np.stack([np.sin(v1) * r, np.cos(v1) * r], axis=2).astype(np.float32).reshape(-1)[:n]
+        lg = np.log(u1.astype(np.float64)).astype(np.float32)
+        r = np.sqrt((np.float32(-2.0) * lg).astype(np.float64)).astype(np.float32)
+        s = np.sin(v1.astype(np.float64)).astype(np.float32)
+        c = np.cos(v1.astype(np.float64)).astype(np.float32)
+        return np.stack([s * r, c * r], axis=2).astype(np.float32).reshape(-1)[:n]
     w = blocks(key, w2, w3, 0, (n + 1) // 2)
     u1 = np.maximum(_f64(w[:, 0], w[:, 1]), 1.0e-20)
     v1 = 2.0 * np.pi * _f64(w[:, 2], w[:, 3])

@@ -17,16 +17,28 @@ import tensorflow as tf
 from tensorflow import _philox
 
 _trace_margin = [None]
+_tie_eps = [0.0]
 
 
-def set_margin_trace(fn):
-    """fn(site_name, min |u - p| over the draw): lets the fixture generator reject inputs with near-ties"""
+def set_margin_trace(fn, tie_eps=0.0):
+    """fn(scope, min |u - p| over the draw, near_ties, number of draws): lets the fixture generator COUNT the draws whose outcome the
+    float32 round-off of another summation order could flip.  near_ties = [n, 3] float64 rows (row, column, u - p)
+    of every draw with |u - p| < tie_eps (row = flat index / last dimension: the minibatch row / particle / chain)"""
     _trace_margin[0] = fn
+    _tie_eps[0] = float(tie_eps)
 
 
 def _k_bernoulli_less(ctx, t, u, p):
     if _trace_margin[0] is not None and np.size(u):
-        _trace_margin[0](t.scope, float(np.min(np.abs(np.asarray(u, dtype=np.float64) - np.asarray(p, dtype=np.float64)))))
+        d = np.asarray(u, dtype=np.float64) - np.asarray(p, dtype=np.float64)
+        a = np.abs(d)
+        ties = np.zeros((0, 3))
+        if _tie_eps[0] > 0.0:
+            idx = np.flatnonzero(a.reshape(-1) < _tie_eps[0])
+            if idx.size:
+                ncol = a.shape[-1] if a.ndim else 1
+                ties = np.stack([idx // ncol, idx % ncol, d.reshape(-1)[idx]], axis=1).astype(np.float64)
+        _trace_margin[0](t.scope, float(a.min()), ties, int(a.size))
     return np.less(u, p)
 
 
