@@ -275,7 +275,9 @@ class EngineModel(BaseModel, DtypeMixin):
         try:
             self._save_thread = threading.Thread(target=self._save_writer, args=(job, lock), daemon=False)
             self._save_thread.start()
-        except BaseException:               # e.g. the process is out of threads: write this checkpoint synchronously
+        except (RuntimeError, OSError):     # "can't start new thread": write this checkpoint synchronously
+            # (only the failure to START is handled: a KeyboardInterrupt / SystemExit that arrives while the thread is
+            # already running must propagate, or two writers would run on the same .tmp files - round-4 advisor)
             self._save_thread = None
             self._save_writer(job, lock)    # (drains a waiting snapshot and clears _save_busy like the thread would)
 

@@ -233,10 +233,14 @@ static inline int chain_mode(ChainState &cs) {
     if (cs.mode < 0) {
         const char *e = getenv("BM355_CHAIN");
         cs.mode = e ? atoi(e) : 1;
-        hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d);
-        cs.ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 0;
-        // teams are XCDs: an 8-XCD part in single-partition mode (MI355X SPX: 256 CUs).  Anything else: per-pass launches.
-        if (cs.ncu != 256) cs.mode = 0;
+        hipDeviceProp_t pr; int d = 0, nxcc = 0; (void)hipGetDevice(&d);
+        const bool have = hipGetDeviceProperties(&pr, d) == hipSuccess;
+        cs.ncu = have ? pr.multiProcessorCount : 0;
+        if (hipDeviceGetAttribute(&nxcc, hipDeviceAttributeNumberOfXccs, d) != hipSuccess) nxcc = 0;
+        // teams are XCDs: a gfx950 / gfx942 part with 8 XCDs in single-partition mode (MI355X SPX: 256 CUs, round-robin
+        // dispatch over the XCDs, one 4 MiB L2 each).  Anything else keeps its per-pass launches.
+        const bool arch = have && (strncmp(pr.gcnArchName, "gfx950", 6) == 0 || strncmp(pr.gcnArchName, "gfx942", 6) == 0);
+        if (!(arch && nxcc == 8 && cs.ncu == 256)) cs.mode = 0;
     }
     return cs.mode;
 }

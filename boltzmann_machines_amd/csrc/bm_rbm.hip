@@ -33,10 +33,15 @@ struct bm_xchg;
 // (bm_xchg.hip, later in this translation unit)
 static int xchg_check_status(bm_xchg *x);                    // error when a wait of the exchange ever expired
 static void xchg_bind_user(bm_xchg *x, bm_xchg **slot);      // the engine field that points at x (cleared by bm_xchg_destroy)
+static void xchg_dw_replaced(bm_xchg *x);                    // every replica's dW was overwritten whole (set_param)
 
 struct bm_rbm {
     bm_rbm_config cfg;
     bm_xchg *xchg_used = nullptr;     // the direct exchange this engine's gradients last went through (bm_rbm_sync checks it)
+    // set by bm_rbm_exchange_apply_direct on more than one rank: every rank then holds only ITS slice of the momentum
+    // buffer dW.  Cleared by bm_rbm_exchange_gather_dw (collective) and by a set_param of dW.  While it is set every
+    // reader of dW - get_param, stage (checkpoints), apply_step and the single-GPU fused update - fails (check_dw)
+    bool dw_sharded = false;
     int V, H, maxB;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -103,6 +108,13 @@ struct bm_rbm {
 };
 
 enum { KC_UP = 0, KC_DOWN = 1, KC_GRAD = 2, KC_COLSUM = 3, KC_BIAS = 4, KC_OTHER = 5 };
+
+// the momentum buffer is complete on this rank (see bm_rbm::dw_sharded)
+static int check_dw(const bm_rbm *h, const char *what) {
+    BM_CHECK(!h->dw_sharded, "%s: after bm_rbm_exchange_apply_direct this rank holds only its slice of the momentum buffer dW; "
+             "every rank must call bm_rbm_exchange_gather_dw first (DirectExchange.gather_dw())", what);
+    return 0;
+}
 
 struct ProfScope {
     bm_rbm *h; hipEvent_t b = nullptr;
@@ -534,9 +546,33 @@ int bm_rbm_destroy(bm_rbm *h) {
     return 0;
 }
 
+// Status words the device leaves behind (the stream `s` is idle up to the point of interest when this is called):
+// the direct exchange's time-out word and the chained launches' (bm_chain.h).  A failed chained launch is reported
+// ONCE - the results since the last check are invalid - and switches chaining off for this handle: later passes run as
+// per-pass launches instead of leaving the handle poisoned (round-4 advisor).
+static int check_device_status(bm_rbm *h) {
+    if (h->xchg_used) BM_TRY(xchg_check_status(h->xchg_used));      // a lost rank is an ERROR here, never a silent wrong sum
+    if (h->chain.status) {      // chained launches (bm_chain.h): an expired wait or a tile nobody computed is an ERROR
+        int st[2] = {0, 0};
+        BM_HIP(hipMemcpy(st, h->chain.status, sizeof(st), hipMemcpyDeviceToHost));
+        const long long expect = h->chain.tiles_expected & 0xffffffffLL;
+        if (st[0] != 0 || (long long)(unsigned)st[1] != expect) {
+            h->chain.mode = 0;                                   // per-pass launches from here on
+            h->chain.tiles_expected = 0;
+            BM_HIP(hipMemset(h->chain.status, 0, sizeof(st)));
+            BM_CHECK(st[0] == 0, "chained propagation launch failed (status %d: %s); the results since the last check are "
+                     "invalid, chained launches are now off for this handle", st[0],
+                     st[0] == CHAIN_ERR_TIMEOUT ? "a wait for a producing tile expired" : "not an 8-XCD device");
+            BM_CHECK(false, "chained propagation launches computed %u tiles, expected %lld; the results since the last check "
+                     "are invalid, chained launches are now off for this handle", (unsigned)st[1], expect);
+        }
+    }
+    return 0;
+}
+
 int bm_rbm_sync(bm_rbm *h) {
     BM_HIP(hipStreamSynchronize(h->stream));
-    if (h->xchg_used) BM_TRY(xchg_check_status(h->xchg_used));      // a lost rank is an ERROR here, never a silent wrong sum
+    BM_TRY(check_device_status(h));
     if (h->nonbinary) {
         int bad = 0;
         BM_HIP(hipMemcpy(&bad, h->nonbinary, sizeof(int), hipMemcpyDeviceToHost));
@@ -544,15 +580,6 @@ int bm_rbm_sync(bm_rbm *h) {
             BM_HIP(hipMemset(h->nonbinary, 0, sizeof(int)));
             BM_CHECK(false, "fast-binary mode: bm_rbm_gibbs was given hidden states that are not a {0,1} bitmap");
         }
-    }
-    if (h->chain.status) {      // chained launches (bm_chain.h): an expired wait or a tile nobody computed is an ERROR
-        int st[2] = {0, 0};
-        BM_HIP(hipMemcpy(st, h->chain.status, sizeof(st), hipMemcpyDeviceToHost));
-        BM_CHECK(st[0] == 0, "chained propagation launch failed (status %d: %s); results are invalid", st[0],
-                 st[0] == CHAIN_ERR_TIMEOUT ? "a wait for a producing tile expired" : "not an 8-XCD device");
-        BM_CHECK((long long)(unsigned)st[1] == (h->chain.tiles_expected & 0xffffffffLL),
-                 "chained propagation launches computed %u tiles, expected %lld; results are invalid", (unsigned)st[1],
-                 h->chain.tiles_expected & 0xffffffffLL);
     }
     return 0;
 }
@@ -584,6 +611,7 @@ int bm_rbm_set_param(bm_rbm *h, const char *name, const float *host, size_t n) {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
         BM_TRY((nm == "W" ? h->W : h->dW).upload(host));
         if (nm == "W") h->wt_valid = false;
+        else { h->dw_sharded = false; if (h->xchg_used) xchg_dw_replaced(h->xchg_used); }
         return 0;
     }
     DevBuf *b = find_vec(h, nm);
@@ -602,6 +630,7 @@ int bm_rbm_set_param_dev(bm_rbm *h, const char *name, const float *src_dev, size
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
         Mat &m = nm == "W" ? h->W : h->dW;
         if (nm == "W") h->wt_valid = false;
+        else { h->dw_sharded = false; if (h->xchg_used) xchg_dw_replaced(h->xchg_used); }
         BM_HIP(hipMemcpy2DAsync(m.p, (size_t)m.ld * sizeof(float), src_dev, (size_t)m.cols * sizeof(float),
                                 (size_t)m.cols * sizeof(float), m.rows, hipMemcpyDeviceToDevice, h->stream));
         return 0;
@@ -616,8 +645,10 @@ int bm_rbm_set_param_dev(bm_rbm *h, const char *name, const float *src_dev, size
 int bm_rbm_get_param(bm_rbm *h, const char *name, float *host, size_t n) {
     const std::string nm(name ? name : "");
     BM_HIP(hipStreamSynchronize(h->stream));
+    BM_TRY(check_device_status(h));        // never hand out variables computed from invalid tiles / a lost rank's sums
     if (nm == "W" || nm == "dW") {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
+        if (nm == "dW") BM_TRY(check_dw(h, "bm_rbm_get_param(dW)"));
         return (nm == "W" ? h->W : h->dW).download(host);
     }
     DevBuf *b = find_vec(h, nm);
@@ -638,6 +669,7 @@ int bm_rbm_stage(bm_rbm *h, int32_t slot) {
     // a slot that another thread is reading back must not be overwritten under it (any caller of the C API, not
     // only the Python bookkeeping of base.py: round-3 advisor)
     BM_CHECK(sg.readers.load() == 0, "stage slot %d is being read by bm_rbm_get_staged: use the other slot", (int)slot);
+    BM_TRY(check_dw(h, "bm_rbm_stage"));
     if (!sg.ev) {
         BM_TRY(sg.W.alloc(h->V, h->H)); BM_TRY(sg.dW.alloc(h->V, h->H));
         BM_TRY(sg.vb.alloc(h->V)); BM_TRY(sg.dvb.alloc(h->V)); BM_TRY(sg.sigma.alloc(h->V));
@@ -673,6 +705,14 @@ int bm_rbm_get_staged(bm_rbm *h, int32_t slot, const char *name, float *host, si
     BM_HIP(hipEventSynchronize(sg.ev));
     const size_t need = (size_t)h->V * h->H * sizeof(float);
     if (!h->stage_host) BM_HIP(hipHostMalloc((void **)&h->stage_host, need, hipHostMallocDefault));
+    if (h->chain.status) {
+        // the sticky error word of the chained launches (not the tile count: the training thread may be ahead of the
+        // device): a checkpoint must not be written from tiles a failed launch left invalid
+        BM_HIP(hipMemcpyAsync(h->stage_host, h->chain.status, sizeof(int), hipMemcpyDeviceToHost, h->stage_stream));
+        BM_HIP(hipStreamSynchronize(h->stage_stream));
+        BM_CHECK(*(const int *)h->stage_host == 0, "a chained propagation launch failed (status %d) before this snapshot: "
+                 "it is invalid (bm_rbm_sync reports and recovers)", *(const int *)h->stage_host);
+    }
     if (nm == "W" || nm == "dW") {
         BM_CHECK(n == (size_t)h->V * h->H, "variable '%s' has %zu elements, got %zu", name, (size_t)h->V * h->H, n);
         const Mat &m = nm == "W" ? sg.W : sg.dW;
@@ -706,6 +746,7 @@ int bm_rbm_seed(bm_rbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 
 int bm_rbm_set_row_offset(bm_rbm *h, int64_t row0) { h->row0 = row0; return 0; }
 
 int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k) {
+    BM_TRY(check_dw(h, "bm_rbm_train_step"));
     BM_TRY(run_chain(h, X_dev, B, k, nullptr, false, true));
     launch_update_fused(h, B, lr, mom);
     h->call++;
@@ -715,6 +756,7 @@ int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float 
 
 int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k,
                               float *out4) {
+    BM_TRY(check_dw(h, "bm_rbm_train_step_metrics"));
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
     BM_TRY(metrics_from_chain(h, B, out4));
     launch_update_fused(h, B, lr, mom);
@@ -735,6 +777,7 @@ int bm_rbm_train_step_metrics_async(bm_rbm *h, const float *X_dev, int32_t B, fl
         h->mring_B.resize(bm_rbm::MRING);
     }
     BM_CHECK(h->mring_n < bm_rbm::MRING, "%d metric fetches are pending: call bm_rbm_collect_metrics", h->mring_n);
+    BM_TRY(check_dw(h, "bm_rbm_train_step_metrics_async"));
     BM_TRY(run_chain(h, X_dev, B, k, nullptr));
     BM_TRY(metrics_from_chain(h, B, nullptr));
     hipLaunchKernelGGL(scal_to_host_kernel, dim3(1), dim3(64), 0, h->stream, (const double *)h->scal,
@@ -750,6 +793,10 @@ int bm_rbm_collect_metrics(bm_rbm *h, float *out4n, int32_t max_n, int32_t *out_
     BM_CHECK(h && out_n && (out4n || max_n == 0), "null argument");
     BM_CHECK(h->mring_n <= max_n, "%d fetches pending, room for %d", h->mring_n, (int)max_n);
     BM_HIP(hipStreamSynchronize(h->stream));
+    {   // the pending fetches are dropped either way: an error must not leave them for the next epoch's mean
+        const int rc = check_device_status(h);
+        if (rc) { h->mring_n = 0; *out_n = 0; return rc; }
+    }
     for (int i = 0; i < h->mring_n; ++i) metrics_to_out4(h, h->mring + (size_t)i * 6, h->mring_B[i], out4n + 4 * (size_t)i);
     *out_n = h->mring_n;
     h->mring_n = 0;
@@ -815,6 +862,7 @@ int bm_rbm_wait_grads(bm_rbm *h, int32_t slot) {
 }
 
 int bm_rbm_apply_step(bm_rbm *h, int32_t B_global, float lr, float mom) {
+    BM_TRY(check_dw(h, "bm_rbm_apply_step"));
     ProfScope _ps(h, KC_BIAS);
     RbmBiasArgs b;
     fill_bias(h, (float)B_global, lr, mom, b);

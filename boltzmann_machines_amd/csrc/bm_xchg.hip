@@ -406,6 +406,7 @@ static int xchg_check_status(bm_xchg *x) {
 }
 
 static void xchg_bind_user(bm_xchg *x, bm_xchg **slot) { if (x) x->user = slot; }
+static void xchg_dw_replaced(bm_xchg *x) { if (x) x->dw_stale = false; }
 
 extern "C" {
 
@@ -599,13 +600,15 @@ int bm_rbm_exchange_apply_direct(bm_rbm *h, bm_xchg *x, int32_t B_global, float 
     BM_CHECK(h && x, "null argument");
     BM_TRY(xchg_launch_apply(h, x, (float)B_global, lr, mom, 0));
     x->dw_stale = x->nranks > 1;
+    h->dw_sharded = x->dw_stale;       // readers of dW fail until bm_rbm_exchange_gather_dw (check_dw, bm_rbm.hip)
     return 0;
 }
 int bm_rbm_exchange_gather_dw(bm_rbm *h, bm_xchg *x) {
     BM_CHECK(h && x, "null argument");
-    if (!x->dw_stale) return 0;
+    if (!x->dw_stale) { h->dw_sharded = false; return 0; }
     BM_TRY(xchg_launch_apply(h, x, 1.f, 0.f, 0.f, 1));
     x->dw_stale = false;
+    h->dw_sharded = false;
     return 0;
 }
 

@@ -425,9 +425,11 @@ class DBM(EngineModel):
     def set_ais_accumulation(self, dtype='float64'):
         """How `log_Z` accumulates the AIS log-weights.  'float64' (default): per chain the difference of consecutive
         log p*, row sums and running sum in double, fixed order - deterministic and closer to the exactly enumerable
-        log Z.  'float32': LITERALLY the reference graph (dbm.py:650-660, :708-728) - every log p*_beta(x) formed and
-        added / subtracted in float32 in the graph's order (the reference's README notes the nats this loses at many
-        betas).  Both agree with the reference to the 1e-5 the parity bar asks for at the beta counts tested."""
+        log Z.  'float32': the reference graph's ORDER of float32 accumulation (dbm.py:650-660, :708-728) - every
+        log p*_beta(x) formed and added / subtracted in float32 in the graph's order (the reference's README notes the
+        nats this loses at many betas); the row sums inside one log p* are the engine's slot partials, not
+        TensorFlow's reduce_sum / einsum order, so this is the reference's arithmetic up to float32 round-off of
+        those sums, not bit for bit.  Both agree with the reference to the 1e-5 the parity bar asks for at the beta counts tested."""
         if dtype not in ('float32', 'float64'):
             raise ValueError("dtype must be 'float32' or 'float64'")
         self._ais_literal = dtype == 'float32'

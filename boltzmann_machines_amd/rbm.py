@@ -275,32 +275,41 @@ class BaseRBM(EngineModel):
                 for m in names:
                     results[m].append(vals[m])
             return 0
-        for start in range(0, N, self.batch_size):
-            B = min(self.batch_size, N - start)
-            self.iter_ += 1
-            if self.iter_ % every == 0:
-                if run_start is not None:
-                    eng.train_epoch(Xd, start - run_start, self.batch_size, lr, mom, k, row=run_start)
-                    run_start = None
-                if deferred:
-                    if pending >= eng.MAX_PENDING_METRICS:
-                        pending = collect()
-                    eng.train_step_metrics_async(Xd, B, lr, mom, k, row=start)
-                    pending += 1
+        try:
+            for start in range(0, N, self.batch_size):
+                B = min(self.batch_size, N - start)
+                self.iter_ += 1
+                if self.iter_ % every == 0:
+                    if run_start is not None:
+                        eng.train_epoch(Xd, start - run_start, self.batch_size, lr, mom, k, row=run_start)
+                        run_start = None
+                    if deferred:
+                        if pending >= eng.MAX_PENDING_METRICS:
+                            pending = collect()
+                        eng.train_step_metrics_async(Xd, B, lr, mom, k, row=start)
+                        pending += 1
+                    else:
+                        out = eng.train_step_metrics(Xd, B, lr, mom, k, row=start)
+                        vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
+                        for m in names:
+                            results[m].append(vals[m])
+                elif fused:
+                    if run_start is None:
+                        run_start = start
                 else:
-                    out = eng.train_step_metrics(Xd, B, lr, mom, k, row=start)
-                    vals = dict(msre=out[0], pll=out[1], l2_loss=out[2])
-                    for m in names:
-                        results[m].append(vals[m])
-            elif fused:
-                if run_start is None:
-                    run_start = start
-            else:
-                eng.train_step(Xd, B, lr, mom, k, row=start)
-        if run_start is not None:
-            eng.train_epoch(Xd, N - run_start, self.batch_size, lr, mom, k, row=run_start)
-        if pending:
-            collect()
+                    eng.train_step(Xd, B, lr, mom, k, row=start)
+            if run_start is not None:
+                eng.train_epoch(Xd, N - run_start, self.batch_size, lr, mom, k, row=run_start)
+            if pending:
+                pending = collect()
+        finally:
+            # an aborted epoch (KeyboardInterrupt, an engine error in a later batch) must not leave its deferred fetches
+            # in the ring: the next epoch's collect() would average them into ITS metrics (round-4 advisor)
+            if deferred and pending:
+                try:
+                    eng.collect_metrics()
+                except Exception:
+                    pass
         return {m: (np.mean(r) if r else None) for m, r in results.items()}
 
     def _run_val_metrics(self, Xvd, N):

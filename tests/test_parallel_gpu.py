@@ -47,7 +47,17 @@ def _worker(rank, world, port, out, fused=False, cost=1e-2):
     for step in range(3):
         dp.train_step(Xd, 0.05, 0.5, K)
     if fused:
-        own = eng.get('dW')                 # between updates a rank holds ITS slice of the momentum buffer ...
+        # between updates a rank holds ITS slice of the momentum buffer: every reader of dW refuses until the replicas
+        # are completed (round-4 advisor: a checkpoint or the unfused step would silently use inconsistent momentum)
+        for reader in (lambda: eng.get('dW'), lambda: eng.train_step(Xd, BL, 0.05, 0.5, K),
+                       lambda: eng.apply_step(world * BL, 0.05, 0.5)):
+            try:
+                reader()
+            except RuntimeError as e:
+                assert 'gather_dw' in str(e), e
+            else:
+                raise AssertionError('dW was read while it is sharded over the ranks')
+        eng.get('W')                        # the other variables are whole on every rank
         xchg.gather_dw()                    # ... the replicas are completed on demand
         xchg.gather_dw()                    # (a no-op the second time)
     eng.sync()
