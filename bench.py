@@ -669,10 +669,19 @@ def choose_collective(args, eng, rank, world, dist):
             x.set_timeout(float(os.environ.get('BM_XCHG_TIMEOUT_S', '20')))
             note = 'start-up self-check against the gloo all-reduce passed on every rank'
             if world > 1 and not args._shared_devices and not args.no_collective_race:
-                # ... and the faster of the two device collectives is used, by measurement on this very buffer
+                # ... and the faster of the two device collectives is used, by measurement on this very buffer.  Every
+                # rank takes the same branch: whether RCCL came up is agreed on first (a communicator that fails on ONE
+                # rank must not leave the others in a collective)
+                comm, err = None, ''
                 try:
                     comm = get_comm(rank, world)
-
+                except Exception as e:       # noqa: BLE001
+                    err = str(e)[:120]
+                have = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+                dist.all_reduce(have, op=dist.ReduceOp.MIN)
+                if int(have.item()) == 0:
+                    note += '; rccl could not be set up on every rank (%s): not raced' % (err or 'another rank failed',)
+                else:
                     def timed(fn, iters=30):
                         for _ in range(3):
                             fn()
@@ -686,12 +695,23 @@ def choose_collective(args, eng, rank, world, dist):
                         return float(t.item())
                     t_direct = timed(x.allreduce_grads)
                     t_rccl = timed(lambda: comm.allreduce_grads(eng))
-                    _h2d(grad, np.zeros(n, dtype=np.float32))
                     note += '; all-reduce of the %.1f MB buffer: direct %.1f us, rccl %.1f us' % (4e-6 * n, 1e6 * t_direct, 1e6 * t_rccl)
+                    if hasattr(x, 'exchange_apply') and hasattr(eng, 'H') and eng.H % 4 == 0 and not args.no_fused_exchange:
+                        # the fused launch (reduce-scatter -> update of the owned slice -> all-gather of W) on zero
+                        # gradients with lr = 0: the parameters do not move
+                        t_fused = timed(lambda: x.exchange_apply(B * world, 0.0, 0.0))
+                        x.gather_dw()
+                        note += ', fused exchange + update %.1f us (against rccl + apply_step as two launches)' % (1e6 * t_fused,)
+                    _h2d(grad, np.zeros(n, dtype=np.float32))
+                    st = torch.tensor([int(x.status())], dtype=torch.int32)
+                    dist.all_reduce(st, op=dist.ReduceOp.MAX)
+                    note += '; exchange status after the race: %d on every rank' % int(st.item()) if int(st.item()) == 0 else \
+                        '; a wait expired during the race (status %d)' % int(st.item())
+                    if int(st.item()) != 0:
+                        x.close()
+                        return 'rccl', note + ' -> rccl'
                     if t_rccl < t_direct:
                         return 'rccl', note + ' -> rccl'
-                except Exception as e:       # noqa: BLE001 - RCCL unusable: the direct path stands
-                    note += '; rccl could not be timed (%s)' % (str(e)[:120],)
             return 'direct', note
         note = 'direct exchange failed its start-up self-check on %d rank(s): fell back' % int(flag.item())
         x.close()
@@ -729,6 +749,28 @@ def check_data_parallel_run(wl, args, rank, world, dist):
         sys.stderr.write('bench: a wait of the direct exchange expired (status %d): the run is invalid\n' % worst)
         sys.exit(3)
     return {'exchange_status': 0, 'replicas_identical': bool(hi == -neg_lo)}
+
+
+def start_guardian(line_out, record):
+    """fork a child that prints `record` as the JSON line if this process dies before emit(); returns the write end of
+    the pipe (None if fork is unavailable).  The child touches nothing but the pipe and the duplicated stdout."""
+    try:
+        r, w = os.pipe()
+        line = json.dumps(record) + '\n'
+        line_out.flush()
+        pid = os.fork()
+    except OSError:
+        return None
+    if pid == 0:
+        try:
+            os.close(w)
+            got = os.read(r, 1)            # b'd': the parent is about to print; b'': the parent died
+            if got != b'd':
+                os.write(line_out.fileno(), line.encode())
+        finally:
+            os._exit(0)
+    os.close(r)
+    return w
 
 
 def _h2d(darr, host):
@@ -897,7 +939,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('gloo', rank=rank, world_size=world)     # rendezvous + timing barrier only
+        # rendezvous + timing barrier only.  A bounded time-out: a rank that died leaves the others in a gloo collective;
+        # they must raise and exit non-zero, not wait for gloo's default half hour
+        import datetime
+        dist.init_process_group('gloo', rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=float(os.environ.get('BM_BENCH_GLOO_TIMEOUT_S', '240'))))
 
     def barrier():
         torch.cuda.synchronize()         # device-wide: covers the engine's streams
@@ -919,9 +965,18 @@ def main():
     if rank == 0 and args.config == 'rbm' and args._shared_devices:
         out['config']['devices_shared'] = 'DRY RUN: %d ranks on %d device(s); not a scaling figure' % (world, ndev)
 
+    guardian = [None]
+
     def emit():
         if rank != 0:
             return
+        if guardian[0] is not None:
+            try:
+                os.write(guardian[0], b'd')    # the parent prints its own line: the guardian leaves silently
+                os.close(guardian[0])
+            except OSError:
+                pass
+            guardian[0] = None
         # the ONE line of the contract is the last thing on stdout: flush what C libraries (the RCCL banner under
         # NCCL_DEBUG=VERSION) still hold in their stdio buffers first
         try:
@@ -939,6 +994,11 @@ def main():
         import threading
         others = {}
         if rank == 0:
+            # The headline is measured; what follows (eight more workloads, collectives included at N > 1) must not be
+            # able to lose it.  The watchdog below covers a hang; a GUARDIAN child covers a hard crash (a fault inside a
+            # kernel or a collective kills the process without running any Python): it holds the finished headline
+            # line and prints it if the parent's end of the pipe closes without the 'done' byte.
+            guardian[0] = start_guardian(line_out, dict(out, other_configs={'_aborted': 'the process died during the other_configs passes'}))
             out['other_configs'] = others
         done = threading.Event()
 

@@ -73,6 +73,10 @@ struct NoSide {
     // pipeline fill requests the P pieces first, calls wait_inputs() (spin on the producers' flags), then the Q pieces;
     // kCohQ: every Q load bypasses the CU's vector L1 (sc1), which may hold the previous contents of those lines.
     static constexpr bool kSplitFill = false, kCohQ = false;
+    // kCanAbort (bm_dbmchain.h): wait_inputs() may set `aborted` (workgroup-uniform): the main loop returns at once, with
+    // the weight pieces of the fill still in flight (the caller waits vmcnt(0) and meets at a barrier before the LDS ring
+    // is used again)
+    static constexpr bool kCanAbort = false;
     __device__ __forceinline__ void wait_inputs() {}
     __device__ __forceinline__ void fill() {}
     __device__ __forceinline__ void drain() {}
@@ -491,7 +495,6 @@ __device__ __forceinline__ void dma_chunk(const KRange &kr, const DmaPlan<G, DW>
 template <int QL, class G, bool FAST, bool SEG2, int PL = KM, bool COHQ = false>
 __device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, int nch1, int i0, int j0, int c, int tid) {
     constexpr int BK = G::BK;
-    static_assert(!COHQ || !SEG2, "coherent Q loads: single segment");
     if (!SEG2) {
         g2r<PL, G::TI, BK, G::NT, FAST>(r.p, kr.P1.ptr, kr.P1.ld, kr.P1.nx, kr.P1.vec, i0, c * BK, kr.K1, tid);
         g2r<QL, G::TJ, BK, G::NT, FAST, COHQ>(r.q, kr.Q1.ptr, kr.Q1.ld, kr.Q1.nx, kr.Q1.vec, j0, c * BK, kr.K1, tid);
@@ -501,8 +504,8 @@ __device__ __forceinline__ void load_chunk(ChunkRegs<G> &r, const KRange &kr, in
         const int K = sel_i(kr.K1, kr.K2, m);
         g2r<PL, G::TI, BK, G::NT, FAST>(r.p, sel_p(kr.P1.ptr, kr.P2.ptr, m), sel_i(kr.P1.ld, kr.P2.ld, m),
                                         sel_i(kr.P1.nx, kr.P2.nx, m), sel_i(kr.P1.vec, kr.P2.vec, m), i0, kc * BK, K, tid);
-        g2r<QL, G::TJ, BK, G::NT, FAST>(r.q, sel_p(kr.Q1.ptr, kr.Q2.ptr, m), sel_i(kr.Q1.ld, kr.Q2.ld, m),
-                                        sel_i(kr.Q1.nx, kr.Q2.nx, m), sel_i(kr.Q1.vec, kr.Q2.vec, m), j0, kc * BK, K, tid);
+        g2r<QL, G::TJ, BK, G::NT, FAST, COHQ>(r.q, sel_p(kr.Q1.ptr, kr.Q2.ptr, m), sel_i(kr.Q1.ld, kr.Q2.ld, m),
+                                              sel_i(kr.Q1.nx, kr.Q2.nx, m), sel_i(kr.Q1.vec, kr.Q2.vec, m), j0, kc * BK, K, tid);
     }
 }
 
@@ -674,7 +677,9 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         // K1 >= PF * BK: chunks 0 .. PF-1 are full DMA chunks).  The P pieces (weights: constant during the launch) go
         // out first, then the wave waits for the producers of its Q rows, then the Q pieces.  The vector-memory queue
         // completes in order: with only the Q pieces of chunk PF-1 .. 2 still in flight, chunks 0 and 1 are complete.
-        static_assert(FAST && !SEG2 && STG == STG_DMA && DW == G::NW, "chained fill");
+        // A second segment (bm_dbmchain.h) changes nothing here: the fill only touches segment 1 (host: K1 >= PF * BK), and
+        // wait_inputs() waits for the producers of BOTH Q operands.
+        static_assert(FAST && STG == STG_DMA && DW == G::NW, "chained fill");
         const unsigned l0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
         const unsigned lP = l0 + (unsigned)w * 1024u, lQ = l0 + (unsigned)(NBUF * P_BUF * 4) + (unsigned)w * 1024u;
 #pragma unroll
@@ -687,6 +692,7 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         side.fill();
         __builtin_amdgcn_sched_barrier(0);
         side.wait_inputs();
+        if constexpr (Side::kCanAbort) { if (side.aborted) return; }
 #pragma unroll
         for (int c = 0; c < PF; ++c) {
             const char *qb = (const char *)kr.Q1.ptr + (size_t)c * ((QL == KM) ? (size_t)BK * kr.Q1.ld * 4 : (size_t)BK * 4);

@@ -164,7 +164,7 @@ template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
 // act_kernel's side work for the main loop's pipeline fill
 template <int E, class Rng> struct ActSide {
     static constexpr bool kFinalSync = false;    // one pipeline per kernel: waves enter the epilogue as they finish
-    static constexpr bool kSplitFill = false, kCohQ = false;
+    static constexpr bool kSplitFill = false, kCohQ = false, kCanAbort = false;
     const float *bias, *sigma;
     const float *prev_row;       // mean-field: &prev[j][ib0] when the row is valid, else null
     int ib0, I, with_rng;

@@ -26,7 +26,7 @@ def _inputs(world=2):
     return W, Xg
 
 
-def _worker(rank, world, port, out, fused=False, cost=1e-2):
+def _worker(rank, world, port, out, fused=False, cost=1e-2, skew_rank=-1, die_rank=-1):
     sys.path.insert(0, ROOT)
     KW = dict(sample_v_states=True, l2=1e-3, sparsity_cost=cost)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -44,7 +44,30 @@ def _worker(rank, world, port, out, fused=False, cost=1e-2):
                                   fused=xchg if fused else None)
     assert (dp.fused is not None) == bool(fused)
     Xd = as_device(Xg[rank * BL:(rank + 1) * BL])
+    if die_rank >= 0:
+        # a rank that disappears mid-run: the survivors' waits must expire (bounded), the status word turn sticky and
+        # sync() raise - within the time-out, never a hang and never a silently wrong sum
+        import time
+        xchg.set_timeout(1.0)
+        dp.train_step(Xd, 0.05, 0.5, K)
+        eng.sync()
+        if rank == die_rank:
+            os._exit(0)                          # no clean-up, no farewell: what a crashed process looks like
+        t0 = time.time()
+        try:
+            for step in range(2):
+                dp.train_step(Xd, 0.05, 0.5, K)
+            eng.sync()
+        except RuntimeError as e:
+            with open(out + '.r%d.err' % rank, 'w') as f:
+                f.write('%.2f %s' % (time.time() - t0, e))
+            os._exit(0)
+        os._exit(7)                              # two updates "succeeded" without one of the ranks
     for step in range(3):
+        if rank == skew_rank:                    # skewed arrivals, what a real fabric adds: 50 ms late every step
+            import time
+            eng.sync()
+            time.sleep(0.05)
         dp.train_step(Xd, 0.05, 0.5, K)
     if fused:
         # between updates a rank holds ITS slice of the momentum buffer: every reader of dW refuses until the replicas
@@ -111,6 +134,37 @@ def test_dp_direct_exchange_on_gpu(gpu_lib, tmp_path, world, fused, cost):
     for step in range(3):
         ref.train_step(Xg, 0.05, 0.5, K)
     np.testing.assert_allclose(rs[0]['W'], ref.p['W'], rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_dp_direct_exchange_with_a_late_rank(gpu_lib, tmp_path, fused):
+    """one rank arrives 50 ms late at every exchange (flags, generations and the staging buffers must not care):
+    bit-identical to the run without the delay"""
+    import torch.multiprocessing as mp
+    world = 3
+    outs = []
+    for tag, skew in (('ontime', -1), ('late', 1)):
+        out = str(tmp_path / tag)
+        mp.spawn(_worker, args=(world, _free_port(), out, fused, 1e-2, skew), nprocs=world, join=True)
+        outs.append([np.load(out + '.r%d.npz' % r) for r in range(world)])
+    for r in range(world):
+        for n in outs[0][r].files:
+            assert np.array_equal(outs[0][r][n].view(np.uint32), outs[1][r][n].view(np.uint32)), (r, n)
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_dp_direct_exchange_when_a_rank_dies(gpu_lib, tmp_path, fused):
+    """a rank exits without a word after the first update: every survivor's next exchange must fail with an error
+    inside the time-out (1 s per wait here) - no hang, no result built on a partial sum"""
+    import torch.multiprocessing as mp
+    world = 3
+    out = str(tmp_path / 'dead')
+    mp.spawn(_worker, args=(world, _free_port(), out, fused, 1e-2, -1, 2), nprocs=world, join=True)
+    for r in (0, 1):
+        with open(out + '.r%d.err' % r) as f:
+            secs, msg = f.read().split(' ', 1)
+        assert float(secs) < 20.0, secs
+        assert 'expired' in msg or 'exchange' in msg, msg
 
 
 DV, DNH, DN, DM = 36, [24, 16], 12, 8
