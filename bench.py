@@ -350,7 +350,7 @@ class RbmGibbs(Workload):
         n, _, mode = self.eng.chain_stats()
         if n:
             return ('chained: the %d passes of a call are workgroups of ONE launch that hand their rows over inside an '
-                    "XCD's L2 (csrc/bm_chain.h; BM355_CHAIN=%d; bit-identical to the per-pass launches)" % (2 * self.k, mode))
+                    "XCD's L2 (csrc/bm_chain.h; BM355_DEBUG=chain=%d; bit-identical to the per-pass launches)" % (2 * self.k, mode))
         return 'one launch per pass'
 
     def report(self, args, world, dt, ev_ms):

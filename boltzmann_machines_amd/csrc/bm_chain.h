@@ -48,7 +48,7 @@ struct ChainArgs {
     unsigned *claim;          // [8][32] (128-byte spacing): this launch's claim counters, zero at launch
     unsigned *claim_zero;     // the counters a LATER launch will use: zeroed here by workgroup 0
     int *status;              // [0] != 0: a wait expired (sticky; results invalid)   [1] tiles computed (all launches)
-    long long *stamps;        // developer timeline (BM355_CHAIN_STAMPS=file): [block][16 tiles][8] 100 MHz clock values, else null
+    long long *stamps;        // developer timeline (BM355_DEBUG=chain_stamps=file): [block][16 tiles][8] 100 MHz clock values, else null
     int tp0[CHAIN_MAXPH + 1]; // prefix sums of the tile columns per pass
     ChainPhase ph[CHAIN_MAXPH];
 };
@@ -124,7 +124,7 @@ __device__ __forceinline__ void chain_tile(const ActArgs &a, int i0, int j0, flo
     if (stamps && tid == 0) stamps[3] = wall_clock64();
 }
 
-// c.dbg (BM355_CHAIN_DBG): measurements only - 2: no waits (WRONG results: prices the hand-overs), 4: poll without s_sleep.
+// c.dbg (BM355_DEBUG=chain_dbg): measurements only - 2: no waits (WRONG results: prices the hand-overs), 4: poll without s_sleep.
 // COH = false (plain Q loads) measured the same time as sc1 loads and is not instantiated.
 template <bool COH>
 __global__ __launch_bounds__(GeoChain::NT, 1) void act_chain_kernel(ChainArgs c) {
@@ -202,19 +202,19 @@ struct ChainState {
     unsigned launches = 0;
     long long tiles_expected = 0;                    // what status[1] must read when the stream is idle
     bool on = false;                                 // recording
-    int mode = -1;                                   // BM355_CHAIN: 0 off, 1 auto (default), 2 force where legal
+    int mode = -1;                                   // BM355_DEBUG=chain: 0 off, 1 auto (default), 2 force where legal
     int ncu = 0;
     std::vector<ActArgs> rec;
     // per recorded pass: an x-major P operand (W^T) the PER-PASS launch should use instead of rec[i].P1 (ptr null: none).
     // A chained launch keeps the k-major W: with both W and W^T streaming through an XCD's 4 MiB L2 neither stays
     // resident (measured: 26.0 against 25.2 us per sweep).
     std::vector<Operand> alt_p;
-    long long *stamps = nullptr;                     // BM355_CHAIN_STAMPS=file: timeline of the LAST chained launch, dumped at release
+    long long *stamps = nullptr;                     // BM355_DEBUG=chain_stamps=file: timeline of the LAST chained launch, dumped at release
     static constexpr int CLAIM_SLOTS = 16;
     static constexpr size_t STAMP_WORDS = 256 * 16 * 8;
     void release() {
         if (stamps) {
-            const char *f = getenv("BM355_CHAIN_STAMPS");
+            const char *f = bm::dbg("chain_stamps");
             std::vector<long long> hst(STAMP_WORDS);
             if (f && hipMemcpy(hst.data(), stamps, STAMP_WORDS * 8, hipMemcpyDeviceToHost) == hipSuccess) {
                 FILE *fp = fopen(f, "wb");
@@ -231,7 +231,7 @@ struct ChainState {
 
 static inline int chain_mode(ChainState &cs) {
     if (cs.mode < 0) {
-        const char *e = getenv("BM355_CHAIN");
+        const char *e = bm::dbg("chain");
         cs.mode = e ? atoi(e) : 1;
         hipDeviceProp_t pr; int d = 0, nxcc = 0; (void)hipGetDevice(&d);
         const bool have = hipGetDeviceProperties(&pr, d) == hipSuccess;
@@ -335,8 +335,8 @@ static inline int chain_flush(ChainState &cs, hipStream_t st, int maxB) {
         cs.tiles_expected += (long long)tiles * tiles_j;
         // one workgroup per CU (96 KiB of LDS each), fewer when the whole launch has fewer tiles
         const int grid = std::min(cs.ncu, std::max(8, tiles * tiles_j));
-        static const int dbg = getenv("BM355_CHAIN_DBG") ? atoi(getenv("BM355_CHAIN_DBG")) : 0;
-        if (getenv("BM355_CHAIN_STAMPS") && !cs.stamps && hipMalloc((void **)&cs.stamps, ChainState::STAMP_WORDS * 8) != hipSuccess) cs.stamps = nullptr;
+        static const int dbg = bm::dbg("chain_dbg") ? atoi(bm::dbg("chain_dbg")) : 0;
+        if (bm::dbg("chain_stamps") && !cs.stamps && hipMalloc((void **)&cs.stamps, ChainState::STAMP_WORDS * 8) != hipSuccess) cs.stamps = nullptr;
         if (cs.stamps) (void)hipMemsetAsync(cs.stamps, 0, ChainState::STAMP_WORDS * 8, st);
         c.stamps = cs.stamps;
         c.dbg = dbg;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <map>
@@ -11,6 +12,31 @@
 namespace bm {
 
 void set_error(const char *fmt, ...);
+
+// Developer switches live in ONE environment variable: BM355_DEBUG="name=value,name=value" (DESIGN.md 9 lists the names:
+// forced tile geometries, the launch tuner's log, chained-launch modes and measurement aids).  dbg("name") returns the value
+// text or null.  None of them changes results; the variables a USER may set (BM355_HOST_WAIT, BM355_FAST_BINARY,
+// BM355_AIS_LITERAL, BM355_DATA_PARALLEL, BM355_STAGED_SAVE, BM355_RCCL_LIB, BM_XCHG_TIMEOUT_S) keep names of their own.
+static inline const char *dbg(const char *name) {
+    static const std::map<std::string, std::string> *tab = [] {
+        auto *m = new std::map<std::string, std::string>();
+        const char *e = getenv("BM355_DEBUG");
+        std::string cur;
+        for (const char *c = e ? e : ""; ; ++c) {
+            if (*c == ',' || *c == ';' || *c == ' ' || *c == 0) {
+                if (!cur.empty()) {
+                    const size_t q = cur.find('=');
+                    (*m)[q == std::string::npos ? cur : cur.substr(0, q)] = q == std::string::npos ? std::string("1") : cur.substr(q + 1);
+                }
+                cur.clear();
+                if (*c == 0) break;
+            } else cur += *c;
+        }
+        return m;
+    }();
+    const auto it = tab->find(name);
+    return it == tab->end() ? nullptr : it->second.c_str();
+}
 
 #define BM_HIP(expr)                                                                          \
     do {                                                                                      \

@@ -92,15 +92,15 @@ struct bm_dbm {
     int64_t row0 = 0, prow0 = 0;
     // mean-field loop + particle sweeps of one update as ONE launch (bm_dbmchain.h)
     struct Dch {
-        int mode = -1, ncu = 0;                    // BM355_DBM_CHAIN: 0 off (default: measured no gain, see below), 1 auto, 2 wherever legal
+        int mode = -1, ncu = 0;                    // BM355_DEBUG=dbm_chain: 0 off (default: measured no gain, see below), 1 auto, 2 wherever legal
         unsigned *flags_mf = nullptr, *flags_pc = nullptr, *claim = nullptr, *words = nullptr;
         int *status = nullptr;                     // [0] != 0: a wait expired (reported once by bm_dbm_sync)
         unsigned gen = 0, launches = 0;
         Mat mu_c[MAXL];                            // the third mean-field buffer
         bool have_c = false;
         long long used = 0;                        // updates that took this path (bm_dbm_chain_stats)
-        long long *stamps = nullptr;               // BM355_DCH_STAMPS=file (measurements): timeline of the LAST chained launch
-        hipEvent_t t0 = nullptr, t1 = nullptr;     // BM355_DCH_TIME=1 (measurements): duration of the chained launches
+        long long *stamps = nullptr;               // BM355_DEBUG=dch_stamps=file (measurements): timeline of the LAST chained launch
+        hipEvent_t t0 = nullptr, t1 = nullptr;     // BM355_DEBUG=dch_time=1 (measurements): duration of the chained launches
         double t_ms = 0.0; long long t_n = 0;
     } dch;
     std::vector<ActArgs> *rec = nullptr;           // non-null: layer updates are recorded, not launched (dbm_chain_update)
@@ -158,9 +158,9 @@ static int fast_build_planes(bm_dbm *h, hipStream_t st = nullptr, bool skip_t0 =
 
 // Single-segment passes read their weights x-major ([i][k], k contiguous: one ds_read_b128 per 16 k and lane where the
 // k-major image needs four ds_read_b32; 12.95 -> 12.5 us per pass at 784 x 1024, bm_rbm.hip) - the engine keeps W_l and
-// W_l^T anyway, so the x-major image of either direction is the OTHER matrix.  BM355_DBM_XM=0: k-major as before.
+// W_l^T anyway, so the x-major image of either direction is the OTHER matrix.  BM355_DEBUG=dbm_xm=0: k-major as before.
 static bool dbm_xm() {
-    static const bool on = !(getenv("BM355_DBM_XM") && atoi(getenv("BM355_DBM_XM")) == 0);
+    static const bool on = !(bm::dbg("dbm_xm") && atoi(bm::dbg("dbm_xm")) == 0);
     return on;
 }
 
@@ -518,7 +518,7 @@ static int dbm_chain_mode(bm_dbm *h) {
         // OFF unless asked for: bit-exact, but measured at 784-512-1024 x 512 it ties with the per-pass launches + the particle
         // sweeps on a second stream (1.499 vs 1.497 ms per update at 50 sweeps, 1.03 vs 1.00 ms at 29;
         // profiles/r5_dbm_chain_timeline.txt says why)
-        const char *e = getenv("BM355_DBM_CHAIN");
+        const char *e = bm::dbg("dbm_chain");
         d.mode = e ? atoi(e) : 0;
         hipDeviceProp_t pr; int dev = 0, nxcc = 0; (void)hipGetDevice(&dev);
         const bool have = hipGetDeviceProperties(&pr, dev) == hipSuccess;
@@ -614,7 +614,7 @@ static int dbm_chain_update(bm_dbm *h, const float *X_dev, int k, int *out_n, bo
     }
     BM_HIP(hipMemsetAsync(d.words, 0, NWORDS * 4, h->stream));
     c.gen = d.gen;
-    static const int dbg = getenv("BM355_CHAIN_DBG") ? atoi(getenv("BM355_CHAIN_DBG")) : 0;
+    static const int dbg = bm::dbg("chain_dbg") ? atoi(bm::dbg("chain_dbg")) : 0;
     c.dbg = dbg;
     c.flags_mf = d.flags_mf; c.flags_pc = d.flags_pc;
     c.claim = d.claim + (size_t)(d.launches % CLAIM_SLOTS) * 8 * 32;
@@ -636,7 +636,7 @@ static int dbm_chain_update(bm_dbm *h, const float *X_dev, int k, int *out_n, bo
     c.pc_sweeps = k; c.J_pc = h->M; c.tiles_pc = h->M / G::TJ;
     // slots for particle tiles per sweep of the main sequence: what the h1 pass leaves idle of a team's 32 workgroups
     c.slots = 32 - c.mf[0].ntile > 0 ? 32 - c.mf[0].ntile : 0;
-    static const int slots_env = getenv("BM355_DCH_SLOTS") ? atoi(getenv("BM355_DCH_SLOTS")) : -1;     // measurements only
+    static const int slots_env = bm::dbg("dch_slots") ? atoi(bm::dbg("dch_slots")) : -1;     // measurements only
     if (slots_env >= 0) c.slots = slots_env;
     c.pv[0] = h->v.p; c.pv[1] = h->v_new.p; c.ld_v = h->v.ld;
     BM_CHECK(h->v_new.ld == h->v.ld, "particle buffers of different pitch");
@@ -646,13 +646,13 @@ static int dbm_chain_update(bm_dbm *h, const float *X_dev, int k, int *out_n, bo
     }
     c.prow0 = h->prow0;
     {
-        static const char *sf = getenv("BM355_DCH_STAMPS");
+        static const char *sf = bm::dbg("dch_stamps");
         const size_t nst = (size_t)256 * DCH_STAMP_TILES * 8;
         if (sf && !d.stamps && hipMalloc((void **)&d.stamps, nst * 8) != hipSuccess) d.stamps = nullptr;
         if (d.stamps) BM_HIP(hipMemsetAsync(d.stamps, 0, nst * 8, h->stream));
         c.stamps = d.stamps;
     }
-    static const bool timing = getenv("BM355_DCH_TIME") && atoi(getenv("BM355_DCH_TIME")) != 0;
+    static const bool timing = bm::dbg("dch_time") && atoi(bm::dbg("dch_time")) != 0;
     if (timing) {
         if (!d.t0) { BM_HIP(hipEventCreate(&d.t0)); BM_HIP(hipEventCreate(&d.t1)); }
         BM_HIP(hipEventRecord(d.t0, h->stream));
@@ -698,7 +698,7 @@ static int dbm_chain_update(bm_dbm *h, const float *X_dev, int k, int *out_n, bo
 // between a fork event (everything enqueued so far, i.e. the previous parameter update) and a join event the main
 // stream waits for before anything reads the particles.  Same kernels, same RNG streams: results do not change.
 static bool pcd_overlap_ok(const bm_dbm *h) {
-    static const bool off = getenv("BM355_DBM_OVERLAP") && atoi(getenv("BM355_DBM_OVERLAP")) == 0;
+    static const bool off = bm::dbg("dbm_overlap") && atoi(bm::dbg("dbm_overlap")) == 0;
     if (off || h->updates_seen < 2) return false;          // the first updates tune their launches undisturbed
     for (int i = 0; i < h->L; ++i) if (h->multinomial(i)) return false;     // one logits row store per layer
     return true;
@@ -934,7 +934,7 @@ int bm_dbm_destroy(bm_dbm *h) {
     h->mfblk.release();
     h->xw0.release();
     if (h->dch.stamps) {
-        const char *f = getenv("BM355_DCH_STAMPS");
+        const char *f = bm::dbg("dch_stamps");
         const size_t nst = (size_t)256 * DCH_STAMP_TILES * 8;
         std::vector<long long> hst(nst);
         if (f && hipMemcpy(hst.data(), h->dch.stamps, nst * 8, hipMemcpyDeviceToHost) == hipSuccess) {

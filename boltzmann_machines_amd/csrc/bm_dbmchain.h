@@ -65,7 +65,7 @@ struct DchArgs {
     float *pv[2]; int ld_v;
     float *ph[2][2]; int ld_h[2];  // [buffer][layer]
     long long prow0;
-    long long *stamps;             // developer timeline (BM355_DCH_STAMPS=file): [block][DCH_STAMP_TILES][8] 100 MHz clock values, else null
+    long long *stamps;             // developer timeline (BM355_DEBUG=dch_stamps=file): [block][DCH_STAMP_TILES][8] 100 MHz clock values, else null
 };
 constexpr int DCH_STAMP_TILES = 160;
 static_assert(sizeof(DchArgs) <= 4096, "kernel arguments");

@@ -963,7 +963,7 @@ __device__ __forceinline__ void lane_outputs(const f32x4 (&acc)[G::MI][G::NJ], i
 //     so that the gj j-panels of a group stay L2 resident while the i-panels stream past them (the 3072 x 5000 outer
 //     products: 6.3 MB of X / v column panels per slab did not fit the L2 and were re-streamed once per tile row,
 //     683 MB per launch for 124 MB of operands).
-// xi, xj, gj are chosen on the host by make_tile_map (modelled fill traffic; BM355_XCD_MAP=xi:gj overrides).
+// xi, xj, gj are chosen on the host by make_tile_map (modelled fill traffic; BM355_DEBUG=xcd_map=xi:gj overrides).
 // Rectangle sizes and the number of blocks an XCD receives differ by a few tiles: tiles beyond an XCD's block count
 // are handed, in a fixed order, to the XCDs with spare blocks.
 struct TileMap {
@@ -980,13 +980,13 @@ struct TileMap {
     unsigned int spare[8];
 };
 
-// force_xi: 0 = the traffic model's choice (or BM355_XCD_MAP=xi[:gj]); 8 / 4 / 2 / 1 = that grid; -1 = the slab order
+// force_xi: 0 = the traffic model's choice (or BM355_DEBUG=xcd_map=xi[:gj]); 8 / 4 / 2 / 1 = that grid; -1 = the slab order
 // (the launch tuner measures all five per shape)
 static inline TileMap make_tile_map(int tiles_i, int tiles_j, double bytes_i, double bytes_j, int force_xi = 0) {
     // bytes_i / bytes_j: operand bytes one tile row / column pulls in (K * tile extent * 4)
     static int env_xi = -1, env_gj = 0;
     if (env_xi < 0) {
-        const char *e = getenv("BM355_XCD_MAP");
+        const char *e = bm::dbg("xcd_map");
         env_xi = 0;
         if (e) { env_xi = atoi(e); const char *c = strchr(e, ':'); env_gj = c ? atoi(c + 1) : 0; }
     }

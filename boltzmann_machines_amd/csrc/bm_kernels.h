@@ -424,7 +424,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tma
 // [tj0, tj1): the first chunks of tile tj+1 are requested BEFORE the epilogue of tile tj runs, the bias / sigma
 // loads and the DMA plan of the weight planes are done once per strip.
 struct Bf3Strip { int tiles_i, tiles_j, strips, abl; };  // grid = tiles_i * strips; strip s of row ti: blocks ti * strips + s
-                                                         // abl (BM355_BF3_ABL, measurements only): 1 no epilogue, 2 no K loop
+                                                         // abl (BM355_DEBUG=bf3_abl, measurements only): 1 no epilogue, 2 no K loop
 
 template <class G, bool SEG2, int MINW>
 __global__ __launch_bounds__(G::NT, MINW) void act_bf3_kernel(ActArgs a, Bf3Strip sp) {
@@ -1662,14 +1662,14 @@ static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
 // fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
 // ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
 // sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
-// tile columns.  BM355_BF3_GEO=8|4|2 forces one.
+// tile columns.  BM355_DEBUG=bf3_geo=8|4|2 forces one.
 template <class G, int WGS_PER_CU>
 static inline void launch_act_bf3_geo(const ActArgs &a, hipStream_t st) {
     static int ncu = 0;
     if (!ncu) { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); ncu = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
     Bf3Strip sp;
     sp.tiles_i = (a.I + G::TI - 1) / G::TI; sp.tiles_j = (a.J + G::TJ - 1) / G::TJ;
-    static const int abl_env = getenv("BM355_BF3_ABL") ? atoi(getenv("BM355_BF3_ABL")) : 0;
+    static const int abl_env = bm::dbg("bf3_abl") ? atoi(bm::dbg("bf3_abl")) : 0;
     sp.abl = abl_env;
     sp.strips = (ncu * WGS_PER_CU) / sp.tiles_i;
     if (sp.strips < 1) sp.strips = 1;
@@ -1697,11 +1697,11 @@ static inline void launch_act_bf3_as(int geo, const ActArgs &a, hipStream_t st) 
 // with one HIP event pair around TUNE_REP back-to-back launches, best of TUNE_ROUNDS rounds.
 // After that the launch path is one table lookup: no event, no allocation, no synchronisation
 // (round 1 rotated the candidates through the first 12 real launches, which put slower
-// geometries and event markers into short timed runs).  BM355_ACT_GEO=4|8|1|3 forces one
-// geometry (experiments, tests); BM355_TUNE_LOG=1 prints the decisions.
+// geometries and event markers into short timed runs).  BM355_DEBUG=act_geo=4|8|1|3 forces one
+// geometry (experiments, tests); BM355_DEBUG=tune_log=1 prints the decisions.
 static inline int act_geo_override() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("BM355_ACT_GEO"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char *e = bm::dbg("act_geo"); v = e ? atoi(e) : 0; }
     return v;
 }
 // geo: tile geometry 8 | 4 | 1 | 3, + 100 for register staging of the full chunks (default: LDS-DMA)
@@ -1833,7 +1833,7 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
     // one of the four; which one is fastest also depends on how the panels fall onto the memory channels)
     float xi_us[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     static const int cand_xi[5] = {8, 4, 2, 1, -1};
-    static const bool tune_xi = !(getenv("BM355_XCD_MAP") || (getenv("BM355_TUNE_XCD") && atoi(getenv("BM355_TUNE_XCD")) == 0));
+    static const bool tune_xi = !(bm::dbg("xcd_map") || (bm::dbg("tune_xcd") && atoi(bm::dbg("tune_xcd")) == 0));
     T.xi = -1;                                   // the slab order unless a grid is measurably (>= 2 %) faster
     if (tune_xi) {
         for (int round = 0; round < TUNE_ROUNDS; ++round)
@@ -1852,7 +1852,7 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
         if (xi_us[bx] < 0.98f * xi_us[4]) T.xi = cand_xi[bx];
     } else T.xi = 0;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
+    static const bool log = bm::dbg("tune_log") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us, dma: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; "
                         "reg: 8w %.1f, 64x32 %.1f, 32x32 %.1f, 32x32/bk32 %.1f; 64x64 8w: %.1f; 64x32/bk32 x3: %.1f, x2: %.1f; 64x64/bk32 x2: %.1f)\n",
@@ -1866,10 +1866,10 @@ static inline void tune_act_shape(const ActArgs &a, hipStream_t st, ActTune &T, 
 // fast-binary launches: three tile geometries (2: 64 x 32 tiles, two workgroups per CU; 4: 64 x 64, one; 8: 128 x 32
 // with 8 waves), measured once per shape like the fp32 ones.  Which one wins follows the tile count and K, not one
 // rule: 20000 AIS chains take 2, the 3072 x 256 x 5000 top-down pass of BASELINE configs[2] takes 8 or 2 (68 / 71 us)
-// where 4 needs 117 us (192 tiles on 256 CUs).  BM355_BF3_GEO=8|4|2 forces one.
+// where 4 needs 117 us (192 tiles on 256 CUs).  BM355_DEBUG=bf3_geo=8|4|2 forces one.
 static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
     static int geo_env = -1;
-    if (geo_env < 0) { const char *e = getenv("BM355_BF3_GEO"); geo_env = e ? atoi(e) : 0; }
+    if (geo_env < 0) { const char *e = bm::dbg("bf3_geo"); geo_env = e ? atoi(e) : 0; }
     if (geo_env) { launch_act_bf3_as(geo_env, a, st); return; }
     static std::mutex mu;
     static std::map<std::array<long long, 6>, int> table;
@@ -1901,7 +1901,7 @@ static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
             int b = 0;
             for (int c = 1; c < 3; ++c) if (best[c] < best[b]) b = c;
             if (best[b] < 1e29f) geo = cand[b];
-            static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
+            static const bool log = bm::dbg("tune_log") != nullptr;
             if (log) fprintf(stderr, "bm355 tune: bf16x3 act I=%d J=%d K=%d+%d flags=%lld -> geometry %d (us: 64x32 %.1f, 128x32 8w %.1f, 64x64 %.1f)\n",
                              a.I, a.J, a.b3.K1, a.b3.K2, flags, geo, best[0], best[1], best[2]);
         } else (void)hipGetLastError();
@@ -1948,7 +1948,7 @@ static inline void launch_act_f32(const ActArgs &a, hipStream_t st) {
 
 // ---- grad_kernel geometry choice: 4 waves of 32 x 32 or 8 waves of 32 x 16 (bit-identical results), measured
 // once per shape like the act geometries (tune_act_shape), on scratch copies of every buffer the kernel writes.
-// BM355_GRAD_GEO=4|8 forces one.
+// BM355_DEBUG=grad_geo=4|8 forces one.
 template <class G, int STG, int MINB = 1>
 static inline void launch_grad_geo(const GradArgs &g_in, hipStream_t st) {
     const GradArgs &g = g_in;
@@ -2009,7 +2009,7 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
     // the XCD grid of the block -> tile map with that geometry (see tune_act_shape)
     float xi_us[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
     static const int cand_xi[5] = {8, 4, 2, 1, -1};
-    static const bool tune_xi = !(getenv("BM355_XCD_MAP") || (getenv("BM355_TUNE_XCD") && atoi(getenv("BM355_TUNE_XCD")) == 0));
+    static const bool tune_xi = !(bm::dbg("xcd_map") || (bm::dbg("tune_xcd") && atoi(bm::dbg("tune_xcd")) == 0));
     int xi = 9;                                  // 9 = the slab order (map_xi -1), unless a grid is >= 2 % faster
     if (tune_xi) {
         for (int round = 0; round < 3; ++round)
@@ -2028,7 +2028,7 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
         if (xi_us[bx] < 0.98f * xi_us[4]) xi = cand_xi[bx];
     } else xi = 0;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    static const bool log = getenv("BM355_TUNE_LOG") != nullptr;
+    static const bool log = bm::dbg("tune_log") != nullptr;
     if (log)
         fprintf(stderr, "bm355 tune: grad I=%d J=%d K=%d+%d form=%d fused=%d -> geometry %d (us, dma: 4w %.1f, 8w %.1f; reg: 4w %.1f, 8w %.1f; 8w bk32 x2: %.1f), "
                         "tile map %d (9 slab, else XCD grid xi; us: slab %.1f, 8x1 %.1f, 4x2 %.1f, 2x4 %.1f, 1x8 %.1f)\n",
@@ -2036,9 +2036,9 @@ static inline int tune_grad_shape(const GradArgs &g, hipStream_t st) {
     return best + 1000 * xi;
 }
 static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
-    static int fetch_env = -1, geo_env = -1;          // BM355_GRAD_FETCH=0|1, BM355_GRAD_GEO=4|8 override (experiments)
-    if (fetch_env < 0) { const char *e = getenv("BM355_GRAD_FETCH"); fetch_env = e ? 2 + atoi(e) : 0; }
-    if (geo_env < 0) { const char *e = getenv("BM355_GRAD_GEO"); geo_env = e ? atoi(e) : 0; }
+    static int fetch_env = -1, geo_env = -1;          // BM355_DEBUG=grad_fetch=0|1, BM355_DEBUG=grad_geo=4|8 override (experiments)
+    if (fetch_env < 0) { const char *e = bm::dbg("grad_fetch"); fetch_env = e ? 2 + atoi(e) : 0; }
+    if (geo_env < 0) { const char *e = bm::dbg("grad_geo"); geo_env = e ? atoi(e) : 0; }
     GradArgs g = g_in;
     g.fetch_at_fill = fetch_env >= 2 ? fetch_env - 2 : 0;      // measured (same box, 784x1024x512): epilogue 66.6 us/update, fill 67.5
     int geo = geo_env;

@@ -50,7 +50,7 @@ struct bm_rbm {
     // the transpose [H][V], written by the fused update next to W: the prop-up then reads its weights x-major as well
     // (one ds_read_b128 per 16 k and lane instead of four ds_read_b32): 12.95 -> 12.5 us per prop-up, +0.45 us in the
     // update's epilogue (3.2 MB more stores): 64.1 -> 63.7 us per CD-1 update, same box, alternating runs
-    // (tools/upxm_ab.sh; BM355_UP_XM=0 switches it off).  Valid only while every write of W went through that kernel
+    // (tools/upxm_ab.sh; BM355_DEBUG=up_xm=0 switches it off).  Valid only while every write of W went through that kernel
     // (wt_valid: cleared by set_param, apply_step and the exchange); otherwise the prop-up reads W k-major as before.
     Mat Wt;
     bool use_wt = false, wt_valid = false;
@@ -450,10 +450,10 @@ int bm_set_device(int device) {
 int bm_dev_alloc(size_t bytes, void **out_dev) { BM_HIP(hipMalloc(out_dev, bytes ? bytes : 1)); return 0; }
 int bm_dev_free(void *dev) { BM_HIP(hipFree(dev)); return 0; }
 // Host -> device.  Large pageable sources (a training set) are pinned in place for the duration of the copy: the
-// runtime otherwise stages them through its own bounce buffers at a fraction of the link rate.  BM355_H2D_PIN=0
+// runtime otherwise stages them through its own bounce buffers at a fraction of the link rate.  BM355_DEBUG=h2d_pin=0
 // keeps the plain copy; any failure of the registration falls back to it.
 int bm_h2d(void *dst, const void *src, size_t bytes) {
-    static const bool pin = !(getenv("BM355_H2D_PIN") && atoi(getenv("BM355_H2D_PIN")) == 0);
+    static const bool pin = !(bm::dbg("h2d_pin") && atoi(bm::dbg("h2d_pin")) == 0);
     if (pin && bytes >= ((size_t)32 << 20)) {
         if (hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
             const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
@@ -490,7 +490,7 @@ int bm_rbm_create(const bm_rbm_config *cfg, bm_rbm **out) {
     BM_HIP(hipEventCreate(&h->ev1));
     BM_TRY(h->W.alloc(V, H)); BM_TRY(h->dW.alloc(V, H));
     {
-        const char *e = getenv("BM355_UP_XM");          // default on; 0 keeps the k-major prop-up
+        const char *e = bm::dbg("up_xm");          // default on; 0 keeps the k-major prop-up
         h->use_wt = !(e && atoi(e) == 0) && (V % 4 == 0) && !h->multinomial();
         if (h->use_wt) BM_TRY(h->Wt.alloc(H, V));
     }
@@ -680,7 +680,7 @@ int bm_rbm_stage(bm_rbm *h, int32_t slot) {
     // Bound the host's run-ahead to one snapshot interval: a training loop that never fetches anything would otherwise
     // queue every epoch of the call at once (measured: 4000 updates = 16 000 launches in flight ran 101 instead of
     // 77 us per update).  Waiting for the PREVIOUS snapshot's copies leaves the whole current epoch queued: no bubble.
-    static const bool bound = !(getenv("BM355_STAGE_AHEAD") && atoi(getenv("BM355_STAGE_AHEAD")) == 0);
+    static const bool bound = !(bm::dbg("stage_ahead") && atoi(bm::dbg("stage_ahead")) == 0);
     if (bound && h->last_stage >= 0) BM_HIP(hipEventSynchronize(h->stage[h->last_stage].ev));
     BM_HIP(hipMemcpyAsync(sg.W.p, h->W.p, h->W.count() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     BM_HIP(hipMemcpyAsync(sg.dW.p, h->dW.p, h->dW.count() * sizeof(float), hipMemcpyDeviceToDevice, h->stream));

@@ -172,7 +172,7 @@ int bm_rbm_profile(bm_rbm *h, int32_t enable);
 int bm_rbm_kernel_times(bm_rbm *h, float *ms6, int32_t *n6);
 
 /* Chained launches (csrc/bm_chain.h): h0 and the k Gibbs steps of base_rbm.py:417-426 / the sweeps of bm_rbm_gibbs run as
- * ONE launch where the shape allows it (BM355_CHAIN=0: never, 1: default rule, 2: wherever legal).  out3 = {chained
+ * ONE launch where the shape allows it (BM355_DEBUG=chain=0: never, 1: default rule, 2: wherever legal).  out3 = {chained
  * launches issued so far, tiles they must compute, mode}; bm_rbm_sync reports a launch that did not complete as an error. */
 int bm_rbm_chain_stats(bm_rbm *h, int64_t *out3);
 
@@ -242,7 +242,7 @@ int bm_dbm_destroy(bm_dbm *h);
 int bm_dbm_sync(bm_dbm *h);
 /* Chained updates (csrc/bm_dbmchain.h): the mean-field loop (dbm.py:429-478) and the particle sweeps (dbm.py:480-509) of one
  * bm_dbm_train_step can run as ONE launch where the shape allows it (2 Bernoulli hidden layers, 64-row blocks for all 8 XCD
- * teams, no communicator), bit-identical to the per-pass launches.  OPT-IN (BM355_DBM_CHAIN=1: that rule, 2: wherever legal;
+ * teams, no communicator), bit-identical to the per-pass launches.  OPT-IN (BM355_DEBUG=dbm_chain=1: that rule, 2: wherever legal;
  * default 0): measured, it ties with the per-pass launches at the BASELINE shape (profiles/r5_dbm_chain_timeline.txt).
  * out3 = {updates that ran chained, chained launches issued, mode}; bm_dbm_sync reports a launch that did not complete. */
 int bm_dbm_chain_stats(bm_dbm *h, int64_t *out3);

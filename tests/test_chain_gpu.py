@@ -1,6 +1,6 @@
 """-m gpu: the chained launch (csrc/bm_chain.h) - h0 and the k Gibbs steps of a CD-k update, or the sweeps of
 bm_rbm_gibbs, as ONE launch whose workgroups hand their rows to each other through the XCD's L2 - against the oracle,
-bit for bit, and against the per-pass launches.  BM355_CHAIN is read when the first handle is used, so every mode runs in
+bit for bit, and against the per-pass launches.  BM355_DEBUG=chain=<mode> is read when the first handle is used, so every mode runs in
 its own subprocess: 2 forces the chained path wherever it is legal (also for shapes the default rule leaves alone:
 fewer than 8 row blocks, several rounds per team), 0 switches it off, 1 is the default rule."""
 import os
@@ -80,7 +80,7 @@ print('CHAIN_OK', chained)
 
 @pytest.mark.parametrize('mode', [2, 1, 0])
 def test_chained_launch_bit_exact(gpu_lib, mode):
-    env = dict(os.environ, BM355_CHAIN=str(mode))
+    env = dict(os.environ, BM355_DEBUG='chain=%d' % mode)
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT, mode=mode)], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and 'CHAIN_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -109,7 +109,7 @@ print('CRC', zlib.crc32(eng.get('W').tobytes()), zlib.crc32(eng.get('hb').tobyte
 '''
     out = []
     for mode in ('2', '0'):
-        r = subprocess.run([sys.executable, '-c', script % dict(root=ROOT)], env=dict(os.environ, BM355_CHAIN=mode),
+        r = subprocess.run([sys.executable, '-c', script % dict(root=ROOT)], env=dict(os.environ, BM355_DEBUG='chain=%s' % mode),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and 'CRC' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         out.append(r.stdout.strip().splitlines()[-1].split())

@@ -1,7 +1,7 @@
 """-m gpu: the chained DBM update (csrc/bm_dbmchain.h) - the mean-field loop (dbm.py:429-478) and the particle sweeps
 (dbm.py:480-509) of one train step as workgroups of ONE launch, with the data-dependent trip count decided inside the
 launch (one speculative sweep, three rotating mu buffers) - against the oracle, bit for bit, INCLUDING the executed sweep
-count, and against the per-pass launches.  BM355_DBM_CHAIN is read when the first handle is used, so every mode runs in
+count, and against the per-pass launches.  BM355_DEBUG=dbm_chain=<mode> is read when the first handle is used, so every mode runs in
 its own subprocess: 2 forces the chained path wherever it is legal (also with fewer than 8 row blocks: teams without
 rows), 0 (the default: the path is bit-exact but measured no faster, profiles/r5_dbm_chain_timeline.txt) switches it off, 1 is
 the rule for where it would apply (8 row blocks, from the third update of a handle on)."""
@@ -74,7 +74,7 @@ print('CHAINED_UPDATES', total)
 
 
 def _run(mode, big):
-    env = dict(os.environ, BM355_DBM_CHAIN=str(mode))
+    env = dict(os.environ, BM355_DEBUG='dbm_chain=%d' % mode)
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT, mode=mode, big=big)], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:]

@@ -1,6 +1,6 @@
 """-m gpu: every act_kernel geometry, deterministically.  The launcher picks a geometry per shape by
 measurement (bm_kernels.h launch_act), so a normal test run exercises whichever wins on that box;
-here each one is forced through BM355_ACT_GEO (read once per process -> one subprocess per geometry)
+here each one is forced through BM355_DEBUG=act_geo=<n> (read once per process -> one subprocess per geometry)
 and must reproduce the oracle bit for bit on an RBM update, a DBM update and a mean-field pass."""
 import os
 import subprocess
@@ -56,9 +56,9 @@ print('GEOMETRY_OK')
 @pytest.mark.parametrize('geo', ['8', '4', '1', '3', '108', '104', '101', '103', '208', '6', '5', '7', '9', 'g4', 'g8', 'g104', 'g108', 'g208', 'g9'])
 def test_forced_geometry_bit_exact(gpu_lib, geo):
     # 8 | 4 | 1 | 3: act_kernel tile geometries with LDS-DMA staging, + 100: the same with register staging;
-    # 'g4' / 'g8' (+ 100): the grad_kernel geometries (4 waves of 32 x 32, 8 waves of 32 x 16) through BM355_GRAD_GEO;
+    # 'g4' / 'g8' (+ 100): the grad_kernel geometries (4 waves of 32 x 32, 8 waves of 32 x 16) through BM355_DEBUG=grad_geo=<n>;
     # 'g9': 8 waves with BK = 32, two workgroups per CU
-    env = dict(os.environ, BM355_GRAD_GEO=geo[1:]) if geo.startswith('g') else dict(os.environ, BM355_ACT_GEO=geo)
+    env = dict(os.environ, BM355_DEBUG=('grad_geo=' + geo[1:]) if geo.startswith('g') else ('act_geo=' + geo))
     r = subprocess.run([sys.executable, '-c', SCRIPT % dict(root=ROOT)], env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and 'GEOMETRY_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Developer tool: print the timeline of the last chained launch (BM355_CHAIN_STAMPS=file, csrc/bm_chain.h) for one team.
+"""Developer tool: print the timeline of the last chained launch (BM355_DEBUG=chain_stamps=file, csrc/bm_chain.h) for one team.
 usage: chain_timeline.py file [team]"""
 import sys
 import numpy as np

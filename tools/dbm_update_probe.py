@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """DBM 784-512-1024 updates only (BASELINE configs[3] shape), for rocprofv3 kernel traces and A/B runs of the chained update
-(BM355_DBM_CHAIN=0|1, csrc/bm_dbmchain.h):  python tools/dbm_update_probe.py [rows=512] [updates=40] [mf_tol=1e-7] [k=5]"""
+(BM355_DEBUG=dbm_chain=0|1, csrc/bm_dbmchain.h):  python tools/dbm_update_probe.py [rows=512] [updates=40] [mf_tol=1e-7] [k=5]"""
 import os
 import sys
 import time

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Timeline of the last chained DBM launch (BM355_DCH_STAMPS=file, csrc/bm_dbmchain.h):
+"""Timeline of the last chained DBM launch (BM355_DEBUG=dch_stamps=file, csrc/bm_dbmchain.h):
    python tools/dch_timeline.py file [team=0]
 per tile: start, end of the wait, end of the main loop, end of the epilogue, end of the publish (100 MHz clock -> us)."""
 import sys

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Reproduces profiles/r3_*: rocprofv3 kernel-trace stats for every bench configuration (and the fast-binary AIS), PMC
+# Reproduces profiles/r<N>_*: rocprofv3 kernel-trace stats for every bench configuration (and the fast-binary AIS), PMC
 # passes in their own runs (FETCH_SIZE / WRITE_SIZE separately, one SQ pass) of the bench command.
-# Run on the GPU box from the repo root:  bash tools/profile_r3.sh [configs...]
+# Run on the GPU box from the repo root:  ROUND=r5 bash tools/profile.sh [configs...]
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-OUT=$R/gpurun_out/prof_r3
+OUT=$R/gpurun_out/prof_${ROUND:-r5}
 mkdir -p $OUT
 CONFIGS=${@:-rbm gibbs grbm dbm ais aisfast}
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_BF16"

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """One-off parity stress of the chained launch (developer tool; csrc/bm_chain.h): random RBM shapes the chained path
 accepts (16-byte operands, K >= 192), batches from one row to several rounds per team, k = 1 .. 4, updates and sampling
-sweeps against the oracle, bit for bit.  usage: BM355_CHAIN=2 python tools/stress_chain.py [n] [seed]"""
+sweeps against the oracle, bit for bit.  usage: BM355_DEBUG=chain=2 python tools/stress_chain.py [n] [seed]"""
 import os, sys
-os.environ.setdefault('BM355_CHAIN', '2')
+os.environ.setdefault('BM355_DEBUG', 'chain=2')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests.helpers import assert_state_equal, make_pair, synth_data

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One-off parity stress (developer tool): many random RBM shapes against the oracle under the geometry given
-by BM355_ACT_GEO; larger dimension range than the committed randomised test (K up to 700: several K chunks,
-tails of every length).  usage: BM355_ACT_GEO=8 python tools/stress_parity.py [n] [seed]"""
+by BM355_DEBUG=act_geo=<n>; larger dimension range than the committed randomised test (K up to 700: several K chunks,
+tails of every length).  usage: BM355_DEBUG=act_geo=8 python tools/stress_parity.py [n] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -33,5 +33,5 @@ for case in range(n):
         bad += 1
         print('MISMATCH case %d V=%d H=%d B=%d k=%d %r: %s' % (case, V, H, B, k, kw, e))
     eng.close()
-print('geometry %s: %d cases, %d mismatches' % (os.environ.get('BM355_ACT_GEO', 'tuned'), n, bad))
+print('geometry %s: %d cases, %d mismatches' % (os.environ.get('BM355_DEBUG', 'tuned'), n, bad))
 sys.exit(1 if bad else 0)

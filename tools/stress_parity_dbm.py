@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One-off DBM parity stress (developer tool): random layer counts / sizes / flags, two updates each, against
-the oracle under BM355_ACT_GEO.  usage: BM355_ACT_GEO=8 python tools/stress_parity_dbm.py [n] [seed]"""
+the oracle under BM355_DEBUG=act_geo=<n>.  usage: BM355_DEBUG=act_geo=8 python tools/stress_parity_dbm.py [n] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -35,5 +35,5 @@ for case in range(n):
         bad += 1
         print('MISMATCH case %d V=%d nh=%r N=%d M=%d k=%d %r: %s' % (case, V, nh, N, M, k, kw, e))
     eng.close()
-print('geometry %s: %d DBM cases, %d mismatches' % (os.environ.get('BM355_ACT_GEO', 'tuned'), n, bad))
+print('geometry %s: %d DBM cases, %d mismatches' % (os.environ.get('BM355_DEBUG', 'tuned'), n, bad))
 sys.exit(1 if bad else 0)
