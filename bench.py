@@ -154,7 +154,7 @@ def cpu_baseline(k, budget_s=2.5):
 
 def pmc_traffic(config):
     """HBM-side bytes per step from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
-    runs of this same command, tools/profile_r2.sh + tools/summarize_profile.py); None when no profile has
+    runs of this same command, tools/profile.sh + tools/summarize_profile.py); None when no profile has
     been collected for this configuration.  Counters cannot be read live from inside the process, so this
     is the one roofline field that comes from profiles/."""
     import glob

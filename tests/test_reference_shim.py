@@ -81,3 +81,30 @@ def test_reference_ais_is_the_literal_float32_accumulation(tmp_path, monkeypatch
     dbl = twin.ais(600, 12, 1, seeds[-1])
     np.testing.assert_allclose(lit, values, rtol=2e-6)
     np.testing.assert_allclose(dbl, values, rtol=1e-5)
+
+
+def test_float32_sigmoid_of_the_reference_is_coarser_than_mf_tol():
+    """Why the executed mean-field sweeps at the reference's default mf_tol = 1e-7 are reported, not compared, where the
+    tolerance sits this low (tests/golden/scenarios.py MF_TRIPS_UNPINNED): `tf.sigmoid` as float32
+    `1 / (1 + exp(-x))` (Eigen in TF 1.3, NumPy in the stand-in) jumps by MORE than 1e-7 between consecutive float32
+    arguments somewhere in the range the means of a 784-512-1024 stack live in - more than the loop condition of
+    dbm.py:449-452 allows a mean to move - while the engine's sigmoid (`e / (1 + e)` for x < 0, one division:
+    csrc/bm_numerics.h = orc_sigmoid) never does: a one-ulp flicker of a pre-activation keeps the reference's loop
+    running to max_mf_updates and lets the engine's end."""
+    import numpy as np
+    tf, _ = reference_shim.activate()
+    from oracle import oracle as orc
+    worst_ref, worst_ours, err_ref, err_ours = 0.0, 0.0, 0.0, 0.0
+    for start in (-0.9, -0.6, -0.4, -0.24, -0.1, 0.1, 0.3, 0.7):
+        x0 = np.float32(start)
+        x = x0 + np.arange(3000, dtype=np.float32) * np.spacing(x0)          # consecutive float32 arguments
+        ref = np.asarray(tf._sigmoid(x), dtype=np.float32)
+        ours = np.array([orc.lib().orc_sigmoid(float(v)) for v in x], dtype=np.float32)
+        exact = 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
+        worst_ref = max(worst_ref, float(np.abs(np.diff(ref)).max()))
+        worst_ours = max(worst_ours, float(np.abs(np.diff(ours)).max()))
+        err_ref = max(err_ref, float((np.abs(ref - exact) / np.spacing(ref)).max()))
+        err_ours = max(err_ours, float((np.abs(ours - exact) / np.spacing(ours)).max()))
+    assert worst_ref > 1e-7, worst_ref               # the reference's sigmoid alone can keep `max |mu - mu_new| > tol` true
+    assert worst_ours <= 1e-7, worst_ours            # the engine's cannot
+    assert err_ours < err_ref, (err_ours, err_ref)   # (and it is the more accurate of the two: ~1.3 against ~2.2 ulp)
