@@ -734,6 +734,14 @@ def check_data_parallel_run(wl, args, rank, world, dist):
     import torch
     status = 0
     for x in getattr(args, '_xchg', {}).values():
+        # the fused exchange leaves the momentum buffer sharded over the ranks: complete the replicas (a collective: every
+        # rank is here) before anything - the instrumented kernel pass, a checkpoint - reads or updates it
+        if getattr(wl, 'dp', None) is not None and getattr(wl.dp, 'fused', None) is x:
+            try:
+                x.gather_dw()
+                wl.eng.sync()
+            except Exception as e:       # noqa: BLE001 - shows up as a non-zero status below
+                sys.stderr.write('bench: gather_dw failed: %s\n' % (str(e)[:200],))
         status = max(status, int(x.status()))
     crc = 0
     try:
