@@ -708,6 +708,7 @@ def choose_collective(args, eng, rank, world, dist):
                     note += '; exchange status after the race: %d on every rank' % int(st.item()) if int(st.item()) == 0 else \
                         '; a wait expired during the race (status %d)' % int(st.item())
                     if int(st.item()) != 0:
+                        args._xchg.pop(id(eng), None)      # (nothing may ask a closed exchange for its status later)
                         x.close()
                         return 'rccl', note + ' -> rccl'
                     if t_rccl < t_direct:
