@@ -220,6 +220,7 @@ class RbmCD(Workload):
                 return
             mode, note = choose_collective(args, eng, rank, world, dist)
             self.collective, self.collective_note = mode, note
+            self.reset()                 # (the start-up race ran the fused exchange on this engine's parameters)
             fused = None
             if mode == 'direct':
                 ar = parallel.direct_allreduce_on_engine_stream(eng, args._xchg[id(eng)])
@@ -258,7 +259,7 @@ class RbmCD(Workload):
         return int(seconds * 12500)
 
     def reset(self):
-        if self.use_dp and hasattr(self.dp, 'flush'):
+        if self.use_dp and hasattr(getattr(self, 'dp', None), 'flush'):
             self.dp.flush()                      # delayed-gradient mode: nothing in flight across the reset
         for name, d in self.init.items():
             self.eng.set_from_device(name, d)
