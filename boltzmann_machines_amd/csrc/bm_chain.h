@@ -170,6 +170,8 @@ __global__ __launch_bounds__(GeoChain::NT, 1) void act_chain_kernel(ChainArgs c)
         a.acc_init = nullptr; a.ld_init = 0; a.skip = nullptr;
         a.chk_ctl = nullptr; a.chk_slots = nullptr; a.chk_n = 0; a.chk_tol = 0.f;
         a.b3 = Bf3Range{}; a.states16 = nullptr; a.ld16 = 0; a.map_xi = 0;
+        a.fe_rowacc2 = nullptr; a.fe_flip = nullptr; a.fe_x = nullptr; a.fe_ldx = 0; a.fe_w = nullptr; a.fe_ldw = 0;
+        a.fe_zero = nullptr; a.fe_rm = 0; a.fe_key = PhiloxKey{0u, 0u, 0u, 0u};
 #ifdef BM_PROBE
         a.dbg = nullptr;
 #endif
@@ -249,7 +251,7 @@ static inline int chain_mode(ChainState &cs) {
 static inline bool chain_phase_ok(const ActArgs &a) {
     using G = GeoChain;
     if (a.K2 > 0 || a.b3.K1 > 0 || a.prev || a.maxdiff || a.maxdiff_blk || a.rowacc || a.rowdot_out || a.acc_init ||
-        a.skip || a.chk_ctl || a.states16 || a.dot_mat) return false;
+        a.skip || a.chk_ctl || a.states16 || a.dot_mat || a.fe_flip) return false;
     if (a.kind != 0 && a.kind != 1) return false;
     const int pl = a.p_xm ? XM : KM;
     if (!(operand_fast(a.P1, pl, a.K1) && operand_fast(a.Q1, XM, a.K1))) return false;

@@ -297,6 +297,8 @@ __global__ __launch_bounds__(GeoChain::NT, 1) void dbm_chain_kernel(DchArgs c) {
         a.acc_init = nullptr; a.ld_init = 0; a.skip = nullptr; a.prev = nullptr;
         a.chk_ctl = nullptr; a.chk_slots = nullptr; a.chk_n = 0; a.chk_tol = 0.f;
         a.b3 = Bf3Range{}; a.states16 = nullptr; a.ld16 = 0; a.map_xi = 0;
+        a.fe_rowacc2 = nullptr; a.fe_flip = nullptr; a.fe_x = nullptr; a.fe_ldx = 0; a.fe_w = nullptr; a.fe_ldw = 0;
+        a.fe_zero = nullptr; a.fe_rm = 0; a.fe_key = PhiloxKey{0u, 0u, 0u, 0u};
         a.mult = 1.f; a.bmult = 1.f;
 #ifdef BM_PROBE
         a.dbg = nullptr;

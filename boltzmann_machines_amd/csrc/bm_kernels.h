@@ -82,6 +82,21 @@ struct ActArgs {
     Bf3Range b3;
     uint16_t *states16; int ld16;
     int map_xi;                  // block -> tile map: 0 = the traffic model's XCD grid, 8 / 4 / 2 / 1 that grid, -1 the slab order (launch tuner)
+    // Metric fetch of a training iteration (base_rbm.py:496-517, rbm.py:17-22): the h0 pass already holds the pre-activations
+    // x.W + hb the free energy needs, so ITS epilogue leaves, per row j, sum_i softplus(z + b) (through `rowacc`) and the same for
+    // the PLL partner x~ (one flipped column fc = fe_flip[j]: z~ = z + (1 - 2 x[j][fc]) W[fc][:], a rank-1 correction; through
+    // fe_rowacc2) - what fe_hidden_kernel computes from a GEMM of its own (15 us at 784 x 1024 x 512).  Through the slot
+    // partials of `rowacc` (rowacc_single = 1, beta_b = 1: sum_i softplus(z + b) per 16-column slot, no atomics, any tile
+    // geometry the same bits); fe_rowacc2 is a second partial array [ceil(I/16)][ld_part] for the partner.  Null: off
+    // (every other launch).  Needs mult == 1.
+    float *fe_rowacc2;
+    PhiloxKey fe_key;                    // fe_flip == FE_FLIP_FROM_KEY: the flip column is pll_flip_col(fe_key, row0 + j, K1) (no prep launch)
+    double *fe_zero;                     // six accumulators this pass zeroes for the kernels of the fetch that follow it (or null)
+    int fe_rm;                           // pitch of the two partial arrays when fe_flip is set: they are ROW major ([J][fe_rm]: the
+                                         // row kernel reads a row's slots as one line), not slot major like the AIS partials
+    const int *fe_flip;
+    const float *fe_x; int fe_ldx;       // the pass's own input rows [J][K] (for x[j][fc])
+    const float *fe_w; int fe_ldw;       // W [K][I] row-major (row fc)
 #ifdef BM_PROBE
     long long *dbg;              // [grid][4] s_memtime stamps (tools/probe_act.hip only)
 #endif
@@ -92,6 +107,13 @@ struct ActArgs {
 #define BM_STAMP(n) do {} while (0)
 #endif
 
+// pll_rand = tf.random_uniform([B], 0, V, int32) (base_rbm.py:500-501): the column flipped in row `idx` (global row)
+__device__ __forceinline__ int pll_flip_col(const PhiloxKey &key, unsigned long long idx, int V) {
+    uint32_t w[4];
+    philox_block(key, idx >> 2, w);
+    return (int)(w[idx & 3] % (uint32_t)V);
+}
+#define FE_FLIP_FROM_KEY (reinterpret_cast<const int *>(uintptr_t(1)))
 constexpr int BM_MF_SLOTS = 1024;      // per-workgroup residual slots per layer (ActArgs::maxdiff_blk)
 
 // draw for 4 consecutive outputs starting at flat index `flat` (multiple of 4 on the fast path)
@@ -278,13 +300,19 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
             }
         }
     }
+    if (a.fe_zero && i0 == 0 && j0 == 0 && tid < 6) a.fe_zero[tid] = 0.0;          // (the first tile of the h0 pass of a fused fetch)
     if (a.rowacc || a.rowdot_out) {           // wave-uniform
         // per-lane quads (4 consecutive i, left to right); MI == 2: the lane's two quads are added
-        float racc = 0.f, rdot = 0.f;
+        float racc = 0.f, rdot = 0.f, racc2 = 0.f;
         if (j < a.J) {
+            int fc = 0; float delta = 0.f;
+            if (a.fe_flip) {                                                                                   // wave-uniform branch
+                fc = (a.fe_flip == FE_FLIP_FROM_KEY) ? pll_flip_col(a.fe_key, (unsigned long long)(a.row0 + j), a.K1) : a.fe_flip[j];
+                delta = 1.0f - 2.0f * a.fe_x[(size_t)j * a.fe_ldx + fc];
+            }
 #pragma unroll
             for (int hlf = 0; hlf < NH; ++hlf) {
-                float qa = 0.f, qd = 0.f;
+                float qa = 0.f, qd = 0.f, qa2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e = 4 * hlf + r, i = ib0 + e;
@@ -294,6 +322,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                             qa += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
                         } else {
                             const float t = z[e] + bs[e];
+                            if (a.fe_flip) qa2 += softplus(t + delta * a.fe_w[(size_t)fc * a.fe_ldw + i]);       // the PLL partner's row (beta_b == 1)
                             if (a.rowacc_single) qa += HWMATH ? softplus_hw(a.beta_b * t) : softplus(a.beta_b * t);
                             else qa += HWMATH ? softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t)
                                               : softplus(a.beta_b * t) - softplus(a.beta_a * t);
@@ -304,6 +333,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                 }
                 racc = (hlf == 0) ? qa : racc + qa;
                 rdot = (hlf == 0) ? qd : rdot + qd;
+                racc2 = (hlf == 0) ? qa2 : racc2 + qa2;
             }
         }
         // 16-column slot sums: MI == 1: lanes g = 0..3 hold q0..q3 -> (q0+q1)+(q2+q3);
@@ -311,11 +341,17 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
         racc += __shfl_xor(racc, 16);
         rdot += __shfl_xor(rdot, 16);
         if (G::MI == 1) { racc += __shfl_xor(racc, 32); rdot += __shfl_xor(rdot, 32); }
+        if (a.fe_flip) { racc2 += __shfl_xor(racc2, 16); if (G::MI == 1) racc2 += __shfl_xor(racc2, 32); }
         const bool writer = (G::MI == 1) ? (g == 0) : ((g & 1) == 0);
         const int slot = (i0 + wi * (16 * G::MI)) / 16 + ((G::MI == 2) ? (g >> 1) : 0);
         if (writer && j < a.J && slot * 16 < a.I) {
-            if (a.rowacc) a.rowacc[(size_t)slot * a.ld_part + j] = racc;
-            if (a.rowdot_out) a.rowdot_out[(size_t)slot * a.ld_part + j] = rdot;
+            if (a.fe_flip) {             // metric fetch (wave-uniform): row-major partials
+                a.rowacc[(size_t)j * a.fe_rm + slot] = racc;
+                a.fe_rowacc2[(size_t)j * a.fe_rm + slot] = racc2;
+            } else {
+                if (a.rowacc) a.rowacc[(size_t)slot * a.ld_part + j] = racc;
+                if (a.rowdot_out) a.rowdot_out[(size_t)slot * a.ld_part + j] = rdot;
+            }
         }
     }
     return dmax;
@@ -1201,23 +1237,45 @@ __global__ __launch_bounds__(256) void metrics_prep_kernel(MetricsPrepArgs a) {
     if (t < 6) a.scal[t] = 0.0;
     for (int e = t; e < a.n_rowacc; e += nt) a.rowacc[e] = 0.f;
     for (int b = t; b < a.B; b += nt) {                 // pll_rand = tf.random_uniform([B], 0, V, int32) (base_rbm.py:500-501)
-        const unsigned long long idx = a.row0 + b;
-        uint32_t w[4];
-        philox_block(a.key, idx >> 2, w);
-        a.flip[b] = (int)(w[idx & 3] % (uint32_t)a.V);
+        a.flip[b] = pll_flip_col(a.key, a.row0 + b, a.V);
     }
 }
 struct SqJob { const float *A; int lda; const float *B; int ldb; int rows, cols; double *out; };
-__global__ __launch_bounds__(256) void sqdiff2_kernel(SqJob j0, SqJob j1) {
-    const int half = gridDim.x >> 1;
-    const bool second = (int)blockIdx.x >= half;
+__device__ __forceinline__ void sqdiff2_body(const SqJob &j0, const SqJob &j1, int blk, int nblk) {
+    // (round 5: this kernel took 19.5 us of a 118 us metrics iteration - 256 waves walking 784 + 512 rows with ONE dependent
+    //  load per trip.  Now 1024+ waves, four 16-byte loads of a row in flight per lane where the pitch allows it.)
+    const int half = nblk >> 1;
+    const bool second = blk >= half;
     const SqJob &j = second ? j1 : j0;
-    const int nb = second ? (int)gridDim.x - half : half, b = second ? (int)blockIdx.x - half : (int)blockIdx.x;
+    const int nb = second ? nblk - half : half, b = second ? blk - half : blk;
     const int lane = threadIdx.x & 63, wv = b * (blockDim.x >> 6) + (threadIdx.x >> 6), nwv = nb * (blockDim.x >> 6);
     double s = 0.0;
+    const bool vec = (j.lda & 3) == 0 && (((uintptr_t)j.A) & 15u) == 0 && (!j.B || ((j.ldb & 3) == 0 && (((uintptr_t)j.B) & 15u) == 0));
     for (int r = wv; r < j.rows; r += nwv) {
         const float *pa = j.A + (size_t)r * j.lda, *pb = j.B ? j.B + (size_t)r * j.ldb : nullptr;
-        for (int c = lane; c < j.cols; c += 64) {
+        int c = 0;
+        if (vec) {
+            const int c4n = j.cols >> 2;                     // whole 16-byte groups of the row
+            for (int g0 = 0; g0 < c4n; g0 += 256) {          // 4 groups per lane and trip, all loads before any use
+                float4 x[4], y[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * 64 + lane;
+                    const int gc = g < c4n ? g : c4n - 1;
+                    x[u] = *reinterpret_cast<const float4 *>(pa + 4 * gc);
+                    y[u] = pb ? *reinterpret_cast<const float4 *>(pb + 4 * gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (g0 + u * 64 + lane < c4n) {
+                        const float d0 = x[u].x - y[u].x, d1 = x[u].y - y[u].y, d2 = x[u].z - y[u].z, d3 = x[u].w - y[u].w;
+                        s += (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2 + (double)d3 * (double)d3;
+                    }
+                }
+            }
+            c = 4 * c4n;
+        }
+        for (c += lane; c < j.cols; c += 64) {
             const float d = pb ? (pa[c] - pb[c]) : pa[c];
             s += (double)d * (double)d;
         }
@@ -1227,8 +1285,9 @@ __global__ __launch_bounds__(256) void sqdiff2_kernel(SqJob j0, SqJob j1) {
     s = wave_sum(s);
     if (lane == 0) s_part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(j.out, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+    if (threadIdx.x == 0 && j.rows > 0) atomicAdd(j.out, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
 }
+__global__ __launch_bounds__(256) void sqdiff2_kernel(SqJob j0, SqJob j1) { sqdiff2_body(j0, j1, (int)blockIdx.x, (int)gridDim.x); }
 __global__ void scal_to_host_kernel(const double *scal, double *dst) {
     if (threadIdx.x < 6) dst[threadIdx.x] = scal[threadIdx.x];
 }
@@ -1312,18 +1371,53 @@ struct FeRowArgs {
     const float *rowacc, *rowacc2, *rowacc3;    // rowacc3: MultinomialRBM's second F(x) (out[2]) or null
     const int *flip_col;
     double *out;
+    // nslot > 0: rowacc / rowacc2 are slot partials [B][ld_part] (row major) left by the h0 pass (ActArgs::fe_flip): the hidden
+    // term of row j is their sum over the slots in a fixed order
+    int nslot, ld_part;
+    // flip_col == null and has_key: the flip column of row j is computed here, pll_flip_col(key, row0 + j, V) (fused fetch)
+    int has_key; PhiloxKey key; unsigned long long row0;
 };
-constexpr int FE_ROWS_PER_WG = 16;      // 4 waves x 4 rows: one atomic per target and workgroup (see sqdiff2_kernel)
-__global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) {
+constexpr int FE_ROWS_PER_WG = 8;       // 4 waves x 2 rows (round 5: 16 rows per workgroup left 32 workgroups walking four rows each
+                                        // with dependent loads - 21.9 us; fewer rows mean more same-address double atomics at ~16 ns)
+__device__ __forceinline__ void fe_row_body(const FeRowArgs &a, int blk) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int q = 0; q < FE_ROWS_PER_WG / 4; ++q) {
-        const int row = blockIdx.x * FE_ROWS_PER_WG + q * 4 + wv;
+        const int row = blk * FE_ROWS_PER_WG + q * 4 + wv;
         if (row >= a.B) break;                       // wave-uniform
         const float *x = a.X + (size_t)row * a.ld;
-        const int fc = a.flip_col ? a.flip_col[row] : -1;
+        const int fc = a.flip_col ? a.flip_col[row] : (a.has_key ? pll_flip_col(a.key, a.row0 + row, a.V) : -1);
         double t = 0.0, t2 = 0.0;
-        for (int c = lane; c < a.V; c += 64) {
+        int c = lane;
+        if (!a.sigma && (a.ld & 3) == 0 && (((uintptr_t)a.X | (uintptr_t)a.vb) & 15u) == 0) {
+            // Bernoulli visible term, 16-byte loads, all of a row's loads in flight before the first use (the scalar loop below
+            // walked 13 dependent trips per row: most of this kernel's 12 us)
+            const int c4n = a.V >> 2;
+            for (int g0 = 0; g0 < c4n; g0 += 256) {
+                float4 xv[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * 64 + lane, gc = g < c4n ? g : c4n - 1;
+                    xv[u] = *reinterpret_cast<const float4 *>(x + 4 * gc);
+                    bv[u] = *reinterpret_cast<const float4 *>(a.vb + 4 * gc);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = g0 + u * 64 + lane;
+                    if (g < c4n) {
+                        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, bs4[4] = {bv[u].x, bv[u].y, bv[u].z, bv[u].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xf = (4 * g + r == fc) ? 1.0f - xs[r] : xs[r];
+                            t -= (double)(xs[r] * bs4[r]);
+                            t2 -= (double)(xf * bs4[r]);
+                        }
+                    }
+                }
+            }
+            c = 4 * c4n + lane;
+        }
+        for (; c < a.V; c += 64) {
             const float xv = x[c];
             const float xf = (c == fc) ? 1.0f - xv : xv;
             if (a.sigma) {
@@ -1337,8 +1431,19 @@ __global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) {
         }
         t = wave_sum(t);
         t2 = wave_sum(t2);
-        s0 += t - (double)a.rowacc[row];
-        if (a.rowacc2) s1 += t2 - (double)a.rowacc2[row];
+        double h1 = 0.0, h2 = 0.0;
+        if (a.nslot > 0) {
+            for (int q = lane; q < a.nslot; q += 64) {
+                h1 += (double)a.rowacc[(size_t)row * a.ld_part + q];
+                h2 += (double)a.rowacc2[(size_t)row * a.ld_part + q];
+            }
+            h1 = wave_sum(h1); h2 = wave_sum(h2);            // (a fixed tree: the same bits every run)
+        } else {
+            h1 = (double)a.rowacc[row];
+            if (a.rowacc2) h2 = (double)a.rowacc2[row];
+        }
+        s0 += t - h1;
+        if (a.rowacc2) s1 += t2 - h2;
         if (a.rowacc3) s2 += t - (double)a.rowacc3[row];
     }
     __shared__ double s_part[3][4];
@@ -1348,6 +1453,12 @@ __global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) {
         const double v = (s_part[threadIdx.x][0] + s_part[threadIdx.x][1]) + (s_part[threadIdx.x][2] + s_part[threadIdx.x][3]);
         if (threadIdx.x == 0 || (threadIdx.x == 1 && a.rowacc2) || (threadIdx.x == 2 && a.rowacc3)) atomicAdd(a.out + threadIdx.x, v);
     }
+}
+__global__ __launch_bounds__(256) void fe_row_kernel(FeRowArgs a) { fe_row_body(a, (int)blockIdx.x); }
+// the tail of a fused metric fetch in ONE launch: blocks [0, nb_sq) the two squared sums, the rest the free-energy rows
+__global__ __launch_bounds__(256) void metrics_tail_kernel(SqJob j0, SqJob j1, FeRowArgs r, int nb_sq) {
+    if ((int)blockIdx.x < nb_sq) sqdiff2_body(j0, j1, (int)blockIdx.x, nb_sq);     // workgroup-uniform
+    else fe_row_body(r, (int)blockIdx.x - nb_sq);
 }
 
 // pll_rand = tf.random_uniform([B], 0, V, int32): minval + u32 % range (base_rbm.py:500-501)
@@ -1761,15 +1872,17 @@ static inline bool tune_redirect(const ActArgs &a, ActArgs &t) {
     const size_t mat = ((size_t)a.J * (size_t)a.ldo + 3) & ~(size_t)3;
     const size_t rowv = (((size_t)((a.I + 15) / 16) * (size_t)(a.ld_part > a.J ? a.ld_part : a.J)) + 3) & ~(size_t)3;   // slot partials
     const size_t sh16 = a.states16 ? ((size_t)a.J * (size_t)a.ld16 / 2 + 4) & ~(size_t)3 : 0;                           // bf16 shadow, in floats
-    float *s = pool.get(3 * mat + 2 * rowv + BM_MF_SLOTS + 4 + sh16);
+    const size_t fe = a.fe_flip ? ((size_t)a.J * (size_t)a.fe_rm + 3) & ~(size_t)3 : 0;
+    float *s = pool.get(3 * mat + 2 * rowv + BM_MF_SLOTS + 4 + sh16 + fe);
     if (!s) return false;
     t = a;
+    if (a.fe_flip) t.fe_rowacc2 = s + 3 * mat + 2 * rowv + BM_MF_SLOTS + 4 + sh16;
     t.skip = nullptr;
     t.chk_ctl = nullptr;
     if (a.means) t.means = s;
     if (a.states) t.states = s + mat;
     if (a.negmeans) t.negmeans = s + 2 * mat;
-    if (a.rowacc) t.rowacc = s + 3 * mat;
+    if (a.rowacc) t.rowacc = s + 3 * mat;        // (fe_flip: [J][fe_rm] <= rowv floats: fe_rm >= ceil(I/16), ld_part >= J)
     if (a.rowdot_out) t.rowdot_out = s + 3 * mat + rowv;
     if (a.maxdiff_blk) t.maxdiff_blk = s + 3 * mat + 2 * rowv;
     if (a.maxdiff) t.maxdiff = reinterpret_cast<unsigned *>(s + 3 * mat + 2 * rowv + BM_MF_SLOTS);

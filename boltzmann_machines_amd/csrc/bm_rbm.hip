@@ -78,6 +78,8 @@ struct bm_rbm {
     const float *Xin = nullptr;
     int Xin_ld = 0;
     bool hm_is_neg = false;    // the last run_chain() wrote -h_k (hneg) instead of h_k (hm)
+    bool fe_in_chain = false;  // the last run_chain() left the free-energy slot partials of its input in fe_part (metric fetch)
+    DevBuf fe_part;            // [2][ceil(H/16)][maxB]: slot partials of sum softplus for x and for its PLL partner
     // fast-binary mode (bm_bf3.h, bm_rbm_set_fast_binary): bf16 planes of W ([V][H]: the prop-down operand) and of
     // W^T ([H][V]: the prop-up operand), bf16 shadows of the state workspaces hs / vs; `fast_now` while a sweep with
     // {0,1} states on both sides runs (bm_rbm_gibbs)
@@ -98,6 +100,8 @@ struct bm_rbm {
     double *mring = nullptr, *mring_dev = nullptr;    // pinned host ring and its device-side address
     std::vector<int> mring_B;
     int mring_n = 0;
+    hipEvent_t ev_mlast = nullptr;   // behind the last pending fetch: bm_rbm_collect_metrics waits for IT, not for the stream -
+                                     // updates queued after the fetch (the next epoch's first run) keep the device busy meanwhile
     // optional per-kernel-class event timing
     bool prof = false;
     struct Rec { int cls; hipEvent_t a, b; };
@@ -171,7 +175,7 @@ static void ensure_wt(bm_rbm *h) {
 
 // E[h|v] (+ sample): base_rbm.py:339-351.  v [B][V] pitch ldv
 static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, float *states, int ldo,
-                      int sample, uint32_t site, int t, float *negmeans = nullptr) {
+                      int sample, uint32_t site, int t, float *negmeans = nullptr, bool fe = false) {
     ProfScope _ps(h, KC_UP);
     ActArgs a;
     memset(&a, 0, sizeof(a));
@@ -187,6 +191,15 @@ static void launch_up(bm_rbm *h, const float *v, int ldv, int B, float *means, f
     a.means = means; a.states = states; a.negmeans = negmeans; a.ldo = ldo;
     a.key = make_key(h, site, t);
     a.row0 = h->row0;
+    if (fe) {                                    // metric fetch: the free-energy row sums from this pass's pre-activations
+        const int nslot = (h->H + 15) / 16, rm = (nslot + 3) & ~3;
+        a.rowacc = h->fe_part.p; a.rowacc_single = 1; a.beta_b = 1.f; a.ld_part = h->maxB; a.fe_rm = rm;
+        a.fe_rowacc2 = h->fe_part.p + (size_t)rm * h->maxB;
+        // the flip columns straight from their Philox stream and the zeroing of the six accumulators ride on this pass: the
+        // fused fetch has no prep launch
+        a.fe_flip = FE_FLIP_FROM_KEY; a.fe_key = make_key(h, SITE_PLL, 0); a.fe_zero = h->scal;
+        a.fe_x = v; a.fe_ldx = ldv; a.fe_w = h->W.p; a.fe_ldw = h->W.ld;
+    }
     if (h->fast_now && v == h->vs.p) {           // fast-binary: W^T planes x the bf16 shadow of the visible bitmap
         a.b3.P1 = Bf3Operand{h->W3t.p, h->W3t.plane_stride(), h->W3t.ld, h->H};
         a.b3.Q1 = Bf3Operand{h->vs16.p, 0, h->vs16.ld, B};
@@ -246,8 +259,10 @@ static void launch_down(bm_rbm *h, const float *hs, int ldh, int B, float *means
 // need_vm: the last step's visible MEANS are wanted (msre metric); a plain update only consumes the
 // visible states, and nothing consumes the hidden STATES of the last step: those stores (and their
 // share of the kernel-boundary L2 writeback) are skipped.
+static bool metrics_fused_ok(const bm_rbm *h);
+static void metrics_prep(bm_rbm *h, int B);
 static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out, bool need_vm = true, bool for_update = false,
-                     bool split_step = false) {
+                     bool split_step = false, bool fetch = false) {
     BM_CHECK(B >= 1 && B <= h->maxB, "batch %d outside [1, max_batch=%d]", B, h->maxB);
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
     if (!split_step) ensure_wt(h);
@@ -265,8 +280,14 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out,
         Xin = h->Xd.p; ldx = h->Xd.ld;
     }
     h->Xin = Xin; h->Xin_ld = ldx;
+    // a metrics iteration: the flip columns and the zeroed accumulators first, then the h0 pass adds the free-energy row
+    // sums of x and of its PLL partner from its own pre-activations (ActArgs::fe_flip) - no GEMM of their own
+    const bool fe = fetch && metrics_fused_ok(h);
+    if (fe && !h->fe_part.p) BM_TRY(h->fe_part.alloc((size_t)2 * ((((h->H + 15) / 16) + 3) & ~3) * h->maxB));
+    h->fe_in_chain = fe;
+    if (fetch && !fe) metrics_prep(h, B);
     chain_begin(h);               // h0 and the k Gibbs steps: one launch where the shape allows it (bm_chain.h)
-    launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0);      // :421-422
+    launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0, nullptr, fe);      // :421-422
     const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
     for (int t = 0; t < k; ++t) {                                                 // :367-378
         const bool last = t == k - 1;
@@ -394,15 +415,36 @@ static double mn_fe_const(const bm_rbm *h) {
 
 // metrics from the chain currently in the handle (base_rbm.py:482-517)
 static void metrics_to_out4(const bm_rbm *h, const double *host, int B, float *out4);
-static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
+// The h0 pass can carry the free-energy sums when its pre-activation IS the free energy's (no dbm_first doubling), the hidden
+// units are Bernoulli and the epilogue in use is act_kernel's (not the fast-binary strip kernel)
+static bool metrics_fused_ok(const bm_rbm *h) {
+    static const bool off = bm::dbg("metrics_fused") && atoi(bm::dbg("metrics_fused")) == 0;
+    return !off && !h->multinomial() && !h->cfg.dbm_first && !h->fast_now && (h->W.ld & 3) == 0;
+}
+static void metrics_prep(bm_rbm *h, int B) {
     MetricsPrepArgs mp;
     mp.scal = h->scal; mp.rowacc = h->rowacc.p; mp.n_rowacc = 3 * h->maxB; mp.flip = h->flip; mp.B = B; mp.V = h->V;
     mp.key = make_key(h, SITE_PLL, 0); mp.row0 = (unsigned long long)h->row0;
     hipLaunchKernelGGL(metrics_prep_kernel, dim3(8), dim3(256), 0, h->stream, mp);
+}
+// the rest of the fetch, behind a run_chain(..., fetch = true): squared sums, the visible terms of the free energies
+static int metrics_from_chain(bm_rbm *h, int B, float *out4) {
     const SqJob msre{h->Xin, h->Xin_ld, h->vm.p, h->vm.ld, B, h->V, h->scal + 0};                        // :486-488
     const SqJob l2{h->W.p, h->W.ld, nullptr, 0, h->V, h->H, h->scal + 1};                                 // :482-484
-    hipLaunchKernelGGL(sqdiff2_kernel, dim3(128), dim3(256), 0, h->stream, msre, l2);
-    launch_fe(h, h->Xin, h->Xin_ld, B, true);
+    if (h->fe_in_chain) {       // the hidden terms are in fe_part already: squared sums and the row sums as ONE launch
+        FeRowArgs r;
+        memset(&r, 0, sizeof(r));
+        r.X = h->Xin; r.ld = h->Xin_ld; r.V = h->V; r.B = B;
+        r.vb = h->vb.p; r.sigma = (h->cfg.v_unit == BM_UNIT_GAUSSIAN) ? h->sigma.p : nullptr;
+        r.nslot = (h->H + 15) / 16; r.ld_part = (r.nslot + 3) & ~3;
+        r.rowacc = h->fe_part.p; r.rowacc2 = h->fe_part.p + (size_t)r.ld_part * h->maxB; r.out = h->scal + 2;
+        r.flip_col = nullptr; r.has_key = 1; r.key = make_key(h, SITE_PLL, 0); r.row0 = (unsigned long long)h->row0;
+        const int nb_sq = 256, nb_fe = (B + FE_ROWS_PER_WG - 1) / FE_ROWS_PER_WG;
+        hipLaunchKernelGGL(metrics_tail_kernel, dim3(nb_sq + nb_fe), dim3(256), 0, h->stream, msre, l2, r, nb_sq);
+    } else {
+        hipLaunchKernelGGL(sqdiff2_kernel, dim3(256), dim3(256), 0, h->stream, msre, l2);
+        launch_fe(h, h->Xin, h->Xin_ld, B, true);
+    }
     if (!out4) return 0;                                    // asynchronous caller: the sums stay in h->scal
     double host[6];
     BM_HIP(hipMemcpyAsync(host, h->scal, sizeof(host), hipMemcpyDeviceToHost, h->stream));
@@ -517,7 +559,7 @@ int bm_rbm_destroy(bm_rbm *h) {
     if (h->xchg_used) xchg_bind_user(h->xchg_used, nullptr);
     Mat *mats[] = {&h->W, &h->dW, &h->Wt, &h->h0m, &h->h0s, &h->hm, &h->hs, &h->hneg, &h->vm, &h->vs, &h->Xs, &h->Xd};
     for (Mat *m : mats) m->release();
-    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->grad_alt, &h->pen, &h->rowacc, &h->hhat};
+    DevBuf *all[] = {&h->vb, &h->hb, &h->dvb, &h->dhb, &h->q, &h->sigma, &h->grad, &h->grad_alt, &h->pen, &h->rowacc, &h->hhat, &h->fe_part};
     for (int i = 0; i < 2; ++i) {
         if (h->ev_ready[i]) (void)hipEventDestroy(h->ev_ready[i]);
         if (h->ev_reduced[i]) (void)hipEventDestroy(h->ev_reduced[i]);
@@ -526,6 +568,7 @@ int bm_rbm_destroy(bm_rbm *h) {
     if (h->stage_stream) { (void)hipStreamSynchronize(h->stage_stream); (void)hipStreamDestroy(h->stage_stream); }
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->mring) (void)hipHostFree(h->mring);
+    if (h->ev_mlast) (void)hipEventDestroy(h->ev_mlast);
     for (auto &sg : h->stage) {
         sg.W.release(); sg.dW.release();
         DevBuf *sv[] = {&sg.vb, &sg.hb, &sg.dvb, &sg.dhb, &sg.q, &sg.sigma};
@@ -757,7 +800,7 @@ int bm_rbm_train_step(bm_rbm *h, const float *X_dev, int32_t B, float lr, float 
 int bm_rbm_train_step_metrics(bm_rbm *h, const float *X_dev, int32_t B, float lr, float mom, int32_t k,
                               float *out4) {
     BM_TRY(check_dw(h, "bm_rbm_train_step_metrics"));
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, true, false, false, true));
     BM_TRY(metrics_from_chain(h, B, out4));
     launch_update_fused(h, B, lr, mom);
     h->call++;
@@ -778,10 +821,12 @@ int bm_rbm_train_step_metrics_async(bm_rbm *h, const float *X_dev, int32_t B, fl
     }
     BM_CHECK(h->mring_n < bm_rbm::MRING, "%d metric fetches are pending: call bm_rbm_collect_metrics", h->mring_n);
     BM_TRY(check_dw(h, "bm_rbm_train_step_metrics_async"));
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, true, false, false, true));
     BM_TRY(metrics_from_chain(h, B, nullptr));
     hipLaunchKernelGGL(scal_to_host_kernel, dim3(1), dim3(64), 0, h->stream, (const double *)h->scal,
                        h->mring_dev + (size_t)h->mring_n * 6);
+    if (!h->ev_mlast) BM_HIP(hipEventCreateWithFlags(&h->ev_mlast, hipEventDisableTiming));
+    BM_HIP(hipEventRecord(h->ev_mlast, h->stream));
     h->mring_B[h->mring_n++] = B;
     launch_update_fused(h, B, lr, mom);
     h->call++;
@@ -792,8 +837,13 @@ int bm_rbm_train_step_metrics_async(bm_rbm *h, const float *X_dev, int32_t B, fl
 int bm_rbm_collect_metrics(bm_rbm *h, float *out4n, int32_t max_n, int32_t *out_n) {
     BM_CHECK(h && out_n && (out4n || max_n == 0), "null argument");
     BM_CHECK(h->mring_n <= max_n, "%d fetches pending, room for %d", h->mring_n, (int)max_n);
-    BM_HIP(hipStreamSynchronize(h->stream));
-    {   // the pending fetches are dropped either way: an error must not leave them for the next epoch's mean
+    // wait for the last FETCH, not for the stream: what was queued behind it keeps running while the host reads the ring
+    if (h->mring_n > 0 && h->ev_mlast) BM_HIP(hipEventSynchronize(h->ev_mlast));
+    if (h->chain.status || h->xchg_used) {
+        // (status words are read with a blocking copy: that waits for the whole stream - only handles that use chained
+        //  launches or a direct exchange pay it)
+        BM_HIP(hipStreamSynchronize(h->stream));
+        // the pending fetches are dropped either way: an error must not leave them for the next epoch's mean
         const int rc = check_device_status(h);
         if (rc) { h->mring_n = 0; *out_n = 0; return rc; }
     }
@@ -894,7 +944,7 @@ int bm_rbm_transform(bm_rbm *h, const float *X_dev, int32_t B, int32_t k, float 
 }
 
 int bm_rbm_metrics(bm_rbm *h, const float *X_dev, int32_t B, int32_t k, float *out4) {
-    BM_TRY(run_chain(h, X_dev, B, k, nullptr));
+    BM_TRY(run_chain(h, X_dev, B, k, nullptr, true, false, false, true));
     BM_TRY(metrics_from_chain(h, B, out4));
     h->call++;
     return 0;
