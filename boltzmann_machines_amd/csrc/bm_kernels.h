@@ -214,7 +214,7 @@ template <int E, class Rng> struct ActSide {
 // act_kernel's epilogue for the lane's outputs of ONE output tile (i0, j0): activation, draw, stores, the per-row
 // partial sums.  Returns the lane's mean-field residual max|m - prev| (0 without a.prev).  A function so that the
 // persistent fast-binary kernel (act_bf3_kernel) can call it once per tile of its strip.
-template <class G, int ABL, class SideT, bool HWMATH = false>
+template <class G, int ABL, class SideT, bool HWMATH = false, bool FE = false>
 __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey &key, const f32x4 (&acc)[G::MI][1], const SideT &side,
                                               int i0, int j0) {
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
@@ -300,13 +300,15 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
             }
         }
     }
-    if (a.fe_zero && i0 == 0 && j0 == 0 && tid < 6) a.fe_zero[tid] = 0.0;          // (the first tile of the h0 pass of a fused fetch)
+    // (FE: the h0 pass of a fused metric fetch - a compile-time flavour of its own (act_kernel<..., FE = true>): as a runtime
+    //  branch of the shared epilogue the extra code cost every propagation pass 0.1 - 0.2 us, 0.5 us per CD-1 update, same-box A/B)
+    if constexpr (FE) { if (a.fe_zero && i0 == 0 && j0 == 0 && tid < 6) a.fe_zero[tid] = 0.0; }     // the first tile zeroes the fetch's accumulators
     if (a.rowacc || a.rowdot_out) {           // wave-uniform
         // per-lane quads (4 consecutive i, left to right); MI == 2: the lane's two quads are added
         float racc = 0.f, rdot = 0.f, racc2 = 0.f;
         if (j < a.J) {
             int fc = 0; float delta = 0.f;
-            if (a.fe_flip) {                                                                                   // wave-uniform branch
+            if constexpr (FE) {
                 fc = (a.fe_flip == FE_FLIP_FROM_KEY) ? pll_flip_col(a.fe_key, (unsigned long long)(a.row0 + j), a.K1) : a.fe_flip[j];
                 delta = 1.0f - 2.0f * a.fe_x[(size_t)j * a.fe_ldx + fc];
             }
@@ -322,7 +324,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                             qa += z[e] * a.dot_mat[(size_t)j * a.ld_dot + i];
                         } else {
                             const float t = z[e] + bs[e];
-                            if (a.fe_flip) qa2 += softplus(t + delta * a.fe_w[(size_t)fc * a.fe_ldw + i]);       // the PLL partner's row (beta_b == 1)
+                            if constexpr (FE) qa2 += softplus(t + delta * a.fe_w[(size_t)fc * a.fe_ldw + i]);    // the PLL partner's row (beta_b == 1)
                             if (a.rowacc_single) qa += HWMATH ? softplus_hw(a.beta_b * t) : softplus(a.beta_b * t);
                             else qa += HWMATH ? softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t)
                                               : softplus(a.beta_b * t) - softplus(a.beta_a * t);
@@ -341,11 +343,11 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
         racc += __shfl_xor(racc, 16);
         rdot += __shfl_xor(rdot, 16);
         if (G::MI == 1) { racc += __shfl_xor(racc, 32); rdot += __shfl_xor(rdot, 32); }
-        if (a.fe_flip) { racc2 += __shfl_xor(racc2, 16); if (G::MI == 1) racc2 += __shfl_xor(racc2, 32); }
+        if constexpr (FE) { racc2 += __shfl_xor(racc2, 16); if (G::MI == 1) racc2 += __shfl_xor(racc2, 32); }
         const bool writer = (G::MI == 1) ? (g == 0) : ((g & 1) == 0);
         const int slot = (i0 + wi * (16 * G::MI)) / 16 + ((G::MI == 2) ? (g >> 1) : 0);
         if (writer && j < a.J && slot * 16 < a.I) {
-            if (a.fe_flip) {             // metric fetch (wave-uniform): row-major partials
+            if constexpr (FE) {          // metric fetch: row-major partials
                 a.rowacc[(size_t)j * a.fe_rm + slot] = racc;
                 a.fe_rowacc2[(size_t)j * a.fe_rm + slot] = racc2;
             } else {
@@ -359,7 +361,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
 
 // MINB: HIP's second __launch_bounds__ argument = WAVES PER SIMD the register budget must allow (for the 4-wave
 // geometries that equals the workgroups per CU; an 8-wave workgroup that should run twice per CU passes 4)
-template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA>
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA, bool FE = false>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tmap) {
     // (the block -> tile map is an argument of its own: the grid path indexes it with blockIdx & 7, and a dynamically
     //  indexed member made hipcc fetch EVERY ActArgs field lazily in small pieces - 50 scalar loads with their waits
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tma
     mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
 #endif
     BM_STAMP(1);
-    float dmax = act_epilogue<G, ABL>(a, key, acc, side, i0, j0);
+    float dmax = act_epilogue<G, ABL, decltype(side), false, FE>(a, key, acc, side, i0, j0);
     if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
                                // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
         __shared__ float s_wavemax[G::NT / 64];
@@ -1770,6 +1772,24 @@ static inline void launch_act_geo(const ActArgs &a_in, hipStream_t st) {
     }
 }
 
+// the h0 pass of a fused metric fetch (ActArgs::fe_flip): the 8-wave 32 x 64 tile, LDS-DMA, slab order - a compile-time
+// flavour of its own (FE) and not a tuner case, so that the kernels of the plain update carry none of its code (same-box A/B:
+// a runtime branch in the shared epilogue cost the headline 0.5 us per update).  The 32 x 32 tiles measured within 1 us of it.
+static inline void launch_act_fe(const ActArgs &a, hipStream_t st) {
+    using G = GeoAct8;
+    const double kt = (double)a.K1;
+    const TileMap tmap = make_tile_map((a.I + G::TI - 1) / G::TI, (a.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, -1);
+    const bool fast = operand_fast(a.P1, a.p_xm ? XM : KM, a.K1) && operand_fast(a.Q1, XM, a.K1);
+    const dim3 grid(tile_grid<G>(a.I, a.J)), blk(G::NT);
+    if (a.p_xm) {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, 1, false, true, 0, XM, STG_DMA, true>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, 1, false, false, 0, XM, STG_DMA, true>), grid, blk, 0, st, a, tmap);
+    } else {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, 1, false, true, 0, KM, STG_DMA, true>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, 1, false, false, 0, KM, STG_DMA, true>), grid, blk, 0, st, a, tmap);
+    }
+}
+
 // fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
 // ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
 // sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
@@ -2026,6 +2046,7 @@ static inline void launch_act_bf3(const ActArgs &a, hipStream_t st) {
 static inline void launch_act_f32(const ActArgs &a, hipStream_t st);
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     if (a.b3.K1 > 0) { launch_act_bf3(a, st); return; }
+    if (a.fe_flip) { launch_act_fe(a, st); return; }     // the h0 pass of a fused metric fetch: its own kernel flavour
     launch_act_f32(a, st);
     // fast-binary mode, an fp32 launch whose sampled states the NEXT launches read as a bf16 shadow: converted here (the
     // strip kernel writes its shadow itself; keeping the branch out of the fp32 epilogue is worth ~0.2 us per launch)
