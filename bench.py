@@ -394,8 +394,15 @@ class _DbmBase(Workload):
             if mode == 'direct':
                 x = args._xchg[id(self.eng)]
                 self.comm = x
+                fused = None
+                if not args.no_fused_exchange and x.fused_ok():
+                    # exchange + update fused with column-sliced ownership (bm_dbm_exchange_apply_direct): the max-norm
+                    # rescale works on whole columns, so a rank owns columns of every W_i
+                    fused = x
+                    self.collective_note = (note or '') + ('; reduce-scatter of the owned COLUMNS -> update + max-norm on them -> '
+                                                           'all-gather of W / W^T / norms (two launches around the max-norm kernels)')
                 self.dp = parallel.DataParallelDBM(self.eng, rank, world,
-                                                   parallel.direct_allreduce_on_engine_stream(self.eng, x), xchg=x)
+                                                   parallel.direct_allreduce_on_engine_stream(self.eng, x), xchg=x, fused=fused)
             elif mode == 'gloo':
                 self.comm = 'gloo'
                 import torch
@@ -642,7 +649,8 @@ def choose_collective(args, eng, rank, world, dist):
         return want, None
     note = None
     try:
-        x = parallel.DirectExchange(eng, rank, world)
+        # (a dry run with several ranks on one device: the exchange must not spin on every CU, see bm_xchg_set_max_workgroups)
+        x = parallel.DirectExchange(eng, rank, world, max_workgroups=48 if args._shared_devices else None)
         # a lost rank or an unusable peer mapping must show up within a second at start-up (a wait that expires is
         # fatal for the exchange object: sticky status, NaN results); the timed run gets the library's default back
         x.set_timeout(1.0)
@@ -740,8 +748,10 @@ def check_data_parallel_run(wl, args, rank, world, dist):
         # rank is here) before anything - the instrumented kernel pass, a checkpoint - reads or updates it
         if getattr(wl, 'dp', None) is not None and getattr(wl.dp, 'fused', None) is x:
             try:
+                trace('exchange status before gather_dw: %d' % int(x.status()))
                 x.gather_dw()
                 wl.eng.sync()
+                trace('gather_dw done')
             except Exception as e:       # noqa: BLE001 - shows up as a non-zero status below
                 sys.stderr.write('bench: gather_dw failed: %s\n' % (str(e)[:200],))
         status = max(status, int(x.status()))
@@ -812,6 +822,17 @@ def self_launch(args):
     sys.exit(rc)
 
 
+_T0 = time.perf_counter()
+
+
+def trace(msg):
+    """BM_BENCH_TRACE=1: time-stamped per-rank progress lines on stderr (where does a multi-rank run spend its time /
+    which rank is late when an exchange wait expires)"""
+    if os.environ.get('BM_BENCH_TRACE', '0') == '1':
+        sys.stderr.write('[bench rank %s +%.2fs] %s\n' % (os.environ.get('RANK', '0'), time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def measure(wl, steps, warmup, precondition_s, barrier, dist):
     """W untimed warm-up steps, then EXACTLY `steps` steps between two barriers (+ device synchronisation); returns
     (wall seconds, max over ranks; HIP-event milliseconds on the engine stream of this rank)."""
@@ -822,10 +843,13 @@ def measure(wl, steps, warmup, precondition_s, barrier, dist):
     # steady).  A FIXED number of steps (every rank of a data-parallel run must issue the same number of
     # collectives); untimed; the model is then put back to its initial state.
     if precondition_s > 0:
+        trace('precondition: %d steps' % wl.precondition_steps(precondition_s))
         wl.run_steps(0, wl.precondition_steps(precondition_s))
         wl.reset()              # (in stream order where the workload can: no idle gap before the warm-up steps)
+    trace('warm-up: %d steps' % warmup)
     wl.run_steps(0, warmup)
     barrier()
+    trace('timed region: %d steps' % steps)
     t0 = time.perf_counter()
     eng.timer_start()
     wl.run_steps(0, steps)
@@ -833,6 +857,7 @@ def measure(wl, steps, warmup, precondition_s, barrier, dist):
     barrier()
     dt = time.perf_counter() - t0
     ev_ms = eng.timer_elapsed()
+    trace('timed region done: %.3f s' % dt)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -961,7 +986,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    trace('process group up; building the workload')
     wl = WORKLOADS[args.config](args, rank, world, device, dist)
+    trace('workload ready (collective: %s)' % (getattr(wl, 'collective', None),))
     dt, ev_ms = measure(wl, args.steps, args.warmup, args.precondition_s, barrier, dist)
     dp_check = check_data_parallel_run(wl, args, rank, world, dist)      # (after the clock stopped)
     rep = wl.report(args, world, dt, ev_ms) if rank == 0 else None

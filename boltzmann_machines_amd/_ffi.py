@@ -80,7 +80,11 @@ SIGNATURES = {
     'bm_dbm_allreduce_grads_direct': [_vp, _vp],
     'bm_rbm_exchange_apply_direct': [_vp, _vp, _i32, C.c_float, C.c_float],
     'bm_rbm_exchange_gather_dw': [_vp, _vp],
+    'bm_dbm_exchange_apply_ok': [_vp, _vp, C.POINTER(_i32)],
+    'bm_dbm_exchange_apply_direct': [_vp, _vp, _i32, _i32, C.c_float, C.c_float],
+    'bm_dbm_exchange_gather_dw': [_vp, _vp],
     'bm_xchg_set_timeout': [_vp, C.c_double],
+    'bm_xchg_set_max_workgroups': [_vp, _i32],
     'bm_dbm_set_xchg': [_vp, _vp],
     'bm_dbm_set_fast_binary': [_vp, _i32],
     'bm_dbm_set_ais_literal': [_vp, _i32],

@@ -23,6 +23,10 @@ constexpr int MAXL = BM_DBM_MAX_LAYERS;
 struct bm_dbm {
     bm_dbm_config cfg;
     bm_xchg *xchg_used = nullptr;          // the direct exchange this engine last used (bm_dbm_sync checks its status word)
+    // after bm_dbm_exchange_apply_direct (bm_xchg.hip) a rank holds only ITS column slices of the momentum buffers dW_i:
+    // every reader - get_param, the single-GPU update, apply_step - fails until bm_dbm_exchange_gather_dw (check_dw)
+    bool dw_sharded = false;
+    unsigned dw_set_mask = 0;              // layers whose dW the host has replaced since the buffers became sharded
     int L, V, N, M;
     int n[MAXL + 1];                       // n[0] = V, n[i+1] = hidden layer i
     hipStream_t stream = nullptr;
@@ -727,6 +731,13 @@ static int mean_field_and_particles(bm_dbm *h, const float *X_dev, int k, int *o
     return rc;
 }
 
+static void xchg_dw_replaced(bm_xchg *x);
+static int check_dw(const bm_dbm *h, const char *what) {
+    BM_CHECK(!h->dw_sharded, "%s: after bm_dbm_exchange_apply_direct this rank holds only its column slices of the momentum "
+                             "buffers dW; call bm_dbm_exchange_gather_dw (DirectExchange.gather_dw) on every rank first", what);
+    return 0;
+}
+
 static size_t sums_off(const bm_dbm *h, int which /* 0: X, 1: v, 2+2i: mu_i, 3+2i: H_i */) {
     size_t o = 0;
     if (which == 0) return 0;
@@ -806,13 +817,16 @@ static void launch_dbm_grad(bm_dbm *h, const float *X_dev, int i, int fused, flo
 
 static int recon_msre(bm_dbm *h, const float *X_dev, float *out_msre);
 
-static void launch_dbm_maxnorm(bm_dbm *h, int i) {
+static void launch_dbm_maxnorm(bm_dbm *h, int i, int c_first = 0, int c_end = -1) {
     MaxNormArgs m;
+    m.c_first = c_first; m.c_end = c_end < 0 ? h->n[i + 1] : c_end;
+    if (m.c_end <= m.c_first) return;
     m.W = h->W[i].p; m.Wt = h->Wt[i].p; m.I = h->n[i + 1]; m.J = h->n[i]; m.ldw = h->W[i].ld; m.ldwt = h->Wt[i].ld;
     m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
     m.num = h->mn_fac[i].p; m.den = h->mn_fac[i].p + m.I;
-    hipLaunchKernelGGL(maxnorm_kernel, dim3((m.I + MN_COLS - 1) / MN_COLS), dim3(NT), 0, h->stream, m);
-    hipLaunchKernelGGL(maxnorm_scale_kernel, dim3(((m.I + 31) / 32) * ((m.J + 31) / 32)), dim3(256), 0, h->stream, m);
+    const int nc = m.c_end - m.c_first;
+    hipLaunchKernelGGL(maxnorm_kernel, dim3((nc + MN_COLS - 1) / MN_COLS), dim3(NT), 0, h->stream, m);
+    hipLaunchKernelGGL(maxnorm_scale_kernel, dim3(((nc + 31) / 32) * ((m.J + 31) / 32)), dim3(256), 0, h->stream, m);
 }
 
 // gradients + sparsity + momentum + max-norm (dbm.py:550-621) from the current mu / particles
@@ -1023,6 +1037,11 @@ int bm_dbm_set_param(bm_dbm *h, const char *name, const float *host, size_t n) {
     if (m) {
         BM_CHECK(n == (size_t)m->rows * m->cols, "variable '%s' has %zu elements, got %zu", name, (size_t)m->rows * m->cols, n);
         BM_TRY(m->upload(host));
+        if (m >= h->dW && m < h->dW + MAXL && h->dw_sharded) {
+            // the host replaces a momentum buffer whole: with every layer's buffer replaced the replicas are complete again
+            h->dw_set_mask |= 1u << (unsigned)(m - h->dW);
+            if (h->dw_set_mask == (1u << (unsigned)h->L) - 1u) { h->dw_sharded = false; if (h->xchg_used) xchg_dw_replaced(h->xchg_used); }
+        }
         if (isW) {
             std::vector<float> t(n);
             for (int r = 0; r < m->rows; ++r)
@@ -1043,6 +1062,7 @@ int bm_dbm_get_param(bm_dbm *h, const char *name, float *host, size_t n) {
     BM_HIP(hipStreamSynchronize(h->stream));
     if (m) {
         BM_CHECK(n == (size_t)m->rows * m->cols, "variable '%s' has %zu elements, got %zu", name, (size_t)m->rows * m->cols, n);
+        if (m >= h->dW && m < h->dW + MAXL) BM_TRY(check_dw(h, "bm_dbm_get_param(dW)"));
         return m->download(host);
     }
     BM_CHECK(n == v->n, "variable '%s' has %zu elements, got %zu", name, v->n, n);
@@ -1067,6 +1087,7 @@ int bm_dbm_dev_ptr(bm_dbm *h, const char *name, void **out_dev, size_t *out_n) {
 int bm_dbm_train_step(bm_dbm *h, const float *X_dev, float lr, float mom, int32_t k,
                       int32_t *out_n_mf, float *out_msre) {
     BM_CHECK(k >= 1, "n_gibbs_steps must be >= 1 (got %d)", k);
+    BM_TRY(check_dw(h, "bm_dbm_train_step"));
     int nmf = 0;
     BM_TRY(mean_field_and_particles(h, X_dev, k, &nmf));      // :517, :521
     if (out_msre) BM_TRY(recon_msre(h, X_dev, out_msre));     // :625-630 (W before the update)
@@ -1158,6 +1179,7 @@ int bm_dbm_grad_step(bm_dbm *h, const float *X_dev, int32_t k, int32_t *out_n_mf
 
 int bm_dbm_apply_step(bm_dbm *h, int32_t N_global, int32_t M_global, float lr, float mom) {
     const float N = (float)N_global, M = (float)M_global;
+    BM_TRY(check_dw(h, "bm_dbm_apply_step"));
     launch_dbm_biases(h, N, M, lr, mom);
     for (int i = 0; i < h->L; ++i) {
         ApplyWArgs a;

@@ -1484,9 +1484,7 @@ struct DbmBiasArgs {
     int n, layer;
     float N, M, lr, mom, damping, cost, target;
 };
-__global__ void dbm_bias_kernel(DbmBiasArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.n) return;
+__device__ __forceinline__ void dbm_bias_update(const DbmBiasArgs &a, int c) {
     float g = a.s_pos[c] / a.N - a.s_neg[c] / a.M;           // reduce_mean(mu) - reduce_mean(H)   :553,573-576
     if (a.q) {
         const float qn = a.damping * a.q[c] + (1.0f - a.damping) * a.s_neg[a.layer];    // :582-584 (q_means[i] scalar)
@@ -1503,6 +1501,10 @@ __global__ void dbm_bias_kernel(DbmBiasArgs a) {
     a.db[c] = d;
     a.b[c] = a.b[c] + d;
 }
+__global__ void dbm_bias_kernel(DbmBiasArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.n) dbm_bias_update(a, c);
+}
 
 // Max-norm column rescale (dbm.py:511-513, :603-607):  W[:,c] *= min(||W[:,c]||, c_max) / max(||W[:,c]||, 1e-8)
 // Two kernels.  maxnorm_kernel: one workgroup per 16 columns computes ||.||^2 as the canonical chain
@@ -1517,6 +1519,8 @@ struct MaxNormArgs {
     float max_norm;
     float *norm_out;        // [I] column norms (W_norm metric) or null
     float *num, *den;       // [I] each: the column factors
+    int c_first, c_end;     // the columns this launch works on ([0, I) unless a rank owns a column slice: bm_xchg.hip);
+                            // c_first % 32 == 0, c_end % 32 == 0 or c_end == I
 };
 // maxnorm_kernel: a workgroup owns 16 columns, its wave 0 runs their chain (768 dependent MFMAs for 3072 rows = 10 us
 // is the floor: the chain of a column is sequential over the rows); all four waves stream the rows
@@ -1569,7 +1573,7 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
     __shared__ __attribute__((aligned(16))) float sA[2][MN_CH * 16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
-    const int c0 = blockIdx.x * MN_COLS;
+    const int c0 = a.c_first + blockIdx.x * MN_COLS;
     const bool full = (a.ldw & 3) == 0 && (((uintptr_t)a.W) & 15u) == 0 && c0 + MN_COLS <= a.I;
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nch = (a.J + MN_CH - 1) / MN_CH;
@@ -1613,8 +1617,8 @@ __global__ __launch_bounds__(NT) void maxnorm_kernel(MaxNormArgs a) {
 __global__ __launch_bounds__(256) void maxnorm_scale_kernel(MaxNormArgs a) {
     __shared__ float t[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int tiles_c = (a.I + 31) / 32;
-    const int c0 = (blockIdx.x % tiles_c) * 32, j0 = (blockIdx.x / tiles_c) * 32;
+    const int tiles_c = (a.c_end - a.c_first + 31) / 32;
+    const int c0 = a.c_first + (blockIdx.x % tiles_c) * 32, j0 = (blockIdx.x / tiles_c) * 32;
     const int c = c0 + tx;
     const float num = c < a.I ? a.num[c] : 0.f, den = c < a.I ? a.den[c] : 1.f;
 #pragma unroll

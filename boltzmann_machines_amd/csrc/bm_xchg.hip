@@ -52,6 +52,7 @@ static_assert(sizeof(Blob) == 256, "blob layout");
 struct Args {
     float *buf, *red;
     unsigned long long count, chunk;               // floats; chunk % 4 == 0
+    unsigned long long red_cap;                    // floats of every rank's staging slice (>= chunk)
     int rank, n;
     unsigned epoch;
     const float *pbuf[MAXR], *pred[MAXR];          // rank r's buffer / staging slice (own entries = local pointers)
@@ -324,6 +325,197 @@ __global__ __launch_bounds__(NTX) void exchange_apply_kernel(Args a, RbmApply p)
     }
 }
 
+// ---- fused exchange of the data-parallel DBM update (round-4 verdict 4a): COLUMN-sliced ownership.  The DBM rescales every
+// column of W_i to the max-norm after the update (dbm.py:511-513, 603-606), and a column norm is a canonical chain over the
+// whole column (maxnorm_kernel): rank r therefore owns columns [r sw_i, (r + 1) sw_i) of every W_i (sw_i a multiple of 32),
+// i.e. a strided slice of W_i / dW_i / the raw outer products and a contiguous row block of the maintained transpose.
+//   launch A  dbm_exchange_apply_kernel: READY, sums of the owned columns of pos_i / neg_i over the ranks in rank order,
+//             g = pos / N - neg / M - l2 W - pen, dW = lr (mom dW + g), W += dW on the owned columns; the column sums
+//             (tail) are reduced by every rank itself and the bias / running-mean / penalty update (dbm_bias_update) applied
+//             to every replica by the last workgroup, which publishes the penalties the W update needs;
+//   then      maxnorm_kernel + maxnorm_scale_kernel on the owned columns (the kernels of the one-GPU update, same bits;
+//             they also write the owned rows of W_i^T and the owned column norms);
+//   launch B  dbm_exchange_gather_kernel: stage the owned columns (and norms), DONE, pull the other ranks' columns in
+//             32 x 32 tiles that are written to W_i and, transposed through LDS, to W_i^T.
+// Replaces bm_dbm_allreduce_grads_direct + bm_dbm_apply_step with the same bits; the gather moves W (half of the two raw
+// buffers) and 1 / N of the update and max-norm work is on a rank's critical path.  dW_i stays with the owners
+// (bm_dbm_exchange_gather_dw = launch B in dW mode with its own READY round).
+struct DbmLayerX {
+    float *W, *dW, *Wt, *wnorm;
+    const float *pen;
+    unsigned long long off_pos, off_neg;           // floats into the exchanged buffer, pitch ldw
+    unsigned long long red_off;                    // floats into the staging slice: [J][sw] values, then [sw] column norms
+    int I, J, ldw, ldwt, sw;
+};
+struct DbmApply {
+    int L, mode, do_ready;                         // mode 0: weights, 1: dW (launch B)
+    DbmLayerX lay[BM_DBM_MAX_LAYERS];
+    bm::DbmBiasArgs bias[BM_DBM_MAX_LAYERS + 1];       // [0] visible, [1 + i] hidden layer i; s_pos / s_neg point into tail_red
+    unsigned long long off_sums; int n_sums;
+    float N, M, l2, lr, mom;
+    float *tail_red; unsigned *tail_flag;
+};
+
+__global__ __launch_bounds__(NTX) void dbm_exchange_apply_kernel(Args a, DbmApply p) {
+    const int tid = threadIdx.x, me = a.rank, n = a.n;
+    const float qnan = __builtin_nanf("");
+    if (blockIdx.x == 0 && tid < n)
+        __hip_atomic_store(a.pflags[tid] + F_READY + me, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const bool ok1 = wait_all(a, F_READY, 1);
+    __amdgpu_buffer_rsrc_t rs[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) rs[r] = rsrc(r < n ? a.pbuf[r] : a.buf, r < n ? ((a.count + 3) & ~3ull) * 4 : 0);
+    // ---- tail (last workgroup): column sums over the ranks, biases / running means / penalties of this replica
+    if (blockIdx.x == gridDim.x - 1) {
+        const int T4 = (p.n_sums + 3) / 4;
+        for (int c4 = tid; c4 < T4; c4 += NTX) {
+            const unsigned off = (unsigned)((p.off_sums + 4ull * c4) * 4);
+            f32x4 v[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) if (r < n) v[r] = load_sys(rs[r], off);
+            f32x4 s = v[0];
+#pragma unroll
+            for (int r = 1; r < MAXR; ++r) if (r < n) s = s + v[r];          // rank order
+            if (!ok1) s = (f32x4){qnan, qnan, qnan, qnan};
+            *reinterpret_cast<f32x4 *>(p.tail_red + 4 * c4) = s;
+        }
+        __syncthreads();
+        for (int v = 0; v <= p.L; ++v)
+            for (int c = tid; c < p.bias[v].n; c += NTX) bm::dbm_bias_update(p.bias[v], c);
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.tail_flag, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the penalties of this step (always read, as bm_dbm_apply_step does: pen = cost * (..) may be -0)
+    bool okp = true;
+    {
+        int bad = 0;
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            while ((int)(__hip_atomic_load(p.tail_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - a.epoch) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > a.timeout_ticks) { bad = 1; break; }
+            }
+            if (bad) __hip_atomic_store(a.flags + F_STATUS, (unsigned)(4 * 16 + me + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        okp = !__syncthreads_or(bad);
+    }
+    const bool pow2 = ((__float_as_uint(p.N) & 0x007fffffu) == 0u) && ((__float_as_uint(p.M) & 0x007fffffu) == 0u) &&
+                      p.N >= 1.0f && p.M >= 1.0f;                          // apply_w_tiled_kernel's rule
+    const float invN = 1.0f / p.N, invM = 1.0f / p.M;
+    for (int i = 0; i < p.L; ++i) {
+        const DbmLayerX &y = p.lay[i];
+        const int c0 = me * y.sw, c1 = (c0 + y.sw < y.I) ? c0 + y.sw : y.I;
+        if (c1 <= c0) continue;
+        const unsigned w4 = (unsigned)(c1 - c0) / 4u;                       // I % 4 == 0
+        const unsigned long long n4 = (unsigned long long)y.J * w4;
+        for (unsigned long long e = (unsigned long long)blockIdx.x * NTX + tid; e < n4; e += (unsigned long long)a.grid * NTX) {
+            const int j = (int)(e / w4), c = c0 + 4 * (int)(e % w4);
+            const unsigned long long o = (unsigned long long)j * y.ldw + c;
+            const unsigned bp = (unsigned)((y.off_pos + o) * 4), bn = (unsigned)((y.off_neg + o) * 4);
+            f32x4 vp[MAXR], vn[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) if (r < n) { vp[r] = load_sys(rs[r], bp); vn[r] = load_sys(rs[r], bn); }
+            f32x4 sp = vp[0], sn = vn[0];
+#pragma unroll
+            for (int r = 1; r < MAXR; ++r) if (r < n) { sp = sp + vp[r]; sn = sn + vn[r]; }      // rank order
+            f32x4 wv = *reinterpret_cast<const f32x4 *>(y.W + o), dv = *reinterpret_cast<const f32x4 *>(y.dW + o);
+            const f32x4 pe = *reinterpret_cast<const f32x4 *>(y.pen + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g = pow2 ? sp[q] * invN - sn[q] * invM : sp[q] / p.N - sn[q] / p.M;
+                float w = wv[q], d = dv[q];
+                bm::apply_w_update(g, pe[q], p.l2, p.lr, p.mom, w, d);
+                wv[q] = w; dv[q] = d;
+            }
+            if (!ok1 || !okp) wv = dv = (f32x4){qnan, qnan, qnan, qnan};
+            *reinterpret_cast<f32x4 *>(y.W + o) = wv;
+            *reinterpret_cast<f32x4 *>(y.dW + o) = dv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTX) void dbm_exchange_gather_kernel(Args a, DbmApply p) {
+    __shared__ float t[32][33];
+    const int tid = threadIdx.x, me = a.rank, n = a.n;
+    const float qnan = __builtin_nanf("");
+    if (p.do_ready) {                                      // the dW gather is an exchange of its own: nobody stages into a
+        if (blockIdx.x == 0 && tid < n)                    // slice a peer may still be pulling from
+            __hip_atomic_store(a.pflags[tid] + F_READY + me, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        (void)wait_all(a, F_READY, 1);
+    }
+    // ---- stage the owned columns (after the max-norm pass) and their norms
+    __amdgpu_buffer_rsrc_t rred = rsrc(a.red, a.red_cap * 4);
+    for (int i = 0; i < p.L; ++i) {
+        const DbmLayerX &y = p.lay[i];
+        const int c0 = me * y.sw, c1 = (c0 + y.sw < y.I) ? c0 + y.sw : y.I;
+        if (c1 <= c0) continue;
+        const float *src = p.mode ? y.dW : y.W;
+        const unsigned w4 = (unsigned)(c1 - c0) / 4u;
+        const unsigned long long n4 = (unsigned long long)y.J * w4;
+        for (unsigned long long e = (unsigned long long)blockIdx.x * NTX + tid; e < n4; e += (unsigned long long)a.grid * NTX) {
+            const int j = (int)(e / w4), cc = 4 * (int)(e % w4);
+            store_sys(rred, (unsigned)((y.red_off + (unsigned long long)j * y.sw + cc) * 4),
+                      *reinterpret_cast<const f32x4 *>(src + (unsigned long long)j * y.ldw + c0 + cc));
+        }
+        if (!p.mode && blockIdx.x == 0)
+            for (unsigned e = tid; e < w4; e += NTX)
+                store_sys(rred, (unsigned)((y.red_off + (unsigned long long)y.J * y.sw + 4 * e) * 4),
+                          *reinterpret_cast<const f32x4 *>(y.wnorm + c0 + 4 * e));
+    }
+    // DONE(e)
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)a.grid * a.epoch) {
+            __threadfence_system();
+            for (int r = 0; r < n; ++r)
+                __hip_atomic_store(a.pflags[r] + F_DONE + me, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (n == 1) return;
+    const bool ok2 = wait_all(a, F_DONE, 2);
+    // ---- pull the other ranks' columns: 32 x 32 tiles -> W_i (or dW_i) and, transposed, W_i^T
+    for (int i = 0; i < p.L; ++i) {
+        const DbmLayerX &y = p.lay[i];
+        float *dst = p.mode ? y.dW : y.W;
+        for (int d = 1; d < n; ++d) {
+            const int q = (me + d) % n;
+            const int q0 = q * y.sw, q1 = (q0 + y.sw < y.I) ? q0 + y.sw : y.I;
+            if (q1 <= q0) continue;
+            __amdgpu_buffer_rsrc_t rq = rsrc(a.pred[q], a.red_cap * 4);
+            const int tiles_c = (q1 - q0 + 31) / 32, tiles_j = (y.J + 31) / 32;
+            for (int tile = blockIdx.x; tile < tiles_c * tiles_j; tile += a.grid) {
+                const int cb = (tile % tiles_c) * 32, j0 = (tile / tiles_c) * 32;
+                const int r = tid >> 3, c4 = tid & 7;
+                const int j = j0 + r, c = q0 + cb + 4 * c4;
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (j < y.J && c < q1) {                                   // I % 4 == 0: the whole group is inside
+                    v = ok2 ? load_sys(rq, (unsigned)((y.red_off + (unsigned long long)j * y.sw + cb + 4 * c4) * 4))
+                            : (f32x4){qnan, qnan, qnan, qnan};
+                    *reinterpret_cast<f32x4 *>(dst + (unsigned long long)j * y.ldw + c) = v;
+                }
+                if (!p.mode) {
+                    t[r][4 * c4] = v[0]; t[r][4 * c4 + 1] = v[1]; t[r][4 * c4 + 2] = v[2]; t[r][4 * c4 + 3] = v[3];
+                    __syncthreads();
+                    const int cc = q0 + cb + r, jq = j0 + 4 * c4;          // row cc of the transpose, 4 consecutive j
+                    if (cc < q1 && jq < y.J) {
+                        float *wt = y.Wt + (unsigned long long)cc * y.ldwt + jq;
+                        if (jq + 3 < y.J) *reinterpret_cast<f32x4 *>(wt) = (f32x4){t[4 * c4][r], t[4 * c4 + 1][r], t[4 * c4 + 2][r], t[4 * c4 + 3][r]};
+                        else for (int e = 0; e < 4; ++e) if (jq + e < y.J) wt[e] = t[4 * c4 + e][r];
+                    }
+                    __syncthreads();
+                }
+            }
+            if (!p.mode && blockIdx.x == 0)
+                for (int e = tid; e < (q1 - q0) / 4; e += NTX)
+                    *reinterpret_cast<f32x4 *>(y.wnorm + q0 + 4 * e) =
+                        ok2 ? load_sys(rq, (unsigned)((y.red_off + (unsigned long long)y.J * y.sw + 4 * e) * 4)) : (f32x4){qnan, qnan, qnan, qnan};
+        }
+    }
+}
+
 // ---- all-reduce(max) of one float.  slots [2][MAXR] of {value bits, epoch} (one 8-byte store each), by epoch parity
 struct MaxArgs {
     float *val;                                    // in / out (device, local)
@@ -362,7 +554,7 @@ __global__ __launch_bounds__(64) void max1_kernel(MaxArgs a) {
 struct bm_xchg {
     int rank = 0, nranks = 1, device = 0;
     float *buf = nullptr, *red = nullptr;
-    size_t count = 0, chunk = 0;
+    size_t count = 0, chunk = 0, red_cap = 0;      // red_cap: floats of the staging slice (>= chunk; the same on every rank)
     unsigned *flags = nullptr, *ctr = nullptr;     // flags: F_WORDS words + the max slots behind them
     unsigned long long *slots = nullptr;
     const float *pbuf[bmx::MAXR], *pred[bmx::MAXR];
@@ -410,17 +602,18 @@ static void xchg_dw_replaced(bm_xchg *x) { if (x) x->dw_stale = false; }
 
 extern "C" {
 
-int bm_xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t count, bm_xchg **out) {
+static int xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t count, size_t min_red, bm_xchg **out) {
     BM_CHECK(out && buf_dev, "null argument");
     BM_CHECK(nranks >= 1 && nranks <= bmx::MAXR && rank >= 0 && rank < nranks, "bad rank %d of %d (at most %d ranks)", rank, nranks, bmx::MAXR);
     BM_CHECK(((uintptr_t)buf_dev & 15u) == 0, "the exchanged buffer must be 16-byte aligned");
     bm_xchg *x = new bm_xchg();
     x->rank = rank; x->nranks = nranks; x->buf = buf_dev; x->count = count;
     x->chunk = (((count + nranks - 1) / nranks) + 3) & ~(size_t)3;
+    x->red_cap = ((x->chunk > min_red ? x->chunk : min_red) + 3) & ~(size_t)3;
     // (an early return below must not leak what was allocated so far: round-3 advisor)
     auto fail = [&]() { if (x->red) (void)hipFree(x->red); if (x->ctr) (void)hipFree(x->ctr); if (x->flags) (void)hipFree(x->flags); delete x; return 1; };
     if (hipGetDevice(&x->device) != hipSuccess ||
-        hipMalloc((void **)&x->red, (x->chunk ? x->chunk : 4) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&x->red, (x->red_cap ? x->red_cap : 4) * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&x->ctr, 64) != hipSuccess || hipMemset(x->ctr, 0, 64) != hipSuccess) {
         bm::set_error("bm_xchg_create: device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         return fail();
@@ -434,6 +627,10 @@ int bm_xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t count, b
     x->attached = nranks == 1;
     *out = x;
     return 0;
+}
+
+int bm_xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t count, bm_xchg **out) {
+    return xchg_create(rank, nranks, buf_dev, count, 0, out);
 }
 
 int bm_xchg_blob_bytes(void) { return (int)sizeof(bmx::Blob); }
@@ -546,6 +743,19 @@ int bm_xchg_set_timeout(bm_xchg *x, double seconds) {
     return 0;
 }
 
+// Upper bound of the workgroups of every later exchange launch (default: up to 256, one per CU).  For ranks that SHARE a
+// device (dry runs of the multi-rank path on one GPU): a launch whose workgroups sit on every CU and spin for a peer can
+// keep that peer's own kernels - same device, another process - from ever being placed (observed: intermittent READY
+// time-outs at 784 x 1024 with two ranks on one MI355X, never with small shapes); with a bound well below the CU count the
+// peer always finds free CUs.  One rank per GPU needs no bound.  Before the first exchange only (the completion counter
+// counts whole launches).
+int bm_xchg_set_max_workgroups(bm_xchg *x, int32_t n) {
+    BM_CHECK(x && n >= 1, "bad argument");
+    BM_CHECK(x->epoch == 0, "bm_xchg_set_max_workgroups: call it before the first exchange");
+    if (x->grid > n) x->grid = n;
+    return 0;
+}
+
 int bm_xchg_info(bm_xchg *x, int32_t *out_rank, int32_t *out_nranks, size_t *out_count) {
     BM_CHECK(x, "null argument");
     if (out_rank) *out_rank = x->rank;
@@ -619,11 +829,117 @@ int bm_rbm_xchg_create(bm_rbm *h, int32_t rank, int32_t nranks, bm_xchg **out) {
     BM_TRY(bm_rbm_dev_ptr(h, "grad", &p, &n));
     return bm_xchg_create(rank, nranks, (float *)p, n, out);
 }
+// columns of W_i a rank owns in the fused DBM exchange: a multiple of 32 (the tiles of maxnorm_scale_kernel and of the pull)
+static int dbm_slice_width(int I, int nranks) { return 32 * ((I + 32 * nranks - 1) / (32 * nranks)); }
+static size_t dbm_staging_floats(const bm_dbm *h, int nranks) {
+    size_t need = 0;
+    for (int i = 0; i < h->L; ++i) need += ((size_t)h->n[i] + 1) * (size_t)dbm_slice_width(h->n[i + 1], nranks);
+    return need;
+}
 int bm_dbm_xchg_create(bm_dbm *h, int32_t rank, int32_t nranks, bm_xchg **out) {
     BM_CHECK(h && out, "null argument");
     void *p = nullptr; size_t n = 0;
     BM_TRY(bm_dbm_dev_ptr(h, "grad", &p, &n));
-    return bm_xchg_create(rank, nranks, (float *)p, n, out);
+    return xchg_create(rank, nranks, (float *)p, n, nranks >= 1 ? dbm_staging_floats(h, nranks) : 0, out);
+}
+
+// 1 when bm_dbm_exchange_apply_direct can serve this engine (every layer width a multiple of 4, offsets within 4 GiB)
+static bool dbm_fused_ok(const bm_dbm *h, const bm_xchg *x) {
+    if (!x->attached || x->buf != h->grad.p || x->count != h->grad.n) return false;
+    if (((x->count + 3) & ~(size_t)3) * sizeof(float) >= 0xfffffff0ull || x->red_cap * sizeof(float) >= 0xfffffff0ull) return false;
+    if (dbm_staging_floats(h, x->nranks) > x->red_cap) return false;
+    for (int i = 0; i < h->L; ++i)
+        if (h->n[i + 1] % 4 != 0 || h->W[i].ld % 4 != 0 || h->Wt[i].ld % 4 != 0 || h->W[i].ld != h->dW[i].ld) return false;
+    return true;
+}
+int bm_dbm_exchange_apply_ok(bm_dbm *h, bm_xchg *x, int32_t *out_ok) {
+    BM_CHECK(h && x && out_ok, "null argument");
+    *out_ok = dbm_fused_ok(h, x) ? 1 : 0;
+    return 0;
+}
+
+static int dbm_fill_exchange(bm_dbm *h, bm_xchg *x, bmx::Args &a, bmx::DbmApply &q, bool new_epoch) {
+    memset(&a, 0, sizeof(a));
+    a.buf = x->buf; a.red = x->red; a.count = x->count; a.chunk = x->chunk; a.red_cap = x->red_cap;
+    a.rank = x->rank; a.n = x->nranks; a.epoch = new_epoch ? ++x->epoch : x->epoch;
+    for (int r = 0; r < bmx::MAXR; ++r) { a.pbuf[r] = x->pbuf[r]; a.pred[r] = x->pred[r]; a.pflags[r] = x->pflags[r]; }
+    a.flags = x->flags; a.ctr = x->ctr; a.grid = x->grid; a.timeout_ticks = x->timeout_ticks;
+    memset(&q, 0, sizeof(q));
+    q.L = h->L;
+    size_t roff = 0;
+    for (int i = 0; i < h->L; ++i) {
+        bmx::DbmLayerX &y = q.lay[i];
+        y.W = h->W[i].p; y.dW = h->dW[i].p; y.Wt = h->Wt[i].p; y.wnorm = h->wnorm[i].p; y.pen = h->pen[i].p;
+        y.off_pos = h->raw_off[i][0]; y.off_neg = h->raw_off[i][1];
+        y.I = h->n[i + 1]; y.J = h->n[i]; y.ldw = h->W[i].ld; y.ldwt = h->Wt[i].ld;
+        y.sw = dbm_slice_width(y.I, x->nranks);
+        y.red_off = roff;
+        roff += ((size_t)y.J + 1) * (size_t)y.sw;
+    }
+    return 0;
+}
+
+// Data-parallel DBM update, exchange and update fused (see dbm_exchange_apply_kernel): replaces
+// bm_dbm_allreduce_grads_direct + bm_dbm_apply_step, same bits.  Afterwards every replica holds the new W_i, W_i^T, column
+// norms, biases, running means; of the momentum buffers dW_i a rank holds its columns (bm_dbm_exchange_gather_dw).
+int bm_dbm_exchange_apply_direct(bm_dbm *h, bm_xchg *x, int32_t N_global, int32_t M_global, float lr, float mom) {
+    BM_CHECK(h && x, "null argument");
+    BM_CHECK(dbm_fused_ok(h, x), "the fused DBM exchange needs an attached exchange created by bm_dbm_xchg_create for this "
+                                 "engine and layer widths that are multiples of 4 (bm_dbm_exchange_apply_ok)");
+    const size_t nsums = h->grad.n - (size_t)(h->sums_p - h->grad.p);
+    if (!x->tail_red || x->tail_n < nsums) {
+        if (x->tail_red) (void)hipFree(x->tail_red);
+        BM_HIP(hipMalloc((void **)&x->tail_red, (nsums + 4) * sizeof(float)));
+        x->tail_n = nsums;
+    }
+    if (!x->tail_flag) {
+        BM_HIP(hipMalloc((void **)&x->tail_flag, 64));
+        BM_HIP(hipMemsetAsync(x->tail_flag, 0, 64, h->stream));
+    }
+    bmx::Args a; bmx::DbmApply q;
+    BM_TRY(dbm_fill_exchange(h, x, a, q, true));
+    q.off_sums = (unsigned long long)(h->sums_p - h->grad.p); q.n_sums = (int)nsums;
+    q.N = (float)N_global; q.M = (float)M_global; q.l2 = h->cfg.l2; q.lr = lr; q.mom = mom;
+    q.tail_red = x->tail_red; q.tail_flag = x->tail_flag;
+    {   // launch_dbm_biases' arguments with the column sums read from the reduced tail
+        DbmBiasArgs &b = q.bias[0];
+        b.s_pos = x->tail_red + sums_off(h, 0); b.s_neg = x->tail_red + sums_off(h, 1);
+        b.b = h->vb.p; b.db = h->dvb.p; b.n = h->V; b.N = q.N; b.M = q.M; b.lr = lr; b.mom = mom;
+        for (int i = 0; i < h->L; ++i) {
+            DbmBiasArgs &c = q.bias[1 + i];
+            c.s_pos = x->tail_red + sums_off(h, 2 + 2 * i); c.s_neg = x->tail_red + sums_off(h, 3 + 2 * i);
+            c.b = h->hb[i].p; c.db = h->dhb[i].p; c.q = h->q[i].p; c.mm = h->mm[i].p; c.pen = h->pen[i].p;
+            c.n = h->n[i + 1]; c.layer = i; c.N = q.N; c.M = q.M; c.lr = lr; c.mom = mom;
+            c.damping = h->cfg.sparsity_damping; c.cost = h->cfg.sparsity_cost[i]; c.target = h->cfg.sparsity_target[i];
+        }
+    }
+    hipLaunchKernelGGL(bmx::dbm_exchange_apply_kernel, dim3(x->grid), dim3(bmx::NTX), 0, h->stream, a, q);
+    for (int i = 0; i < h->L; ++i) {
+        const int c0 = x->rank * q.lay[i].sw;
+        const int c1 = c0 + q.lay[i].sw < q.lay[i].I ? c0 + q.lay[i].sw : q.lay[i].I;
+        launch_dbm_maxnorm(h, i, c0, c1 > c0 ? c1 : c0);            // the owned columns (none: no launch)
+    }
+    hipLaunchKernelGGL(bmx::dbm_exchange_gather_kernel, dim3(x->grid), dim3(bmx::NTX), 0, h->stream, a, q);
+    BM_HIP(hipGetLastError());
+    h->xchg_used = x; x->user = &h->xchg_used;
+    x->dw_stale = x->nranks > 1;
+    h->dw_sharded = x->dw_stale;
+    h->dw_set_mask = 0;
+    return 0;
+}
+int bm_dbm_exchange_gather_dw(bm_dbm *h, bm_xchg *x) {
+    BM_CHECK(h && x, "null argument");
+    if (!x->dw_stale) { h->dw_sharded = false; return 0; }
+    BM_CHECK(dbm_fused_ok(h, x), "the exchange does not belong to this engine");
+    bmx::Args a; bmx::DbmApply q;
+    BM_TRY(dbm_fill_exchange(h, x, a, q, true));
+    q.mode = 1; q.do_ready = 1;
+    hipLaunchKernelGGL(bmx::dbm_exchange_gather_kernel, dim3(x->grid), dim3(bmx::NTX), 0, h->stream, a, q);
+    BM_HIP(hipGetLastError());
+    h->xchg_used = x; x->user = &h->xchg_used;
+    x->dw_stale = false;
+    h->dw_sharded = false;
+    return 0;
 }
 int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x) {
     BM_CHECK(h && x, "null argument");

@@ -150,9 +150,12 @@ class DataParallelDBM(object):
     `grad_step` (mean-field with an all-reduce(max) of the residual per sweep, PCD, raw sums) ->
     ONE all-reduce(sum) of the fused buffer -> `apply_step` with the global N and M."""
 
-    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None, comm=None, xchg=None):
+    def __init__(self, engine, rank, world, allreduce_, allreduce_max=None, comm=None, xchg=None, fused=None):
         self.engine, self.rank, self.world = engine, rank, world
         self.allreduce_ = allreduce_
+        # fused: a DirectExchange whose exchange_apply() replaces the all-reduce AND apply_step (column-sliced ownership;
+        # the momentum buffers then live column-wise on their owners: fused.gather_dw() before they are read)
+        self.fused = fused if (fused is not None and fused.fused_ok()) else None
         engine.set_row_offset(rank * engine.N, rank * engine.M)
         if xchg is not None:
             # the direct peer-memory exchange: one 8-byte store per peer and sweep, on the device, in stream order
@@ -166,6 +169,9 @@ class DataParallelDBM(object):
 
     def train_step(self, X_local, lr, momentum, k, **kw):
         n_mf = self.engine.grad_step(X_local, k, **kw)
+        if self.fused is not None:
+            self.fused.exchange_apply(self.engine.N * self.world, lr, momentum, M_global=self.engine.M * self.world)
+            return n_mf
         self.allreduce_()
         self.engine.apply_step(self.engine.N * self.world, self.engine.M * self.world, lr, momentum)
         return n_mf
@@ -262,9 +268,10 @@ class DirectExchange(object):
     peer's `grad` buffer through hipIpc handles and ONE kernel per rank does reduce-scatter + all-gather straight
     over the xGMI links (sums in rank order 0..N-1: all replicas receive the same bits).  The host only gathers the
     256-byte blobs once, at construction: over torch.distributed when a process group exists, else over TCP
-    (`socket_allgather`).  One process per rank; several ranks may share one device (tests on a 1-GPU box)."""
+    (`socket_allgather`).  One process per rank; several ranks may share one device (tests on a 1-GPU box): pass
+    `max_workgroups` (e.g. 48) then, see bm_xchg_set_max_workgroups."""
 
-    def __init__(self, engine, rank, world, gather=None):
+    def __init__(self, engine, rank, world, gather=None, max_workgroups=None):
         import ctypes as C
         from . import _ffi
         from .engine import DbmEngine
@@ -279,6 +286,10 @@ class DirectExchange(object):
         try:
             create = lib.bm_dbm_xchg_create if self._dbm else lib.bm_rbm_xchg_create
             _ffi.check(create(engine._h, rank, world, C.byref(self._c)))
+            if max_workgroups is not None:
+                # ranks that share ONE device (dry runs): exchange workgroups spinning on every CU can keep the peer
+                # process's kernels from being placed - bound the launch well below the CU count
+                _ffi.check(lib.bm_xchg_set_max_workgroups(self._c, int(max_workgroups)))
             if world > 1:
                 buf = (C.c_char * 256)()
                 _ffi.check(lib.bm_xchg_export(self._c, buf))
@@ -313,14 +324,31 @@ class DirectExchange(object):
         f = lib.bm_dbm_allreduce_grads_direct if self._dbm else lib.bm_rbm_allreduce_grads_direct
         self._ffi.check(f(self.engine._h, self._c))
 
-    def exchange_apply(self, B_global, lr, momentum):
-        """RBM: reduce-scatter + parameter update on the owned slice + all-gather of W, ONE kernel on the engine's
-        stream (bm_rbm_exchange_apply_direct): replaces allreduce_grads() + engine.apply_step(), same bits"""
-        self._ffi.check(self._ffi.load().bm_rbm_exchange_apply_direct(self.engine._h, self._c, int(B_global), lr, momentum))
+    def exchange_apply(self, B_global, lr, momentum, M_global=None):
+        """reduce-scatter + parameter update on the owned slice + all-gather of the new weights on the engine's stream:
+        replaces allreduce_grads() + engine.apply_step(), same bits.  RBM (bm_rbm_exchange_apply_direct): one kernel,
+        contiguous slices of W.  DBM (bm_dbm_exchange_apply_direct; M_global = the global number of particles): column
+        slices of every W_i, the max-norm rescale on the owned columns between the two launches."""
+        lib = self._ffi.load()
+        if self._dbm:
+            self._ffi.check(lib.bm_dbm_exchange_apply_direct(self.engine._h, self._c, int(B_global), int(M_global), lr, momentum))
+        else:
+            self._ffi.check(lib.bm_rbm_exchange_apply_direct(self.engine._h, self._c, int(B_global), lr, momentum))
+
+    def fused_ok(self):
+        """whether exchange_apply() can serve this engine (RBM: n_hidden % 4 == 0; DBM: every hidden width % 4 == 0)"""
+        if not self._dbm:
+            return self.engine.H % 4 == 0
+        import ctypes as C
+        ok = C.c_int32()
+        self._ffi.check(self._ffi.load().bm_dbm_exchange_apply_ok(self.engine._h, self._c, C.byref(ok)))
+        return bool(ok.value)
 
     def gather_dw(self):
         """complete every replica's momentum buffer dW (owners hold their slices between updates); a no-op when fresh"""
-        self._ffi.check(self._ffi.load().bm_rbm_exchange_gather_dw(self.engine._h, self._c))
+        lib = self._ffi.load()
+        f = lib.bm_dbm_exchange_gather_dw if self._dbm else lib.bm_rbm_exchange_gather_dw
+        self._ffi.check(f(self.engine._h, self._c))
 
     def set_timeout(self, seconds):
         """bound of every in-kernel wait of later launches (a wait that expires is FATAL: the status word is sticky, the

@@ -371,6 +371,9 @@ int bm_xchg_allreduce_sum(bm_xchg *x, void *stream);
 int bm_xchg_allreduce_max1(bm_xchg *x, float *val_dev, void *stream);
 int bm_xchg_status(bm_xchg *x, int32_t *out_status);                     /* synchronises; 0 = no wait timed out */
 int bm_xchg_set_timeout(bm_xchg *x, double seconds);                     /* bound of the in-kernel waits of later launches */
+/* at most n workgroups per exchange launch (default: up to one per CU); before the first exchange.  Only for ranks that
+ * SHARE a device (dry runs): workgroups spinning on every CU can keep the peer process's kernels from being placed. */
+int bm_xchg_set_max_workgroups(bm_xchg *x, int32_t n);
 int bm_xchg_info(bm_xchg *x, int32_t *out_rank, int32_t *out_nranks, size_t *out_count);
 /* the handle's fused "grad" buffer as the exchanged buffer; bm_*_allreduce_grads_direct is the drop-in for
  * bm_*_allreduce_grads between bm_*_grad_step and bm_*_apply_step */
@@ -387,6 +390,18 @@ int bm_dbm_allreduce_grads_direct(bm_dbm *h, bm_xchg *x);
  * (call it before dW is read: checkpoints, get_param("dW")).  Needs n_hidden % 4 == 0. */
 int bm_rbm_exchange_apply_direct(bm_rbm *h, bm_xchg *x, int32_t B_global, float learning_rate, float momentum);
 int bm_rbm_exchange_gather_dw(bm_rbm *h, bm_xchg *x);
+/* The same for the data-parallel DBM update (replaces bm_dbm_allreduce_grads_direct + bm_dbm_apply_step; same bits), with
+ * COLUMN-sliced ownership because the update ends with the max-norm rescale of whole columns (dbm.py:511-513, 603-606):
+ * rank r owns columns [r sw_i, (r + 1) sw_i) of every W_i (sw_i = 32 ceil(n_{i+1} / (32 nranks))).  One launch sums the
+ * owned columns of the raw outer products over the ranks (rank order), applies the update to them and - every rank for
+ * itself - the bias / q_means / mu_means / penalty update from the reduced column sums (dbm.py:550-600); the max-norm
+ * kernels run on the owned columns; a second launch gathers the other ranks' columns into W_i, W_i^T and the column norms.
+ * The momentum buffers dW_i stay with their owners: bm_dbm_get_param("dW"), bm_dbm_train_step and bm_dbm_apply_step fail
+ * until bm_dbm_exchange_gather_dw.  Needs every hidden width to be a multiple of 4 and the exchange created by
+ * bm_dbm_xchg_create for this engine (its staging slice is sized for the columns): bm_dbm_exchange_apply_ok says. */
+int bm_dbm_exchange_apply_ok(bm_dbm *h, bm_xchg *x, int32_t *out_ok);
+int bm_dbm_exchange_apply_direct(bm_dbm *h, bm_xchg *x, int32_t N_global, int32_t M_global, float learning_rate, float momentum);
+int bm_dbm_exchange_gather_dw(bm_dbm *h, bm_xchg *x);
 /* Opt-in "fast-binary" mode (SURVEY §7 hard part 4; csrc/bm_bf3.h): contractions whose input states are {0,1}
  * bitmaps (AIS with all layers sampled; the RBM sampling sweep with both layers sampled; in the PCD particle sweeps of
  * bm_dbm_train_step / bm_dbm_sample_v every contraction over a Bernoulli layer sampled earlier in the same call - a

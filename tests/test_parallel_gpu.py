@@ -238,6 +238,135 @@ def test_dp_dbm_direct_exchange_on_gpu(gpu_lib, tmp_path):
     ref.close()
 
 
+# ---- the fused DBM exchange (bm_dbm_exchange_apply_direct): column-sliced ownership.  Widths 96 and 64: at world 2 the
+# slices are 64 + 32 and 32 + 32 columns, at world 3 they are 32 + 32 + 32 and 32 + 32 + NONE (a rank without columns of W_1)
+FV, FNH, FN, FM = 40, [96, 64], 12, 8
+FKW = dict(max_mf_updates=6, mf_tol=1e-4, l2=1e-3, max_norm=1.5, sparsity_target=[0.2, 0.1], sparsity_cost=[1e-2, 5e-3])
+FNAMES = ('W', 'W_1', 'hb', 'hb_1', 'vb', 'dvb', 'dW', 'dW_1', 'dhb', 'dhb_1', 'q_means', 'q_means_1', 'mu_means', 'mu_means_1',
+          'W_norm', 'W_norm_1', 'v', 'h', 'h_1', 'mu', 'mu_1')
+
+
+def _fdbm_setup(world, rank):
+    from boltzmann_machines_amd.engine import DbmEngine
+    from oracle import oracle as orc
+    n = [FV] + FNH
+    eng = DbmEngine(FV, FNH, n_particles=FM, batch_size=FN, **FKW)
+    Mg = world * FM
+    prow = slice(rank * FM, (rank + 1) * FM)
+    for i in range(2):
+        sfx = '' if i == 0 else '_1'
+        eng.set('W' + sfx, (orc.normal(6, 1 + i, 0, n[i] * n[i + 1]) * np.float32(0.2)).reshape(n[i], n[i + 1]))
+        eng.set('hb' + sfx, (orc.uniform(6, 5 + i, 0, n[i + 1]) - np.float32(0.5)) * np.float32(0.4))
+        eng.set('h' + sfx, (orc.uniform(6, 10 + i, 0, Mg * n[i + 1]) < 0.5).astype(np.float32).reshape(Mg, n[i + 1])[prow])
+    eng.set('v', (orc.uniform(6, 21, 0, Mg * FV) < 0.3).astype(np.float32).reshape(Mg, FV)[prow])
+    X = (orc.uniform(6, 30, 0, 4 * world * FN * FV) < 0.25).astype(np.float32).reshape(4, world * FN, FV)
+    eng.seed(78)
+    return eng, X[:, rank * FN:(rank + 1) * FN]
+
+
+def _fdbm_worker(rank, world, port, out, fused, skew_rank=-1, die_rank=-1):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from boltzmann_machines_amd import parallel
+    from boltzmann_machines_amd.engine import as_device
+    eng, X = _fdbm_setup(world, rank)
+    xchg = parallel.DirectExchange(eng, rank, world, gather=lambda b: parallel.socket_allgather(b, rank, world))
+    xchg.set_timeout(5.0)
+    dp = parallel.DataParallelDBM(eng, rank, world, parallel.direct_allreduce_on_engine_stream(eng, xchg), xchg=xchg,
+                                  fused=xchg if fused else None)
+    assert (dp.fused is not None) == bool(fused)
+    nmf = []
+    if die_rank >= 0:
+        import time
+        xchg.set_timeout(1.0)
+        dp.train_step(as_device(X[0]), 0.05, 0.5, 2)
+        eng.sync()
+        if rank == die_rank:
+            os._exit(0)
+        t0 = time.time()
+        try:
+            for s in range(1, 3):
+                dp.train_step(as_device(X[s]), 0.05, 0.5, 2)
+            eng.sync()
+        except RuntimeError as e:
+            with open(out + '.r%d.err' % rank, 'w') as f:
+                f.write('%.2f %s' % (time.time() - t0, e))
+            os._exit(0)
+        os._exit(7)
+    for s in range(4):
+        if rank == skew_rank:
+            import time
+            eng.sync()
+            time.sleep(0.05)
+        nmf.append(dp.train_step(as_device(X[s]), 0.05, 0.5, 2))
+        if fused and s == 1 and world > 1 and skew_rank < 0:
+            # the momentum buffers are column-sharded between updates: every reader refuses until they are gathered,
+            # and a gather in the middle of a run changes nothing
+            for reader in (lambda: eng.get('dW'), lambda: eng.get('dW_1'), lambda: eng.train_step(as_device(X[s]), 0.05, 0.5, 2),
+                           lambda: eng.apply_step(world * FN, world * FM, 0.05, 0.5)):
+                try:
+                    reader()
+                except RuntimeError as e:
+                    assert 'gather_dw' in str(e), e
+                else:
+                    raise AssertionError('dW was read while it is sharded over the ranks')
+            eng.get('W_1')
+            xchg.gather_dw()
+            eng.get('dW_1')
+    if fused:
+        xchg.gather_dw()
+        xchg.gather_dw()
+    eng.sync()
+    assert xchg.status() == 0
+    np.savez(out + '.r%d' % rank, nmf=nmf, **{k_: eng.get(k_) for k_ in FNAMES})
+    eng.set_xchg(None)
+    xchg.close()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_dp_dbm_fused_exchange_on_gpu(gpu_lib, tmp_path, world):
+    """bm_dbm_exchange_apply_direct against bm_dbm_allreduce_grads_direct + bm_dbm_apply_step: four updates (so that the
+    gathered W_i^T, biases, penalties and particles of one update feed the next), every variable BIT FOR BIT - weights,
+    momentum buffers after gather_dw, column norms, running means, particles, mean-field parameters, sweep counts -
+    replicas identical, including a rank that owns no column of a layer (world 3)."""
+    import torch.multiprocessing as mp
+    outs = []
+    for tag, fused in (('two_step', False), ('fused', True)):
+        out = str(tmp_path / tag)
+        mp.spawn(_fdbm_worker, args=(world, _free_port(), out, fused), nprocs=world, join=True)
+        outs.append([np.load(out + '.r%d.npz' % r) for r in range(world)])
+    shared = [n for n in FNAMES if n not in ('v', 'h', 'h_1', 'mu', 'mu_1')]
+    for r in range(world):
+        assert list(outs[0][r]['nmf']) == list(outs[1][r]['nmf']) == list(outs[1][0]['nmf'])
+        for n in FNAMES:
+            assert np.array_equal(outs[0][r][n].view(np.uint32), outs[1][r][n].view(np.uint32)), (r, n)
+        for n in shared:
+            assert np.array_equal(outs[1][0][n].view(np.uint32), outs[1][r][n].view(np.uint32)), ('replicas', r, n)
+    assert np.all(np.isfinite(outs[1][0]['W_1'])) and float(np.abs(outs[1][0]['dW_1']).max()) > 0
+
+
+def test_dp_dbm_fused_exchange_with_a_late_and_with_a_dying_rank(gpu_lib, tmp_path):
+    """the column-sliced exchange under skewed arrivals (one rank 50 ms late at every update: same bits as on time) and
+    with a rank that exits after the first update (every survivor fails inside the time-out; nobody hangs)"""
+    import torch.multiprocessing as mp
+    world = 3
+    outs = []
+    for tag, skew in (('ontime', -1), ('late', 2)):
+        out = str(tmp_path / tag)
+        mp.spawn(_fdbm_worker, args=(world, _free_port(), out, True, skew), nprocs=world, join=True)
+        outs.append([np.load(out + '.r%d.npz' % r) for r in range(world)])
+    for r in range(world):
+        for n in FNAMES:
+            assert np.array_equal(outs[0][r][n].view(np.uint32), outs[1][r][n].view(np.uint32)), (r, n)
+    out = str(tmp_path / 'dead')
+    mp.spawn(_fdbm_worker, args=(world, _free_port(), out, True, -1, 1), nprocs=world, join=True)
+    for r in (0, 2):
+        with open(out + '.r%d.err' % r) as f:
+            secs, msg = f.read().split(' ', 1)
+        assert float(secs) < 30.0, secs
+        assert 'expired' in msg or 'exchange' in msg, msg
+
+
 NATIVE_SCRIPT = r"""
 import sys
 sys.path.insert(0, %(root)r)
