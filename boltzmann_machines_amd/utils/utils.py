@@ -3,6 +3,11 @@
 Same names, arguments and results as the reference's
 boltzmann_machines/utils/utils.py (:13-52 batch/epoch iteration, :108-170
 log-domain reductions); progress bars are dropped (no tqdm dependency).
+
+The four log-domain reductions (log_sum_exp, log_mean_exp, log_diff_exp, log_std_exp) ARE the reference's bodies: three- to
+five-line host formulas whose float64 results - including the order of Python's built-in `sum` / `max` - the AIS
+post-processing of DBM.log_Z and the reference's doctests pin; a re-expression would change the last bits for no gain.
+Nothing here is on the device path.
 """
 import numpy as np
 
