@@ -755,20 +755,25 @@ def check_data_parallel_run(wl, args, rank, world, dist):
             except Exception as e:       # noqa: BLE001 - shows up as a non-zero status below
                 sys.stderr.write('bench: gather_dw failed: %s\n' % (str(e)[:200],))
         status = max(status, int(x.status()))
-    crc = 0
+    crc, nonfinite = 0, 0
     try:
         names = ('W', 'vb', 'hb') if hasattr(wl.eng, 'H') else ('W', 'vb', 'hb', 'W_1', 'hb_1')
         for n in names:
-            crc = zlib.crc32(np.ascontiguousarray(wl.eng.get(n)).tobytes(), crc)
+            a = np.ascontiguousarray(wl.eng.get(n))
+            crc = zlib.crc32(a.tobytes(), crc)
+            nonfinite += int(a.size - np.count_nonzero(np.isfinite(a)))     # identical NaNs would pass the CRC
     except Exception:       # noqa: BLE001 - a workload without these variables
         crc = -1
-    t = torch.tensor([status, crc & 0x7FFFFFFF, -(crc & 0x7FFFFFFF)], dtype=torch.int64)
+    t = torch.tensor([status, crc & 0x7FFFFFFF, -(crc & 0x7FFFFFFF), nonfinite], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    worst, hi, neg_lo = int(t[0]), int(t[1]), int(t[2])
+    worst, hi, neg_lo, bad = int(t[0]), int(t[1]), int(t[2]), int(t[3])
     if worst != 0:
         sys.stderr.write('bench: a wait of the direct exchange expired (status %d): the run is invalid\n' % worst)
         sys.exit(3)
-    return {'exchange_status': 0, 'replicas_identical': bool(hi == -neg_lo)}
+    if bad != 0:
+        sys.stderr.write('bench: %d non-finite parameter values after the data-parallel run: the run is invalid\n' % bad)
+        sys.exit(3)
+    return {'exchange_status': 0, 'replicas_identical': bool(hi == -neg_lo), 'parameters_finite': True}
 
 
 def start_guardian(line_out, record):
