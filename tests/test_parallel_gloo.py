@@ -313,3 +313,53 @@ def test_dp_dbm_world2_with_mean_field_max(tmp_path):
         assert np.array_equal(np.concatenate([r0[k_], r1[k_]]), ref_m.P[k_]), k_
     for k_ in ('mu', 'mu_1'):
         np.testing.assert_allclose(np.concatenate([r0[k_], r1[k_]]), ref_m.P[k_], rtol=1e-10, atol=1e-13)
+
+
+class _RecordingDbm(object):
+    """the calls DataParallelDBM makes, in order (host logic of the fused / two-step exchange; no device)"""
+    N, M = 12, 8
+
+    def __init__(self):
+        self.calls = []
+
+    def set_row_offset(self, row0, prow0):
+        self.calls.append(('row_offset', row0, prow0))
+
+    def set_xchg(self, x):
+        self.calls.append(('set_xchg', x is not None))
+
+    def grad_step(self, X, k, **kw):
+        self.calls.append(('grad_step', k, kw.get('row', 0)))
+        return 7
+
+    def apply_step(self, N_global, M_global, lr, momentum):
+        self.calls.append(('apply_step', N_global, M_global, lr, momentum))
+
+
+class _RecordingExchange(object):
+    def __init__(self, ok):
+        self.ok, self.calls = ok, []
+
+    def fused_ok(self):
+        return self.ok
+
+    def exchange_apply(self, B_global, lr, momentum, M_global=None):
+        self.calls.append(('exchange_apply', B_global, M_global, lr, momentum))
+
+
+@pytest.mark.parametrize('ok', [True, False])
+def test_dp_dbm_host_logic_of_the_fused_exchange(ok):
+    """fused: grad_step -> exchange_apply(N * world, lr, momentum, M_global = M * world), no all-reduce, no apply_step;
+    an exchange that cannot serve the engine (fused_ok() false: a hidden width that is no multiple of 4) falls back to
+    all-reduce + apply_step with the same global sizes; the executed sweep count is returned either way"""
+    from boltzmann_machines_amd import parallel
+    eng, x, reduced = _RecordingDbm(), _RecordingExchange(ok), []
+    dp = parallel.DataParallelDBM(eng, 2, 3, lambda: reduced.append(1), xchg=x, fused=x)
+    assert (dp.fused is x) == ok
+    assert eng.calls[:2] == [('row_offset', 2 * eng.N, 2 * eng.M), ('set_xchg', True)]
+    assert dp.train_step('X', 0.05, 0.5, 4, row=24) == 7
+    assert eng.calls[2] == ('grad_step', 4, 24)
+    if ok:
+        assert x.calls == [('exchange_apply', 3 * eng.N, 3 * eng.M, 0.05, 0.5)] and not reduced and len(eng.calls) == 3
+    else:
+        assert not x.calls and reduced == [1] and eng.calls[3] == ('apply_step', 3 * eng.N, 3 * eng.M, 0.05, 0.5)
