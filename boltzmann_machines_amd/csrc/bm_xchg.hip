@@ -549,6 +549,54 @@ __global__ __launch_bounds__(64) void max1_kernel(MaxArgs a) {
     if (tid == 0) *a.val = got;                    // residuals are >= 0
 }
 
+// mean-field loop control of a data-parallel DBM in ONE launch: mf_resid_kernel (local residual from the per-workgroup
+// slots and the atomic cell, both reset), max1_kernel (max over the ranks) and mf_latch_kernel (counter / `done`), same
+// operations in the same order.  The exchange runs whether or not `done` is latched: every rank issues the same sequence.
+__global__ __launch_bounds__(256) void mf_ctl_max1_kernel(MaxArgs a, bm::MfCtl *c, float *blk, int nblk, float tol, int init) {
+    __shared__ float s_m[4];
+    __shared__ float s_resid;
+    const int tid = threadIdx.x;
+    float m = 0.f;
+    for (int e = tid; e < nblk; e += 256) { m = fmaxf(m, blk[e]); blk[e] = 0.f; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) s_m[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        s_resid = fmaxf(fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3])), __uint_as_float(c->maxdiff));
+        c->maxdiff = 0u;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    const unsigned par = a.epoch & 1u;
+    const float mine = s_resid;
+    float got = 0.f;
+    if (tid < a.n) {
+        const unsigned long long word = ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(mine);
+        __hip_atomic_store(a.pslots[tid] + par * MAXR + a.rank, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        unsigned long long w;
+        bool ok = true;
+        while ((unsigned)((w = __hip_atomic_load(a.slots + par * MAXR + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >> 32) != a.epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > a.timeout_ticks) { ok = false; break; }
+        }
+        if (ok) got = __uint_as_float((unsigned)w);
+        else __hip_atomic_store(a.flags + F_STATUS, (unsigned)(3 * 16 + tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) got = fmaxf(got, __shfl_xor(got, off));
+    if (tid != 0) return;
+    c->resid = got;
+    if (init) {
+        c->steps = 0;
+        c->done = !(got > tol);
+    } else if (!c->done) {
+        c->steps += 1;
+        c->done = !(got > tol);
+    }
+}
+
 }  // namespace bmx
 
 struct bm_xchg {
@@ -599,6 +647,19 @@ static int xchg_check_status(bm_xchg *x) {
 
 static void xchg_bind_user(bm_xchg *x, bm_xchg **slot) { if (x) x->user = slot; }
 static void xchg_dw_replaced(bm_xchg *x) { if (x) x->dw_stale = false; }
+
+static int xchg_mf_ctl_step(bm_xchg *x, bm::MfCtl *ctl, float *blk, int nblk, float tol, int init, hipStream_t stream) {
+    BM_CHECK(x && x->attached && ctl, "exchange not attached / null argument");
+    bmx::MaxArgs a;
+    memset(&a, 0, sizeof(a));
+    a.val = &ctl->resid; a.slots = x->slots; a.flags = x->flags; a.rank = x->rank; a.n = x->nranks;
+    a.epoch = ++x->epoch_max; a.timeout_ticks = x->timeout_ticks;
+    for (int r = 0; r < bmx::MAXR; ++r)
+        a.pslots[r] = (unsigned long long *)((char *)x->pflags[r] + bmx::F_WORDS * sizeof(unsigned));
+    hipLaunchKernelGGL(bmx::mf_ctl_max1_kernel, dim3(1), dim3(256), 0, stream, a, ctl, blk, nblk, tol, init);
+    BM_HIP(hipGetLastError());
+    return 0;
+}
 
 extern "C" {
 
