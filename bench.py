@@ -733,7 +733,7 @@ def choose_collective(args, eng, rank, world, dist):
     return fallback, note
 
 
-def check_data_parallel_run(wl, args, rank, world, dist):
+def check_data_parallel_run(wl, args, rank, world, dist, fatal=True):
     """After the timed region of a data-parallel run: (1) no in-kernel wait of the direct exchange ever expired - a
     wait that expires is fatal (sticky status word, NaN results): the run is then INVALID and the bench exits non-zero
     on every rank instead of printing a throughput built on partial sums; (2) the replicas hold identical parameters
@@ -767,12 +767,13 @@ def check_data_parallel_run(wl, args, rank, world, dist):
     t = torch.tensor([status, crc & 0x7FFFFFFF, -(crc & 0x7FFFFFFF), nonfinite], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     worst, hi, neg_lo, bad = int(t[0]), int(t[1]), int(t[2]), int(t[3])
-    if worst != 0:
-        sys.stderr.write('bench: a wait of the direct exchange expired (status %d): the run is invalid\n' % worst)
-        sys.exit(3)
-    if bad != 0:
-        sys.stderr.write('bench: %d non-finite parameter values after the data-parallel run: the run is invalid\n' % bad)
-        sys.exit(3)
+    if worst != 0 or bad != 0:
+        why = ('a wait of the direct exchange expired (status %d)' % worst) if worst != 0 else \
+            ('%d non-finite parameter values after the data-parallel run' % bad)
+        sys.stderr.write('bench: %s: the run is invalid\n' % why)
+        if fatal:
+            sys.exit(3)
+        return {'invalid': why}         # (every rank sees the same reduced values and takes the same branch)
     return {'exchange_status': 0, 'replicas_identical': bool(hi == -neg_lo), 'parameters_finite': True}
 
 
@@ -1065,12 +1066,19 @@ def main():
                     raise RuntimeError('skipped in a shared-device dry run (the chain all-gather is RCCL)')
                 w2 = WORKLOADS[name_wl](a2, rank, world, device, dist)
                 dt2, ev2 = measure(w2, st, wu, pre, barrier, dist)
+                # the same post-run check as the headline's (a collective: every rank is here): a pass whose exchange lost a
+                # rank or whose parameters are not finite is recorded as an error, never as a throughput
+                chk = check_data_parallel_run(w2, a2, rank, world, dist, fatal=False)
+                if chk is not None and 'invalid' in chk:
+                    raise RuntimeError(chk['invalid'])
                 if rank == 0:
                     rec = make_record(w2, w2.report(argparse.Namespace(**dict(vars(a2), steps=st)), world, dt2, ev2),
                                       world, st, wu, pre, dt2, ev2)
                     for k_ in ('higher_is_better', 'vs_baseline', 'data', 'n_gpus'):
                         rec.pop(k_, None)
                     rec['pass_seconds'] = round(time.time() - t_begin, 1)
+                    if chk is not None:
+                        rec['config']['data_parallel_check'] = chk
                     others[name] = rec
                 barrier()
                 w2.eng.close()
