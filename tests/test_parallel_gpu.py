@@ -397,7 +397,9 @@ def test_dp_dbm_fused_exchange_with_a_late_and_with_a_dying_rank(gpu_lib, tmp_pa
     for r in (0, 2):
         with open(out + '.r%d.err' % r) as f:
             secs, msg = f.read().split(' ', 1)
-        assert float(secs) < 30.0, secs
+        # (two updates of up to 7 loop-control exchanges + 2 launches each, 1 s per expired wait: ~18 s; the bound only says
+        # "no hang")
+        assert float(secs) < 60.0, secs
         assert 'expired' in msg or 'exchange' in msg, msg
 
 
