@@ -88,6 +88,7 @@ SIGNATURES = {
     'bm_dbm_set_xchg': [_vp, _vp],
     'bm_dbm_set_fast_binary': [_vp, _i32],
     'bm_dbm_set_ais_literal': [_vp, _i32],
+    'bm_dbm_set_sigmoid_literal': [_vp, _i32],
     'bm_rbm_set_fast_binary': [_vp, _i32],
     'bm_rbm64_create': [C.POINTER(RbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
     'bm_rbm64_destroy': [_vp],

@@ -85,6 +85,7 @@ struct bm_dbm {
     // fast-binary mode (bm_bf3.h, bm_dbm_set_fast_binary): bf16 planes of W_l (x = below unit, k = above unit) and of
     // W_l^T, bf16 shadows of the AIS state matrices; `fast_now` is set while a sweep with all-binary states runs
     int ais_literal = 0;                           // bm_dbm_set_ais_literal: float32 accumulation in the reference's order
+    int sigmoid_literal = 0;                       // bm_dbm_set_sigmoid_literal: every Bernoulli activation as float32 1 / (1 + exp(-x))
     int fast = 0;
     bool fast_now = false;
     bool fast_ais = false;                         // the running fast sweep is AIS (fp32 copies of v / h2 are not needed)
@@ -211,6 +212,7 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
     a.means = means; a.states = states; a.ldo = ldo;
     a.key = key; a.row0 = row0;
     a.prev = prev; a.maxdiff = maxdiff;
+    a.lit = h->sigmoid_literal;
     if (h->fast_now && !h->multinomial(layer) && a.kind != 2) {
         // fast-binary: the same contraction from the bf16 weight planes and the bf16 shadows of the {0,1} inputs
         // (a state matrix without a valid shadow - real-valued visibles, the first PCD sweep - keeps the fp32 path)
@@ -298,7 +300,7 @@ static void gibbs_sweep(bm_dbm *h, int J, LayerIn vin, const Mat *Hin, Mat *vout
             e.K1 = h->n[2];
             if (dbm_xm() && (e.K1 & 3) == 0) { e.P1 = make_operand(h->W[1].p, h->W[1].ld, e.I); e.p_xm = 1; }   // W[1] [i = h1][k = h2]
             e.bias = h->hb[0].p; e.kind = BM_UNIT_BERNOULLI;
-            e.mult = 1.f; e.bmult = 1.f; e.sample = 0;
+            e.mult = 1.f; e.bmult = 1.f; e.sample = 0; e.lit = h->sigmoid_literal;
             e.means = Hout[0].p; e.ldo = Hout[0].ld;
             e.prev = maxdiff ? Hin[0].p : nullptr; e.maxdiff = maxdiff;
             issue_act(h, e);
@@ -564,7 +566,7 @@ static bool dch_pass_from(const ActArgs &a, bool seg2, DchPass &ph) {
 static bool dbm_chain_ok(bm_dbm *h, int k) {
     using G = GeoChain;
     const int mode = dbm_chain_mode(h);
-    if (mode <= 0 || h->L != 2 || h->comm || h->xchg || h->mf_reduce || h->fast || !dbm_xm()) return false;
+    if (mode <= 0 || h->L != 2 || h->comm || h->xchg || h->mf_reduce || h->fast || h->sigmoid_literal || !dbm_xm()) return false;
     if (h->multinomial(0) || h->multinomial(1)) return false;
     if (h->N % G::TJ || h->M % G::TJ || h->N / G::TJ > 8 || h->M / G::TJ > 8) return false;
     if (h->cfg.max_mf_updates < 1 || h->cfg.max_mf_updates > DCH_MAXSW || k < 1 || k > DCH_MAXPC) return false;
@@ -1143,6 +1145,7 @@ int bm_dbm_set_comm(bm_dbm *h, bm_comm *c) {
 // fp32 round-off, not bit for bit.  0 restores the default.
 int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
+    BM_CHECK(!(on && h->sigmoid_literal), "fast-binary mode and the literal sigmoid exclude each other");
     h->fast = on ? 1 : 0;
     return 0;
 }
@@ -1154,6 +1157,19 @@ int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on) {
 int bm_dbm_set_ais_literal(bm_dbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
     h->ais_literal = on ? 1 : 0;
+    return 0;
+}
+
+// 1: every Bernoulli activation of this engine - mean-field, particle sweeps, AIS transitions, reconstruction - is the literal
+// float32 `1 / (1 + exp(-x))` of tf.nn.sigmoid (layers.py:47-48; bm_numerics.h sigmoid_literal) instead of the engine's own
+// one-division form.  The values agree to float32 round-off; what changes is the mean-field trip count at an mf_tol near
+// that round-off (dbm.py:449-452 at the default 1e-7 is decided in the last bits of the means): with the literal form the
+// engine executes the sweeps the reference's graph executes.  Turns the fast-binary mode off for this engine (its epilogue
+// is the hardware sigmoid).
+int bm_dbm_set_sigmoid_literal(bm_dbm *h, int32_t on) {
+    BM_CHECK(h, "null argument");
+    h->sigmoid_literal = on ? 1 : 0;
+    if (on) h->fast = 0;
     return 0;
 }
 

@@ -39,6 +39,8 @@ struct ActArgs {
     int kind;                    // 0 BERNOULLI: sigmoid(mult*z + mult*b); 1 GAUSSIAN: (mult*z)*sigma + mult*b;
                                  // 2: raw mult*z; 3: logits mult*z + bmult*b (input of softmax_multinomial_kernel)
     int sample;                  // 1: states = draw(means); 0: states = means
+    int lit;                     // 1: Bernoulli units use sigmoid_literal (bm_numerics.h; bm_dbm_set_sigmoid_literal) - a launch
+                                 //    flavour of its own (launch_act_lit), never a branch of the default kernels
     float *means;                // may be null
     float *states;               // may be null
     float *negmeans;             // may be null: -means (P operand of the negative phase in grad_kernel form 0)
@@ -214,7 +216,7 @@ template <int E, class Rng> struct ActSide {
 // act_kernel's epilogue for the lane's outputs of ONE output tile (i0, j0): activation, draw, stores, the per-row
 // partial sums.  Returns the lane's mean-field residual max|m - prev| (0 without a.prev).  A function so that the
 // persistent fast-binary kernel (act_bf3_kernel) can call it once per tile of its strip.
-template <class G, int ABL, class SideT, bool HWMATH = false, bool FE = false>
+template <class G, int ABL, class SideT, bool HWMATH = false, bool FE = false, bool LIT = false>
 __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey &key, const f32x4 (&acc)[G::MI][1], const SideT &side,
                                               int i0, int j0) {
     constexpr int E = G::E, NH = G::MI;            // NH = Philox blocks (groups of 4 outputs) per lane
@@ -248,7 +250,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
             for (int r = 0; r < 4; ++r) {
                 const float x = a.mult * z[4 * hlf + r];
                 const float b = a.bmult * bs[4 * hlf + r];
-                m[r] = (a.kind == 0) ? (HWMATH ? sigmoid_hw(x + b) : sigmoid(x + b))
+                m[r] = (a.kind == 0) ? (LIT ? sigmoid_literal(x + b) : (HWMATH ? sigmoid_hw(x + b) : sigmoid(x + b)))
                                      : (a.kind == 1 ? (x * sg[4 * hlf + r] + b) : (a.kind == 3 ? x + b : x));
                 s[r] = m[r];
             }
@@ -361,7 +363,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
 
 // MINB: HIP's second __launch_bounds__ argument = WAVES PER SIMD the register budget must allow (for the 4-wave
 // geometries that equals the workgroups per CU; an 8-wave workgroup that should run twice per CU passes 4)
-template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA, bool FE = false>
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA, bool FE = false, bool LIT = false>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tmap) {
     // (the block -> tile map is an argument of its own: the grid path indexes it with blockIdx & 7, and a dynamically
     //  indexed member made hipcc fetch EVERY ActArgs field lazily in small pieces - 50 scalar loads with their waits
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tma
     mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
 #endif
     BM_STAMP(1);
-    float dmax = act_epilogue<G, ABL, decltype(side), false, FE>(a, key, acc, side, i0, j0);
+    float dmax = act_epilogue<G, ABL, decltype(side), false, FE, LIT>(a, key, acc, side, i0, j0);
     if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
                                // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
         __shared__ float s_wavemax[G::NT / 64];
@@ -1794,6 +1796,30 @@ static inline void launch_act_fe(const ActArgs &a, hipStream_t st) {
     }
 }
 
+// "reference arithmetic" launches (ActArgs::lit, bm_dbm_set_sigmoid_literal): the literal float32 tf.sigmoid in the epilogue -
+// a compile-time flavour (LIT) on ONE geometry (32 x 32 tiles, LDS-DMA, slab order; x-major P needs MI == 1): a parity mode,
+// not a tuner case, so the kernels of the default path carry none of its code.  Same canonical accumulation order as
+// every other geometry (bm_gemm.h), hence the same pre-activations bit for bit.
+static inline void launch_act_lit(const ActArgs &a, hipStream_t st) {
+    using G = GeoActS;
+    const double kt = (double)a.K1 + (double)a.K2;
+    const TileMap tmap = make_tile_map((a.I + G::TI - 1) / G::TI, (a.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, -1);
+    const bool seg2 = a.K2 > 0;
+    const bool fast = operand_fast(a.P1, a.p_xm ? XM : KM, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
+                      (!seg2 || (operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2)));
+    const dim3 grid(tile_grid<G>(a.I, a.J)), blk(G::NT);
+    if (a.p_xm) {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, 2, false, true, 0, XM, STG_DMA, false, true>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, 2, false, false, 0, XM, STG_DMA, false, true>), grid, blk, 0, st, a, tmap);
+    } else if (seg2) {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, 2, true, true, 0, KM, STG_DMA, false, true>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, 2, true, false, 0, KM, STG_DMA, false, true>), grid, blk, 0, st, a, tmap);
+    } else {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, 2, false, true, 0, KM, STG_DMA, false, true>), grid, blk, 0, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, 2, false, false, 0, KM, STG_DMA, false, true>), grid, blk, 0, st, a, tmap);
+    }
+}
+
 // fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
 // ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
 // sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
@@ -2051,6 +2077,7 @@ static inline void launch_act_f32(const ActArgs &a, hipStream_t st);
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     if (a.b3.K1 > 0) { launch_act_bf3(a, st); return; }
     if (a.fe_flip) { launch_act_fe(a, st); return; }     // the h0 pass of a fused metric fetch: its own kernel flavour
+    if (a.lit && a.kind == 0) { launch_act_lit(a, st); return; }   // literal tf.sigmoid: its own kernel flavour
     launch_act_f32(a, st);
     // fast-binary mode, an fp32 launch whose sampled states the NEXT launches read as a bf16 shadow: converted here (the
     // strip kernel writes its shadow itself; keeping the branch out of the fp32 epilogue is worth ~0.2 us per launch)

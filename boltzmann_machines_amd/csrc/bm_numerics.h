@@ -41,6 +41,40 @@ __device__ __forceinline__ float sigmoid(float x) {
     return num / d;                                // ONE correctly rounded IEEE division
 }
 
+// "Reference arithmetic" (bm_dbm_set_sigmoid_literal): tf.nn.sigmoid as TensorFlow 1.3 evaluates it on the CPU,
+//     y = 1 / (1 + exp(-x))        in float32 (Eigen scalar_sigmoid_op: pdiv(one, padd(one, pexp(pnegate(x)))))
+// with exp = Eigen 3.3's pexp<Packet4f> (the Cephes expf scheme; the TF 1.3 wheels are SSE builds without FMA, so every
+// pmadd is a rounded multiply followed by a rounded add).  TF and Eigen are not in /root/reference (pip dependency
+// `tensorflow-gpu~=1.3.0`, requirements.txt:11): the algorithm is restated from Eigen/src/Core/arch/SSE/MathFunctions.h,
+// operation by operation, so that oracle/bm_oracle.c (orc_exp_eigen) and the stand-in's tf.sigmoid (tests/tf1_shim) produce
+// the same bits.  The point of the mode: the mean-field loop (dbm.py:449-452) ends when no mean moves by more than
+// mf_tol = 1e-7, i.e. it is decided in the last bits of the sigmoid; with the literal form the engine executes the sweeps the
+// reference's graph executes (5 - 6 per update at 784-512-1024, where the default form above runs 7 - 8).  ~1.8 ulp against
+// the default's ~1.4.  The library is built with -ffp-contract=off: nothing below fuses.
+__device__ __forceinline__ float exp_eigen(float x0) {
+    float x = fminf(x0, 88.3762626647950f);
+    x = fmaxf(x, -88.3762626647949f);
+    float fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    fx = floorf(fx);
+    const float tmp = fx * 0.693359375f;
+    const float zz = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - zz;
+    const float z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z; y = y + x;
+    y = y + 1.0f;
+    const float p2 = __uint_as_float((unsigned)((int)fx + 127) << 23);      // 2^fx, fx in [-127, 127]
+    return fmaxf(y * p2, x0);
+}
+__device__ __forceinline__ float sigmoid_literal(float x) { return 1.0f / (1.0f + exp_eigen(-x)); }
+
 // metrics only (tolerance-checked, not bit-pinned): softplus(x) = max(x, 0) + log1p(exp(-|x|)).
 // The AIS log-weight epilogue evaluates it twice per output and was VALU-bound on the libm calls
 // (expf + log1pf, ~100 instructions each): exp(-|x|) reuses exp_neg, and log1p(e), e in [0, 1], is

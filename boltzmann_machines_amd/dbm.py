@@ -96,6 +96,8 @@ class DBM(EngineModel):
         self.n_samples_generated_ = 0
         # log_Z accumulation (not a constructor keyword of the reference: set_ais_accumulation / BM355_AIS_LITERAL=1)
         self._ais_literal = os.environ.get('BM355_AIS_LITERAL', '0') == '1'
+        # sigmoid of the Bernoulli layers (set_mean_field_arithmetic / BM355_SIGMOID_LITERAL=1)
+        self._sigmoid_literal = os.environ.get('BM355_SIGMOID_LITERAL', '0') == '1'
 
     # ---- composition from pre-trained RBMs (reference dbm.py:207-231) ------------------
     def load_rbms(self, rbms):
@@ -209,8 +211,10 @@ class DBM(EngineModel):
                                  h_units=self.h_units_ or None, n_samples=self.h_n_samples_ or None)
         # opt-in speed mode for log_Z (AIS): exact-product bf16 x 3 for the {0,1}-state contractions; tolerance parity
         # (DESIGN.md 3.9).  The reference API has no switch for it, so it is read from the environment.
-        if os.environ.get('BM355_FAST_BINARY', '0') == '1':
+        if os.environ.get('BM355_FAST_BINARY', '0') == '1' and not self._sigmoid_literal:
             self._engine.set_fast_binary(True)
+        if self._sigmoid_literal:
+            self._engine.set_sigmoid_literal(True)
         if self._pending_vars is None:          # fresh model (load_model uploads its checkpoint instead)
             self._upload_variables(self._initial_variables())
         # Multi-GPU job (one process per GPU): rank r owns rows [r*batch_size, ...) of every global
@@ -433,6 +437,22 @@ class DBM(EngineModel):
         if dtype not in ('float32', 'float64'):
             raise ValueError("dtype must be 'float32' or 'float64'")
         self._ais_literal = dtype == 'float32'
+        return self
+
+    def set_mean_field_arithmetic(self, mode='engine'):
+        """Which sigmoid the Bernoulli layers evaluate (not a keyword of the reference: it has only its own).
+        'engine' (default): one correctly rounded division, `e / (1 + e)` for x < 0 (~1.4 ulp).
+        'reference': literally `tf.nn.sigmoid` as TensorFlow 1.3 computes it in float32, `1 / (1 + exp(-x))` with Eigen's
+        exp (layers.py:47-48; ~1.8 ulp), in every pass of the engine.
+        Parameters, means and metrics agree between the modes to float32 round-off.  What differs is the number of executed
+        mean-field sweeps (`n_mf_updates` of the progress line): at the default mf_tol = 1e-7 the loop of reference
+        dbm.py:449-452 is decided in the last bits of the means, and only with the reference's own sigmoid does the engine
+        execute the reference's sweeps (784-512-1024, batch 512: 5-6 per update; 7-8 in the 'engine' arithmetic)."""
+        if mode not in ('engine', 'reference'):
+            raise ValueError("mode must be 'engine' or 'reference'")
+        self._sigmoid_literal = mode == 'reference'
+        if getattr(self, '_engine', None) is not None:
+            self._engine.set_sigmoid_literal(self._sigmoid_literal)
         return self
 
     @run_on_engine(update_seed=True)

@@ -398,6 +398,10 @@ class DbmEngine(object):
         """AIS log-weights accumulated in float32 in the reference graph's order (bm_dbm_set_ais_literal)"""
         check(self.lib.bm_dbm_set_ais_literal(self._h, int(bool(on))))
 
+    def set_sigmoid_literal(self, on):
+        """every Bernoulli activation as the reference's float32 `1 / (1 + exp(-x))` (bm_dbm_set_sigmoid_literal)"""
+        check(self.lib.bm_dbm_set_sigmoid_literal(self._h, int(bool(on))))
+
     def set_xchg(self, xchg):
         """like set_comm, with the per-sweep residual max over the direct peer-memory exchange (bm_dbm_set_xchg)"""
         self._xchg = xchg

@@ -416,6 +416,12 @@ int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on);
  * (dbm.py:650-660, :708-728): each log p*_beta(x) formed in float32 and added to / subtracted from a float32
  * log-weight in the graph's order; two extra score-only passes per beta. */
 int bm_dbm_set_ais_literal(bm_dbm *h, int32_t on);
+/* Sigmoid of the Bernoulli layers.  0 (default): the engine's form (one correctly rounded division, e / (1 + e) for x < 0;
+ * ~1.4 ulp).  1: LITERALLY tf.nn.sigmoid as the reference evaluates it (layers.py:47-48 -> float32 1 / (1 + exp(-x)), exp
+ * as Eigen's pexp of TensorFlow 1.3; ~1.8 ulp) in every pass of this engine: the same values to float32 round-off, and the
+ * reference's mean-field trip counts - the loop of dbm.py:449-452 at mf_tol = 1e-7 is decided in the last bits of the
+ * means (784-512-1024: 5 - 6 sweeps per update with the literal form, 7 - 8 with the default). */
+int bm_dbm_set_sigmoid_literal(bm_dbm *h, int32_t on);
 /* like bm_dbm_set_comm, with the per-sweep residual max going through bm_xchg_allreduce_max1; NULL removes it */
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x);
 

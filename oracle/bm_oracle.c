@@ -189,6 +189,37 @@ float orc_sigmoid(float x) {
     return (x >= 0.0f) ? (1.0f / d) : (e / d);
 }
 
+/* "Reference arithmetic" (orc_dbm_cfg.sigmoid_literal; engine: bm_dbm_set_sigmoid_literal): tf.nn.sigmoid as TensorFlow 1.3
+ * evaluates it on the CPU (layers.py:47-48): float32 1 / (1 + exp(-x)) (Eigen scalar_sigmoid_op), exp = Eigen 3.3's
+ * pexp<Packet4f> - the Cephes expf scheme, every pmadd a rounded multiply + a rounded add (SSE build, no FMA).  TensorFlow
+ * (requirements.txt:11 `tensorflow-gpu~=1.3.0`) and its Eigen are not in /root/reference: restated from the published
+ * algorithm, operation by operation, identically in csrc/bm_numerics.h (exp_eigen) and tests/tf1_shim (tf.sigmoid).
+ * Built with -ffp-contract=off (Makefile): nothing below may fuse. */
+float orc_exp_eigen(float x0) {
+    float x = fminf(x0, 88.3762626647950f);
+    x = fmaxf(x, -88.3762626647949f);
+    float fx = x * 1.44269504088896341f;
+    fx = fx + 0.5f;
+    fx = floorf(fx);
+    const float tmp = fx * 0.693359375f;
+    const float zz = fx * -2.12194440e-4f;
+    x = x - tmp;
+    x = x - zz;
+    const float z = x * x;
+    float y = 1.9875691500E-4f;
+    y = y * x; y = y + 1.3981999507E-3f;
+    y = y * x; y = y + 8.3334519073E-3f;
+    y = y * x; y = y + 4.1665795894E-2f;
+    y = y * x; y = y + 1.6666665459E-1f;
+    y = y * x; y = y + 5.0000001201E-1f;
+    y = y * z; y = y + x;
+    y = y + 1.0f;
+    union { uint32_t u; float f; } p2;
+    p2.u = (uint32_t)((int32_t)fx + 127) << 23;
+    return fmaxf(y * p2.f, x0);
+}
+float orc_sigmoid_literal(float x) { return 1.0f / (1.0f + orc_exp_eigen(-x)); }
+
 static double softplus_d(double x) { return fmax(x, 0.0) + log1p(exp(-fabs(x))); }
 
 /* ------------------------------------------------------------ contractions */
@@ -213,7 +244,8 @@ static float *transpose(const float *A, int R, int C) {   /* A[R][C] -> T[C][R] 
     return T;
 }
 
-enum { UNIT_BERNOULLI = 0, UNIT_GAUSSIAN = 1, UNIT_MULTINOMIAL = 2 };
+enum { UNIT_BERNOULLI = 0, UNIT_GAUSSIAN = 1, UNIT_MULTINOMIAL = 2,
+       UNIT_BERNOULLI_LIT = 4 /* orc_act2 only: Bernoulli with orc_sigmoid_literal */ };
 
 /* One fused "activation" stage = what act_kernel does on the GPU:
  *   z[j][i] = chain(seg1) then chain(seg2);  x = mult*z; b = mult*bias[i]
@@ -306,11 +338,13 @@ void orc_act2(const float *Q1, int K1, const float *P1k,
             for (int i = 0; i < I; ++i) {
                 const float x = mult * acc[i];
                 const float b = bmult * bias[i];
-                const float m = (kind == UNIT_BERNOULLI) ? orc_sigmoid(x + b) : (x * sigma[i] + b);
+                const int bern = (kind == UNIT_BERNOULLI || kind == UNIT_BERNOULLI_LIT);
+                const float m = (kind == UNIT_BERNOULLI) ? orc_sigmoid(x + b)
+                              : (kind == UNIT_BERNOULLI_LIT) ? orc_sigmoid_literal(x + b) : (x * sigma[i] + b);
                 float s = m;
                 if (sample) {
                     const uint64_t idx = (uint64_t)(row0 + j) * (uint64_t)I + (uint64_t)i;
-                    if (kind == UNIT_BERNOULLI) s = (uniform_at(key, idx) < m) ? 1.0f : 0.0f;
+                    if (bern) s = (uniform_at(key, idx) < m) ? 1.0f : 0.0f;
                     else s = normal_at(key, idx) * sigma[i] + m;
                 }
                 if (means) means[(size_t)j * I + i] = m;
@@ -564,12 +598,18 @@ typedef struct {
     int32_t N, M, max_mf;
     float mf_tol, l2, max_norm, sp_target[ORC_MAXL], sp_cost[ORC_MAXL], sp_damping;
     int32_t h_unit[ORC_MAXL], n_samples[ORC_MAXL];   /* hidden layer kinds (layers.py:39-70): Bernoulli | Multinomial(n_samples) */
+    int32_t sigmoid_literal;              /* 1: Bernoulli layers use orc_sigmoid_literal (the reference's float32 tf.sigmoid) */
 } orc_dbm_cfg;
 
 /* activation kind of hidden layer i for orc_act2 (Multinomial: 16 + n_samples) */
 static int hkind(const orc_dbm_cfg *c, int i) {
-    return (c->h_unit[i] == UNIT_MULTINOMIAL) ? 16 + c->n_samples[i] : UNIT_BERNOULLI;
+    return (c->h_unit[i] == UNIT_MULTINOMIAL) ? 16 + c->n_samples[i] : (c->sigmoid_literal ? UNIT_BERNOULLI_LIT : UNIT_BERNOULLI);
 }
+/* the same for the visible layer / an all-Bernoulli stack (AIS) */
+static int vkind(const orc_dbm_cfg *c) {
+    return (c->v_unit == UNIT_BERNOULLI && c->sigmoid_literal) ? UNIT_BERNOULLI_LIT : c->v_unit;
+}
+static int bkind(const orc_dbm_cfg *c) { return c->sigmoid_literal ? UNIT_BERNOULLI_LIT : UNIT_BERNOULLI; }
 
 typedef struct {
     float *W[ORC_MAXL], *dW[ORC_MAXL], *hb[ORC_MAXL], *dhb[ORC_MAXL], *q[ORC_MAXL], *mm[ORC_MAXL];
@@ -600,7 +640,7 @@ static void dbm_sweep(const orc_dbm_cfg *c, const orc_dbm_state *s, int J, const
     if (update_v) {
         float *Wt0 = transpose(s->W[0], c->V, dn(c, 1));
         const int smp = sample && c->sample_v;
-        orc_act2(Hout[0], dn(c, 1), Wt0, NULL, 0, NULL, c->V, J, s->vb, s->sigma, 1.0f, 1.0f, c->v_unit, smp,
+        orc_act2(Hout[0], dn(c, 1), Wt0, NULL, 0, NULL, c->V, J, s->vb, s->sigma, 1.0f, 1.0f, vkind(c), smp,
                  NULL, vout, seed, SITE_DBM_V + 16u * (uint32_t)t, call, row0);
         free(Wt0);
     }
@@ -662,7 +702,7 @@ void orc_dbm_particles(const orc_dbm_cfg *c, orc_dbm_state *s, int k, int sample
 /* reconstruction sigma(mu0 W0^T + vb) (dbm.py:625-628) */
 void orc_dbm_reconstruct_from_mu(const orc_dbm_cfg *c, const orc_dbm_state *s, float *R) {
     float *Wt0 = transpose(s->W[0], c->V, dn(c, 1));
-    orc_act2(s->mu[0], dn(c, 1), Wt0, NULL, 0, NULL, c->V, c->N, s->vb, s->sigma, 1.0f, 1.0f, c->v_unit, 0,
+    orc_act2(s->mu[0], dn(c, 1), Wt0, NULL, 0, NULL, c->V, c->N, s->vb, s->sigma, 1.0f, 1.0f, vkind(c), 0,
              R, NULL, 0, 0, 0, 0);
     free(Wt0);
 }
@@ -817,11 +857,11 @@ void orc_dbm_ais(const orc_dbm_cfg *c, const orc_dbm_state *s, int n_betas, int 
     const float db = 1.0f / (float)n_betas;
 #define AIS_TRANSIT(BETA, STEP)                                                                             \
     for (int t = 0; t < k; ++t) {                                                                           \
-        orc_act2(x, H1, Wt0, NULL, 0, NULL, V, R, s->vb, s->sigma, (BETA), (BETA), UNIT_BERNOULLI,         \
+        orc_act2(x, H1, Wt0, NULL, 0, NULL, V, R, s->vb, s->sigma, (BETA), (BETA), bkind(c),               \
                  c->sample_v, NULL, v, seed, SITE_DBM_V + 16u * (uint32_t)t, (STEP), chain0);               \
-        orc_act2(x, H1, s->W[1], NULL, 0, NULL, H2, R, s->hb[1], NULL, (BETA), (BETA), UNIT_BERNOULLI,     \
+        orc_act2(x, H1, s->W[1], NULL, 0, NULL, H2, R, s->hb[1], NULL, (BETA), (BETA), bkind(c),           \
                  c->sample_h[1], NULL, h2, seed, SITE_DBM_H + 1 + 16u * (uint32_t)t, (STEP), chain0);       \
-        orc_act2(v, V, s->W[0], h2, H2, Wt1, H1, R, s->hb[0], NULL, (BETA), (BETA), UNIT_BERNOULLI,        \
+        orc_act2(v, V, s->W[0], h2, H2, Wt1, H1, R, s->hb[0], NULL, (BETA), (BETA), bkind(c),              \
                  c->sample_h[0], NULL, xn, seed, SITE_DBM_H + 0 + 16u * (uint32_t)t, (STEP), chain0);       \
         float *tx = x; x = xn; xn = tx;                                                                     \
     }
@@ -890,11 +930,11 @@ void orc_dbm_ais_literal(const orc_dbm_cfg *c, const orc_dbm_state *s, int n_bet
     const float db = 1.0f / (float)n_betas;
 #define AIS_TRANSIT_L(BETA, STEP)                                                                           \
     for (int t = 0; t < k; ++t) {                                                                           \
-        orc_act2(x, H1, Wt0, NULL, 0, NULL, V, R, s->vb, s->sigma, (BETA), (BETA), UNIT_BERNOULLI,         \
+        orc_act2(x, H1, Wt0, NULL, 0, NULL, V, R, s->vb, s->sigma, (BETA), (BETA), bkind(c),               \
                  c->sample_v, NULL, v, seed, SITE_DBM_V + 16u * (uint32_t)t, (STEP), chain0);               \
-        orc_act2(x, H1, s->W[1], NULL, 0, NULL, H2, R, s->hb[1], NULL, (BETA), (BETA), UNIT_BERNOULLI,     \
+        orc_act2(x, H1, s->W[1], NULL, 0, NULL, H2, R, s->hb[1], NULL, (BETA), (BETA), bkind(c),           \
                  c->sample_h[1], NULL, h2, seed, SITE_DBM_H + 1 + 16u * (uint32_t)t, (STEP), chain0);       \
-        orc_act2(v, V, s->W[0], h2, H2, Wt1, H1, R, s->hb[0], NULL, (BETA), (BETA), UNIT_BERNOULLI,        \
+        orc_act2(v, V, s->W[0], h2, H2, Wt1, H1, R, s->hb[0], NULL, (BETA), (BETA), bkind(c),              \
                  c->sample_h[0], NULL, xn, seed, SITE_DBM_H + 0 + 16u * (uint32_t)t, (STEP), chain0);       \
         float *tx = x; x = xn; xn = tx;                                                                     \
     }

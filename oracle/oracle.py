@@ -59,6 +59,8 @@ def lib():
         L = C.CDLL(LIB)
         L.orc_sigmoid.restype = C.c_float
         L.orc_sigmoid.argtypes = [C.c_float]
+        for f in (L.orc_sigmoid_literal, L.orc_exp_eigen):
+            f.restype, f.argtypes = C.c_float, [C.c_float]
         L.orc_philox_words.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, u32p]
         L.orc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, f32p]
         L.orc_normal.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, f32p]
@@ -325,7 +327,7 @@ class DbmCfg(C.Structure):
                 ('N', C.c_int32), ('M', C.c_int32), ('max_mf', C.c_int32),
                 ('mf_tol', C.c_float), ('l2', C.c_float), ('max_norm', C.c_float),
                 ('sp_target', C.c_float * MAXL), ('sp_cost', C.c_float * MAXL), ('sp_damping', C.c_float),
-                ('h_unit', C.c_int32 * MAXL), ('n_samples', C.c_int32 * MAXL)]
+                ('h_unit', C.c_int32 * MAXL), ('n_samples', C.c_int32 * MAXL), ('sigmoid_literal', C.c_int32)]
 
 
 class DbmState(C.Structure):
@@ -357,7 +359,8 @@ class OracleDBM(object):
 
     def __init__(self, n_visible, n_hiddens, v_unit=0, sample_v_states=True, sample_h_states=None,
                  n_particles=100, batch_size=100, max_mf_updates=10, mf_tol=1e-7, l2=0., max_norm=np.inf,
-                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, h_units=None, n_samples=None):
+                 sparsity_target=0.1, sparsity_cost=0., sparsity_damping=0.9, h_units=None, n_samples=None,
+                 sigmoid_literal=False):
         self.V, self.nh = int(n_visible), [int(x) for x in n_hiddens]
         self.L, self.N, self.M = len(self.nh), int(batch_size), int(n_particles)
         c = DbmCfg()
@@ -373,6 +376,7 @@ class OracleDBM(object):
         c.N, c.M, c.max_mf = self.N, self.M, int(max_mf_updates)
         c.mf_tol, c.l2, c.sp_damping = mf_tol, l2, sparsity_damping
         c.max_norm = float(max_norm)
+        c.sigmoid_literal = int(bool(sigmoid_literal))
         self.cfg = c
         n = [self.V] + self.nh
         z = lambda *s: np.zeros(s, dtype=np.float32)
@@ -391,6 +395,10 @@ class OracleDBM(object):
 
     def set_seed(self, seed):
         self.seed, self.call = int(seed), 0
+
+    def set_sigmoid_literal(self, on):
+        """Bernoulli activations as the reference's float32 tf.sigmoid (orc_sigmoid_literal) - bm_dbm_set_sigmoid_literal"""
+        self.cfg.sigmoid_literal = int(bool(on))
 
     def _state(self):
         s = DbmState()

@@ -411,16 +411,13 @@ ROW_AGGREGATE = {'ais_config4_slice': {'log_Z': 'log_Z_values'}}
 # half an ulp per operation of the exact value, and the scenarios hold north_star's 1e-5 like all others)
 GAUSSIAN = {'rbm_gaussian', 'dbm_gaussian_bernoulli_multinomial'}
 
-# Executed mean-field sweeps at mf_tol = 1e-7, the reference's default (dbm.py:91).  The loop ends when
-# max |mu - mu_new| <= 1e-7 (dbm.py:449-452), i.e. when no mean in [0.5, 1) moves by 2 float32 ulps and none in
-# [0.25, 0.5) by 4.  `tf.sigmoid` = 1 / (1 + exp(-x)) evaluated in float32 (Eigen's scalar_sigmoid_op in TF 1.3,
-# NumPy in the stand-in) is quantised MORE COARSELY than that for x < 0: d = 1 + exp(|x|) lies in [2, 4) where one ulp
-# is 2.4e-7, and 1 / d then moves in steps of up to 4 ulps of the result (measured: tests/test_reference_shim.py).  A
-# one-ulp flicker of a pre-activation therefore keeps such a mean jumping by 1.19e-7 > tol for ever, and the
-# reference runs to `max_mf_updates` although mu has long converged (784-512-1024, batch 512: 50 of 50 sweeps, every
-# update).  The engine's sigmoid (e / (1 + e) for x < 0, one correctly rounded division) has no such steps and stops
-# when the fixed point is reached (7-8 sweeps on the same inputs).  mu, the parameters and the metrics agree to 1e-5
-# either way - the sweeps the reference adds change nothing but the last bits - so the trip COUNT is reported, and
-# bounded by max_mf_updates, but not compared where the tolerance sits below that quantisation.
-MF_TRIPS_UNPINNED = {'dbm_three_layers': 1.0, 'dbm_gaussian_bernoulli_multinomial': 6.0,
-                     'dbm_config3_shape_b100': 50.0, 'dbm_config3_shape_b512': 50.0}
+# Executed mean-field sweeps (dbm.py:449-452; `metrics_n_mf_updates`).  The DBM scenarios are compared in the engine's
+# "reference arithmetic" (DBM.set_mean_field_arithmetic('reference') / BM355_SIGMOID_LITERAL=1: the literal float32 tf.sigmoid,
+# bit-identical between kernel, oracle and stand-in) and the trip counts must then be the reference's - exactly, except for the
+# single sweep of a loop the GENERATOR recorded as ending at the float32 noise floor of mf_tol (`mf_loops` of the fixture,
+# tests/golden/make_golden_from_reference.py; the rule is tests/reference_fixtures.py mf_trip_bounds).  In the default
+# arithmetic the loop runs a sweep or two longer at mf_tol = 1e-7 (the engine's sigmoid, one correctly rounded division, passes
+# a one-ulp movement of a pre-activation on to the mean where the literal form's coarser steps for x < 0 absorb it):
+# tests/test_reference_fixtures*.py state those counts separately.
+DBM_SCENARIOS = ('dbm_two_layers', 'dbm_three_layers', 'dbm_gaussian_bernoulli_multinomial',
+                 'dbm_config3_shape_b100', 'dbm_config3_shape_b512')

@@ -172,6 +172,9 @@ class OracleDbmEngine(object):
     def set_ais_literal(self, on):
         self._ais_literal = bool(on)
 
+    def set_sigmoid_literal(self, on):
+        self.twin.set_sigmoid_literal(on)
+
     def _rows(self, Xd, row):
         return Xd.a[row:row + self.N]
 

@@ -33,8 +33,6 @@ def tolerances(name):
         tol = dict(rtol=1e-11, metrics_rtol=1e-7, atol=1e-15)      # progress lines carry 9 significant digits
     else:
         tol = dict(rtol=1e-5, metrics_rtol=1e-5)
-    if name in scenarios.MF_TRIPS_UNPINNED:                          # see the comment there
-        tol['n_mf_atol'] = scenarios.MF_TRIPS_UNPINNED[name]
     return tol
 
 
@@ -45,7 +43,23 @@ def check(name, got):
                    row_aggregate=scenarios.ROW_AGGREGATE.get(name), **tolerances(name))
 
 
-BOOKKEEPING = ('min_bernoulli_margin', 'near_ties', 'near_tie_labels', 'near_tie_scopes', 'n_bernoulli_draws')
+BOOKKEEPING = ('min_bernoulli_margin', 'near_ties', 'near_tie_labels', 'near_tie_scopes', 'n_bernoulli_draws', 'mf_loops')
+
+
+def mf_trip_bounds(ref):
+    """[lines, 2, 3] = (lowest, highest, flagged loops) mean trip count the progress-line entry (line, train / validation)
+    may show: the reference's own counts, widened by ONE sweep for every loop the generator recorded as ending at the float32
+    noise floor of its tolerance (tests/golden/make_golden_from_reference.py, `mf_loops`).  NaN where no loop was recorded
+    (the entry repeats the last validation run of the same fit, or is absent)."""
+    loops = np.asarray(ref.get('mf_loops', np.zeros((0, 7)))).reshape(-1, 7)
+    n_lines = int(np.asarray(ref['metrics_n_mf_updates']).shape[0])
+    out = np.full((n_lines, 2, 3), np.nan)
+    for line in range(n_lines):
+        for col in (0, 1):
+            sel = loops[(loops[:, 0] == line) & (loops[:, 1] == col)]
+            if len(sel):
+                out[line, col] = (np.mean(sel[:, 2] - sel[:, 3]), np.mean(sel[:, 2] + sel[:, 4]), np.sum((sel[:, 3] + sel[:, 4]) > 0))
+    return out
 
 
 def near_ties(ref, label=None):
@@ -136,11 +150,23 @@ def compare(name, got, ref, rtol=1e-5, metrics_rtol=1e-5, atol=1e-7, n_mf_atol=0
         scale = max(float(np.max(np.abs(r64))) if r64.size else 0.0, 1e-30)
         diff = float(np.max(np.abs(r64 - g64))) if r64.size else 0.0
         tol = metrics_rtol if k == 'metrics' else rtol
-        if k == 'metrics_n_mf_updates':              # epoch means of integer trip counts
-            report.append('%-60s reference %s, here %s (allowed difference %.1f)'
-                          % (k, np.round(r64.reshape(-1), 2).tolist(), np.round(g64.reshape(-1), 2).tolist(), n_mf_atol))
-            if not diff <= n_mf_atol + 1e-9:
-                errors.append('%s: executed mean-field sweeps differ by %.2f (allowed %.2f)' % (k, diff, n_mf_atol))
+        if k == 'metrics_n_mf_updates':              # epoch means of integer trip counts, printed with one decimal
+            bounds = mf_trip_bounds(full)
+            r2, g2 = np.asarray(ref[k], dtype=np.float64), np.asarray(got[k], dtype=np.float64)
+            lo, hi = r2 - n_mf_atol, r2 + n_mf_atol
+            have = ~np.isnan(bounds[:, :r2.shape[1], 0])
+            lo[have] = np.minimum(lo[have], bounds[:, :r2.shape[1], 0][have] - 0.05 - n_mf_atol)   # 0.05: the `.1f` of the progress line
+            hi[have] = np.maximum(hi[have], bounds[:, :r2.shape[1], 1][have] + 0.05 + n_mf_atol)
+            nflag = int(np.nansum(bounds[:, :, 2]))
+            exact = bool(np.array_equal(np.isnan(r2), np.isnan(g2)) and np.array_equal(np.nan_to_num(r2), np.nan_to_num(g2)))
+            report.append('%-60s reference %s, here %s: %s' % (
+                k, np.round(r2.reshape(-1), 2).tolist(), np.round(g2.reshape(-1), 2).tolist(),
+                'EXACT' if exact else 'within the one sweep of the %d loop(s) recorded at the noise floor of mf_tol' % nflag))
+            ok = np.array_equal(np.isnan(r2), np.isnan(g2)) and bool(np.all((np.nan_to_num(g2) >= np.nan_to_num(lo) - 1e-9) &
+                                                                          (np.nan_to_num(g2) <= np.nan_to_num(hi) + 1e-9)))
+            if not ok:
+                errors.append('%s: executed mean-field sweeps %s outside [%s, %s] (reference %s; %d loop(s) recorded at the noise floor)'
+                              % (k, g2.tolist(), lo.tolist(), hi.tolist(), r2.tolist(), nflag))
             continue
         report.append('%-60s %.2e (abs %.2e)' % (k, diff / scale, diff))
         if not diff <= tol * scale + atol:

@@ -69,6 +69,62 @@ def test_train_steps_bit_exact(gpu_lib, V, nh, N, M, kw):
     eng.close()
 
 
+@pytest.mark.parametrize('V,nh,N,M,kw', CASES)
+def test_reference_arithmetic_train_steps_bit_exact(gpu_lib, V, nh, N, M, kw):
+    """bm_dbm_set_sigmoid_literal: the literal float32 tf.sigmoid (layers.py:47-48) in every pass - same trip counts, same
+    bits as the oracle in ITS literal mode (orc_sigmoid_literal), and not the default arithmetic's bits"""
+    from boltzmann_machines_amd.engine import as_device
+    eng, twin = make_pair(V, nh, N, M, **kw)
+    base, _ = make_pair(V, nh, N, M, **kw)
+    eng.set_sigmoid_literal(True); twin.set_sigmoid_literal(True)
+    eng.seed(42); base.seed(42); twin.set_seed(42)
+    names = ['vb', 'dvb', 'v']
+    for i in range(len(nh)):
+        sfx = '' if i == 0 else '_%d' % i
+        names += [b + sfx for b in ('W', 'dW', 'hb', 'dhb', 'q_means', 'mu_means', 'mu', 'h')]
+    for s in range(2 if V < 500 else 1):
+        X = data(N, V, s)
+        n1, m1 = eng.train_step(as_device(X), 0.05, 0.5, 2, want_msre=True)
+        n2, m2 = twin.train_step(X, 0.05, 0.5, 2, want_msre=True)
+        base.train_step(as_device(X), 0.05, 0.5, 2)
+        assert n1 == n2
+        np.testing.assert_allclose(m1, m2, rtol=1e-5)
+        assert_equal(eng, twin, names)
+    mu, mu0 = eng.get('mu'), base.get('mu')
+    assert not np.array_equal(mu.view(np.uint32), mu0.view(np.uint32))        # the mode does change the last bits ...
+    np.testing.assert_allclose(mu, mu0, rtol=0, atol=5e-7)                     # ... and nothing else
+    eng.set_sigmoid_literal(False)                                             # and it can be switched back
+    twin.set_sigmoid_literal(False)
+    X = data(N, V, 7)
+    assert eng.train_step(as_device(X), 0.05, 0.5, 2) == twin.train_step(X, 0.05, 0.5, 2)[0]
+    assert_equal(eng, twin, names)
+    eng.close(); base.close()
+
+
+def test_reference_arithmetic_inference_and_ais_bit_exact(gpu_lib):
+    """mean-field / reconstruct / sample_v bit-exact and AIS within 1e-5 of the oracle, both in the literal-sigmoid mode"""
+    from boltzmann_machines_amd._ffi import DeviceArray
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N, M = 20, [12, 16], 10, 10
+    eng, twin = make_pair(V, nh, N, M, max_mf_updates=8, mf_tol=1e-7)
+    eng.set_sigmoid_literal(True); twin.set_sigmoid_literal(True)
+    eng.seed(7); twin.set_seed(7)
+    X = data(N, V, 5)
+    top = DeviceArray((N, nh[-1]))
+    assert eng.mean_field(as_device(X), out=top) == twin.mean_field(X)
+    assert np.array_equal(top.numpy(), twin.p['mu_1'])
+    Rd = DeviceArray((N, V))
+    eng.reconstruct(as_device(X), Rd)
+    eng.sync()
+    assert np.array_equal(Rd.numpy(), twin.reconstruct(X))
+    Vd = DeviceArray((M, V))
+    eng.sample_v(3, Vd)
+    assert np.array_equal(Vd.numpy(), twin.sample_v(3))
+    assert_equal(eng, twin, ['v', 'h', 'h_1'])
+    np.testing.assert_allclose(eng.ais(30, 8, 2, seed=5), twin.ais(30, 8, 2, 5), rtol=1e-5)
+    eng.close()
+
+
 def test_overlapped_particles_and_predicted_mean_field_bit_exact(gpu_lib):
     # from the third update on the PCD sweeps run on a second stream next to the mean-field, and the mean-field's
     # first group of sweeps is sized from the previous trip count (too long / too short both occur here)

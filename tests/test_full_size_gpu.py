@@ -77,6 +77,25 @@ def test_config3_dbm_784_512_1024_batch512_pcd5(gpu_lib):
     eng.close()
 
 
+def test_config3_dbm_reference_arithmetic_batch512(gpu_lib):
+    """the same update in the engine's reference arithmetic (bm_dbm_set_sigmoid_literal: tf.sigmoid as float32
+    1 / (1 + exp(-x)), layers.py:47-48): bit-exact against the oracle's literal mode incl. the executed sweep count"""
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N = 784, [512, 1024], 512
+    kw = dict(max_mf_updates=50, mf_tol=1e-7, l2=1e-7, max_norm=6., sparsity_target=[0.2, 0.1],
+              sparsity_cost=[1e-4, 5e-5])
+    eng, twin = D.make_pair(V, nh, N, N, **kw)
+    eng.set_sigmoid_literal(True); twin.set_sigmoid_literal(True)
+    eng.seed(42); twin.set_seed(42)
+    X = D.data(N, V, 1)
+    g = eng.train_step(as_device(X), 2e-3, 0.9, 5, want_msre=True)
+    c = twin.train_step(X, 2e-3, 0.9, 5, want_msre=True)
+    assert g[0] == c[0] and g[0] > 1, (g, c)
+    np.testing.assert_allclose(g[1], c[1], rtol=1e-5)
+    D.assert_equal(eng, twin, ['W', 'W_1', 'vb', 'hb', 'hb_1', 'dW', 'dW_1', 'v', 'h', 'h_1', 'mu', 'mu_1'])
+    eng.close()
+
+
 def test_config4_ais_20000_chains_slice_property(gpu_lib):
     """AIS on the 784-512-1024 DBM with 20 000 chains (12 betas here): chains [7000, 7016) and the last 8
     of the full run equal the oracle's standalone evaluation of just those chains."""

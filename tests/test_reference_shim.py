@@ -83,28 +83,39 @@ def test_reference_ais_is_the_literal_float32_accumulation(tmp_path, monkeypatch
     np.testing.assert_allclose(dbl, values, rtol=1e-5)
 
 
-def test_float32_sigmoid_of_the_reference_is_coarser_than_mf_tol():
-    """Why the executed mean-field sweeps at the reference's default mf_tol = 1e-7 are reported, not compared, where the
-    tolerance sits this low (tests/golden/scenarios.py MF_TRIPS_UNPINNED): `tf.sigmoid` as float32
-    `1 / (1 + exp(-x))` (Eigen in TF 1.3, NumPy in the stand-in) jumps by MORE than 1e-7 between consecutive float32
-    arguments somewhere in the range the means of a 784-512-1024 stack live in - more than the loop condition of
-    dbm.py:449-452 allows a mean to move - while the engine's sigmoid (`e / (1 + e)` for x < 0, one division:
-    csrc/bm_numerics.h = orc_sigmoid) never does: a one-ulp flicker of a pre-activation keeps the reference's loop
-    running to max_mf_updates and lets the engine's end."""
+def test_literal_sigmoid_is_the_stand_ins_tf_sigmoid_bit_for_bit():
+    """`tf.sigmoid` as float32 `1 / (1 + exp(-x))` (layers.py:47-48): Eigen's scalar_sigmoid_op over Eigen's pexp in TF 1.3,
+    restated operation by operation in the stand-in (tests/tf1_shim `_exp_eigen_f32`).  The engine's reference arithmetic
+    (orc_sigmoid_literal = csrc/bm_numerics.h sigmoid_literal) is that function BIT FOR BIT - which is what lets the fixtures
+    compare the executed mean-field sweeps (dbm.py:449-452; tests/reference_fixtures.py mf_trip_bounds).  The engine's
+    DEFAULT sigmoid (`e / (1 + e)` for x < 0, one division: orc_sigmoid) differs from it in the last bit and is the more
+    accurate of the two.
+
+    (Round 5's stand-in evaluated the same formula with NumPy's float32 exp: that combination steps by 1.19e-7 > mf_tol
+    between consecutive arguments, kept the stand-in's loop running to max_mf_updates = 50, and was reported as the
+    reference's behaviour.  With Eigen's exp restated no step exceeds 5.96e-8 and the stand-in runs 5 - 6 sweeps at
+    784-512-1024: the 50 was NumPy's, not the reference's.  Asserted below so the finding stays checked.)"""
     import numpy as np
     tf, _ = reference_shim.activate()
     from oracle import oracle as orc
-    worst_ref, worst_ours, err_ref, err_ours = 0.0, 0.0, 0.0, 0.0
-    for start in (-0.9, -0.6, -0.4, -0.24, -0.1, 0.1, 0.3, 0.7):
+    step = dict(lit=0.0, ours=0.0, npexp=0.0)
+    err = dict(lit=0.0, ours=0.0)
+    for start in (-0.9, -0.6, -0.4, -0.24, -0.1, 0.1, 0.3, 0.7, -30.0, -8.0, 8.0, 30.0):
         x0 = np.float32(start)
         x = x0 + np.arange(3000, dtype=np.float32) * np.spacing(x0)          # consecutive float32 arguments
         ref = np.asarray(tf._sigmoid(x), dtype=np.float32)
         ours = np.array([orc.lib().orc_sigmoid(float(v)) for v in x], dtype=np.float32)
+        lit = np.array([orc.lib().orc_sigmoid_literal(float(v)) for v in x], dtype=np.float32)
+        assert np.array_equal(lit.view(np.uint32), ref.view(np.uint32)), start
+        if abs(start) > 1:
+            continue
+        npexp = (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
         exact = 1.0 / (1.0 + np.exp(-x.astype(np.float64)))
-        worst_ref = max(worst_ref, float(np.abs(np.diff(ref)).max()))
-        worst_ours = max(worst_ours, float(np.abs(np.diff(ours)).max()))
-        err_ref = max(err_ref, float((np.abs(ref - exact) / np.spacing(ref)).max()))
-        err_ours = max(err_ours, float((np.abs(ours - exact) / np.spacing(ours)).max()))
-    assert worst_ref > 1e-7, worst_ref               # the reference's sigmoid alone can keep `max |mu - mu_new| > tol` true
-    assert worst_ours <= 1e-7, worst_ours            # the engine's cannot
-    assert err_ours < err_ref, (err_ours, err_ref)   # (and it is the more accurate of the two: ~1.3 against ~2.2 ulp)
+        for k, v in (('lit', lit), ('ours', ours), ('npexp', npexp)):
+            step[k] = max(step[k], float(np.abs(np.diff(v)).max()))
+        err['lit'] = max(err['lit'], float((np.abs(lit - exact) / np.spacing(lit)).max()))
+        err['ours'] = max(err['ours'], float((np.abs(ours - exact) / np.spacing(ours)).max()))
+    assert step['lit'] <= 6e-8 and step['ours'] <= 6e-8, step      # neither form steps by more than mf_tol = 1e-7 ...
+    assert err['ours'] < err['lit'] < 2.0, err                     # (~1.4 against ~1.8 ulp)
+    if step['npexp'] <= 1e-7:                                      # ... NumPy's exp in the same formula did (NumPy-version dependent)
+        pytest.skip('this NumPy\'s float32 exp no longer shows the 1.19e-7 step')

@@ -523,6 +523,21 @@ def set_rng_trace(fn):
     _rng_trace[0] = fn
 
 
+_compare_trace = [None]
+
+
+def set_compare_trace(fn):
+    """fn(scope, lhs, rhs) after every execution of a SCALAR `greater` (diagnostics of the generator: the loop condition
+    `residual > mf_tol` of the mean-field while_loop, dbm.py:449-452)"""
+    _compare_trace[0] = fn
+
+
+def _k_greater(ctx, t, a, b):
+    if _compare_trace[0] is not None and np.ndim(a) == 0 and np.ndim(b) == 0:
+        _compare_trace[0](t.scope, float(a), float(b))
+    return np.greater(a, b)
+
+
 def _stream_of(node, ctx):
     seed = node.attrs.get('seed')
     site = RandomSite(node, ctx)
@@ -649,10 +664,43 @@ def _softplus(x):
         return np.where(x > -thr, x, np.where(x < thr, e, np.log1p(e))).astype(x.dtype)
 
 
+def _exp_eigen_f32(x0):
+    """float32 exp as TensorFlow 1.3's CPU kernels compute it: Eigen 3.3 pexp<Packet4f> (Cephes expf; SSE build without FMA,
+    so every pmadd is a rounded multiply and a rounded add).  Every line is ONE correctly rounded float32 operation of
+    NumPy; the same sequence as oracle/bm_oracle.c orc_exp_eigen and csrc/bm_numerics.h exp_eigen (checked bit for bit by
+    tests/test_oracle.py)."""
+    f = np.float32
+    x0 = np.asarray(x0, dtype=f)
+    x = np.minimum(x0, f(88.3762626647950))
+    x = np.maximum(x, f(-88.3762626647949))
+    fx = x * f(1.44269504088896341)
+    fx = fx + f(0.5)
+    fx = np.floor(fx)
+    tmp = fx * f(0.693359375)
+    zz = fx * f(-2.12194440e-4)
+    x = x - tmp
+    x = x - zz
+    z = x * x
+    y = np.full_like(x, f(1.9875691500E-4))
+    for c in (1.3981999507E-3, 8.3334519073E-3, 4.1665795894E-2, 1.6666665459E-1, 5.0000001201E-1):
+        y = y * x
+        y = y + f(c)
+    y = y * z
+    y = y + x
+    y = y + f(1)
+    p2 = ((fx.astype(np.int32) + np.int32(127)).astype(np.uint32) << np.uint32(23)).view(f)
+    return np.maximum(y * p2, x0)
+
+
 def _sigmoid(x):
+    """tf.sigmoid = Eigen scalar_sigmoid_op: 1 / (1 + exp(-x)) in the operand's dtype.  float32 with Eigen's own exp (above)
+    rather than NumPy's: the quantisation of this form decides how long the reference's mean-field loop runs
+    (dbm.py:449-452), so the stand-in pins it operation by operation instead of inheriting libm's."""
     x = np.asarray(x)
     one = x.dtype.type(1)
     with np.errstate(over='ignore'):
+        if x.dtype == np.float32:
+            return (one / (one + _exp_eigen_f32(-x))).astype(x.dtype)
         return (one / (one + np.exp(-x))).astype(x.dtype)
 
 
@@ -765,7 +813,7 @@ _KERNELS = {
     'mul': lambda ctx, t, a, b: np.asarray(a * b, dtype=t.dtype),
     'div': lambda ctx, t, a, b: np.asarray(a / b, dtype=t.dtype) if t.dtype.kind == 'f' else np.asarray(a // b, dtype=t.dtype),
     'less': lambda ctx, t, a, b: np.less(a, b),
-    'greater': lambda ctx, t, a, b: np.greater(a, b),
+    'greater': _k_greater,
     'less_equal': lambda ctx, t, a, b: np.less_equal(a, b),
     'greater_equal': lambda ctx, t, a, b: np.greater_equal(a, b),
     'logical_and': lambda ctx, t, a, b: np.logical_and(a, b),
