@@ -152,11 +152,27 @@ def cpu_baseline(k, budget_s=2.5):
             'detail': detail}
 
 
+def kernel_source_sha16():
+    """identifies the library a profile was taken on: sha256 over the sources of the shared library (csrc/, include/).  (The
+    GPU box receives a snapshot without .git, so a commit id cannot be read there; tools/summarize_profile.py adds the
+    commit whose tree has this hash when it files the profile.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'boltzmann_machines_amd', 'csrc', '*.h')) +
+                   glob.glob(os.path.join(ROOT, 'boltzmann_machines_amd', 'csrc', '*.hip')) +
+                   glob.glob(os.path.join(ROOT, 'include', '*.h')))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0' + open(f, 'rb').read() + b'\0')
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(config):
     """HBM-side bytes per step from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
     runs of this same command, tools/profile.sh + tools/summarize_profile.py); None when no profile has
     been collected for this configuration.  Counters cannot be read live from inside the process, so this
-    is the one roofline field that comes from profiles/."""
+    is the one roofline field that comes from profiles/ - and ONLY from a profile taken on the library that is
+    running: a file whose recorded source hash differs from this tree's yields `traffic: null` and says so."""
     import glob
     pats = ['r*_%s_pmc.json' % config] + (['r[0-9]_pmc.json'] if config == 'rbm' else [])
     files = []
@@ -166,8 +182,15 @@ def pmc_traffic(config):
     if not files:
         return None
     try:
-        return (float(json.load(open(files[-1]))['traffic_bytes_per_update']),
-                'profiles/' + os.path.basename(files[-1]) + ' (rocprofv3 --pmc passes of this command; not measured in this run)')
+        d = json.load(open(files[-1]))
+        name = 'profiles/' + os.path.basename(files[-1])
+        have, mine = d.get('source_sha16'), kernel_source_sha16()
+        if have != mine:
+            return (None, '%s is STALE: taken on library sources %s (commit %s), running %s - re-collect with tools/profile.sh'
+                    % (name, have or 'unrecorded', d.get('head', 'unrecorded'), mine))
+        return (float(d['traffic_bytes_per_update']),
+                '%s (rocprofv3 --pmc passes of this command on these library sources, %s / commit %s; not measured in this run)'
+                % (name, mine, d.get('head', '?')))
     except Exception:
         return None
 
@@ -373,14 +396,15 @@ class RbmGibbs(Workload):
             'roofline_extra': {
                 'bf16x3_flop_fraction': 1.0 if self.fast else 0.0,
                 'traffic_per_sweep_over_algorithmic': (round(pmc_traffic('gibbs')[0] / k / bytes_sweep, 2)
-                                                       if pmc_traffic('gibbs') else None),
+                                                       if pmc_traffic('gibbs') and pmc_traffic('gibbs')[0] else None),
                 'scope': '%d sweeps per call, 2*2*B*V*H = %.3f GFLOP per sweep; the sweep is MFMA-bound (the 6.4 MB of W '
                          'and the 3.7 MB of states are L2 / Infinity-Cache resident), the HBM figure is the secondary '
                          'number north_star asks for' % (k, 2 * F / 1e9),
                 'hbm': {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': PEAK_HBM, 'unit': 'GB/s',
                         'frac': round(gbps / PEAK_HBM, 4),
                         'algorithmic_bytes_per_sweep': bytes_sweep,
-                        'traffic_per_sweep': (round(pmc_traffic('gibbs')[0] / k, 1) if pmc_traffic('gibbs') else None)}},
+                        'traffic_per_sweep': (round(pmc_traffic('gibbs')[0] / k, 1)
+                                              if pmc_traffic('gibbs') and pmc_traffic('gibbs')[0] else None)}},
         }
 
 
@@ -902,6 +926,27 @@ def make_record(wl, rep, world, steps, warmup, precondition_s, dt, ev_ms):
             'data': 'synthetic', 'config': rep['config'], 'roofline': roof}
 
 
+def with_summary(out):
+    """the line with a compact `summary` of EVERY configuration right behind metric / value / unit - {config: [ms_per_step,
+    roofline.frac (HIP events), roofline.frac_wall]} - so that a reader who keeps only the head or the tail of the line (the
+    driver's record truncates the middle of `other_configs`) still sees the default-mode gibbs / grbm / dbm / ais numbers"""
+    if not isinstance(out, dict) or 'roofline' not in out:
+        return out
+    summ = {out['config'].get('name', 'headline') if isinstance(out.get('config'), dict) else 'headline':
+            [out['ms_per_step'], out['roofline'].get('frac'), out['roofline'].get('frac_wall')]}
+    for name, rec in (out.get('other_configs') or {}).items():
+        if isinstance(rec, dict) and 'roofline' in rec:
+            summ[name] = [rec['ms_per_step'], rec['roofline'].get('frac'), rec['roofline'].get('frac_wall')]
+        elif isinstance(rec, dict) and 'error' in rec:
+            summ[name] = 'error'
+    front = ('metric', 'value', 'unit')
+    res = {k: out[k] for k in front if k in out}
+    res['summary'] = summ
+    res['summary_fields'] = '{config: [ms_per_step, roofline.frac, roofline.frac_wall]}'
+    res.update({k: v for k, v in out.items() if k not in front})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -1027,7 +1072,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        line_out.write(json.dumps(out) + '\n')
+        line_out.write(json.dumps(with_summary(out)) + '\n')
         line_out.flush()
 
     # ---- the other BASELINE configurations, short passes, embedded in the same line (rbm default run only).

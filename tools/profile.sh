@@ -8,6 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_${ROUND:-r5}
 mkdir -p $OUT
 CONFIGS=${@:-rbm gibbs grbm dbm ais aisfast}
+# which library the counters belong to (bench.py refuses a traffic figure whose sources differ from the running tree's)
+(cd $R && python -c 'import bench; print(bench.kernel_source_sha16())') > $OUT/source_sha16.txt
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_BF16"
 for c in $CONFIGS; do
   X=""; cc=$c

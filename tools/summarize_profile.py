@@ -20,6 +20,28 @@ configs = sys.argv[3:] or ['rbm', 'gibbs', 'grbm', 'dbm', 'ais', 'aisfast', 'grb
 os.makedirs('profiles', exist_ok=True)
 
 
+def provenance():
+    """source hash the profile was taken on (written by tools/profile.sh on the GPU box) and, when the tree this script runs
+    in has the same library sources, its commit"""
+    try:
+        sha = open(os.path.join(src, 'source_sha16.txt')).read().strip()
+    except OSError:
+        return {}
+    out = {'source_sha16': sha}
+    try:
+        import subprocess
+        sys.path.insert(0, os.getcwd())
+        import bench
+        if bench.kernel_source_sha16() == sha:
+            dirty = subprocess.run(['git', 'status', '--porcelain', '--', 'boltzmann_machines_amd/csrc', 'include'],
+                                   capture_output=True, text=True).stdout.strip()
+            head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+            out['head'] = head + (' + uncommitted changes of the library sources' if dirty else '')
+    except Exception:
+        pass
+    return out
+
+
 def find(d, pat):
     f = glob.glob(os.path.join(d, '**', pat), recursive=True)
     return f[0] if f else None
@@ -73,7 +95,9 @@ for cfg in configs:
         n_steps = max(1, sum(n for k, n in ndisp.items() if 'act_chain_kernel' in k) +
                       sum(n for k, n in ndisp.items() if 'act_kernel' in k) // 20)
     traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_steps
+    prov = provenance()
     lines = ['# rocprofv3 summary %s / %s - `python bench.py --config %s` on 1x MI355X' % (tag, cfg, cfg), '',
+             'library sources %s, commit %s' % (prov.get('source_sha16', 'unrecorded'), prov.get('head', 'unrecorded')), '',
              '| kernel | calls | avg us (kernel-trace) | total % | FETCH_SIZE KiB | x2 corrected MB | WRITE_SIZE KiB | MFMA busy % | issue-stalled % (WAIT_INST_ANY) | parked % (WAIT_ANY) | MFMA instr f32 / bf16 | LDS bank-conflict cycles |',
              '|---|---|---|---|---|---|---|---|---|---|---|---|']
     names = sorted(set(pmc) | {k for k in stats if 'bm::' in k or 'bm64::' in k},
@@ -99,6 +123,6 @@ for cfg in configs:
         shutil.copy(b, 'profiles/%s_%s_bench.json' % (tag, cfg))
         lines += ['bench line of the same tree: `%s`' % open(b).read().strip()[:700], '']
     open('profiles/%s_%s_summary.md' % (tag, cfg), 'w').write('\n'.join(lines))
-    json.dump({'traffic_bytes_per_update': traffic, 'steps_in_counter_pass': n_steps, 'pmc': pmc},
+    json.dump(dict(provenance(), **{'traffic_bytes_per_update': traffic, 'steps_in_counter_pass': n_steps, 'pmc': pmc}),
               open('profiles/%s_%s_pmc.json' % (tag, cfg), 'w'), indent=1)
     print('\n'.join(lines))
