@@ -579,13 +579,35 @@ class Ais(_DbmBase):
         eng.set('W_1', philox.tf_random_normal((self.H1, self.H2), 0.01, 1111))
         self.fast = bool(getattr(args, 'fast_binary', False))
         eng.set_fast_binary(self.fast)
-        self.comm = get_comm(rank, world) if (world > 1 or args.force_dp) else None
+        # the all-gather of the per-chain values: the same choice as the gradient exchange (direct peer-memory exchange
+        # after its start-up self-check against gloo, raced against RCCL; --collective overrides)
+        self.comm, self.xchg, self.collective, self.collective_note, self.dist = None, None, None, None, dist
+        if world > 1 or args.force_dp:
+            self.collective, self.collective_note = choose_collective(args, eng, rank, world, dist)
+            if self.collective == 'direct':
+                self.xchg = args._xchg[id(eng)]
+            elif self.collective in ('rccl', 'torch'):
+                self.comm = get_comm(rank, world)
         self.start, self.stop = parallel.shard(self.R, rank, world)
         self.last = None
 
     def step(self, i):
-        if self.comm is not None:
+        if self.xchg is not None:
+            self.last = self.eng.ais_sharded_direct(self.xchg, self.nb, self.R, self.k, 2222)   # shard + ONE exchange launch
+        elif self.comm is not None:
             self.last = self.eng.ais_sharded(self.comm, self.nb, self.R, self.k, 2222)    # shard + ONE all-gather
+        elif self.collective == 'gloo':       # ranks share a device and the direct path is off: through the host
+            import torch
+            from boltzmann_machines_amd import parallel
+
+            def allgather(local, counts):
+                bufs = [torch.zeros(max(counts), dtype=torch.float32) for _ in counts]
+                mine = torch.zeros(max(counts), dtype=torch.float32)
+                mine[:len(local)] = torch.from_numpy(local)
+                self.dist.all_gather(bufs, mine)
+                return np.concatenate([b.numpy()[:c] for b, c in zip(bufs, counts)])
+            self.last = parallel.ais_sharded(lambda n, c0: self.eng.ais(self.nb, n, self.k, 2222, chain0=c0),
+                                             self.R, self.rank, self.world, allgather)
         else:
             self.last = self.eng.ais(self.nb, self.R, self.k, 2222)
 
@@ -600,7 +622,9 @@ class Ais(_DbmBase):
                                    % (self.R, self.nb, self.k),
                        'chains_per_gpu': self.stop - self.start, 'parallelism': 'chains/%d' % world,
                        'fast_binary': FAST_NOTE if self.fast else False,
-                       'collective': 'bm_comm all-gather of the per-chain log-weights (once per run)' if self.comm else None,
+                       'collective': (COLLECTIVE_NAMES.get(self.collective, self.collective) + ': ONE gather of the per-chain '
+                                      'values per run') if self.collective else None,
+                       'collective_note': self.collective_note,
                        'log_Z_estimate': float(log_mean_exp(self.last.astype(np.float64))) if self.last is not None else None},
             'flops_per_step': flops,
             'roofline_extra': {'bf16x3_flop_fraction': 1.0 if self.fast else 0.0,
@@ -1107,8 +1131,6 @@ def main():
                 a2._xchg = {}
                 a2.fast_binary = name.endswith('+fast_binary')
                 name_wl = name.split('+')[0]
-                if name_wl == 'ais' and args._shared_devices:
-                    raise RuntimeError('skipped in a shared-device dry run (the chain all-gather is RCCL)')
                 w2 = WORKLOADS[name_wl](a2, rank, world, device, dist)
                 dt2, ev2 = measure(w2, st, wu, pre, barrier, dist)
                 # the same post-run check as the headline's (a collective: every rank is here): a pass whose exchange lost a

@@ -148,6 +148,7 @@ SIGNATURES = {
     'bm_dbm_set_mf_allreduce': [_vp, _vp, _vp],
     'bm_dbm_set_comm': [_vp, _vp],
     'bm_dbm_ais_sharded': [_vp, _vp, _i32, _i32, _i32, _u64, _vp],
+    'bm_dbm_ais_sharded_direct': [_vp, _vp, _i32, _i32, _i32, _u64, _vp],
     'bm_dbm_stream': [_vp, C.POINTER(_vp)],
     'bm_dbm_mean_field': [_vp, _vp, _vp, _ip],
     'bm_dbm_reconstruct': [_vp, _vp, _vp],

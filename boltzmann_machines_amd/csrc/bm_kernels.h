@@ -756,13 +756,26 @@ struct GradArgs {
 };
 
 // the scalar update rule shared by the fused epilogue and the split (data-parallel) apply kernel
+// (explicit round-to-nearest intrinsics: the replicas of a data-parallel run and the one-engine run apply this formula in
+//  DIFFERENT kernels - apply_w_kernel, apply_w_tiled_kernel, grad_kernel's epilogue, bm_xchg.hip's fused exchanges - and must
+//  produce the same bits whatever a toolchain's -ffp-contract default is; round-5 advisor)
 __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, float lr, float mom,
                                                float &w, float &dw) {
-    g = g - l2 * w;                // dW = ... - l2*W            (base_rbm.py:449)
-    g = g - pen;                   // dW -= sparsity_penalty      (base_rbm.py:462)
-    const float d = lr * (mom * dw + g);   // dW_update          (base_rbm.py:467)
+    g = __fsub_rn(g, __fmul_rn(l2, w));                 // dW = ... - l2*W            (base_rbm.py:449)
+    g = __fsub_rn(g, pen);                              // dW -= sparsity_penalty      (base_rbm.py:462)
+    const float d = __fmul_rn(lr, __fadd_rn(__fmul_rn(mom, dw), g));   // dW_update  (base_rbm.py:467)
     dw = d;
-    w = w + d;                     // W.assign_add               (base_rbm.py:468)
+    w = __fadd_rn(w, d);                                // W.assign_add               (base_rbm.py:468)
+}
+// the gradient such an update starts from: raw / N (RBM: the outer products already hold pos - neg) or raw / N - raw2 / M
+// (DBM: positive phase over N rows, negative over M particles, dbm.py:553-570).  A power-of-two count turns the division
+// into an exact scaling by its reciprocal (same bits as the IEEE division).  ONE definition for every kernel above.
+__device__ __forceinline__ bool grad_pow2(float N) { return ((__float_as_uint(N) & 0x007fffffu) == 0u) && N >= 1.0f; }
+__device__ __forceinline__ float grad_norm1(float r, float N, float invN, bool pow2) {
+    return pow2 ? __fmul_rn(r, invN) : __fdiv_rn(r, N);
+}
+__device__ __forceinline__ float grad_norm2(float r, float r2, float N, float M, float invN, float invM, bool pow2) {
+    return pow2 ? __fsub_rn(__fmul_rn(r, invN), __fmul_rn(r2, invM)) : __fsub_rn(__fdiv_rn(r, N), __fdiv_rn(r2, M));
 }
 
 // x / N, bit-identical to the IEEE division: a power-of-two N (the usual batch sizes) turns it
@@ -770,7 +783,7 @@ __device__ __forceinline__ void apply_w_update(float g, float pen, float l2, flo
 struct DivBy {
     float n, inv; bool pow2;
     __device__ __forceinline__ explicit DivBy(float N) : n(N), inv(1.0f / N),
-        pow2((__float_as_uint(N) & 0x007fffffu) == 0u && N >= 1.0f && N <= 16777216.0f) {}
+        pow2(grad_pow2(N)) {}
 };
 
 // grad_kernel's side work: the W / dW values of the lane's outputs are fetched at the start of
@@ -911,10 +924,12 @@ __global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a, TileMap t
         float gr[8];
         if (divN.pow2 && divM.pow2) {          // wave-uniform: exact scaling instead of 8-16 IEEE divisions
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gr[e] = (a.form == 0) ? pv[e] * divN.inv : (pv[e] * divN.inv - nv[e] * divM.inv);
+            for (int e = 0; e < 8; ++e) gr[e] = (a.form == 0) ? grad_norm1(pv[e], a.N, divN.inv, true)
+                                                              : grad_norm2(pv[e], nv[e], a.N, a.M, divN.inv, divM.inv, true);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gr[e] = (a.form == 0) ? pv[e] / a.N : (pv[e] / a.N - nv[e] / a.M);
+            for (int e = 0; e < 8; ++e) gr[e] = (a.form == 0) ? grad_norm1(pv[e], a.N, 0.f, false)
+                                                              : grad_norm2(pv[e], nv[e], a.N, a.M, 0.f, 0.f, false);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -964,7 +979,7 @@ __global__ void apply_w_kernel(ApplyWArgs a) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const int i = (int)(e % (size_t)a.I), j = (int)(e / (size_t)a.I);
         const size_t o = (size_t)j * a.ldw + i;
-        const float gr = (a.form == 0) ? a.raw[o] / a.N : (a.raw[o] / a.N - a.raw2[o] / a.M);
+        const float gr = (a.form == 0) ? grad_norm1(a.raw[o], a.N, 0.f, false) : grad_norm2(a.raw[o], a.raw2[o], a.N, a.M, 0.f, 0.f, false);
         float wv = a.W[o], dv = a.dW[o];
         apply_w_update(gr, a.pen ? a.pen[i] : 0.f, a.l2, a.lr, a.mom, wv, dv);
         a.W[o] = wv;
@@ -1006,8 +1021,7 @@ __global__ __launch_bounds__(256) void apply_w_tiled_kernel(ApplyWArgs a, RbmBia
     const int tiles_i = (a.I + 63) / 64;
     const int i0 = ((int)blockIdx.x % tiles_i) * 64, j0 = ((int)blockIdx.x / tiles_i) * 64;
     const int tid = threadIdx.x, c4 = tid & 15, r0 = tid >> 4;       // 16 float4 per row, 16 rows per pass
-    const bool pow2 = ((__float_as_uint(a.N) & 0x007fffffu) == 0u) && ((__float_as_uint(a.M) & 0x007fffffu) == 0u) &&
-                      a.N >= 1.0f && a.M >= 1.0f;
+    const bool pow2 = grad_pow2(a.N) && grad_pow2(a.M);
     const float invN = 1.0f / a.N, invM = 1.0f / a.M;
     const int i = i0 + 4 * c4;
     float4 pe = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1021,12 +1035,12 @@ __global__ __launch_bounds__(256) void apply_w_tiled_kernel(ApplyWArgs a, RbmBia
             float4 wv = *reinterpret_cast<const float4 *>(a.W + o), dv = *reinterpret_cast<const float4 *>(a.dW + o);
             float4 g;
             if (a.form == 0) {
-                if (pow2) g = make_float4(r.x * invN, r.y * invN, r.z * invN, r.w * invN);
-                else      g = make_float4(r.x / a.N, r.y / a.N, r.z / a.N, r.w / a.N);
+                g = make_float4(grad_norm1(r.x, a.N, invN, pow2), grad_norm1(r.y, a.N, invN, pow2),
+                                grad_norm1(r.z, a.N, invN, pow2), grad_norm1(r.w, a.N, invN, pow2));
             } else {
                 const float4 r2 = *reinterpret_cast<const float4 *>(a.raw2 + o);
-                if (pow2) g = make_float4(r.x * invN - r2.x * invM, r.y * invN - r2.y * invM, r.z * invN - r2.z * invM, r.w * invN - r2.w * invM);
-                else      g = make_float4(r.x / a.N - r2.x / a.M, r.y / a.N - r2.y / a.M, r.z / a.N - r2.z / a.M, r.w / a.N - r2.w / a.M);
+                g = make_float4(grad_norm2(r.x, r2.x, a.N, a.M, invN, invM, pow2), grad_norm2(r.y, r2.y, a.N, a.M, invN, invM, pow2),
+                                grad_norm2(r.z, r2.z, a.N, a.M, invN, invM, pow2), grad_norm2(r.w, r2.w, a.N, a.M, invN, invM, pow2));
             }
             apply_w_update(g.x, pe.x, a.l2, a.lr, a.mom, wv.x, dv.x);
             apply_w_update(g.y, pe.y, a.l2, a.lr, a.mom, wv.y, dv.y);

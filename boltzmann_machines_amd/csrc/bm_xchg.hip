@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NTX) void exchange_apply_kernel(Args a, RbmApply p)
             }
             okp = !__syncthreads_or(bad);
         }
-        const bool pow2 = ((__float_as_uint(p.N) & 0x007fffffu) == 0u) && p.N >= 1.0f;
+        const bool pow2 = bm::grad_pow2(p.N);
         const float invN = 1.0f / p.N;
         __amdgpu_buffer_rsrc_t rs[MAXR];
 #pragma unroll
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NTX) void exchange_apply_kernel(Args a, RbmApply p)
                 if (p.cost != 0.f) pe = *reinterpret_cast<const f32x4 *>(p.pen + i);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float g = pow2 ? s[c] * invN : s[c] / p.N;
+                    const float g = bm::grad_norm1(s[c], p.N, invN, pow2);
                     float w = wv[c], d = dv[c];
                     bm::apply_w_update(g, pe[c], p.l2, p.lr, p.mom, w, d);
                     wv[c] = w; dv[c] = d;
@@ -400,8 +400,7 @@ __global__ __launch_bounds__(NTX) void dbm_exchange_apply_kernel(Args a, DbmAppl
         }
         okp = !__syncthreads_or(bad);
     }
-    const bool pow2 = ((__float_as_uint(p.N) & 0x007fffffu) == 0u) && ((__float_as_uint(p.M) & 0x007fffffu) == 0u) &&
-                      p.N >= 1.0f && p.M >= 1.0f;                          // apply_w_tiled_kernel's rule
+    const bool pow2 = bm::grad_pow2(p.N) && bm::grad_pow2(p.M);            // apply_w_tiled_kernel's rule
     const float invN = 1.0f / p.N, invM = 1.0f / p.M;
     for (int i = 0; i < p.L; ++i) {
         const DbmLayerX &y = p.lay[i];
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(NTX) void dbm_exchange_apply_kernel(Args a, DbmAppl
             const f32x4 pe = *reinterpret_cast<const f32x4 *>(y.pen + c);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float g = pow2 ? sp[q] * invN - sn[q] * invM : sp[q] / p.N - sn[q] / p.M;
+                const float g = bm::grad_norm2(sp[q], sn[q], p.N, p.M, invN, invM, pow2);
                 float w = wv[q], d = dv[q];
                 bm::apply_w_update(g, pe[q], p.l2, p.lr, p.mom, w, d);
                 wv[q] = w; dv[q] = d;
@@ -680,8 +679,18 @@ static int xchg_create(int32_t rank, int32_t nranks, float *buf_dev, size_t coun
         return fail();
     }
     if (xchg_alloc_flags(x)) return fail();
+    // Launch width: every workgroup of an exchange launch must be CO-RESIDENT (the last one publishes DONE while the others
+    // already wait for the peers), so the bound is what the device can hold at once - one workgroup per CU, checked against
+    // the occupancy of the heaviest exchange kernel - not a constant (round-5 advisor).
+    int ncu = 0, per_cu = 0;
+    {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, x->device) == hipSuccess) ncu = pr.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmx::dbm_exchange_gather_kernel, bmx::NTX, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    }
+    if (ncu < 1 || per_cu < 1) { bm::set_error("bm_xchg_create: cannot establish a co-resident launch width (CUs %d, workgroups per CU %d)", ncu, per_cu); return fail(); }
     const size_t f4 = (x->chunk / 4 + bmx::NTX - 1) / bmx::NTX;
-    x->grid = (int)(f4 < 1 ? 1 : (f4 > 256 ? 256 : f4));
+    x->grid = (int)(f4 < 1 ? 1 : (f4 > (size_t)ncu ? (size_t)ncu : f4));
     const char *t = getenv("BM_XCHG_TIMEOUT_S");
     x->timeout_ticks = (long long)((t ? atof(t) : 20.0) * 1e8);
     for (int r = 0; r < bmx::MAXR; ++r) { x->pbuf[r] = x->buf; x->pred[r] = x->red; x->pflags[r] = x->flags; }
@@ -869,14 +878,21 @@ static int xchg_launch_apply(bm_rbm *h, bm_xchg *x, float N_global, float lr, fl
 // holds ITS slice (bm_rbm_exchange_gather_dw completes the replicas, e.g. before a checkpoint).
 int bm_rbm_exchange_apply_direct(bm_rbm *h, bm_xchg *x, int32_t B_global, float lr, float mom) {
     BM_CHECK(h && x, "null argument");
+    BM_CHECK(B_global > 0, "bm_rbm_exchange_apply_direct: B_global = %d must be positive", B_global);
     BM_TRY(xchg_launch_apply(h, x, (float)B_global, lr, mom, 0));
     x->dw_stale = x->nranks > 1;
     h->dw_sharded = x->dw_stale;       // readers of dW fail until bm_rbm_exchange_gather_dw (check_dw, bm_rbm.hip)
     return 0;
 }
+// COLLECTIVE wherever the fused exchange can serve this engine (a property every rank shares), whether or not THIS rank's
+// copy is stale: a rank that replaced dW itself (bm_rbm_set_param clears its flag) still enters the READY round its peers
+// wait in - skipping on the local flag left them to their time-out (round-5 advisor).  bm_*_set_param(dW) on a
+// data-parallel job must be made on every rank: the gather keeps each OWNER's slice.
 int bm_rbm_exchange_gather_dw(bm_rbm *h, bm_xchg *x) {
     BM_CHECK(h && x, "null argument");
-    if (!x->dw_stale) { h->dw_sharded = false; return 0; }
+    if (x->nranks == 1 || (!x->dw_stale && !(h->H % 4 == 0 && h->W.ld % 4 == 0 && h->W.ld == h->dW.ld))) {
+        x->dw_stale = false; h->dw_sharded = false; return 0;
+    }
     BM_TRY(xchg_launch_apply(h, x, 1.f, 0.f, 0.f, 1));
     x->dw_stale = false;
     h->dw_sharded = false;
@@ -945,6 +961,8 @@ static int dbm_fill_exchange(bm_dbm *h, bm_xchg *x, bmx::Args &a, bmx::DbmApply 
 // norms, biases, running means; of the momentum buffers dW_i a rank holds its columns (bm_dbm_exchange_gather_dw).
 int bm_dbm_exchange_apply_direct(bm_dbm *h, bm_xchg *x, int32_t N_global, int32_t M_global, float lr, float mom) {
     BM_CHECK(h && x, "null argument");
+    BM_CHECK(N_global > 0 && M_global > 0, "bm_dbm_exchange_apply_direct: N_global = %d and M_global = %d must be positive", N_global, M_global);
+    BM_CHECK(!h->failed, "an earlier launch of this engine failed");
     BM_CHECK(dbm_fused_ok(h, x), "the fused DBM exchange needs an attached exchange created by bm_dbm_xchg_create for this "
                                  "engine and layer widths that are multiples of 4 (bm_dbm_exchange_apply_ok)");
     const size_t nsums = h->grad.n - (size_t)(h->sums_p - h->grad.p);
@@ -986,11 +1004,12 @@ int bm_dbm_exchange_apply_direct(bm_dbm *h, bm_xchg *x, int32_t N_global, int32_
     x->dw_stale = x->nranks > 1;
     h->dw_sharded = x->dw_stale;
     h->dw_set_mask = 0;
+    BM_CHECK(!h->failed, "a launch helper of this update could not allocate");       // bm_dbm_apply_step's post-condition
     return 0;
 }
-int bm_dbm_exchange_gather_dw(bm_dbm *h, bm_xchg *x) {
+int bm_dbm_exchange_gather_dw(bm_dbm *h, bm_xchg *x) {          // collective like bm_rbm_exchange_gather_dw, see there
     BM_CHECK(h && x, "null argument");
-    if (!x->dw_stale) { h->dw_sharded = false; return 0; }
+    if (x->nranks == 1 || (!x->dw_stale && !dbm_fused_ok(h, x))) { x->dw_stale = false; h->dw_sharded = false; return 0; }
     BM_CHECK(dbm_fused_ok(h, x), "the exchange does not belong to this engine");
     bmx::Args a; bmx::DbmApply q;
     BM_TRY(dbm_fill_exchange(h, x, a, q, true));
@@ -1002,6 +1021,79 @@ int bm_dbm_exchange_gather_dw(bm_dbm *h, bm_xchg *x) {
     h->dw_sharded = false;
     return 0;
 }
+// ---- chain-sharded AIS over the direct exchange (dbm.py:922-939 returns every chain's value)
+// The all-gather of the per-chain values as an all-reduce(sum) of a window of the registered buffer in which every rank has
+// written ITS chains at their global index and zeros everywhere else: x + 0 + ... + 0 is x exactly, so every rank receives
+// the bits the owner computed, through the one exchange kernel that the gradient path uses (READY / reduce / DONE / gather,
+// bounded waits, NaN poison on a lost rank).  `n` floats of the buffer take part (chunk = ceil(n / ranks), like a buffer of
+// that length); the launch width stays the exchange's own - its completion counter counts whole launches.
+static int xchg_allreduce_prefix(bm_xchg *x, size_t n, hipStream_t stream) {
+    BM_CHECK(x && x->attached && n >= 1 && n <= x->count, "exchange not attached / bad prefix length");
+    bmx::Args a;
+    memset(&a, 0, sizeof(a));
+    a.buf = x->buf; a.red = x->red; a.count = n;
+    a.chunk = (((n + x->nranks - 1) / x->nranks) + 3) & ~(size_t)3;
+    BM_CHECK(a.chunk <= x->red_cap, "staging slice too small");
+    a.rank = x->rank; a.n = x->nranks; a.epoch = ++x->epoch;
+    for (int r = 0; r < bmx::MAXR; ++r) { a.pbuf[r] = x->pbuf[r]; a.pred[r] = x->pred[r]; a.pflags[r] = x->pflags[r]; }
+    a.flags = x->flags; a.ctr = x->ctr; a.grid = x->grid; a.timeout_ticks = x->timeout_ticks;
+    hipLaunchKernelGGL(bmx::allreduce_kernel, dim3(x->grid), dim3(bmx::NTX), 0, stream, a);
+    BM_HIP(hipGetLastError());
+    return 0;
+}
+
+// window[e] = value of global chain lo + e when this rank owns it (chains [a, b)), else 0; `fail`: NaN instead of the values
+__global__ void ais_window_kernel(const double *logw, float *win, int lo, int n_win, int a, int b, double logZ0, int literal, int fail) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_win) return;
+    const int c = lo + e;
+    float v = 0.f;
+    if (c >= a && c < b) v = fail ? __builtin_nanf("") : (literal ? (float)logw[c - a] + (float)logZ0 : (float)(logw[c - a] + logZ0));
+    win[e] = v;
+}
+
+// Like bm_dbm_ais_sharded, with the direct exchange in the place of the RCCL communicator: this rank runs chains [a, b) of
+// n_runs_total (the same contiguous slices), no communication during the sweep, then the values travel through the
+// exchange's registered buffer (the engine's gradient payload: overwritten, it is recomputed by every update) in windows
+// of at most its length - one window, one launch, for any realistic n_runs.  Every rank returns all n_runs_total values.
+int bm_dbm_ais_sharded_direct(bm_dbm *h, bm_xchg *x, int32_t n_betas, int32_t n_runs_total, int32_t k, uint64_t seed,
+                              float *values_host) {
+    BM_CHECK(h && x && values_host, "null argument");
+    BM_CHECK(x->attached, "exchange not attached");
+    BM_CHECK(n_runs_total >= 1, "bad AIS arguments");
+    void *gp = nullptr; size_t gn = 0;
+    BM_TRY(bm_dbm_dev_ptr(h, "grad", &gp, &gn));
+    BM_CHECK(gp == (void *)x->buf && gn == x->count, "the exchange was created for another buffer");
+    BM_CHECK(!h->dw_sharded, "the momentum buffers are sharded (bm_dbm_exchange_gather_dw first)");
+    const int rank = x->rank, world = x->nranks;
+    const int q = n_runs_total / world, rem = n_runs_total % world;
+    const int a = rank * q + (rank < rem ? rank : rem), b = a + q + (rank < rem ? 1 : 0);
+    // A rank whose sweep fails must still enter the exchange - the others would wait for it until their time-out - so the
+    // failure is made collective: the failing rank contributes NaNs and every rank reports the error.
+    std::string first_err;
+    int rc = 0;
+    if (b > a) rc = ais_core(h, n_betas, b - a, k, seed, a);
+    if (rc) { first_err = bm_last_error(); (void)hipGetLastError(); }
+    const double z0 = h->ais_literal ? (double)((float)(h->V + h->n[1] + h->n[2]) * logf(2.0f)) : ais_log_Z0(h);
+    h->xchg_used = x; x->user = &h->xchg_used;
+    int rc_x = 0, rc_m = 0;
+    for (size_t lo = 0; lo < (size_t)n_runs_total && !rc_x && !rc_m; lo += x->count) {
+        const size_t nw = (size_t)n_runs_total - lo < x->count ? (size_t)n_runs_total - lo : x->count;
+        hipLaunchKernelGGL(ais_window_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, h->stream,
+                           (const double *)h->alogw, x->buf, (int)lo, (int)nw, a, b, z0, h->ais_literal, rc ? 1 : 0);
+        rc_x = xchg_allreduce_prefix(x, nw, h->stream);
+        if (rc_x) { if (first_err.empty()) first_err = bm_last_error(); break; }
+        if (hipMemcpyAsync(values_host + lo, x->buf, nw * sizeof(float), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc_m = 1;
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc_m = 1;       // the window is reused by the next round
+    }
+    if (rc || rc_x) { bm::set_error("bm_dbm_ais_sharded_direct (rank %d): %s", rank, first_err.c_str()); return rc ? rc : rc_x; }
+    if (rc_m) { bm::set_error("bm_dbm_ais_sharded_direct: device copy / synchronisation failed"); return 1; }
+    BM_TRY(xchg_check_status(x));                    // a wait that expired (a lost rank): sticky, the values are NaN
+    for (int e = 0; e < n_runs_total; ++e)
+        BM_CHECK(values_host[e] == values_host[e], "bm_dbm_ais_sharded_direct: another rank's AIS sweep failed (chain %d arrived as NaN)", e);
+    return 0;
+}
+
 int bm_rbm_allreduce_grads_direct(bm_rbm *h, bm_xchg *x) {
     BM_CHECK(h && x, "null argument");
     void *p = nullptr, *st = nullptr; size_t n = 0;

@@ -167,7 +167,7 @@ class RbmEngine(object):
         return p.value
 
     def chain_stats(self):
-        """(chained launches issued, tiles they must compute, BM355_CHAIN mode) - csrc/bm_chain.h"""
+        """(chained launches issued, tiles they must compute, BM355_DEBUG=chain=.. mode) - csrc/bm_chain.h"""
         out = (C.c_int64 * 3)()
         check(self.lib.bm_rbm_chain_stats(self._h, out))
         return int(out[0]), int(out[1]), int(out[2])
@@ -358,7 +358,7 @@ class DbmEngine(object):
         check(self.lib.bm_dbm_sync(self._h))
 
     def chain_stats(self):
-        """(updates that ran as one chained launch, chained launches issued, BM355_DBM_CHAIN mode) - csrc/bm_dbmchain.h"""
+        """(updates that ran as one chained launch, chained launches issued, BM355_DEBUG=dbm_chain=.. mode) - csrc/bm_dbmchain.h"""
         out = (C.c_int64 * 3)()
         check(self.lib.bm_dbm_chain_stats(self._h, out))
         return int(out[0]), int(out[1]), int(out[2])
@@ -406,6 +406,14 @@ class DbmEngine(object):
         """like set_comm, with the per-sweep residual max over the direct peer-memory exchange (bm_dbm_set_xchg)"""
         self._xchg = xchg
         check(self.lib.bm_dbm_set_xchg(self._h, xchg._c if xchg is not None else None))
+
+    def ais_sharded_direct(self, xchg, n_betas, n_runs_total, k, seed):
+        """ais_sharded over the direct peer-memory exchange (parallel.DirectExchange of THIS engine) instead of the RCCL
+        communicator: bm_dbm_ais_sharded_direct; returns all n_runs_total values, the owners' bits"""
+        out = np.empty(n_runs_total, dtype=np.float32)
+        check(self.lib.bm_dbm_ais_sharded_direct(self._h, xchg._c, n_betas, n_runs_total, k, int(seed),
+                                                 out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def ais_sharded(self, comm, n_betas, n_runs_total, k, seed):
         """this rank's slice of the chains + ONE all-gather (bm_dbm_ais_sharded); returns all n_runs_total values"""

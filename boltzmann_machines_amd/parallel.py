@@ -330,6 +330,8 @@ class DirectExchange(object):
         contiguous slices of W.  DBM (bm_dbm_exchange_apply_direct; M_global = the global number of particles): column
         slices of every W_i, the max-norm rescale on the owned columns between the two launches."""
         lib = self._ffi.load()
+        if self._dbm and M_global is None:
+            raise ValueError('exchange_apply of a DBM needs M_global, the global number of particles')
         if self._dbm:
             self._ffi.check(lib.bm_dbm_exchange_apply_direct(self.engine._h, self._c, int(B_global), int(M_global), lr, momentum))
         else:
@@ -345,7 +347,8 @@ class DirectExchange(object):
         return bool(ok.value)
 
     def gather_dw(self):
-        """complete every replica's momentum buffer dW (owners hold their slices between updates); a no-op when fresh"""
+        """complete every replica's momentum buffer dW (owners hold their slices between updates).  COLLECTIVE: every rank
+        must call it, whether or not its own copy is stale (a `set('dW', ...)` must likewise be made on every rank)"""
         lib = self._ffi.load()
         f = lib.bm_dbm_exchange_gather_dw if self._dbm else lib.bm_rbm_exchange_gather_dw
         self._ffi.check(f(self.engine._h, self._c))

@@ -11,6 +11,7 @@ of `_make_train_op` (:415-525) is executed by libbm355 (csrc/bm_rbm.hip).
 BernoulliRBM, MultinomialRBM (rbm.py:25-65) and GaussianRBM (rbm.py:68-116) in float32 and float64.
 """
 import os
+import sys
 
 import numpy as np
 
@@ -327,6 +328,14 @@ class BaseRBM(EngineModel):
             elif pending:
                 pending = collect()
         finally:
+            # An epoch that aborts BEFORE its first run of updates was queued still owes the previous epoch's report (its
+            # fetches are the only ones in the ring then): make it now - progress line, scalar logs - instead of dropping
+            # it with the drain below (round-5 advisor).  A report that cannot be made any more is announced, never silent.
+            if after_first is not None and sys.exc_info()[0] is not None:
+                try:
+                    first_done()
+                except Exception as e:       # noqa: BLE001
+                    sys.stderr.write('fit: the report of the previous epoch was lost with the aborted one (%s)\n' % (str(e)[:200],))
             # an aborted epoch (KeyboardInterrupt, an engine error in a later batch) must not leave its deferred fetches
             # in the ring: the next epoch's collect() would average them into ITS metrics (round-4 advisor)
             if deferred and pending:
@@ -375,7 +384,6 @@ class BaseRBM(EngineModel):
         # checkpoint snapshot is staged in stream order at once and the REPORT of the epoch - wait, scalar logs, progress line -
         # is made after the next epoch's first run of updates has been queued (`after_first`): the device never waits for the
         # host's epoch-end work (75 -> 69 us per update with the reference's default cadence of one fetch per 10 updates).
-        report_later = None
         try:
             self._fit_epochs(X, X_val, Xd, N, Xvd, Nv)
         except BaseException:

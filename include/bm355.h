@@ -402,6 +402,13 @@ int bm_rbm_exchange_gather_dw(bm_rbm *h, bm_xchg *x);
 int bm_dbm_exchange_apply_ok(bm_dbm *h, bm_xchg *x, int32_t *out_ok);
 int bm_dbm_exchange_apply_direct(bm_dbm *h, bm_xchg *x, int32_t N_global, int32_t M_global, float learning_rate, float momentum);
 int bm_dbm_exchange_gather_dw(bm_dbm *h, bm_xchg *x);
+/* bm_dbm_ais_sharded over the direct exchange instead of the RCCL communicator (same slices, same values bit for bit): the
+ * per-chain values travel through the exchange's registered buffer as an all-reduce(sum) of a window in which every rank
+ * wrote its own chains and zeros elsewhere (x + 0 = x: every rank receives the owner's bits).  Overwrites the head of the
+ * engine's gradient payload (recomputed by every update).  A rank whose sweep fails contributes NaN and every rank
+ * reports the error; a rank that never arrives ends the wait at the exchange's time-out (sticky status). */
+int bm_dbm_ais_sharded_direct(bm_dbm *h, bm_xchg *x, int32_t n_betas, int32_t n_runs_total, int32_t n_gibbs_steps,
+                              uint64_t seed, float *values_host);
 /* Opt-in "fast-binary" mode (SURVEY §7 hard part 4; csrc/bm_bf3.h): contractions whose input states are {0,1}
  * bitmaps (AIS with all layers sampled; the RBM sampling sweep with both layers sampled; in the PCD particle sweeps of
  * bm_dbm_train_step / bm_dbm_sample_v every contraction over a Bernoulli layer sampled earlier in the same call - a

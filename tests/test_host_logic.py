@@ -360,3 +360,72 @@ def test_bench_fails_loudly_without_a_gpu_and_keeps_stdout_clean():
     assert r.returncode != 0
     assert r.stdout == ''
     assert 'no HIP device' in r.stderr and 'no CPU fallback' in r.stderr
+
+
+# ---- the pipelined epoch loop of fit() (rbm.py `_fit_epochs`): the report of epoch e is made after epoch e+1's first run of
+# updates has been queued.  On the oracle engine, against the same run with the pipelining defeated (a validation set forces
+# the synchronous order) - round-5 advisor.
+def _fit_lines(monkeypatch, tmp_path, tag, every, X_val=None, val_every=1, boom_at=None, **extra):
+    import contextlib
+    import io
+    import json
+    from tests import oracle_engine
+    oracle_engine.install(monkeypatch)
+    import boltzmann_machines_amd as bm
+    rs = np.random.RandomState(3)
+    X = (rs.rand(60, 12) < 0.3).astype(np.float32)
+    rbm = bm.BernoulliRBM(n_visible=12, n_hidden=8, batch_size=10, max_epoch=4, learning_rate=0.05, random_seed=7, verbose=True,
+                          metrics_config=dict(msre=True, pll=True, l2_loss=True, train_metrics_every_iter=every,
+                                              val_metrics_every_epoch=val_every, feg=False),
+                          model_path=str(tmp_path / tag) + '/', **extra)
+    if boom_at is not None:
+        from boltzmann_machines_amd import rbm as rbm_mod
+        name, at = boom_at
+        orig, calls = getattr(rbm_mod.RbmEngine, name), [0]
+
+        def boom(self, *a, **kw):
+            calls[0] += 1
+            if calls[0] == at:
+                raise RuntimeError('boom')
+            return orig(self, *a, **kw)
+        monkeypatch.setattr(rbm_mod.RbmEngine, name, boom)
+    buf, err = io.StringIO(), None
+    with contextlib.redirect_stdout(buf):
+        try:
+            rbm.fit(X, X_val)
+        except RuntimeError as e:
+            err = str(e)
+    lines = [l.strip() for l in buf.getvalue().replace('\r', '\n').split('\n') if l.strip().startswith('epoch:')]
+    logs = sorted((tmp_path / tag).rglob('*.json*')) + sorted((tmp_path / tag).rglob('*.csv'))
+    scal = {str(p.relative_to(tmp_path / tag)): p.read_text() for p in logs if 'logs' in str(p)}
+    W = rbm.get_tf_params(scope='weights')['W'] if err is None else None
+    return lines, scal, W, err
+
+
+@pytest.mark.parametrize('every', [1, 3, 7, 100])
+def test_pipelined_fit_reports_what_the_synchronous_loop_reports(monkeypatch, tmp_path, every):
+    """same progress lines, same scalar logs, same parameters whether the epoch reports are deferred (pipelined) or made in
+    place (a display dump is due every epoch: synchronous; the dump is computed on the host and leaves the RNG stream alone);
+    and with a validation fetch due every second epoch (pipelined and synchronous epochs alternate) the run still reports
+    every epoch once, in order"""
+    lines_p, scal_p, W_p, _ = _fit_lines(monkeypatch, tmp_path, 'pipe', every)
+    lines_s, scal_s, W_s, _ = _fit_lines(monkeypatch, tmp_path, 'sync', every, display_filters=4, v_shape=(3, 4))
+    assert len(lines_p) == 4 and lines_p == lines_s
+    assert np.array_equal(W_p, W_s)
+    assert scal_p == scal_s and scal_p
+    X_val = (np.random.RandomState(4).rand(20, 12) < 0.3).astype(np.float32)
+    lines_m, _, _, _ = _fit_lines(monkeypatch, tmp_path, 'mixed', every, X_val=X_val, val_every=2)
+    assert [l.split(';')[0] for l in lines_m] == ['epoch: %d/4' % e for e in (1, 2, 3, 4)]
+    assert lines_m[0] == lines_p[0]                                   # (the first validation fetch, epoch 2, moves the RNG stream)
+    assert ['val.' in l for l in lines_m] == [False, True, False, True]  # base_rbm.py:641: `val_results = {}` every epoch
+
+
+@pytest.mark.parametrize('every,boom_at', [(1, ('train_step_metrics_async', 7)), (3, ('train_epoch', 3))])
+def test_pipelined_fit_flushes_the_owed_report_when_the_next_epoch_aborts(monkeypatch, tmp_path, every, boom_at):
+    """epoch 2 raises in its first engine call - at its first metrics fetch (every = 1: the report has just been made) or inside
+    its first fused run of updates (every = 3: BEFORE the report of epoch 1 was due): either way epoch 1's progress line and
+    scalar logs are made, and equal those of an undisturbed run"""
+    lines_ok, scal_ok, _, _ = _fit_lines(monkeypatch, tmp_path, 'ok', every)
+    lines, scal, _, err = _fit_lines(monkeypatch, tmp_path, 'boom', every, boom_at=boom_at)
+    assert err == 'boom'
+    assert lines == lines_ok[:1], (lines, lines_ok)

@@ -272,6 +272,93 @@ def test_dp_dbm_direct_exchange_on_gpu(gpu_lib, tmp_path, big):
     ref.close()
 
 
+# ---- chain-sharded AIS over the direct exchange (bm_dbm_ais_sharded_direct; SURVEY 8e, dbm.py:922-939)
+AIS_R, AIS_NB, AIS_K, AIS_SEED = 37, 25, 2, 4242          # 37 chains: uneven slices at world 2 (19 + 18) and 3 (13 + 12 + 12)
+
+
+def _ais_engine(small_buffer=False):
+    from boltzmann_machines_amd.engine import DbmEngine
+    from oracle import oracle as orc
+    dv, dnh = (8, [4, 4]) if small_buffer else (DV, DNH)     # small_buffer: the gradient payload (< 37 floats per window ...
+    n = [dv] + list(dnh)
+    eng = DbmEngine(dv, list(dnh), n_particles=4, batch_size=4)
+    for i in range(2):
+        sfx = '' if i == 0 else '_1'
+        eng.set('W' + sfx, (orc.normal(5, 1 + i, 0, n[i] * n[i + 1]) * np.float32(0.2)).reshape(n[i], n[i + 1]))
+        eng.set('hb' + sfx, (orc.uniform(5, 5 + i, 0, n[i + 1]) - np.float32(0.5)) * np.float32(0.4))
+    eng.set('vb', (orc.uniform(5, 9, 0, dv) - np.float32(0.5)) * np.float32(0.4))
+    return eng
+
+
+def _ais_worker(rank, world, port, out, die_rank=-1, n_runs=AIS_R):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import time
+    from boltzmann_machines_amd import parallel
+    eng = _ais_engine()
+    xchg = parallel.DirectExchange(eng, rank, world, gather=lambda b: parallel.socket_allgather(b, rank, world), max_workgroups=48)
+    if die_rank >= 0:
+        xchg.set_timeout(1.0)
+        v0 = eng.ais_sharded_direct(xchg, AIS_NB, n_runs, AIS_K, AIS_SEED)        # one good round first
+        if rank == die_rank:
+            os._exit(0)
+        t0, err = time.time(), ''
+        try:
+            eng.ais_sharded_direct(xchg, AIS_NB, n_runs, AIS_K, AIS_SEED)
+        except Exception as e:       # noqa: BLE001
+            err = str(e)
+        np.savez(out + '.r%d' % rank, v0=v0, seconds=time.time() - t0, err=np.array(err))
+        os._exit(0)                                                               # (the collective close would wait for the dead rank)
+    vals = [eng.ais_sharded_direct(xchg, AIS_NB, n_runs, AIS_K, AIS_SEED) for _ in range(2)]   # twice: warm flags / staging
+    # and a run with more chains than one window of a tiny registered buffer would hold is covered by the window loop:
+    eng.sync()
+    assert xchg.status() == 0
+    np.savez(out + '.r%d' % rank, v0=vals[0], v1=vals[1])
+    xchg.close()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_ais_sharded_direct(gpu_lib, tmp_path, world):
+    """every rank returns ALL chain values, and they are the single-engine run's values BIT FOR BIT (a chain's RNG stream is
+    addressed by its global index; the exchange adds zeros to the owner's value)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'ais')
+    mp.spawn(_ais_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    eng = _ais_engine()
+    ref = eng.ais(AIS_NB, AIS_R, AIS_K, AIS_SEED)
+    eng.close()
+    assert np.all(np.isfinite(ref))
+    for r in range(world):
+        z = np.load(out + '.r%d.npz' % r)
+        for k_ in ('v0', 'v1'):
+            assert np.array_equal(z[k_].view(np.uint32), ref.view(np.uint32)), (r, k_)
+
+
+def test_ais_sharded_direct_when_a_rank_dies(gpu_lib, tmp_path):
+    """a rank that disappears between two runs: the survivor's wait expires at the exchange's time-out and the call RAISES
+    (sticky status, NaN-poisoned window) - bounded, never a hang and never a silently partial result"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / 'aisdie')
+    mp.spawn(_ais_worker, args=(2, _free_port(), out, 1), nprocs=2, join=True)
+    z = np.load(out + '.r0.npz')
+    assert np.all(np.isfinite(z['v0']))
+    assert str(z['err']) != '' and float(z['seconds']) < 30.0, (str(z['err']), float(z['seconds']))
+
+
+def test_ais_sharded_direct_in_windows(gpu_lib):
+    """world 1, a registered buffer SHORTER than the number of chains (8-4-4 DBM: 2 * (32 + 16) + sums floats): the values
+    travel in several windows and equal bm_dbm_ais"""
+    from boltzmann_machines_amd import parallel
+    eng = _ais_engine(small_buffer=True)
+    xchg = parallel.DirectExchange(eng, 0, 1)
+    n = eng.device_view('grad').shape[0]
+    R = 2 * n + 5
+    got = eng.ais_sharded_direct(xchg, 6, R, 1, 99)
+    ref = eng.ais(6, R, 1, 99)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    xchg.close(); eng.close()
+
+
 # ---- the fused DBM exchange (bm_dbm_exchange_apply_direct): column-sliced ownership.  Widths 96 and 64: at world 2 the
 # slices are 64 + 32 and 32 + 32 columns, at world 3 they are 32 + 32 + 32 and 32 + 32 + NONE (a rank without columns of W_1)
 FV, FNH, FN, FM = 40, [96, 64], 12, 8
