@@ -750,10 +750,6 @@ struct GradArgs {
     RbmBiasFusedArgs bias;
     int fetch_at_fill;                // 1: read W/dW of the lane's outputs during the pipeline fill (set by launch_grad)
     int map_xi;                       // see ActArgs::map_xi
-    // form 0 only: the positive-phase sums are ALREADY in `acc0` ([J][I] pitch ldw, written by pos_kernel under the Gibbs
-    // chain): the chain starts from them and streams only the negative segment.  Continuing an fma chain from a stored fp32
-    // value is the same chain: bit-identical to the one-launch form.  Null: off.
-    const float *acc0;
 #ifdef BM_PROBE
     long long *dbg;
 #endif
@@ -882,29 +878,7 @@ __global__ __launch_bounds__(G::NT, MINB) void grad_kernel(GradArgs a, TileMap t
     side.on = a.fused != 0 && a.fetch_at_fill != 0;
     KRange kr;
     kr.P1 = a.Ppos; kr.Q1 = a.Qpos; kr.K1 = a.Kpos;
-    if (a.form == 0 && a.acc0) {                  // wave-uniform
-        if (ib0 < a.I) {
-#pragma unroll
-            for (int n = 0; n < NJ; ++n) {
-                const int j = side.jb[n];
-                if (j >= a.J) continue;
-                const float *src = a.acc0 + (size_t)j * a.ldw + ib0;
-                float v[8];
-                if (side.vec8) {
-                    const float4 lo = *reinterpret_cast<const float4 *>(src), hi = *reinterpret_cast<const float4 *>(src + 4);
-                    v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (ib0 + e < a.I) ? src[e] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { pos[0][n][r] = v[2 * r]; pos[1][n][r] = v[2 * r + 1]; }
-            }
-        }
-        kr.P1 = a.Pneg; kr.Q1 = a.Qneg; kr.K1 = a.Kneg;
-        kr.P2 = a.Pneg; kr.Q2 = a.Qneg; kr.K2 = 0;
-        mainloop<KM, G, FAST, true, ABL, KM, STG>(pos, kr, i0, j0, smem, side);
-    } else if (a.form == 0) {
+    if (a.form == 0) {
         // RBM: ONE chain, positive rows then negative rows with the product negated: the caller
         // passes Pneg = -h_k (act_kernel's `negmeans` output), fma(-p, q, acc) == acc - p*q exactly
         // (canonical order of the raw CD gradient, oracle: orc_rbm_raw_grads)
@@ -1785,53 +1759,6 @@ __global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda
     }
 }
 
-// ------------------------------------------------------------------ pos_kernel
-// The positive-phase outer product X^T h0 (base_rbm.py:447) ALONE, as raw fp32 accumulators: it depends only on the first
-// launch of a CD-k update, so it can run UNDER the Gibbs chain (second stream) and grad_kernel then starts its chain from the
-// stored sums (GradArgs::acc0).  Small on purpose - 4 waves, 64 x 32 tile, BK = 32: 48 KiB of LDS and one wave per SIMD - so
-// that a workgroup fits on a CU BESIDE a propagation tile (96 KiB, two waves per SIMD at <= 168 VGPRs): round 3's form of
-// this idea used the 128 KiB outer-product tile, which displaces the propagation tiles instead of sharing CUs with them.
-struct PosArgs { Operand P, Q; int K, I, J; float *raw; int ldw; };
-using GeoPos = Geo<2, 2, 2, 1, 32>;
-template <class G, bool FAST>
-__global__ __launch_bounds__(G::NT, 3) void pos_kernel(PosArgs a) {      // (3 waves per SIMD in the register budget: <= 168 VGPRs, what a propagation tile leaves)
-    __shared__ __attribute__((aligned(16))) float smem[G::SMEM_FLOATS];
-    static_assert(G::MI == 2 && G::NJ == 1, "pos_kernel: 8 consecutive outputs per lane");
-    const int tiles_i = (a.I + G::TI - 1) / G::TI;
-    const int ti = (int)blockIdx.x % tiles_i, tj = (int)blockIdx.x / tiles_i;
-    const int i0 = ti * G::TI, j0 = tj * G::TJ;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wi = w % G::WI, wj = w / G::WI;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int ib0 = i0 + wi * 32 + g * 8;
-    const int j = j0 + wj * 16 + l15;
-    f32x4 acc[2][1];
-    acc[0][0] = acc[1][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    KRange kr;
-    kr.P1 = a.P; kr.Q1 = a.Q; kr.K1 = a.K;
-    kr.P2 = a.P; kr.Q2 = a.Q; kr.K2 = 0;
-    NoSide side;
-    mainloop<KM, G, FAST, false, 0, KM, STG_DMA>(acc, kr, i0, j0, smem, side);
-    if (j >= a.J || ib0 >= a.I) return;
-    float v[8];
-    lane_outputs<G>(acc, 0, v);
-    float *dst = a.raw + (size_t)j * a.ldw + ib0;
-    if (ib0 + 7 < a.I && (a.ldw & 3) == 0) {
-        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) if (ib0 + e < a.I) dst[e] = v[e];
-    }
-}
-static inline void launch_pos(const PosArgs &a, hipStream_t st) {
-    using G = GeoPos;
-    const bool fast = operand_fast(a.P, KM, a.K) && operand_fast(a.Q, KM, a.K);
-    const dim3 grid((unsigned)(((a.I + G::TI - 1) / G::TI) * ((a.J + G::TJ - 1) / G::TJ))), blk(G::NT);
-    if (fast) hipLaunchKernelGGL((pos_kernel<G, true>), grid, blk, 0, st, a);
-    else      hipLaunchKernelGGL((pos_kernel<G, false>), grid, blk, 0, st, a);
-}
-
 // ------------------------------------------------------------- host launchers
 template <class G> static inline int tile_grid(int I, int J) { return ((I + G::TI - 1) / G::TI) * ((J + G::TJ - 1) / G::TJ); }
 
@@ -2299,7 +2226,7 @@ static inline void launch_grad(const GradArgs &g_in, hipStream_t st) {
         static std::map<std::array<long long, 7>, int> table;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1) | (g.acc0 ? 4 : 0)), (long long)g.ldw, (long long)dev};
+        const std::array<long long, 7> key = {g.I, g.J, g.Kpos, g.Kneg, (long long)(g.form | (g.fused << 1)), (long long)g.ldw, (long long)dev};
         std::lock_guard<std::mutex> lk(mu);
         int &b = table[key];
         if (!b) b = tune_grad_shape(g, st);

@@ -45,11 +45,6 @@ struct bm_rbm {
     int V, H, maxB;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // positive-phase outer product under the Gibbs chain (pos_kernel on a second stream; BM355_DEBUG=pos_overlap=1)
-    hipStream_t pos_stream = nullptr;
-    hipEvent_t ev_h0 = nullptr, ev_pos = nullptr;
-    int pos_overlap = -1;
-    bool pos_ready = false;            // pos_kernel of the running update is queued: the raw part of `grad` will hold X^T h0
     // variables (padded pitch, see pad_ld).  The prop-down reads W itself as an x-major operand (ActArgs::p_xm).
     Mat W, dW;                         // [V][H], [V][H]
     // the transpose [H][V], written by the fused update next to W: the prop-up then reads its weights x-major as well
@@ -292,27 +287,7 @@ static int run_chain(bm_rbm *h, const float *X_dev, int B, int k, float *hm_out,
     h->fe_in_chain = fe;
     if (fetch && !fe) metrics_prep(h, B);
     chain_begin(h);               // h0 and the k Gibbs steps: one launch where the shape allows it (bm_chain.h)
-    if (h->pos_overlap < 0) { const char *e = bm::dbg("pos_overlap"); h->pos_overlap = e ? atoi(e) : 0; }
-    if (h->pos_overlap > 0 && 2 * k + 1 < 6) h->chain.on = false;     // short chains are issued pass by pass anyway (chain_flush): at once, then
     launch_up(h, Xin, ldx, B, h->h0m.p, h->h0s.p, h->h0m.ld, 1, SITE_H0, 0, nullptr, fe);      // :421-422
-    h->pos_ready = false;
-    if (h->pos_overlap > 0 && !h->chain.on && !h->prof && !split_step && !h->multinomial() && k >= 1) {
-        if (!h->pos_stream) {
-            BM_HIP(hipStreamCreateWithFlags(&h->pos_stream, hipStreamNonBlocking));
-            BM_HIP(hipEventCreateWithFlags(&h->ev_h0, hipEventDisableTiming));
-            BM_HIP(hipEventCreateWithFlags(&h->ev_pos, hipEventDisableTiming));
-        }
-        BM_HIP(hipEventRecord(h->ev_h0, h->stream));
-        BM_HIP(hipStreamWaitEvent(h->pos_stream, h->ev_h0, 0));
-        PosArgs pa;
-        memset(&pa, 0, sizeof(pa));
-        pa.P = make_operand(h->h0m.p, h->h0m.ld, h->H);
-        pa.Q = make_operand(Xin, ldx, h->V);
-        pa.K = B; pa.I = h->H; pa.J = h->V; pa.raw = h->grad.p; pa.ldw = h->W.ld;
-        bm::launch_pos(pa, h->pos_stream);
-        BM_HIP(hipEventRecord(h->ev_pos, h->pos_stream));
-        h->pos_ready = true;
-    }
     const float *hstate = h->cfg.sample_h_states ? h->h0s.p : h->h0m.p;           // :423
     for (int t = 0; t < k; ++t) {                                                 // :367-378
         const bool last = t == k - 1;
@@ -396,11 +371,6 @@ static void rbm_grad(bm_rbm *h, int B, int fused, float N, float lr, float mom, 
     GradArgs g;
     fill_grad(h, B, fused, N, lr, mom, g);
     g.pen = with_bias ? nullptr : h->pen.p;
-    if (h->pos_ready) {
-        (void)hipStreamWaitEvent(h->stream, h->ev_pos, 0);
-        if (fused) g.acc0 = h->grad.p;
-        h->pos_ready = false;
-    }
     if (with_bias) {
         g.nbias = fill_bias_fused(h, B, lr, mom, g.bias);
         g.bias.raw_only = fused ? 0 : 1;      // split (data-parallel) step: raw column sums only
