@@ -135,7 +135,6 @@ SIGNATURES = {
     'bm_dbm_create': [C.POINTER(DbmConfig), C.POINTER(_vp)],
     'bm_dbm_destroy': [_vp],
     'bm_dbm_sync': [_vp],
-    'bm_dbm_chain_stats': [_vp, C.POINTER(C.c_int64)],
     'bm_dbm_seed': [_vp, _u64],
     'bm_dbm_set_row_offset': [_vp, _i64, _i64],
     'bm_dbm_set_param': [_vp, C.c_char_p, _vp, _sz],

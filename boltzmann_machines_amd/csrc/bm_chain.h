@@ -59,7 +59,7 @@ static_assert(sizeof(ChainArgs) <= 4096, "kernel arguments");
 enum : int { CHAIN_ERR_TIMEOUT = 1, CHAIN_ERR_XCC = 2 };
 
 template <int E, class Rng, bool COH> struct ChainSide : ActSide<E, Rng> {
-    static constexpr bool kSplitFill = true, kCohQ = COH;
+    static constexpr bool kSplitFill = true, kCohQ = COH, kCanAbort = false;
     const unsigned *wflags;      // flags of the producing pass for this row block (null: pass 0 reads launch inputs)
     int nwait;
     unsigned gen;

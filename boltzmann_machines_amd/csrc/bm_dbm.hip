@@ -8,7 +8,6 @@
 #include "../../include/bm355.h"
 #include "bm_common.h"
 #include "bm_kernels.h"
-#include "bm_dbmchain.h"
 
 #include <math.h>
 
@@ -100,27 +99,9 @@ struct bm_dbm {
     uint64_t seed = 0;
     uint32_t call = 0;
     int64_t row0 = 0, prow0 = 0;
-    // mean-field loop + particle sweeps of one update as ONE launch (bm_dbmchain.h)
-    struct Dch {
-        int mode = -1, ncu = 0;                    // BM355_DEBUG=dbm_chain: 0 off (default: measured no gain, see below), 1 auto, 2 wherever legal
-        unsigned *flags_mf = nullptr, *flags_pc = nullptr, *claim = nullptr, *words = nullptr;
-        int *status = nullptr;                     // [0] != 0: a wait expired (reported once by bm_dbm_sync)
-        unsigned gen = 0, launches = 0;
-        Mat mu_c[MAXL];                            // the third mean-field buffer
-        bool have_c = false;
-        long long used = 0;                        // updates that took this path (bm_dbm_chain_stats)
-        long long *stamps = nullptr;               // BM355_DEBUG=dch_stamps=file (measurements): timeline of the LAST chained launch
-        hipEvent_t t0 = nullptr, t1 = nullptr;     // BM355_DEBUG=dch_time=1 (measurements): duration of the chained launches
-        double t_ms = 0.0; long long t_n = 0;
-    } dch;
-    std::vector<ActArgs> *rec = nullptr;           // non-null: layer updates are recorded, not launched (dbm_chain_update)
 };
 
-// a propagation pass: launched now, or recorded as the template of a pass of the chained launch
-static void issue_act(bm_dbm *h, const ActArgs &a) {
-    if (h->rec) h->rec->push_back(a);
-    else launch_act(a, h->cur);
-}
+static void issue_act(bm_dbm *h, const ActArgs &a) { launch_act(a, h->cur); }
 
 static PhiloxKey dkey(const bm_dbm *h, uint32_t site, int t, uint64_t seed, uint32_t call) {
     PhiloxKey k;
@@ -524,188 +505,6 @@ static void particles_update(bm_dbm *h, int k, bool sample, bool update_only_v_a
 }
 
 
-// ---- the mean-field loop and the particle sweeps of one update as ONE launch (bm_dbmchain.h) ------------------------
-static int dbm_chain_mode(bm_dbm *h) {
-    bm_dbm::Dch &d = h->dch;
-    if (d.mode < 0) {
-        // OFF unless asked for: bit-exact, but measured at 784-512-1024 x 512 it ties with the per-pass launches + the particle
-        // sweeps on a second stream (1.499 vs 1.497 ms per update at 50 sweeps, 1.03 vs 1.00 ms at 29;
-        // profiles/r5_dbm_chain_timeline.txt says why)
-        const char *e = bm::dbg("dbm_chain");
-        d.mode = e ? atoi(e) : 0;
-        hipDeviceProp_t pr; int dev = 0, nxcc = 0; (void)hipGetDevice(&dev);
-        const bool have = hipGetDeviceProperties(&pr, dev) == hipSuccess;
-        d.ncu = have ? pr.multiProcessorCount : 0;
-        if (hipDeviceGetAttribute(&nxcc, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) nxcc = 0;
-        // teams are XCDs (bm_chain.h): gfx950 / gfx942 with 8 XCDs in single-partition mode
-        const bool arch = have && (strncmp(pr.gcnArchName, "gfx950", 6) == 0 || strncmp(pr.gcnArchName, "gfx942", 6) == 0);
-        if (!(arch && nxcc == 8 && d.ncu == 256)) d.mode = 0;
-    }
-    return d.mode;
-}
-
-static bool dch_pass_from(const ActArgs &a, bool seg2, DchPass &ph) {
-    using G = GeoChain;
-    if (a.b3.K1 > 0 || a.rowacc || a.rowdot_out || a.skip || a.chk_ctl || a.states16 || a.dot_mat || a.negmeans) return false;
-    if (a.kind != 0 && a.kind != 1) return false;
-    if (seg2 != (a.K2 > 0)) return false;
-    if (seg2 && a.p_xm) return false;
-    const int pl = a.p_xm ? XM : KM;
-    if (!(operand_fast(a.P1, pl, a.K1) && operand_fast(a.Q1, XM, a.K1))) return false;
-    if (seg2 && !(operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2))) return false;
-    if (a.K1 < G::PF * G::BK) return false;                      // split fill: chunks 0 .. PF-1 are full chunks of segment 1
-    if ((a.ldo & 3) != 0) return false;
-    ph.P1 = a.P1; ph.P2 = a.P2; ph.K1 = a.K1; ph.K2 = a.K2; ph.p_xm = a.p_xm; ph.I = a.I;
-    ph.ntile = (a.I + G::TI - 1) / G::TI;
-    ph.kind = a.kind; ph.sample = a.sample; ph.bias = a.bias; ph.sigma = a.sigma; ph.key = a.key;
-    return ph.ntile <= DCH_MAXTI;
-}
-
-// may this update run as one chained launch?  (L == 2, Bernoulli hidden layers, row counts that give every XCD team
-// one 64-row block per family, no communicator: the residual of a data-parallel run needs the other ranks)
-static bool dbm_chain_ok(bm_dbm *h, int k) {
-    using G = GeoChain;
-    const int mode = dbm_chain_mode(h);
-    if (mode <= 0 || h->L != 2 || h->comm || h->xchg || h->mf_reduce || h->fast || h->sigmoid_literal || !dbm_xm()) return false;
-    if (h->multinomial(0) || h->multinomial(1)) return false;
-    if (h->N % G::TJ || h->M % G::TJ || h->N / G::TJ > 8 || h->M / G::TJ > 8) return false;
-    if (h->cfg.max_mf_updates < 1 || h->cfg.max_mf_updates > DCH_MAXSW || k < 1 || k > DCH_MAXPC) return false;
-    if (mode == 1 && (h->N / G::TJ < 8 || h->updates_seen < 2)) return false;     // auto: every team has data rows
-    return true;
-}
-
-static int dbm_chain_update(bm_dbm *h, const float *X_dev, int k, int *out_n, bool *taken) {
-    using G = GeoChain;
-    bm_dbm::Dch &d = h->dch;
-    *taken = false;
-    // templates of the five pass types, recorded from the very functions that launch them one by one
-    std::vector<ActArgs> rec;
-    h->rec = &rec;
-    gibbs_sweep(h, h->N, LayerIn{X_dev, h->V}, h->mu, nullptr, h->mu_alt, false, false, 0, 0, h->flag, &h->xw0);
-    gibbs_sweep(h, h->M, LayerIn{h->v.p, h->v.ld}, h->H, &h->v_new, h->H_new, true, true, 0, h->prow0);
-    h->rec = nullptr;
-    DchArgs c;
-    memset(&c, 0, sizeof(c));
-    if (rec.size() != 5 || !rec[0].acc_init || !rec[0].prev || !rec[1].prev) return 0;
-    if (!(dch_pass_from(rec[0], false, c.mf[0]) && dch_pass_from(rec[1], false, c.mf[1]) && dch_pass_from(rec[2], true, c.pc[0]) &&
-          dch_pass_from(rec[3], false, c.pc[1]) && dch_pass_from(rec[4], false, c.pc[2]))) return 0;
-    if (c.pc[2].ntile + c.pc[1].ntile > 62 || c.mf[1].ntile > 62) return 0;        // lanes 62 / 63 of the wait poll control words
-    // The per-pass launches read single-segment passes x-major from whichever of W_l / W_l^T has k contiguous.  Inside ONE
-    // launch what counts is how many weight bytes stream through an XCD's 4 MiB L2 from pass to pass (bm_chain.h made the
-    // same finding for W / W^T of the RBM): the h2 passes take W_1 itself, k-major - the matrix the mean-field's h1 pass
-    // reads x-major - so that the mean-field loop cycles through 2 MiB of weights instead of 4.  Same bits either way.
-    for (DchPass *ph : {&c.mf[1], &c.pc[1]}) {
-        if (ph->p_xm && (h->n[2] & 3) == 0) { ph->P1 = make_operand(h->W[1].p, h->W[1].ld, ph->I); ph->p_xm = 0; }
-        if (!operand_fast(ph->P1, ph->p_xm ? XM : KM, ph->K1)) return 0;
-    }
-    // ---- from here on the update runs chained
-    if (!d.have_c) {
-        for (int i = 0; i < 2; ++i) BM_TRY(d.mu_c[i].alloc(h->N, h->n[i + 1]));
-        d.have_c = true;
-    }
-    const size_t nfl_mf = (size_t)8 * 2 * DCH_MAXSW * DCH_MAXTI, nfl_pc = (size_t)8 * 3 * DCH_MAXPC * DCH_MAXTI;
-    constexpr int CLAIM_SLOTS = 16;
-    constexpr size_t NWORDS = (DCH_MAXSW + 2) + 2;
-    if (!d.flags_mf) {
-        BM_HIP(hipMalloc((void **)&d.flags_mf, (nfl_mf + nfl_pc) * 4));
-        d.flags_pc = d.flags_mf + nfl_mf;
-        BM_HIP(hipMemsetAsync(d.flags_mf, 0, (nfl_mf + nfl_pc) * 4, h->stream));
-        BM_HIP(hipMalloc((void **)&d.claim, (size_t)CLAIM_SLOTS * 8 * 32 * 4));
-        BM_HIP(hipMemsetAsync(d.claim, 0, (size_t)CLAIM_SLOTS * 8 * 32 * 4, h->stream));
-        BM_HIP(hipMalloc((void **)&d.words, NWORDS * 4));
-        BM_HIP(hipMalloc((void **)&d.status, 2 * sizeof(int)));
-        BM_HIP(hipMemsetAsync(d.status, 0, 2 * sizeof(int), h->stream));
-        d.gen = 0;
-    }
-    bool hoist = false;
-    BM_TRY(mf_prologue(h, X_dev, hoist));
-    BM_CHECK(hoist, "chained update without the hoisted X.W0");
-    hipLaunchKernelGGL(mf_ctl_kernel, dim3(1), dim3(256), 0, h->stream, h->ctl, h->cfg.mf_tol, 1, h->mfblk.p, 0);     // step-0 condition from the atomic cell alone
-    if (++d.gen == 0) {                                // generation wrap: start over with clean flags
-        BM_HIP(hipMemsetAsync(d.flags_mf, 0, (nfl_mf + nfl_pc) * 4, h->stream));
-        d.gen = 1;
-    }
-    BM_HIP(hipMemsetAsync(d.words, 0, NWORDS * 4, h->stream));
-    c.gen = d.gen;
-    static const int dbg = bm::dbg("chain_dbg") ? atoi(bm::dbg("chain_dbg")) : 0;
-    c.dbg = dbg;
-    c.flags_mf = d.flags_mf; c.flags_pc = d.flags_pc;
-    c.claim = d.claim + (size_t)(d.launches % CLAIM_SLOTS) * 8 * 32;
-    c.claim_zero = d.claim + (size_t)((d.launches + CLAIM_SLOTS / 2) % CLAIM_SLOTS) * 8 * 32;
-    ++d.launches;
-    c.arrived = d.words; c.stop = d.words + (DCH_MAXSW + 2);
-    c.status = d.status;
-    c.mf_sweeps = h->cfg.max_mf_updates; c.tol = h->cfg.mf_tol;
-    c.J_mf = h->N; c.tiles_mf = h->N / G::TJ;
-    c.arrive_total = c.tiles_mf * (c.mf[0].ntile + c.mf[1].ntile);
-    Mat *bufs[3] = {h->mu, h->mu_alt, d.mu_c};
-    for (int b = 0; b < 3; ++b) for (int i = 0; i < 2; ++i) c.mu[b][i] = bufs[b][i].p;
-    for (int i = 0; i < 2; ++i) {
-        c.ld_mu[i] = h->mu[i].ld;
-        BM_CHECK(h->mu_alt[i].ld == c.ld_mu[i] && d.mu_c[i].ld == c.ld_mu[i], "mean-field buffers of different pitch");
-    }
-    c.xw0 = h->xw0.p; c.ld_xw0 = h->xw0.ld;
-    c.done0 = &h->ctl->done;
-    c.pc_sweeps = k; c.J_pc = h->M; c.tiles_pc = h->M / G::TJ;
-    // slots for particle tiles per sweep of the main sequence: what the h1 pass leaves idle of a team's 32 workgroups
-    c.slots = 32 - c.mf[0].ntile > 0 ? 32 - c.mf[0].ntile : 0;
-    static const int slots_env = bm::dbg("dch_slots") ? atoi(bm::dbg("dch_slots")) : -1;     // measurements only
-    if (slots_env >= 0) c.slots = slots_env;
-    c.pv[0] = h->v.p; c.pv[1] = h->v_new.p; c.ld_v = h->v.ld;
-    BM_CHECK(h->v_new.ld == h->v.ld, "particle buffers of different pitch");
-    for (int i = 0; i < 2; ++i) {
-        c.ph[0][i] = h->H[i].p; c.ph[1][i] = h->H_new[i].p; c.ld_h[i] = h->H[i].ld;
-        BM_CHECK(h->H_new[i].ld == h->H[i].ld, "particle buffers of different pitch");
-    }
-    c.prow0 = h->prow0;
-    {
-        static const char *sf = bm::dbg("dch_stamps");
-        const size_t nst = (size_t)256 * DCH_STAMP_TILES * 8;
-        if (sf && !d.stamps && hipMalloc((void **)&d.stamps, nst * 8) != hipSuccess) d.stamps = nullptr;
-        if (d.stamps) BM_HIP(hipMemsetAsync(d.stamps, 0, nst * 8, h->stream));
-        c.stamps = d.stamps;
-    }
-    static const bool timing = bm::dbg("dch_time") && atoi(bm::dbg("dch_time")) != 0;
-    if (timing) {
-        if (!d.t0) { BM_HIP(hipEventCreate(&d.t0)); BM_HIP(hipEventCreate(&d.t1)); }
-        BM_HIP(hipEventRecord(d.t0, h->stream));
-    }
-    hipLaunchKernelGGL(dbm_chain_kernel, dim3(d.ncu), dim3(G::NT), 0, h->stream, c);
-    if (timing) BM_HIP(hipEventRecord(d.t1, h->stream));
-    hipLaunchKernelGGL(dch_finish_kernel, dim3(1), dim3(64), 0, h->stream, h->ctl, (const unsigned *)c.arrived, c.arrive_total, c.mf_sweeps);
-    BM_HIP(hipGetLastError());
-    BM_HIP(hipMemcpyAsync(&h->ctl_host[0], h->ctl, sizeof(MfCtl), hipMemcpyDeviceToHost, h->stream));
-    BM_HIP(hipStreamSynchronize(h->stream));
-    *taken = true;
-    d.used++;
-    if (timing) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, d.t0, d.t1) == hipSuccess) { d.t_ms += ms; d.t_n++; }
-        if (d.t_n % 20 == 0) fprintf(stderr, "[bm355] chained DBM launch: %.1f us (mean of %lld), last trip count %d\n",
-                                     1e3 * d.t_ms / (double)d.t_n, d.t_n, h->ctl_host[0].steps);
-    }
-    const int n = h->ctl_host[0].steps;
-    if (n < 0) {        // a sweep before the end of the loop is incomplete: a wait expired (status word) or a protocol error
-        int st[2] = {0, 0};
-        BM_HIP(hipMemcpy(st, d.status, sizeof(st), hipMemcpyDeviceToHost));
-        BM_HIP(hipMemset(d.status, 0, sizeof(st)));
-        d.mode = 0;     // per-pass launches from here on (reported once, like bm_rbm_sync does for bm_chain.h)
-        BM_CHECK(false, "chained DBM update failed: mean-field sweep %d is incomplete (status %d); the state of this update is "
-                 "invalid, chained updates are now off for this handle", -n, st[0]);
-    }
-    // the result is buffer n % 3 (sweep s wrote buffer s % 3; 0 = the persistent mu): `self._mu[i].assign(mu[i])` (:477)
-    if (n % 3 == 1) for (int i = 0; i < 2; ++i) { Mat t = h->mu[i]; h->mu[i] = h->mu_alt[i]; h->mu_alt[i] = t; }
-    if (n % 3 == 2) for (int i = 0; i < 2; ++i) { Mat t = h->mu[i]; h->mu[i] = d.mu_c[i]; d.mu_c[i] = t; }
-    // the particles: k sweeps, each swaps the buffers (:493)
-    if (k & 1) {
-        Mat tv = h->v; h->v = h->v_new; h->v_new = tv;
-        for (int i = 0; i < 2; ++i) { Mat th = h->H[i]; h->H[i] = h->H_new[i]; h->H_new[i] = th; }
-    }
-    h->mf_pred = n;
-    if (out_n) *out_n = n;
-    return 0;
-}
-
 // mean-field on the data rows and PCD sweeps on the particles of one update, concurrently (see bm_dbm::stream2).
 // The particle sweeps are enqueued FIRST (mean_field() blocks the host on its loop control), on the second stream,
 // between a fork event (everything enqueued so far, i.e. the previous parameter update) and a join event the main
@@ -717,11 +516,6 @@ static bool pcd_overlap_ok(const bm_dbm *h) {
     return true;
 }
 static int mean_field_and_particles(bm_dbm *h, const float *X_dev, int k, int *out_n) {
-    if (dbm_chain_ok(h, k)) {      // both loops as workgroups of ONE launch (bm_dbmchain.h), same bits
-        bool taken = false;
-        const int rc = dbm_chain_update(h, X_dev, k, out_n, &taken);
-        if (rc || taken) { h->updates_seen++; return rc; }
-    }
     const bool ov = pcd_overlap_ok(h);
     if (ov) {
         BM_HIP(hipEventRecord(h->ev_fork, h->stream));
@@ -956,21 +750,6 @@ int bm_dbm_destroy(bm_dbm *h) {
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     h->mfblk.release();
     h->xw0.release();
-    if (h->dch.stamps) {
-        const char *f = bm::dbg("dch_stamps");
-        const size_t nst = (size_t)256 * DCH_STAMP_TILES * 8;
-        std::vector<long long> hst(nst);
-        if (f && hipMemcpy(hst.data(), h->dch.stamps, nst * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            FILE *fp = fopen(f, "wb");
-            if (fp) { fwrite(hst.data(), 8, nst, fp); fclose(fp); }
-        }
-        (void)hipFree(h->dch.stamps);
-    }
-    if (h->dch.flags_mf) (void)hipFree(h->dch.flags_mf);
-    if (h->dch.claim) (void)hipFree(h->dch.claim);
-    if (h->dch.words) (void)hipFree(h->dch.words);
-    if (h->dch.status) (void)hipFree(h->dch.status);
-    for (int i = 0; i < MAXL; ++i) h->dch.mu_c[i].release();
     if (h->scal) (void)hipFree(h->scal);
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
@@ -982,21 +761,6 @@ int bm_dbm_destroy(bm_dbm *h) {
 int bm_dbm_sync(bm_dbm *h) {
     BM_HIP(hipStreamSynchronize(h->stream));
     if (h->xchg_used) BM_TRY(xchg_check_status(h->xchg_used));      // a lost rank is an ERROR here, never a silent wrong sum
-    if (h->dch.status) {                                            // chained updates (bm_dbmchain.h): an expired wait is an ERROR
-        int st = 0;
-        BM_HIP(hipMemcpy(&st, h->dch.status, sizeof(st), hipMemcpyDeviceToHost));
-        if (st) {
-            BM_HIP(hipMemset(h->dch.status, 0, sizeof(int)));
-            h->dch.mode = 0;
-            BM_CHECK(false, "chained DBM update: a wait for a producing tile expired (status %d); results since the last check are "
-                     "invalid, chained updates are now off for this handle", st);
-        }
-    }
-    return 0;
-}
-int bm_dbm_chain_stats(bm_dbm *h, int64_t *out3) {
-    BM_CHECK(h && out3, "null argument");
-    out3[0] = (int64_t)h->dch.used; out3[1] = (int64_t)h->dch.launches; out3[2] = (int64_t)dbm_chain_mode(h);
     return 0;
 }
 int bm_dbm_seed(bm_dbm *h, uint64_t seed) { h->seed = seed; h->call = 0; return 0; }

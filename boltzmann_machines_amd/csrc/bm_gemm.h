@@ -73,11 +73,11 @@ struct NoSide {
     // pipeline fill requests the P pieces first, calls wait_inputs() (spin on the producers' flags), then the Q pieces;
     // kCohQ: every Q load bypasses the CU's vector L1 (sc1), which may hold the previous contents of those lines.
     static constexpr bool kSplitFill = false, kCohQ = false;
-    // kCanAbort (bm_dbmchain.h): wait_inputs() may set `aborted` (workgroup-uniform): the main loop returns at once, with
-    // the weight pieces of the fill still in flight (the caller waits vmcnt(0) and meets at a barrier before the LDS ring
-    // is used again)
+    // kCanAbort (act_kernel's mean-field flavour): post_fill(), called behind the barrier that ends the pipeline fill, may set
+    // `aborted` (workgroup-uniform): the main loop then waits for its own DMA pieces and returns at once
     static constexpr bool kCanAbort = false;
     __device__ __forceinline__ void wait_inputs() {}
+    __device__ __forceinline__ void post_fill() {}
     __device__ __forceinline__ void fill() {}
     __device__ __forceinline__ void drain() {}
 };
@@ -677,8 +677,6 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         // K1 >= PF * BK: chunks 0 .. PF-1 are full DMA chunks).  The P pieces (weights: constant during the launch) go
         // out first, then the wave waits for the producers of its Q rows, then the Q pieces.  The vector-memory queue
         // completes in order: with only the Q pieces of chunk PF-1 .. 2 still in flight, chunks 0 and 1 are complete.
-        // A second segment (bm_dbmchain.h) changes nothing here: the fill only touches segment 1 (host: K1 >= PF * BK), and
-        // wait_inputs() waits for the producers of BOTH Q operands.
         static_assert(FAST && STG == STG_DMA && DW == G::NW, "chained fill");
         const unsigned l0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
         const unsigned lP = l0 + (unsigned)w * 1024u, lQ = l0 + (unsigned)(NBUF * P_BUF * 4) + (unsigned)w * 1024u;
@@ -692,7 +690,6 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
         side.fill();
         __builtin_amdgcn_sched_barrier(0);
         side.wait_inputs();
-        if constexpr (Side::kCanAbort) { if (side.aborted) return; }
 #pragma unroll
         for (int c = 0; c < PF; ++c) {
             const char *qb = (const char *)kr.Q1.ptr + (size_t)c * ((QL == KM) ? (size_t)BK * kr.Q1.ld * 4 : (size_t)BK * 4);
@@ -726,6 +723,10 @@ __device__ __forceinline__ void mainloop(f32x4 (&acc)[G::MI][G::NJ], const KRang
     }
     BM_MSTAMP(1);
     if (!BM_ABL(5)) wg_barrier();
+    if constexpr (Side::kCanAbort) {
+        side.post_fill();
+        if (side.aborted) { BM_WAIT_VM(0); return; }     // (an LDS-DMA piece must not land in the LDS of a finished workgroup)
+    }
     read_frags<QL, G, ABL, PL>(fa, sP, sQ, wi, wj, lane);
     BM_MSTAMP(2);
     // blocks of 16 k that the last chunk really holds

@@ -185,21 +185,62 @@ __device__ __forceinline__ void store4(float *dst, size_t o, const float *v, int
 template <int MI> struct PhiloxFor { typedef PhiloxPair type; };
 template <> struct PhiloxFor<1> { typedef PhiloxOne type; };
 
-// act_kernel's side work for the main loop's pipeline fill
-template <int E, class Rng> struct ActSide {
+// max over the 64 lanes of a wave, valid in LANE 63: six DPP steps on the vector ALU (quad swaps, row rotations, the two row
+// broadcasts of gfx9) instead of six ds_bpermute round trips through the LDS crossbar (__shfl_xor: ~100 cycles each, dependent)
+__device__ __forceinline__ float wave_max_lane63(float v) {
+#define BM_DPP_MAX(ctrl, rmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rmask, 0xf, false)))
+    BM_DPP_MAX(0xb1, 0xf);     // quad_perm:[1,0,3,2]
+    BM_DPP_MAX(0x4e, 0xf);     // quad_perm:[2,3,0,1]
+    BM_DPP_MAX(0x124, 0xf);    // row_ror:4
+    BM_DPP_MAX(0x128, 0xf);    // row_ror:8
+    BM_DPP_MAX(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+    BM_DPP_MAX(0x143, 0xc);    // row_bcast:31 into rows 2 and 3
+#undef BM_DPP_MAX
+    return v;
+}
+
+// act_kernel's side work for the main loop's pipeline fill.
+// MF = the mean-field flavour (act_kernel<..., MF = true>; launch_act_mf): a pass of the data-dependent mean-field loop
+// (dbm.py:429-478) carries plumbing no other pass has - the previous mu of the lane's outputs (residual), the loop control of
+// the previous sweep (ActArgs::chk_ctl) or the loop's `done` word (ActArgs::skip), a stored partial pre-activation
+// (ActArgs::acc_init).  tools/probe_mf.hip priced it at 2.5 of 12.7 us (h1 pass) and 1.3 of 10.7 us (h2 pass) at 784-512-1024
+// x 512 while all of it sat on the critical path: the control check was one global round trip + a reduction BEFORE the first
+// operand load went out, and the epilogue inputs were loaded behind the LDS-DMA pieces, where the counted wait of the fill
+// (vmcnt(pieces still allowed in flight)) then had to retire a third chunk and the loads themselves.  Here:
+//   * preload(): every epilogue input is requested BEFORE the first DMA piece (16-byte loads where the run is aligned), so
+//     the fill's counted wait is exact again;
+//   * the control check's loads go out BEHIND the DMA pieces (fill()): they return when the fill has landed, the wave
+//     partials meet at the barrier the fill ends with anyway, and post_fill() decides; a finished loop costs a launch and a
+//     fill, not a K loop.
+template <int E, class Rng, bool MF = false, int NTH = 256> struct ActSide {
     static constexpr bool kFinalSync = false;    // one pipeline per kernel: waves enter the epilogue as they finish
-    static constexpr bool kSplitFill = false, kCohQ = false, kCanAbort = false;
+    static constexpr bool kSplitFill = false, kCohQ = false, kCanAbort = MF;
+    static constexpr bool kMF = MF;
     const float *bias, *sigma;
     const float *prev_row;       // mean-field: &prev[j][ib0] when the row is valid, else null
     int ib0, I, with_rng;
     float bs[E], sg[E], pv[E];   // pv: previous mu of the lane's outputs (mean-field residual)
     Rng rng;
-    __device__ __forceinline__ void fill() {
+    // MF only
+    MfCtl *chk_ctl; const float *chk_slots; int chk_n; float chk_tol; const int *skip; float *s_chk; int aborted, nthreads;
+
+    __device__ __forceinline__ void load_inputs() {
         const float *sp = sigma ? sigma : bias;     // unconditional loads + select: no branch, no early wait
         const bool has_sigma = sigma != nullptr;
-        if (prev_row) {                             // wave-uniform per kernel (null for all lanes or row-dependent)
+        if (MF && prev_row) {                       // wave-uniform per kernel (null for all lanes or row-dependent)
+            if (E == 4 && ib0 + 3 < I && (((uintptr_t)prev_row & 15u) == 0)) {
+                const float4 t = *reinterpret_cast<const float4 *>(prev_row);
+                pv[0] = t.x; pv[1] = t.y; pv[2] = t.z; pv[E - 1] = t.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < E; ++e) pv[e] = (ib0 + e < I) ? prev_row[e] : 0.f;
+                for (int e = 0; e < E; ++e) pv[e] = (ib0 + e < I) ? prev_row[e] : 0.f;
+            }
+        }
+        if (MF && E == 4 && ib0 + 3 < I && (((uintptr_t)(bias + ib0) & 15u) == 0) && (((uintptr_t)(sp + ib0) & 15u) == 0)) {
+            const float4 b = *reinterpret_cast<const float4 *>(bias + ib0), v = *reinterpret_cast<const float4 *>(sp + ib0);
+            bs[0] = b.x; bs[1] = b.y; bs[2] = b.z; bs[E - 1] = b.w;
+            sg[0] = has_sigma ? v.x : 1.0f; sg[1] = has_sigma ? v.y : 1.0f; sg[2] = has_sigma ? v.z : 1.0f; sg[E - 1] = has_sigma ? v.w : 1.0f;
+            return;
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -208,7 +249,72 @@ template <int E, class Rng> struct ActSide {
             const float sv = sp[i];
             sg[e] = has_sigma ? sv : 1.0f;
         }
+    }
+    // The control words of the loop (the residual slots of the previous sweep, the `done` word) travel like the operand
+    // chunks: by LDS-DMA, requested in preload() - OLDER than every DMA piece of the fill, so the fill's own counted wait and
+    // barrier retire them - and are read from LDS in post_fill().  (A load into registers would get hipcc's
+    // `s_waitcnt vmcnt(0)` in front of its first use, which also waits for the youngest chunk in flight: +0.6 us per pass.)
+    static constexpr int CHK_MAX = 4096;         // MAXL * BM_MF_SLOTS
+    float *s_slots;                              // [CHK_MAX + 4] LDS
+    static __device__ __forceinline__ void dma4_lane0(const void *src, float *lds_dst) {      // 4 bytes, lane 0 only
+        if ((threadIdx.x & 63) == 0) {
+            unsigned keep;
+            const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)lds_dst;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_addr)) : "memory");
+        }
+    }
+    // before the first DMA piece of the pipeline fill (MF only; the other flavours load inside fill())
+    __device__ __forceinline__ void preload() {
+        if constexpr (MF) {
+            load_inputs();
+            aborted = 0;
+            const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            if (chk_ctl) {                           // wave-uniform: Check(s-1), see ActArgs::chk_ctl
+                for (int p = w; p * 256 < chk_n && p * 256 < CHK_MAX; p += nthreads / 64)
+                    dma16(reinterpret_cast<const char *>(chk_slots + 256 * p) + 16 * lane, s_slots + 256 * p);
+                if (w == 0) dma4_lane0(&chk_ctl->done, s_slots + CHK_MAX);
+            } else if (skip) {
+                if (w == 0) dma4_lane0(skip, s_slots + CHK_MAX);
+            }
+        }
+    }
+    __device__ __forceinline__ void fill() {
+        if (!MF) load_inputs();
         if (with_rng) rng.fill();       // wave-uniform
+    }
+    // behind the counted wait + barrier that end the pipeline fill: everything preload() requested has landed in LDS
+    __device__ __forceinline__ void post_fill() {
+        if constexpr (MF) {
+            if (chk_ctl) {
+                // (16-byte LDS reads, all of a thread's in flight at once)
+                constexpr int NR = CHK_MAX / (4 * NTH);
+                f32x4 v[NR];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const int e = 4 * ((int)threadIdx.x + q * NTH);
+                    v[q] = *reinterpret_cast<const f32x4 *>(s_slots + (e < chk_n ? e : 0));
+                }
+                float m = 0.f;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const bool in = 4 * ((int)threadIdx.x + q * NTH) < chk_n;
+                    m = fmaxf(m, in ? fmaxf(fmaxf(v[q][0], v[q][1]), fmaxf(v[q][2], v[q][3])) : 0.f);
+                }
+                m = wave_max_lane63(m);
+                if ((threadIdx.x & 63) == 63) s_chk[threadIdx.x >> 6] = m;
+                wg_barrier();
+                m = 0.f;
+#pragma unroll
+                for (int q = 0; q < NTH / 64; ++q) m = fmaxf(m, s_chk[q]);
+                const int was = __float_as_int(s_slots[CHK_MAX]);
+                const int done = was || !(m > chk_tol);
+                if (blockIdx.x == 0 && threadIdx.x == 0 && !was) { chk_ctl->steps += 1; chk_ctl->done = done; }
+                aborted = __builtin_amdgcn_readfirstlane(done);
+            } else if (skip) {
+                aborted = __builtin_amdgcn_readfirstlane(__float_as_int(s_slots[CHK_MAX]) != 0);
+            }
+        }
     }
     __device__ __forceinline__ void drain() {}
 };
@@ -273,10 +379,12 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                 }
             }
             const size_t o = (size_t)j * a.ldo + ib;
-            if (a.prev) {
+            if constexpr (SideT::kMF) {
+                if (a.prev) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) dmax = fmaxf(dmax, fabsf(m[r] - side.pv[4 * hlf + r]));
+                    for (int r = 0; r < 4; ++r)
+                        if (r < nvalid) dmax = fmaxf(dmax, fabsf(m[r] - side.pv[4 * hlf + r]));
+                }
             }
             const bool v4 = al_out && nvalid == 4;
             if (a.means) store4<HWMATH>(a.means, o, m, nvalid, v4 && (((uintptr_t)a.means & 15u) == 0));
@@ -363,7 +471,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
 
 // MINB: HIP's second __launch_bounds__ argument = WAVES PER SIMD the register budget must allow (for the 4-wave
 // geometries that equals the workgroups per CU; an 8-wave workgroup that should run twice per CU passes 4)
-template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA, bool FE = false, bool LIT = false>
+template <class G, int MINB, bool SEG2, bool FAST, int ABL = 0, int PL = KM, int STG = STG_DMA, bool FE = false, bool LIT = false, bool MF = false>
 __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tmap) {
     // (the block -> tile map is an argument of its own: the grid path indexes it with blockIdx & 7, and a dynamically
     //  indexed member made hipcc fetch EVERY ActArgs field lazily in small pieces - 50 scalar loads with their waits
@@ -378,21 +486,8 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tma
                        "s"(a.sample), "s"(a.kind), "s"(a.row0), "s"(a.I), "s"(a.J), "s"(a.skip));
     const int tiles_j = (a.J + G::TJ - 1) / G::TJ;
     int ti, tj;
-    if (a.chk_ctl) {                               // wave-uniform: Check(s-1), see ActArgs::chk_ctl
-        __shared__ float s_chk[G::NT / 64];
-        float m = 0.f;
-        for (int e = threadIdx.x; e < a.chk_n; e += G::NT) m = fmaxf(m, a.chk_slots[e]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-        if ((threadIdx.x & 63) == 0) s_chk[threadIdx.x >> 6] = m;
-        wg_barrier();               // LDS-only hand-over: no fence that waits for the global stores / loads in flight
-#pragma unroll
-        for (int q = 0; q < G::NT / 64; ++q) m = fmaxf(m, s_chk[q]);
-        const int was_done = a.chk_ctl->done;
-        const int done = was_done || !(m > a.chk_tol);
-        if (blockIdx.x == 0 && threadIdx.x == 0 && !was_done) { a.chk_ctl->steps += 1; a.chk_ctl->done = done; }
-        if (done) return;
-    } else if (a.skip && *a.skip) return;          // wave-uniform: converged mean-field loop
+    // (the mean-field plumbing - ActArgs::chk_ctl / skip / prev / maxdiff / acc_init - exists in the MF flavour only:
+    //  launch_act routes every launch that carries one of them there, ActSide<.., MF> says how it is scheduled)
     // tile order: 2-D XCD rectangles, L2-sized column groups (tile_of_block)
     if (tmap.slab) {                               // wave-uniform; the launch tuner's choice per shape (TileMap::slab)
         block_to_tile(tiles_j, ti, tj, 0, 0, a.J > 2 * a.I, (a.I + G::TI - 1) / G::TI);
@@ -413,23 +508,37 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tma
     const int j = j0 + wj * 16 + l15;
     // Side work for the pipeline fill (runs while the first operand loads are in flight):
     // the epilogue inputs (bias, sigma) and, when a draw follows, the lane's Philox block(s).
-    ActSide<E, typename PhiloxFor<G::MI>::type> side;
+    ActSide<E, typename PhiloxFor<G::MI>::type, MF, G::NT> side;
     side.bias = a.bias; side.sigma = a.sigma; side.ib0 = ib0; side.I = a.I; side.with_rng = a.sample;
-    side.prev_row = (a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
+    side.prev_row = (MF && a.prev && j < a.J && ib0 < a.I) ? a.prev + (size_t)j * a.ldo + ib0 : nullptr;
     const PhiloxKey key = a.key;
     side.rng.init(key, ((unsigned long long)(a.row0 + j) * (unsigned long long)a.I + ib0) >> 2);
 
     f32x4 acc[G::MI][1];
 #pragma unroll
     for (int t = 0; t < G::MI; ++t) acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.acc_init && j < a.J) {                   // start the chain from a stored partial sum
+    if constexpr (MF) {
+        __shared__ float s_chk[G::NT / 64];
+        __shared__ __attribute__((aligned(16))) float s_slots[ActSide<E, typename PhiloxFor<G::MI>::type, true>::CHK_MAX + 4];
+        side.s_slots = s_slots;
+        side.chk_ctl = a.chk_ctl; side.chk_slots = a.chk_slots; side.chk_n = a.chk_n; side.chk_tol = a.chk_tol;
+        side.skip = a.skip; side.s_chk = s_chk; side.nthreads = G::NT; side.aborted = 0;
+        if (a.acc_init && j < a.J) {               // start the chain from a stored partial sum
+            const float *src = a.acc_init + (size_t)j * a.ld_init + ib0;
+            if (G::MI == 1 && ib0 + 3 < a.I && (((uintptr_t)src & 15u) == 0)) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                acc[0][0] = (f32x4){t4.x, t4.y, t4.z, t4.w};
+            } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int t = 0; t < G::MI; ++t) {
-                const int i = ib0 + G::MI * r + t;
-                if (i < a.I) acc[t][0][r] = a.acc_init[(size_t)j * a.ld_init + i];
+                    for (int t = 0; t < G::MI; ++t) {
+                        const int i = ib0 + G::MI * r + t;
+                        if (i < a.I) acc[t][0][r] = src[G::MI * r + t];
+                    }
             }
+        }
+        side.preload();
     }
 #ifdef BM_PROBE
     mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side, a.dbg ? a.dbg + 2048 + blockIdx.x * 8 : nullptr);
@@ -437,13 +546,13 @@ __global__ __launch_bounds__(G::NT, MINB) void act_kernel(ActArgs a, TileMap tma
     mainloop<XM, G, FAST, SEG2, ABL, PL, STG>(acc, kr, i0, j0, smem, side);
 #endif
     BM_STAMP(1);
+    if constexpr (MF) { if (side.aborted) return; }          // the loop had ended: nothing is written
     float dmax = act_epilogue<G, ABL, decltype(side), false, FE, LIT>(a, key, acc, side, i0, j0);
-    if (a.maxdiff) {           // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
+    if (MF && a.maxdiff) {     // wave-uniform.  ONE atomic per workgroup: thousands of same-address atomics
                                // (one per wave) serialise in the L2 and doubled the duration of the sweep kernels
         __shared__ float s_wavemax[G::NT / 64];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, off));
-        if (lane == 0) s_wavemax[w] = dmax;
+        dmax = wave_max_lane63(dmax);
+        if (lane == 63) s_wavemax[w] = dmax;
         wg_barrier();               // LDS-only hand-over: no fence that waits for the global stores / loads in flight
         if (tid == 0) {
             float m = 0.f;
@@ -790,7 +899,7 @@ struct DivBy {
 // the pipeline drain, so the read-modify-write epilogue does not start with a memory round trip
 template <int NJ> struct GradSide {
     static constexpr bool kFinalSync = true;     // form 1 runs two pipelines through the same LDS ring
-    static constexpr bool kSplitFill = false, kCohQ = false;
+    static constexpr bool kSplitFill = false, kCohQ = false, kCanAbort = false;
     const float *W, *dW; int ldw, I, J, ib0, jb[NJ]; bool on, vec8;
     float4 w[NJ][2], d[NJ][2];
     bool at_fill;
@@ -1834,6 +1943,46 @@ static inline void launch_act_lit(const ActArgs &a, hipStream_t st) {
     }
 }
 
+// mean-field passes (ActArgs::prev / maxdiff / skip / chk_ctl / acc_init): the MF flavour (ActSide<.., MF>), LDS-DMA, slab order.
+// Two tiles, by rule: 32 x 64 (8 waves, one workgroup per CU) where that gives every CU a tile, else 32 x 32 (4 waves) - what the
+// launch tuner picked for these passes at 784-512-1024 x 512 (profiles/r5_dbm_kernel_stats.csv); BM355_DEBUG=mf_geo=8|1 forces
+// one.  The literal-sigmoid mode (LIT) takes the 32 x 32 tile.
+template <class G, int MINB, bool LIT>
+static inline void launch_act_mf_geo(const ActArgs &a, hipStream_t st, unsigned dyn_lds = 0) {
+    const double kt = (double)a.K1 + (double)a.K2;
+    const TileMap tmap = make_tile_map((a.I + G::TI - 1) / G::TI, (a.J + G::TJ - 1) / G::TJ, kt * G::TI * 4.0, kt * G::TJ * 4.0, -1);
+    const bool seg2 = a.K2 > 0;
+    const bool fast = operand_fast(a.P1, a.p_xm ? XM : KM, a.K1) && operand_fast(a.Q1, XM, a.K1) &&
+                      (!seg2 || (operand_fast(a.P2, KM, a.K2) && operand_fast(a.Q2, XM, a.K2)));
+    const dim3 grid(tile_grid<G>(a.I, a.J)), blk(G::NT);
+    if (a.p_xm) {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, XM, STG_DMA, false, LIT, true>), grid, blk, dyn_lds, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, XM, STG_DMA, false, LIT, true>), grid, blk, dyn_lds, st, a, tmap);
+    } else if (seg2) {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, true, true, 0, KM, STG_DMA, false, LIT, true>), grid, blk, dyn_lds, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, true, false, 0, KM, STG_DMA, false, LIT, true>), grid, blk, dyn_lds, st, a, tmap);
+    } else {
+        if (fast) hipLaunchKernelGGL((act_kernel<G, MINB, false, true, 0, KM, STG_DMA, false, LIT, true>), grid, blk, dyn_lds, st, a, tmap);
+        else      hipLaunchKernelGGL((act_kernel<G, MINB, false, false, 0, KM, STG_DMA, false, LIT, true>), grid, blk, dyn_lds, st, a, tmap);
+    }
+}
+static inline void launch_act_mf(const ActArgs &a, hipStream_t st) {
+    if (a.lit && a.kind == 0) { launch_act_mf_geo<GeoActS, 1, true>(a, st); return; }
+    static const int force = bm::dbg("mf_geo") ? atoi(bm::dbg("mf_geo")) : 0;
+    int dev = 0, ncu = 256;
+    static int ncu_cached = 0;
+    if (!ncu_cached) {
+        hipDeviceProp_t pr;
+        (void)hipGetDevice(&dev);
+        ncu_cached = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    ncu = ncu_cached;
+    const bool wide = force ? force == 8 : tile_grid<GeoAct8>(a.I, a.J) >= ncu;
+    // (the 32 x 32 tile of this flavour takes 64 KiB for its ring + 16 KiB for the control words: one workgroup per CU)
+    if (wide) launch_act_mf_geo<GeoAct8, 1, false>(a, st);
+    else      launch_act_mf_geo<GeoActS, 1, false>(a, st);
+}
+
 // fast-binary launch (a.b3 filled).  Three tiles: 64 x 64 / 8 waves and 64 x 32 / 4 waves (one workgroup per CU: the
 // ring takes most of the LDS), 32 x 64 / 4 waves with TWO workgroups per CU (80 KiB each: one workgroup's epilogue -
 // sigmoid, draw, the AIS softplus terms - runs under the other's matrix work).  Every workgroup owns a strip of
@@ -2091,6 +2240,7 @@ static inline void launch_act_f32(const ActArgs &a, hipStream_t st);
 static inline void launch_act(const ActArgs &a, hipStream_t st) {
     if (a.b3.K1 > 0) { launch_act_bf3(a, st); return; }
     if (a.fe_flip) { launch_act_fe(a, st); return; }     // the h0 pass of a fused metric fetch: its own kernel flavour
+    if (a.prev || a.maxdiff || a.skip || a.chk_ctl || a.acc_init) { launch_act_mf(a, st); return; }   // a mean-field pass: its own flavour
     if (a.lit && a.kind == 0) { launch_act_lit(a, st); return; }   // literal tf.sigmoid: its own kernel flavour
     launch_act_f32(a, st);
     // fast-binary mode, an fp32 launch whose sampled states the NEXT launches read as a bf16 shadow: converted here (the

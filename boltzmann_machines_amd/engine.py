@@ -357,13 +357,6 @@ class DbmEngine(object):
     def sync(self):
         check(self.lib.bm_dbm_sync(self._h))
 
-    def chain_stats(self):
-        """(updates that ran as one chained launch, chained launches issued, BM355_DEBUG=dbm_chain=.. mode) - csrc/bm_dbmchain.h"""
-        out = (C.c_int64 * 3)()
-        check(self.lib.bm_dbm_chain_stats(self._h, out))
-        return int(out[0]), int(out[1]), int(out[2])
-
-    # -- fetch sites
     def train_step(self, Xd, lr, momentum, k, row=0, want_msre=False):
         nmf, msre = C.c_int32(), C.c_float()
         check(self.lib.bm_dbm_train_step(self._h, Xd.offset_ptr(row * self.V), lr, momentum, k, C.byref(nmf),

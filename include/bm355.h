@@ -240,12 +240,6 @@ typedef struct bm_dbm_config {
 int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out);
 int bm_dbm_destroy(bm_dbm *h);
 int bm_dbm_sync(bm_dbm *h);
-/* Chained updates (csrc/bm_dbmchain.h): the mean-field loop (dbm.py:429-478) and the particle sweeps (dbm.py:480-509) of one
- * bm_dbm_train_step can run as ONE launch where the shape allows it (2 Bernoulli hidden layers, 64-row blocks for all 8 XCD
- * teams, no communicator), bit-identical to the per-pass launches.  OPT-IN (BM355_DEBUG=dbm_chain=1: that rule, 2: wherever legal;
- * default 0): measured, it ties with the per-pass launches at the BASELINE shape (profiles/r5_dbm_chain_timeline.txt).
- * out3 = {updates that ran chained, chained launches issued, mode}; bm_dbm_sync reports a launch that did not complete. */
-int bm_dbm_chain_stats(bm_dbm *h, int64_t *out3);
 int bm_dbm_seed(bm_dbm *h, uint64_t seed);
 int bm_dbm_set_row_offset(bm_dbm *h, int64_t row0, int64_t particle0);
 
