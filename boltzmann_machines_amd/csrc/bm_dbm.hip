@@ -468,7 +468,10 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
 // fast-binary PCD: the hidden layers are sampled Bernoulli layers (bitmaps from the second sweep on), the visible one
 // may be real valued (then only the top-down half of each sweep runs on the bf16 cores)
 static bool fast_pcd_ok(const bm_dbm *h, bool sample) {
+    // (level 1: only where the particle sweeps gain - from 8M weights in the bottom layer upwards; at 784-512-1024 they lose,
+    //  profiles/r5_dbm_summary.md.  Level 2: wherever legal)
     if (!h->fast || !sample) return false;
+    if (h->fast < 2 && (long long)h->V * h->n[1] < (8ll << 20)) return false;
     for (int i = 0; i < h->L; ++i) if (h->multinomial(i) || !h->cfg.sample_h_states[i]) return false;
     return true;
 }
@@ -906,11 +909,13 @@ int bm_dbm_set_comm(bm_dbm *h, bm_comm *c) {
 
 // Opt-in fast-binary mode (bm_bf3.h): contractions whose input states are {0,1} bitmaps run as exact-product
 // bf16 x 3 on the bf16 matrix cores (AIS with all layers sampled).  Results then agree with the default fp32 chain to
-// fp32 round-off, not bit for bit.  0 restores the default.
+// fp32 round-off, not bit for bit.  0 restores the default.  1 = where it pays: AIS (0.82 -> 0.42 s per 1000-beta run of
+// 20 000 chains) and the particle sweeps of stacks with >= 8M weights in the bottom layer (3072 x 5000: +4 %); 2 = wherever
+// legal (tests, measurements: the particle sweeps of the 784-512-1024 stack are SLOWER in this mode).
 int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
     BM_CHECK(!(on && h->sigmoid_literal), "fast-binary mode and the literal sigmoid exclude each other");
-    h->fast = on ? 1 : 0;
+    h->fast = on >= 2 ? 2 : (on ? 1 : 0);
     return 0;
 }
 

@@ -6,7 +6,7 @@
 // computed with v_mfma_f32_16x16x4_f32 (exact fp32: the instruction is the fma chain
 // acc = fmaf(a[g], b[g], acc) for g = 0..3 over the four k the lanes' 16-groups hold).
 //
-// "Canonical order" (DESIGN.md §5) — the order in which the products of one dot product
+// "Canonical order" (DESIGN.md §3.1, §5) — the order in which the products of one dot product
 // enter the chain, identical in oracle/bm_oracle.c, so that every result is BIT-IDENTICAL
 // between the CPU oracle and the GPU:
 //     for each aligned block of 16 k (m = 0, 1, ...):  for j = 0..3:  for g = 0..3:

@@ -630,9 +630,12 @@ int bm_rbm_sync(bm_rbm *h) {
 // Opt-in fast-binary mode (bm_bf3.h): the sampling sweep (bm_rbm_gibbs) of a Bernoulli-Bernoulli RBM with both layers
 // sampled runs its contractions as exact-product bf16 x 3 on the bf16 matrix cores; agreement with the default path
 // is to fp32 round-off, not bit for bit.  0 restores the default.
+// 1 = where it PAYS: at 784 x 1024 x 512 the bf16 strip kernel is slower than the fp32 path (25.9 against 25.2 us per sweep,
+// profiles/r5_gibbs_summary.md: the pass is bound by its fill and epilogue, not by matrix time), so the switch only takes
+// effect from 8M weights upwards (the 3072 x 5000 shape gains); 2 = wherever legal (tests, measurements).
 int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on) {
     BM_CHECK(h, "null argument");
-    h->fast = on ? 1 : 0;
+    h->fast = (on >= 2 || (on == 1 && (long long)h->V * h->H >= (8ll << 20))) ? 1 : 0;
     return 0;
 }
 
@@ -856,7 +859,7 @@ int bm_rbm_collect_metrics(bm_rbm *h, float *out4n, int32_t max_n, int32_t *out_
 // N rows of X_dev as consecutive minibatches of `batch` rows, driven from C: the same launches and RNG call counters
 // as the caller's own loop over bm_rbm_train_step, without a host round trip per batch.  (Round 3 could replay recurring
 // runs of updates from a HIP graph, bit-exactly, and measured it SLOWER on MI355X / ROCm 7.2 - 66.3 against 65.4 us per
-// update over 2000 updates, 75 - 77 against 69 us for a single 20-update replay; removed in round 4)
+// update over 2000 updates, 75 - 77 against 69 us for a single 20-update replay; removed in round 4, profiles/NOTES.md 3.10.)
 int bm_rbm_train_epoch(bm_rbm *h, const float *X_dev, int64_t N, int32_t batch, float lr, float mom, int32_t k) {
     BM_CHECK(batch >= 1 && N >= 1, "bad N=%lld batch=%d", (long long)N, batch);
     for (int64_t s = 0; s < N; s += batch) {

@@ -79,9 +79,10 @@ class RbmEngine(object):
         check(self.lib.bm_rbm_get_staged(self._h, int(slot), name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
         return a
 
-    def set_fast_binary(self, on):
-        """opt-in exact-product bf16 x 3 mode of the sampling sweep (bm_rbm_set_fast_binary)"""
-        check(self.lib.bm_rbm_set_fast_binary(self._h, int(bool(on))))
+    def set_fast_binary(self, on, everywhere=False):
+        """opt-in exact-product bf16 x 3 mode of the sampling sweep (bm_rbm_set_fast_binary): where it pays (>= 8M weights);
+        everywhere=True: wherever legal (tests, measurements)"""
+        check(self.lib.bm_rbm_set_fast_binary(self._h, (2 if everywhere else 1) if on else 0))
 
     def set_from_device(self, name, darr):
         """variable <- dense DeviceArray, asynchronously on the engine's stream (bm_rbm_set_param_dev)"""
@@ -383,9 +384,10 @@ class DbmEngine(object):
         self._comm = comm
         check(self.lib.bm_dbm_set_comm(self._h, comm._c if comm is not None else None))
 
-    def set_fast_binary(self, on):
-        """opt-in exact-product bf16 x 3 mode of AIS (bm_dbm_set_fast_binary)"""
-        check(self.lib.bm_dbm_set_fast_binary(self._h, int(bool(on))))
+    def set_fast_binary(self, on, everywhere=False):
+        """opt-in exact-product bf16 x 3 mode (bm_dbm_set_fast_binary): AIS, and the particle sweeps where they gain (>= 8M
+        weights in the bottom layer); everywhere=True: wherever legal (tests, measurements)"""
+        check(self.lib.bm_dbm_set_fast_binary(self._h, (2 if everywhere else 1) if on else 0))
 
     def set_ais_literal(self, on):
         """AIS log-weights accumulated in float32 in the reference graph's order (bm_dbm_set_ais_literal)"""

@@ -187,7 +187,7 @@ int bm_rbm_timer_elapsed(bm_rbm *h, float *out_ms);     /* ... wait for it and r
  * tests train a float64 BernoulliRBM (rbm/tests/test_rbm.py:53-56,70-73).  Same fetch sites as
  * the float32 entry points above, every buffer and scalar in double; Bernoulli or Gaussian visible units,
  * Bernoulli or Multinomial hidden units.  Variables as in
- * bm_rbm_set_param.  Compatibility path on the FP64 matrix cores (DESIGN.md 3.8), ~3x the float32 update. */
+ * bm_rbm_set_param.  Compatibility path on the FP64 matrix cores (DESIGN.md 3.10), ~3x the float32 update. */
 typedef struct bm_rbm64 bm_rbm64;
 /* hyper5 = {l2, sparsity_target, sparsity_cost, sparsity_damping, dropout (<0: off)} as doubles (a Python
  * float is a double; the float fields of cfg would round them); NULL: take them from cfg */
@@ -409,7 +409,10 @@ int bm_dbm_ais_sharded_direct(bm_dbm *h, bm_xchg *x, int32_t n_betas, int32_t n_
  * real-valued visible layer and the particles a call starts from are read in fp32) split the fp32 weights
  * EXACTLY into three bf16 planes and run on the bf16 matrix cores - exact products, fp32 accumulation in a
  * different order than the default chain: results agree to fp32 round-off (free energy / log-weights 1e-5, bitmaps
- * identical except where |u - p| is at round-off distance), NOT bit for bit.  Never the default. */
+ * identical except where |u - p| is at round-off distance), NOT bit for bit.  Never the default.
+ * on = 1: where the mode was measured FASTER than the fp32 path - AIS always; the sampling sweep of an RBM and the particle
+ * sweeps of a DBM only from 8M weights in the (bottom) weight matrix upwards (3072 x 5000 gains, 784 x 1024 loses: there the
+ * passes are bound by their fill and epilogue, not by matrix time).  on = 2: wherever legal (tests, measurements). */
 int bm_dbm_set_fast_binary(bm_dbm *h, int32_t on);
 int bm_rbm_set_fast_binary(bm_rbm *h, int32_t on);
 /* bm_dbm_ais accumulation.  0 (default): per chain the DIFFERENCE log p*_b(x) - log p*_a(x) of consecutive betas, its

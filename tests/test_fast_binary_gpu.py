@@ -23,7 +23,7 @@ def _rbm(V, H, B, fast, seed=1337):
     eng.set('vb', (orc.uniform(1, 2, 0, V) - np.float32(0.5)) * np.float32(0.3))
     eng.set('hb', (orc.uniform(1, 3, 0, H) - np.float32(0.5)) * np.float32(0.3))
     eng.seed(7)
-    eng.set_fast_binary(fast)
+    eng.set_fast_binary(fast, everywhere=True)
     return eng
 
 
@@ -82,7 +82,7 @@ def test_non_bitmap_input_is_refused(gpu_lib):
 def test_ais_short_runs_match_the_default_path(gpu_lib, V, nh, R):
     eng, _ = D.make_pair(V, nh, 8, 8)
     ref = eng.ais(n_betas=4, n_runs=R, k=1, seed=2222)
-    eng.set_fast_binary(True)
+    eng.set_fast_binary(True, everywhere=True)
     fast = eng.ais(n_betas=4, n_runs=R, k=1, seed=2222)
     fast2 = eng.ais(n_betas=4, n_runs=R, k=1, seed=2222)
     eng.set_fast_binary(False)
@@ -106,7 +106,7 @@ def test_ais_fast_brackets_exact_log_Z(gpu_lib):
         eng.set(nm, w); twin.p[nm][...] = w
     P = {k: v.astype(np.float64) for k, v in twin.p.items()}
     exact = ref.dbm_exact_log_Z(P['W'], P['W_1'], P['vb'], P['hb'], P['hb_1'])
-    eng.set_fast_binary(True)
+    eng.set_fast_binary(True, everywhere=True)
     vals = eng.ais(n_betas=10000, n_runs=512, k=1, seed=777).astype(np.float64)
     est = log_mean_exp(vals)
     sem = np.exp(log_std_exp(vals) - est) / np.sqrt(len(vals))
@@ -123,7 +123,7 @@ def test_ais_estimate_consistent_at_config4_shape(gpu_lib):
         eng.set(nm, eng.get(nm) * np.float32(0.3))
     est = {}
     for fast in (False, True):
-        eng.set_fast_binary(fast)
+        eng.set_fast_binary(fast, everywhere=True)
         v = eng.ais(n_betas=100, n_runs=2048, k=1, seed=99).astype(np.float64)
         e = log_mean_exp(v)
         est[fast] = (e, np.exp(log_std_exp(v) - e) / np.sqrt(len(v)))
@@ -160,7 +160,7 @@ def test_pcd_sweeps_match_the_default_path_up_to_ties(gpu_lib, V, nh, N, M, kw, 
         if gauss:
             eng.set('v', orc.normal(87654321, 77, 0, M * V).reshape(M, V))
         eng.seed(42)
-        eng.set_fast_binary(mode != 'default')
+        eng.set_fast_binary(mode != 'default', everywhere=True)
         X = orc.normal(87654321, 500, 0, N * V).reshape(N, V) if gauss else D.data(N, V, 0)
         lr = 5e-3 if gauss else 0.05
         for s in range(2):

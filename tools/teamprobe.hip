@@ -1,4 +1,4 @@
-// tools/teamprobe.hip — building blocks of a PERSISTENT update kernel (developer tool):
+// tools/teamprobe.hip — building blocks of a PERSISTENT update kernel (developer tool; profiles/NOTES.md §3.11):
 //   (A) what one `buffer_inv sc1` / `buffer_wbl2 sc1` costs when every workgroup issues it (the agent-scope fences of
 //       tools/chainprobe.hip cost 30 us per phase);
 //   (B) XCD-local teams: the 32 workgroups that share an L2 (identified by HW_REG_XCC_ID + a ticket, not by blockIdx)
