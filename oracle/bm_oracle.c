@@ -1291,3 +1291,6 @@ void orc_rbm_metrics_d(const orc_rbm_cfg *c, const double *hy, const orc_rbm_sta
     out4[3] = fe;
     free(flip);
 }
+
+/* the DBM path in float64 (shares the helpers above) */
+#include "bm_oracle_dbm64.c"

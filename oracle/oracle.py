@@ -35,8 +35,8 @@ class RbmWork(C.Structure):
 
 
 def _stale():
-    src = os.path.join(HERE, 'bm_oracle.c')
-    return not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src)
+    srcs = [os.path.join(HERE, f) for f in ('bm_oracle.c', 'bm_oracle_dbm64.c')]
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs)
 
 
 def build(force=False):
@@ -330,6 +330,16 @@ class DbmCfg(C.Structure):
                 ('h_unit', C.c_int32 * MAXL), ('n_samples', C.c_int32 * MAXL), ('sigmoid_literal', C.c_int32)]
 
 
+class DbmCfg64(C.Structure):
+    """orc_dbm_cfg_d (oracle/bm_oracle_dbm64.c): the same fields, hyper-parameters in double, no literal-sigmoid switch"""
+    _fields_ = [('L', C.c_int32), ('V', C.c_int32), ('n', C.c_int32 * MAXL),
+                ('v_unit', C.c_int32), ('sample_v', C.c_int32), ('sample_h', C.c_int32 * MAXL),
+                ('N', C.c_int32), ('M', C.c_int32), ('max_mf', C.c_int32),
+                ('mf_tol', C.c_double), ('l2', C.c_double), ('max_norm', C.c_double),
+                ('sp_target', C.c_double * MAXL), ('sp_cost', C.c_double * MAXL), ('sp_damping', C.c_double),
+                ('h_unit', C.c_int32 * MAXL), ('n_samples', C.c_int32 * MAXL)]
+
+
 class DbmState(C.Structure):
     _fields_ = [(n, C.c_void_p * MAXL) for n in ('W', 'dW', 'hb', 'dhb', 'q', 'mm', 'mu', 'mu_new', 'H', 'H_new')] + \
                [(n, C.c_void_p) for n in ('vb', 'dvb', 'sigma', 'v', 'v_new')] + [('wnorm', C.c_void_p * MAXL)]
@@ -350,12 +360,24 @@ def _dbm_lib():
         L.orc_dbm_ais.argtypes = [cp, sp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, f32p]
         L.orc_dbm_ais_literal.argtypes = [cp, sp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, f32p]
         L.orc_dbm_log_proba.argtypes = [cp, sp, f32p, f32p]
+        cd = C.POINTER(DbmCfg64)
+        L.orc_dbm_mean_field_d.restype = C.c_int
+        L.orc_dbm_mean_field_d.argtypes = [cd, sp, f64p]
+        L.orc_dbm_particles_d.argtypes = [cd, sp, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int64]
+        L.orc_dbm_reconstruct_from_mu_d.argtypes = [cd, sp, f64p]
+        L.orc_dbm_train_step_d.restype = C.c_int
+        L.orc_dbm_train_step_d.argtypes = [cd, sp, f64p, C.c_double, C.c_double, C.c_int, C.c_uint64, C.c_uint32,
+                                           C.c_int64, C.POINTER(C.c_double)]
+        L.orc_dbm_sample_v_d.argtypes = [cd, sp, C.c_int, C.c_uint64, C.c_uint32, C.c_int64]
+        L.orc_dbm_ais_d.argtypes = [cd, sp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, f64p]
+        L.orc_dbm_log_proba_d.argtypes = [cd, sp, f64p, f64p]
         L._dbm_ready = True
     return L
 
 
 class OracleDBM(object):
     """CPU twin of one bm_dbm handle (same variable names as DbmEngine.get/set)."""
+    REAL, CFG, SFX, CREAL = np.float32, DbmCfg, '', C.c_float
 
     def __init__(self, n_visible, n_hiddens, v_unit=0, sample_v_states=True, sample_h_states=None,
                  n_particles=100, batch_size=100, max_mf_updates=10, mf_tol=1e-7, l2=0., max_norm=np.inf,
@@ -363,7 +385,7 @@ class OracleDBM(object):
                  sigmoid_literal=False):
         self.V, self.nh = int(n_visible), [int(x) for x in n_hiddens]
         self.L, self.N, self.M = len(self.nh), int(batch_size), int(n_particles)
-        c = DbmCfg()
+        c = self.CFG()
         for i in range(self.L):     # hidden layer kinds: 0 Bernoulli, 2 Multinomial(n_samples[i]) (layers.py:39-70)
             c.h_unit[i] = int((h_units or [0] * self.L)[i])
             c.n_samples[i] = int((n_samples or [0] * self.L)[i])
@@ -375,12 +397,13 @@ class OracleDBM(object):
             c.n[i], c.sample_h[i], c.sp_target[i], c.sp_cost[i] = self.nh[i], int(bool(sh[i])), st[i], sc[i]
         c.N, c.M, c.max_mf = self.N, self.M, int(max_mf_updates)
         c.mf_tol, c.l2, c.sp_damping = mf_tol, l2, sparsity_damping
-        c.max_norm = float(max_norm)
-        c.sigmoid_literal = int(bool(sigmoid_literal))
+        c.max_norm = float(max_norm) if np.isfinite(max_norm) or self.REAL is np.float32 else float(np.finfo(np.float64).max)
+        if self.SFX == '':
+            c.sigmoid_literal = int(bool(sigmoid_literal))
         self.cfg = c
         n = [self.V] + self.nh
-        z = lambda *s: np.zeros(s, dtype=np.float32)
-        self.p = dict(vb=z(self.V), dvb=z(self.V), sigma=np.ones(self.V, dtype=np.float32),
+        z = lambda *s: np.zeros(s, dtype=self.REAL)
+        self.p = dict(vb=z(self.V), dvb=z(self.V), sigma=np.ones(self.V, dtype=self.REAL),
                       v=z(self.M, self.V), v_new=z(self.M, self.V))
         for i in range(self.L):
             sfx = '' if i == 0 else '_%d' % i
@@ -420,16 +443,22 @@ class OracleDBM(object):
             sfx = '' if i == 0 else '_%d' % i
             self.p['h' + sfx], self.p['h_new' + sfx] = byaddr[s.H[i]], byaddr[s.H_new[i]]
 
+    def _f(self, name):
+        return getattr(_dbm_lib(), name + self.SFX)
+
+    def _x(self, X):
+        return np.ascontiguousarray(X, dtype=self.REAL)
+
     def mean_field(self, X):
         s = self._state()
-        n = _dbm_lib().orc_dbm_mean_field(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32))
+        n = self._f('orc_dbm_mean_field')(C.byref(self.cfg), C.byref(s), self._x(X))
         self.call += 1
         return n
 
     def train_step(self, X, lr, momentum, k, want_msre=False):
         s = self._state()
-        msre = C.c_float()
-        n = _dbm_lib().orc_dbm_train_step(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32),
+        msre = self.CREAL()
+        n = self._f('orc_dbm_train_step')(C.byref(self.cfg), C.byref(s), self._x(X),
                                           lr, momentum, k, self.seed, self.call, self.prow0,
                                           C.byref(msre) if want_msre else None)
         self._sync_back(s)
@@ -440,28 +469,26 @@ class OracleDBM(object):
         """validation fetch (dbm.py:813 under the control dependencies of :521-523): mean-field, k PCD
         sweeps on the particles, reconstruction msre; no parameter update."""
         s = self._state()
-        L_ = _dbm_lib()
-        X = np.ascontiguousarray(X, dtype=np.float32)
-        n = L_.orc_dbm_mean_field(C.byref(self.cfg), C.byref(s), X)
-        L_.orc_dbm_particles(C.byref(self.cfg), C.byref(s), k, 1, self.seed, self.call, self.prow0)
-        R = np.zeros((self.N, self.V), dtype=np.float32)
-        L_.orc_dbm_reconstruct_from_mu(C.byref(self.cfg), C.byref(s), R)
+        X = self._x(X)
+        n = self._f('orc_dbm_mean_field')(C.byref(self.cfg), C.byref(s), X)
+        self._f('orc_dbm_particles')(C.byref(self.cfg), C.byref(s), k, 1, self.seed, self.call, self.prow0)
+        R = np.zeros((self.N, self.V), dtype=self.REAL)
+        self._f('orc_dbm_reconstruct_from_mu')(C.byref(self.cfg), C.byref(s), R)
         self._sync_back(s)
         self.call += 1
         return n, float(np.mean((X.astype(np.float64) - R.astype(np.float64)) ** 2))
 
     def reconstruct(self, X):
         s = self._state()
-        L_ = _dbm_lib()
-        L_.orc_dbm_mean_field(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32))
-        R = np.zeros((self.N, self.V), dtype=np.float32)
-        L_.orc_dbm_reconstruct_from_mu(C.byref(self.cfg), C.byref(s), R)
+        self._f('orc_dbm_mean_field')(C.byref(self.cfg), C.byref(s), self._x(X))
+        R = np.zeros((self.N, self.V), dtype=self.REAL)
+        self._f('orc_dbm_reconstruct_from_mu')(C.byref(self.cfg), C.byref(s), R)
         self.call += 1
         return R
 
     def sample_v(self, k):
         s = self._state()
-        _dbm_lib().orc_dbm_sample_v(C.byref(self.cfg), C.byref(s), k, self.seed, self.call, self.prow0)
+        self._f('orc_dbm_sample_v')(C.byref(self.cfg), C.byref(s), k, self.seed, self.call, self.prow0)
         self._sync_back(s)
         self.call += 1
         return self.p['v'].copy()
@@ -469,14 +496,24 @@ class OracleDBM(object):
     def ais(self, n_betas, n_runs, k, seed, chain0=0, literal=False):
         """literal: the reference's float32 accumulation order (dbm.py:708-728); default: double, difference form"""
         s = self._state()
-        out = np.zeros(n_runs, dtype=np.float32)
-        f = _dbm_lib().orc_dbm_ais_literal if literal else _dbm_lib().orc_dbm_ais
+        out = np.zeros(n_runs, dtype=self.REAL)
+        f = _dbm_lib().orc_dbm_ais_literal if (literal and self.SFX == '') else self._f('orc_dbm_ais')
         f(C.byref(self.cfg), C.byref(s), n_betas, n_runs, k, int(seed), int(chain0), out)
         return out
 
     def log_proba(self, X):
         s = self._state()
-        out = np.zeros(self.N, dtype=np.float32)
-        _dbm_lib().orc_dbm_log_proba(C.byref(self.cfg), C.byref(s), np.ascontiguousarray(X, dtype=np.float32), out)
+        out = np.zeros(self.N, dtype=self.REAL)
+        self._f('orc_dbm_log_proba')(C.byref(self.cfg), C.byref(s), self._x(X), out)
         self.call += 1
         return out
+
+
+class OracleDBM64(OracleDBM):
+    """the same in IEEE double (oracle/bm_oracle_dbm64.c): the DBM of a reference model built with dtype='float64'
+    (base/mixin.py:14-25)"""
+    REAL, CFG, SFX, CREAL = np.float64, DbmCfg64, '_d', C.c_double
+
+    def set_sigmoid_literal(self, on):
+        if on:
+            raise ValueError('the literal float32 tf.sigmoid is a float32 notion')

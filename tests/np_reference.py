@@ -261,23 +261,26 @@ class NumpyDBM(object):
         return x
 
     def ais(self, n_betas, n_runs, k, seed, chain0=0):
-        """_make_ais (:696-736) with delta_beta = 1/n_betas (:929); beta accumulates in float32 like the graph."""
+        """_make_ais (:696-736) with delta_beta = 1/n_betas (:929); beta accumulates in the model dtype like the graph
+        (`self.real`: float32 unless a test sets float64, together with a float64 `uniform0`)."""
+        R = getattr(self, 'real', np.float32)
         H1 = self.W(0).shape[1]
-        u = philox.uniform(seed, 13, 0, n_runs * H1, idx0=chain0 * H1).reshape(n_runs, H1)
-        x = (u < np.float32(0.5)).astype(np.float64)                            # :699-702
-        db = np.float32(1.0) / np.float32(n_betas)
+        uniform0 = getattr(self, 'uniform0', philox.uniform)
+        u = uniform0(seed, 13, 0, n_runs * H1, idx0=chain0 * H1).reshape(n_runs, H1)
+        x = (u < R(0.5)).astype(np.float64)                                     # :699-702
+        db = R(1.0) / R(n_betas)
         x = self.ais_next(x, float(db), k, seed, 0, chain0)                     # :704-705
         log_Z = -self.log_p_H0(x, 0.)                                           # :708
         beta, step = db, 1
-        while beta < np.float32(1.) - db + np.float32(1e-5):                    # :710-711
+        while beta < R(1.) - db + R(1e-5):                                      # :710-711
             log_Z = log_Z + self.log_p_H0(x, float(beta))                       # :714
-            x = self.ais_next(x, float(np.float32(beta + db)), k, seed, step, chain0)   # :716
+            x = self.ais_next(x, float(R(beta + db)), k, seed, step, chain0)    # :716
             log_Z = log_Z - self.log_p_H0(x, float(beta))                       # :718
-            beta = np.float32(beta + db)
+            beta = R(beta + db)
             step += 1
         log_Z = log_Z + self.log_p_H0(x, 1.)                                    # :728
         V, H2 = self.W(0).shape[0], self.W(1).shape[1]
-        return log_Z + (V + H1 + H2) * float(np.log(np.float32(2.)))            # :731-734
+        return log_Z + (V + H1 + H2) * float(np.log(R(2.)))                     # :731-734
 
     def log_proba(self, X):
         """_make_log_proba (:738-759): ELBO terms per row (log Z not subtracted)."""

@@ -428,3 +428,60 @@ def test_float64_multinomial_oracle_invariants_and_float32_agreement():
     z = X.astype(np.float64) @ W.astype(np.float64) + hb.astype(np.float64)
     sm = np.exp(z - z.max(axis=1, keepdims=True))
     np.testing.assert_allclose(t64.work['h0m'], M * sm / sm.sum(axis=1, keepdims=True), rtol=1e-12)
+
+
+# ---- float64 DBM (oracle/bm_oracle_dbm64.c): the reference's DBM graph built with dtype='float64' (base/mixin.py:14-25)
+@pytest.mark.parametrize('V,nh,N,M,kw', DBM_CASES)
+def test_oracle_dbm64_vs_numpy_restatement(V, nh, N, M, kw, monkeypatch):
+    """the double oracle against the float64 matrix-form restatement drawing from the float64 Philox stream: same sweep
+    counts and bitmaps, every real to double round-off; and its first update next to the float32 oracle's (same inputs, the
+    mean-field runs before any draw: equal to float32 accuracy)"""
+    def bernoulli64(p, seed, site, call, row0=0):
+        B, n = p.shape
+        u = orc.uniform_d(seed, site, call, B * n, idx0=row0 * n).reshape(B, n)
+        return (u < p).astype(np.float64), u
+    monkeypatch.setattr(ref, 'bernoulli', bernoulli64)
+    t32, npm = _dbm_twins(V, nh, N, M, **kw)
+    twin = orc.OracleDBM64(V, nh, n_particles=M, batch_size=N, **kw)
+    for k_, v_ in t32.p.items():
+        twin.p[k_][...] = v_
+    twin.set_seed(42); npm.seed = 42; t32.set_seed(42)
+    L = len(nh)
+    sfx = lambda i: '' if i == 0 else '_%d' % i
+    for s in range(3):
+        X = (orc.uniform(87654321, 99 + s, 0, N * V) < 0.2).astype(np.float64).reshape(N, V)
+        n1, m1 = twin.train_step(X, 0.05, 0.5, 2, want_msre=True)
+        n2, m2 = npm.train_step(X, 0.05, 0.5, 2)
+        assert n1 == n2, (s, n1, n2)
+        assert_allclose(m1, m2, rtol=1e-11)
+        assert npm.ties == 0
+        if s == 0:
+            n3, m3 = t32.train_step(X.astype(np.float32), 0.05, 0.5, 2, want_msre=True)
+            assert n3 == n1
+            assert_allclose(m3, m1, rtol=1e-5)
+            assert_allclose(t32.p['mu'], twin.p['mu'], rtol=1e-5, atol=2e-7)
+        for i in range(L):
+            for b in ('mu', 'h', 'W', 'dW', 'hb', 'dhb', 'q_means', 'mu_means'):
+                assert_allclose(twin.p[b + sfx(i)], npm.P[b + sfx(i)], rtol=1e-11, atol=1e-13, err_msg=b + sfx(i))
+        assert_allclose(twin.p['vb'], npm.P['vb'], rtol=1e-11, atol=1e-13)
+        assert_allclose(twin.p['v'], npm.P['v'], rtol=1e-11, atol=1e-13)
+    assert_allclose(twin.sample_v(2), npm.sample_v(2), rtol=1e-11, atol=1e-13)
+
+
+def test_oracle_dbm64_ais_and_elbo_vs_numpy_restatement(monkeypatch):
+    def bernoulli64(p, seed, site, call, row0=0):
+        B, n = p.shape
+        u = orc.uniform_d(seed, site, call, B * n, idx0=row0 * n).reshape(B, n)
+        return (u < p).astype(np.float64), u
+    monkeypatch.setattr(ref, 'bernoulli', bernoulli64)
+    V, nh, N, M = 20, [12, 16], 10, 10
+    t32, npm = _dbm_twins(V, nh, N, M, max_mf_updates=8, mf_tol=1e-5)
+    twin = orc.OracleDBM64(V, nh, n_particles=M, batch_size=N, max_mf_updates=8, mf_tol=1e-5)
+    for k_, v_ in t32.p.items():
+        twin.p[k_][...] = v_
+    npm.real, npm.uniform0 = np.float64, orc.uniform_d
+    assert_allclose(twin.ais(n_betas=40, n_runs=23, k=2, seed=2224, chain0=5), npm.ais(n_betas=40, n_runs=23, k=2, seed=2224, chain0=5),
+                    rtol=1e-10)
+    twin.set_seed(1); npm.seed = 1; npm.call = 0
+    X = (orc.uniform(87654321, 101, 0, N * V) < 0.2).astype(np.float64).reshape(N, V)
+    assert_allclose(twin.log_proba(X), npm.log_proba(X), rtol=1e-10)
