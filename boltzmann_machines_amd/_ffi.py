@@ -102,6 +102,20 @@ SIGNATURES = {
     'bm_rbm64_transform': [_vp, _vp, C.c_int32, C.c_int32, _vp],
     'bm_rbm64_metrics': [_vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_double)],
     'bm_rbm64_free_energy': [_vp, _vp, C.c_int32, C.POINTER(C.c_double)],
+    'bm_dbm64_create': [C.POINTER(DbmConfig), C.POINTER(C.c_double), C.POINTER(_vp)],
+    'bm_dbm64_destroy': [_vp],
+    'bm_dbm64_sync': [_vp],
+    'bm_dbm64_seed': [_vp, C.c_uint64],
+    'bm_dbm64_set_row_offset': [_vp, C.c_int64, C.c_int64],
+    'bm_dbm64_set_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_dbm64_get_param': [_vp, C.c_char_p, _vp, _sz],
+    'bm_dbm64_train_step': [_vp, _vp, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)],
+    'bm_dbm64_metrics': [_vp, _vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)],
+    'bm_dbm64_mean_field': [_vp, _vp, _vp, C.POINTER(C.c_int32)],
+    'bm_dbm64_reconstruct': [_vp, _vp, _vp],
+    'bm_dbm64_sample_v': [_vp, C.c_int32, _vp],
+    'bm_dbm64_ais': [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int64, _vp],
+    'bm_dbm64_log_proba': [_vp, _vp, _vp],
     'bm_rbm_create': [C.POINTER(RbmConfig), C.POINTER(_vp)],
     'bm_rbm_destroy': [_vp],
     'bm_rbm_sync': [_vp],

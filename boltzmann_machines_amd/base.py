@@ -191,10 +191,9 @@ class EngineModel(BaseModel, DtypeMixin):
 
     def _ensure_engine(self):
         if self._engine is None:
-            if np.dtype(self.dtype) != np.float32 and self._needs_device():
-                raise NotImplementedError("%s has no device path for dtype='%s': float64 runs for the RBMs "
-                                          "(bm_rbm64_*), the DBM computes in float32"
-                                          % (self.__class__.__name__, self.dtype))
+            if np.dtype(self.dtype) not in (np.dtype(np.float32), np.dtype(np.float64)) and self._needs_device():
+                raise NotImplementedError("%s has no device path for dtype='%s' (float32: the tuned path; float64: the "
+                                          "compatibility paths bm_rbm64_* / bm_dbm64_*)" % (self.__class__.__name__, self.dtype))
             # Data parallelism is OPT-IN: BM355_DATA_PARALLEL=1 in the environment of a one-process-per-GPU job
             # (RANK / LOCAL_RANK / WORLD_SIZE from the launcher).  Then this process binds to its GPU and joins the
             # job's communicator before the handle is created (boltzmann_machines_amd/parallel.py), and the semantics

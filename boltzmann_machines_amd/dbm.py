@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _ffi
 from .base import EngineModel, run_on_engine
-from .engine import DbmEngine, as_device
+from .engine import DbmEngine, DbmEngine64
 from .rbm import GaussianRBM
 from .utils import (epoch_iter, make_list_from, write_during_training,
                     log_sum_exp, log_mean_exp, log_diff_exp, log_std_exp)
@@ -25,6 +25,11 @@ from .utils import philox
 
 # Philox sites of the host-evaluated initialisers (`layer.init`, dbm.py:362-383)
 _SITE_V_INIT, _SITE_V_NEW_INIT, _SITE_H_INIT = 20, 21, 22
+
+
+def as_device(X, dtype=np.float32):
+    """host ndarray -> DeviceArray in the engine's dtype; a DeviceArray passes through"""
+    return X if isinstance(X, _ffi.DeviceArray) else _ffi.DeviceArray.from_numpy(np.asarray(X), dtype)
 
 
 class DBM(EngineModel):
@@ -125,11 +130,12 @@ class DBM(EngineModel):
         average the biases that two RBMs give to the same layer."""
         L = self.n_layers_
         W_init, hb_init = [], []
-        vb_init = np.array(self._vb_init[0], dtype=np.float32)
+        dt = self._np_dtype
+        vb_init = np.array(self._vb_init[0], dtype=dt)
         for i in range(L):
-            W = np.array(self._W_init[i], dtype=np.float32)
-            vb = np.array(self._vb_init[i], dtype=np.float32)
-            hb = np.array(self._hb_init[i], dtype=np.float32)
+            W = np.array(self._W_init[i], dtype=dt)
+            vb = np.array(self._vb_init[i], dtype=dt)
+            hb = np.array(self._hb_init[i], dtype=dt)
             if 0 < i < L - 1:
                 W *= 0.5
                 vb *= 0.5
@@ -164,26 +170,27 @@ class DBM(EngineModel):
         L, M, V = self.n_layers_, self.n_particles, self.n_visible_
         seed = self._graph_seed if self._graph_seed is not None else philox.DEFAULT_GRAPH_SEED
         d = dict(vb=vb_init)
+        dt = self._np_dtype
         if self._sigma_init is not None:
-            d['sigma'] = np.asarray(self._sigma_init, dtype=np.float32)
+            d['sigma'] = np.asarray(self._sigma_init, dtype=dt)
 
         def v_init(site):       # `layer.init`: U[0,1) reals for Bernoulli (layers.py:43-45), N(0,1)*sigma for Gaussian
             if self.v_unit_ == _ffi.UNIT_GAUSSIAN:
-                return philox.normal(seed, site, 0, M * V).reshape(M, V) * d.get('sigma', np.float32(1.))
-            return philox.uniform(seed, site, 0, M * V).reshape(M, V)
-        d['v'] = np.asarray(self._v_particle_init, dtype=np.float32) if self._v_particle_init is not None \
+                return philox.normal(seed, site, 0, M * V, dtype=dt).reshape(M, V) * d.get('sigma', dt(1.))
+            return philox.uniform(seed, site, 0, M * V, dtype=dt).reshape(M, V)
+        d['v'] = np.asarray(self._v_particle_init, dtype=dt) if self._v_particle_init is not None \
             else v_init(_SITE_V_INIT)
         d['v_new'] = v_init(_SITE_V_NEW_INIT)
         for i in range(L):
             s, n = self._sfx(i), self.n_hiddens_[i]
             d['W' + s], d['hb' + s] = W_init[i], hb_init[i]
             def h_init(site):       # BernoulliLayer.init: U[0,1) (layers.py:43-45); MultinomialLayer.init: the same
-                t = philox.uniform(seed, site, 0, M * n).reshape(M, n)      # divided by the sum over the WHOLE tensor
+                t = philox.uniform(seed, site, 0, M * n, dtype=dt).reshape(M, n)      # divided by the sum over the WHOLE tensor
                 if self._h_unit(i) == _ffi.UNIT_MULTINOMIAL:                # (layers.py:59-63)
-                    t = (t / np.sum(t, dtype=np.float32)).astype(np.float32)
+                    t = (t / np.sum(t, dtype=dt)).astype(dt)
                 return t
             if self._h_particles_init is not None:
-                d['h' + s] = np.asarray(self._h_particles_init[i], dtype=np.float32).reshape(M, n)
+                d['h' + s] = np.asarray(self._h_particles_init[i], dtype=dt).reshape(M, n)
             else:
                 d['h' + s] = h_init(_SITE_H_INIT + 2 * i)
             d['h_new' + s] = h_init(_SITE_H_INIT + 2 * i + 1)
@@ -200,9 +207,16 @@ class DBM(EngineModel):
     def _make_engine(self):
         if self.n_layers_ is None:
             raise RuntimeError('DBM has no layers: pass `rbms` or use `load_model`')
-        if np.dtype(self.dtype) != np.float32:
-            raise NotImplementedError("the MI355X engine computes in float32 (dtype='%s' requested)" % self.dtype)
-        self._engine = DbmEngine(self.n_visible_, self.n_hiddens_, v_unit=self.v_unit_,
+        f64 = np.dtype(self.dtype) == np.float64
+        if np.dtype(self.dtype) != np.float32 and not f64:
+            raise NotImplementedError("DBM: dtype must be 'float32' or 'float64' (got %r)" % (self.dtype,))
+        if f64:
+            # DBM(dtype='float64') (base/mixin.py:14-25): the float64 compatibility path (csrc/bm_dbm64.hip)
+            if any(self._h_unit(i) != _ffi.UNIT_BERNOULLI for i in range(self.n_layers_)):
+                raise NotImplementedError('float64 DBM: Bernoulli hidden layers only (Multinomial layers run in float32)')
+            if getattr(self, '_comm', None) is not None:
+                raise NotImplementedError('float64 DBM: single-process only')
+        self._engine = (DbmEngine64 if f64 else DbmEngine)(self.n_visible_, self.n_hiddens_, v_unit=self.v_unit_,
                                  sample_v_states=self.sample_v_states, sample_h_states=self.sample_h_states,
                                  n_particles=self.n_particles, batch_size=self.batch_size,
                                  max_mf_updates=self.max_mf_updates, mf_tol=self.mf_tol, l2=self.l2,
@@ -211,9 +225,9 @@ class DBM(EngineModel):
                                  h_units=self.h_units_ or None, n_samples=self.h_n_samples_ or None)
         # opt-in speed mode for log_Z (AIS): exact-product bf16 x 3 for the {0,1}-state contractions; tolerance parity
         # (DESIGN.md 3.9).  The reference API has no switch for it, so it is read from the environment.
-        if os.environ.get('BM355_FAST_BINARY', '0') == '1' and not self._sigmoid_literal:
+        if os.environ.get('BM355_FAST_BINARY', '0') == '1' and not self._sigmoid_literal and not f64:
             self._engine.set_fast_binary(True)
-        if self._sigmoid_literal:
+        if self._sigmoid_literal and not f64:
             self._engine.set_sigmoid_literal(True)
         if self._pending_vars is None:          # fresh model (load_model uploads its checkpoint instead)
             self._upload_variables(self._initial_variables())
@@ -322,14 +336,15 @@ class DBM(EngineModel):
         return np.mean(msres), np.mean(nmfs)
 
     def _fit(self, X, X_val=None, *args, **kwargs):
-        X = np.ascontiguousarray(X, dtype=np.float32)
+        dt = self._engine.dtype
+        X = np.ascontiguousarray(X, dtype=dt)
         self._check_batches(X, sharded=True)
-        Xd, N = as_device(X), len(X)
+        Xd, N = as_device(X, dt), len(X)
         Xvd = None
         if X_val is not None:
-            X_val = np.ascontiguousarray(X_val, dtype=np.float32)
+            X_val = np.ascontiguousarray(X_val, dtype=dt)
             self._check_batches(X_val, sharded=True)
-            Xvd = as_device(X_val)
+            Xvd = as_device(X_val, dt)
         val_msre, val_n_mf_updates = None, None
         for self.epoch_ in epoch_iter(start_epoch=self.epoch_, max_epoch=self.max_epoch, verbose=self.verbose):
             train_msre, train_n_mf_updates = self._train_epoch(Xd, N)
@@ -386,10 +401,11 @@ class DBM(EngineModel):
     def transform(self, X, np_dtype=None):
         """Mean-field activations of the last hidden layer (reference dbm.py:859-872)."""
         np_dtype = np_dtype or self._np_dtype
-        X = np.ascontiguousarray(X, dtype=np.float32)
+        dt = self._engine.dtype
+        X = np.ascontiguousarray(X, dtype=dt)
         self._check_batches(X)
-        Xd = as_device(X)
-        Gd = _ffi.DeviceArray((len(X), self.n_hiddens_[-1]))
+        Xd = as_device(X, dt)
+        Gd = _ffi.DeviceArray((len(X), self.n_hiddens_[-1]), dt)
         snap = self._snapshot(('mu', 'mu_new'))
         for start in range(0, len(X), self.batch_size):
             self._engine.mean_field(Xd, row=start, out=Gd, out_row=start)
@@ -400,10 +416,11 @@ class DBM(EngineModel):
     @run_on_engine(update_seed=True)
     def reconstruct(self, X):
         """p(v | h_0 = q), q = mean-field p(h_0 | v = x) (reference dbm.py:874-885)."""
-        X = np.ascontiguousarray(X, dtype=np.float32)
+        dt = self._engine.dtype
+        X = np.ascontiguousarray(X, dtype=dt)
         self._check_batches(X)
-        Xd = as_device(X)
-        Rd = _ffi.DeviceArray(X.shape)
+        Xd = as_device(X, dt)
+        Rd = _ffi.DeviceArray(X.shape, dt)
         snap = self._snapshot(('mu', 'mu_new'))
         for start in range(0, len(X), self.batch_size):
             self._engine.reconstruct(Xd, Rd, row=start, out_row=start)
@@ -415,7 +432,7 @@ class DBM(EngineModel):
     def sample_v(self, n_gibbs_steps=0, save_model=False):
         """Visible particle activation probabilities after `n_gibbs_steps` sweeps
         (reference dbm.py:887-897, op :641-648)."""
-        Vd = _ffi.DeviceArray((self.n_particles, self.n_visible_))
+        Vd = _ffi.DeviceArray((self.n_particles, self.n_visible_), self._engine.dtype)
         snap = None if save_model else self._snapshot(('v', 'v_new', 'h', 'h_new'))
         self._engine.sample_v(int(n_gibbs_steps), Vd)
         v = Vd.numpy()
@@ -479,9 +496,9 @@ class DBM(EngineModel):
         """Variational lower bound on log p(x) for the 2-layer binary DBM (reference dbm.py:941-957)."""
         assert self.n_layers_ == 2
         assert self._all_bernoulli()           # reference dbm.py:947-948
-        X_test = np.ascontiguousarray(X_test, dtype=np.float32)
+        X_test = np.ascontiguousarray(X_test, dtype=self._engine.dtype)
         self._check_batches(X_test)
-        Xd = as_device(X_test)
+        Xd = as_device(X_test, self._engine.dtype)
         P = np.zeros(len(X_test))
         snap = self._snapshot(('mu', 'mu_new'))
         for start in range(0, len(X_test), self.batch_size):

@@ -307,11 +307,17 @@ class DbmEngine(object):
         cfg.mf_tol, cfg.l2, cfg.max_norm = float(mf_tol), float(l2), float(max_norm)
         cfg.sparsity_damping = float(sparsity_damping)
         self._h = C.c_void_p()
+        self._create(cfg, (float(mf_tol), float(l2), float(max_norm), float(sparsity_damping),
+                           [float(x) for x in st], [float(x) for x in sc]))
+
+    dtype = np.float32
+
+    def _create(self, cfg, hyper):
         check(self.lib.bm_dbm_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
-            self.lib.bm_dbm_destroy(self._h)
+            (self.lib.bm_dbm64_destroy if self.dtype == np.float64 else self.lib.bm_dbm_destroy)(self._h)
             self._h = None
 
     def __del__(self):
@@ -469,3 +475,88 @@ class DbmEngine(object):
         ms = C.c_float()
         check(self.lib.bm_dbm_timer_elapsed(self._h, C.byref(ms)))
         return float(ms.value)
+
+
+
+class DbmEngine64(DbmEngine):
+    """float64 DBM handle (bm_dbm64_*, include/bm355.h): the method names of DbmEngine with float64 device arrays and
+    scalars.  Compatibility path for DBM(dtype='float64') (base/mixin.py:14-25): Bernoulli hidden layers, one process."""
+
+    dtype = np.float64
+
+    def _create(self, cfg, hyper):
+        mf_tol, l2, max_norm, damping, st, sc = hyper
+        if not np.isfinite(max_norm):
+            max_norm = float(np.finfo(np.float64).max)
+        pad = lambda v: list(v) + [0.0] * (4 - len(v))
+        h12 = (C.c_double * 12)(mf_tol, l2, max_norm, damping, *(pad(st) + pad(sc)))
+        check(self.lib.bm_dbm64_create(C.byref(cfg), h12, C.byref(self._h)))
+
+    def set(self, name, value):
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float64), self.shape(name)))
+        check(self.lib.bm_dbm64_set_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+
+    def get(self, name):
+        a = np.empty(self.shape(name), dtype=np.float64)
+        check(self.lib.bm_dbm64_get_param(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size))
+        return a
+
+    def seed(self, seed):
+        check(self.lib.bm_dbm64_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def set_row_offset(self, row0, particle0):
+        check(self.lib.bm_dbm64_set_row_offset(self._h, int(row0), int(particle0)))
+
+    def sync(self):
+        check(self.lib.bm_dbm64_sync(self._h))
+
+    def train_step(self, Xd, lr, momentum, k, row=0, want_msre=False):
+        nmf, msre = C.c_int32(), C.c_double()
+        check(self.lib.bm_dbm64_train_step(self._h, Xd.offset_ptr(row * self.V), lr, momentum, k, C.byref(nmf),
+                                           C.byref(msre) if want_msre else None))
+        return int(nmf.value), (float(msre.value) if want_msre else None)
+
+    def metrics(self, Xd, k, row=0):
+        nmf, msre = C.c_int32(), C.c_double()
+        check(self.lib.bm_dbm64_metrics(self._h, Xd.offset_ptr(row * self.V), k, C.byref(nmf), C.byref(msre)))
+        return int(nmf.value), float(msre.value)
+
+    def mean_field(self, Xd, row=0, out=None, out_row=0):
+        nmf = C.c_int32()
+        p = out.offset_ptr(out_row * self.n_hiddens[-1]) if out is not None else None
+        check(self.lib.bm_dbm64_mean_field(self._h, Xd.offset_ptr(row * self.V), p, C.byref(nmf)))
+        return int(nmf.value)
+
+    def reconstruct(self, Xd, Rd, row=0, out_row=0):
+        check(self.lib.bm_dbm64_reconstruct(self._h, Xd.offset_ptr(row * self.V), Rd.offset_ptr(out_row * self.V)))
+
+    def sample_v(self, k, Vd=None):
+        check(self.lib.bm_dbm64_sample_v(self._h, k, Vd.ptr if Vd is not None else None))
+
+    def ais(self, n_betas, n_runs, k, seed, chain0=0):
+        out = np.empty(n_runs, dtype=np.float64)
+        check(self.lib.bm_dbm64_ais(self._h, n_betas, n_runs, k, int(seed) & 0xFFFFFFFFFFFFFFFF, int(chain0),
+                                    out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def log_proba(self, Xd, row=0):
+        out = np.empty(self.N, dtype=np.float64)
+        check(self.lib.bm_dbm64_log_proba(self._h, Xd.offset_ptr(row * self.V), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def _unsupported(self, *a, **kw):
+        raise NotImplementedError('the float64 DBM path is a single-process compatibility path (csrc/bm_dbm64.hip)')
+
+    grad_step = apply_step = set_comm = set_xchg = ais_sharded = ais_sharded_direct = set_mf_allreduce = _unsupported
+    device_view = stream = timer_start = timer_stop = timer_mark = timer_elapsed = _unsupported
+
+    def set_fast_binary(self, on, everywhere=False):
+        if on:
+            self._unsupported()
+
+    def set_ais_literal(self, on):
+        pass                                    # float64 AIS accumulates in double: the model dtype IS the literal order's dtype
+
+    def set_sigmoid_literal(self, on):
+        if on:
+            raise ValueError('the literal float32 tf.sigmoid is a float32 notion')

@@ -46,8 +46,13 @@ def _u32x2_to_f64(x0, x1):
     return (m | (np.uint64(1023) << np.uint64(52))).view(np.float64) - 1.0
 
 
-def uniform(seed, site, call, n, idx0=0):
-    """n float32 uniforms in [0,1): element i = word i%4 of block i/4 (TF Uint32ToFloat)."""
+def uniform(seed, site, call, n, idx0=0, dtype=np.float32):
+    """n uniforms in [0,1).  float32: element i = word i%4 of block i/4 (TF Uint32ToFloat); float64: element i = the word
+    pair i%2 of block i/2 (TF Uint64ToDouble)."""
+    if np.dtype(dtype) == np.float64:
+        b0, b1 = idx0 // 2, (idx0 + n + 1) // 2
+        w = philox_blocks(seed, site, call, b0, b1 - b0).reshape(-1, 2)      # rows = word pairs
+        return _u32x2_to_f64(w[:, 0], w[:, 1])[idx0 - 2 * b0: idx0 - 2 * b0 + n]
     b0, b1 = idx0 // 4, (idx0 + n + 3) // 4
     w = philox_blocks(seed, site, call, b0, b1 - b0).reshape(-1)
     return _u32_to_f32(w[idx0 - 4 * b0: idx0 - 4 * b0 + n])

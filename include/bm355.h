@@ -426,6 +426,31 @@ int bm_dbm_set_ais_literal(bm_dbm *h, int32_t on);
  * reference's mean-field trip counts - the loop of dbm.py:449-452 at mf_tol = 1e-7 is decided in the last bits of the
  * means (784-512-1024: 5 - 6 sweeps per update with the literal form, 7 - 8 with the default). */
 int bm_dbm_set_sigmoid_literal(bm_dbm *h, int32_t on);
+/* ---- float64 DBM path ----------------------------------------------------------------------
+ * DBM(dtype='float64') (base/mixin.py:14-25; the DBM graph is built "all in model dtype", dbm.py:294-383): the fetch sites
+ * of the float32 entry points above with every buffer, hyper-parameter and random draw in double, on the FP64 tile engine of
+ * the float64 RBM path (sequential ascending-k fma chains: bit-identical to oracle/bm_oracle_dbm64.c for everything that
+ * feeds back into state).  A compatibility path (csrc/bm_dbm64.hip): Bernoulli hidden layers, Bernoulli or Gaussian visible
+ * units, one process; the mean-field loop is driven by the host.  Variables as in bm_dbm_set_param.
+ * hyper12 = {mf_tol, l2, max_norm, sparsity_damping, sparsity_target[4], sparsity_cost[4]} as doubles (NULL: from cfg). */
+typedef struct bm_dbm64 bm_dbm64;
+int bm_dbm64_create(const bm_dbm_config *cfg, const double *hyper12, bm_dbm64 **out);
+int bm_dbm64_destroy(bm_dbm64 *h);
+int bm_dbm64_sync(bm_dbm64 *h);
+int bm_dbm64_seed(bm_dbm64 *h, uint64_t seed);                                           /* tf_model.py:20-21 */
+int bm_dbm64_set_row_offset(bm_dbm64 *h, int64_t row0, int64_t particle0);
+int bm_dbm64_set_param(bm_dbm64 *h, const char *name, const double *host, size_t n);     /* tf_model.py:22-28 */
+int bm_dbm64_get_param(bm_dbm64 *h, const char *name, double *host, size_t n);           /* tf_model.py:183-202 */
+int bm_dbm64_train_step(bm_dbm64 *h, const double *X_dev, double learning_rate, double momentum,   /* dbm.py:805 */
+                        int32_t n_gibbs_steps, int32_t *out_n_mf, double *out_msre);
+int bm_dbm64_metrics(bm_dbm64 *h, const double *X_dev, int32_t n_gibbs_steps, int32_t *out_n_mf, double *out_msre);   /* dbm.py:813 */
+int bm_dbm64_mean_field(bm_dbm64 *h, const double *X_dev, double *out_dev, int32_t *out_n_mf);   /* dbm.py:866 */
+int bm_dbm64_reconstruct(bm_dbm64 *h, const double *X_dev, double *R_dev);                        /* dbm.py:881 */
+int bm_dbm64_sample_v(bm_dbm64 *h, int32_t n_gibbs_steps, double *V_dev);                         /* dbm.py:892 */
+int bm_dbm64_ais(bm_dbm64 *h, int32_t n_betas, int32_t n_runs, int32_t n_gibbs_steps, uint64_t seed, int64_t chain0,
+                 double *values_host);                                                            /* dbm.py:930 */
+int bm_dbm64_log_proba(bm_dbm64 *h, const double *X_dev, double *out_host);                       /* dbm.py:953 */
+
 /* like bm_dbm_set_comm, with the per-sweep residual max going through bm_xchg_allreduce_max1; NULL removes it */
 int bm_dbm_set_xchg(bm_dbm *h, bm_xchg *x);
 

@@ -373,7 +373,7 @@ void orc_dbm_ais_d(const orc_dbm_cfg_d *c, const orc_dbm_state_d *s, int n_betas
         beta = beta + db;
     }
     ais_log_p_d(c, s, x, R, 1.0, lp);                                        /* + log p_M(x_M)          :728 */
-    const double logZ0 = (double)(V + H1 + H2) * (double)log(2.0);        /* :731-734 */
+    const double logZ0 = (double)(V + H1 + H2) * (double)0.693147182464599609375f;   /* :731-734: tf.log(2.) is a float32 node, cast to the model dtype afterwards */
     for (int r = 0; r < R; ++r) values[r] = (double)(lz[r] + lp[r] + logZ0);
     free(x); free(xn); free(v); free(h2); free(lz); free(lp); free(Wt0); free(Wt1);
 #undef AIS_TRANSIT

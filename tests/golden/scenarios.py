@@ -184,7 +184,7 @@ def rbm_config0_shape(pkg, d):
 
 
 # ------------------------------------------------------------------------------------------------ DBM scenarios
-def _pretrain(pkg, d, X, sizes, v_cls='BernoulliRBM', top_cls='BernoulliRBM', epochs=2, seeds=(11, 12, 13), **top_kw):
+def _pretrain(pkg, d, X, sizes, v_cls='BernoulliRBM', top_cls='BernoulliRBM', epochs=2, seeds=(11, 12, 13), dtype=None, **top_kw):
     rbms, Q = [], X
     for i in range(len(sizes) - 1):
         last = i == len(sizes) - 2
@@ -192,6 +192,8 @@ def _pretrain(pkg, d, X, sizes, v_cls='BernoulliRBM', top_cls='BernoulliRBM', ep
         kw = dict(n_visible=sizes[i], n_hidden=sizes[i + 1], dbm_first=(i == 0 and len(sizes) > 2),
                   dbm_last=(last and len(sizes) > 2), max_epoch=epochs, batch_size=10, learning_rate=0.05,
                   random_seed=seeds[i], verbose=False, model_path=os.path.join(d, 'rbm%d/' % i))
+        if dtype:
+            kw['dtype'] = dtype
         if last:
             kw.update(top_kw)
         if i == 0 and v_cls == 'GaussianRBM':
@@ -252,6 +254,20 @@ def dbm_two_layers(pkg, d):
                   learning_rate=[0.02, 0.01], momentum=[0.5, 0.9], max_epoch=2, l2=1e-4, max_norm=0.6,
                   sparsity_cost=[0.01, 0.02], sparsity_target=[0.2, 0.1], random_seed=13, verbose=True,
                   train_metrics_every_iter=2, model_path=os.path.join(d, 'dbm/'))
+    return _dbm_walk(pkg, d, dbm, X, X_val, {})
+
+
+def dbm_float64(pkg, d):
+    """the 20-12-16 walk of `dbm_two_layers` with dtype='float64' (base/mixin.py:14-25; the DBM graph is built "all in model
+    dtype", dbm.py:294-383): float64 RBMs, a float64 DBM, mean-field at the reference's default tolerance, every public call"""
+    V, N = 20, 40
+    X = (pkg.RNG(seed=5).rand(N, V) < 0.3).astype(np.float64)
+    X_val = (pkg.RNG(seed=6).rand(20, V) < 0.3).astype(np.float64)
+    rbms, _ = _pretrain(pkg, d, X, (V, 12, 16), dtype='float64')
+    dbm = pkg.DBM(rbms=rbms, n_particles=10, batch_size=10, n_gibbs_steps=[1, 2, 3], max_mf_updates=20, mf_tol=1e-7,
+                  learning_rate=[0.02, 0.01], momentum=[0.5, 0.9], max_epoch=2, l2=1e-4, max_norm=0.6,
+                  sparsity_cost=[0.01, 0.02], sparsity_target=[0.2, 0.1], random_seed=13, verbose=True,
+                  train_metrics_every_iter=2, dtype='float64', model_path=os.path.join(d, 'dbm/'))
     return _dbm_walk(pkg, d, dbm, X, X_val, {})
 
 
@@ -389,7 +405,7 @@ def ais_config4_slice(pkg, d, seed=2222):
 
 SCENARIOS = dict((f.__name__, f) for f in (
     rbm_reference_test_config, rbm_float64, rbm_multinomial, rbm_gaussian, rbm_schedules, rbm_means_only,
-    rbm_config0_shape, dbm_two_layers, dbm_three_layers, dbm_gaussian_bernoulli_multinomial,
+    rbm_config0_shape, dbm_two_layers, dbm_float64, dbm_three_layers, dbm_gaussian_bernoulli_multinomial,
     rbm_config1_shape, dbm_config3_shape_b100, dbm_config3_shape_b512, ais_config4_slice))
 
 # the scenarios at the BASELINE sizes (slower: seconds on the device, a minute or two on the CPU oracle)

@@ -280,7 +280,7 @@ class NumpyDBM(object):
             step += 1
         log_Z = log_Z + self.log_p_H0(x, 1.)                                    # :728
         V, H2 = self.W(0).shape[0], self.W(1).shape[1]
-        return log_Z + (V + H1 + H2) * float(np.log(R(2.)))                     # :731-734
+        return log_Z + (V + H1 + H2) * float(np.log(np.float32(2.)))            # :731-734: tf.log(2.) is a float32 node in every dtype
 
     def log_proba(self, X):
         """_make_log_proba (:738-759): ELBO terms per row (log Z not subtracted)."""

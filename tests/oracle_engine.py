@@ -39,8 +39,8 @@ class HostArray(object):
         pass
 
 
-def as_device(X):
-    return X if isinstance(X, HostArray) else HostArray.from_numpy(np.asarray(X), np.float32)
+def as_device(X, dtype=np.float32):
+    return X if isinstance(X, HostArray) else HostArray.from_numpy(np.asarray(X), dtype)
 
 
 class _OracleRbmBase(object):
@@ -139,12 +139,14 @@ class OracleRbmEngine64(_OracleRbmBase):
 
 
 class OracleDbmEngine(object):
+    dtype, TWIN = np.float32, orc.OracleDBM
+
     def __init__(self, n_visible, n_hiddens, v_unit=0, sample_v_states=True, sample_h_states=None, n_particles=100,
                  batch_size=100, max_mf_updates=10, mf_tol=1e-7, l2=0., max_norm=np.inf, sparsity_target=0.1,
                  sparsity_cost=0., sparsity_damping=0.9, h_units=None, n_samples=None):
         self.V, self.n_hiddens = int(n_visible), [int(x) for x in n_hiddens]
         self.N, self.M = int(batch_size), int(n_particles)
-        self.twin = orc.OracleDBM(n_visible, n_hiddens, v_unit=v_unit, sample_v_states=sample_v_states,
+        self.twin = self.TWIN(n_visible, n_hiddens, v_unit=v_unit, sample_v_states=sample_v_states,
                                   sample_h_states=sample_h_states, n_particles=n_particles, batch_size=batch_size,
                                   max_mf_updates=max_mf_updates, mf_tol=mf_tol, l2=l2, max_norm=max_norm,
                                   sparsity_target=sparsity_target, sparsity_cost=sparsity_cost,
@@ -155,7 +157,7 @@ class OracleDbmEngine(object):
 
     def set(self, name, value):
         p = self.twin.p[name]
-        p[...] = np.broadcast_to(np.asarray(value, dtype=np.float32), p.shape)
+        p[...] = np.broadcast_to(np.asarray(value, dtype=p.dtype), p.shape)
 
     def get(self, name):
         return self.twin.p[name].copy()
@@ -206,6 +208,10 @@ class OracleDbmEngine(object):
         return self.twin.log_proba(self._rows(Xd, row))
 
 
+class OracleDbmEngine64(OracleDbmEngine):
+    dtype, TWIN = np.float64, orc.OracleDBM64
+
+
 def install(monkeypatch):
     """the model classes of boltzmann_machines_amd run on the oracle for the duration of a test"""
     from boltzmann_machines_amd import _ffi, rbm, dbm, engine
@@ -216,3 +222,4 @@ def install(monkeypatch):
     monkeypatch.setattr(rbm, 'RbmEngine', OracleRbmEngine)
     monkeypatch.setattr(rbm, 'RbmEngine64', OracleRbmEngine64)
     monkeypatch.setattr(dbm, 'DbmEngine', OracleDbmEngine)
+    monkeypatch.setattr(dbm, 'DbmEngine64', OracleDbmEngine64)

@@ -29,7 +29,7 @@ MAX_FORKED_FRACTION = 0.15  # of the rows of a row-local output (64 AIS chains x
 def tolerances(name):
     """north_star's 1e-5 float32 relative for every scenario; float64 at its own round-off"""
     from tests.golden import scenarios
-    if name == 'rbm_float64':
+    if name in ('rbm_float64', 'dbm_float64'):
         tol = dict(rtol=1e-11, metrics_rtol=1e-7, atol=1e-15)      # progress lines carry 9 significant digits
     else:
         tol = dict(rtol=1e-5, metrics_rtol=1e-5)
