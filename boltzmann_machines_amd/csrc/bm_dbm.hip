@@ -41,6 +41,9 @@ struct bm_dbm {
     // small mean-field kernels.  `cur` is the stream layer_update / gibbs_sweep enqueue on.
     hipStream_t stream2 = nullptr, cur = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int pcd_geo = 3;                               // tile of the particle passes while they share the chip with the mean-field
+                                                   // loop (ActArgs::geo_hint; BM355_DEBUG=dbm_pcd_geo=N, 0 = the tuner's choice):
+                                                   // 1.388 -> 1.353 ms per update at 784-512-1024 x 512 (profiles/r6_dbm_ab.txt)
     int updates_seen = 0;                          // the first updates run on one stream (launch tuning measures alone)
     // mean-field loop control mirror: pinned host copies of `ctl`, one per enqueued group of sweeps, so that the next
     // group is enqueued BEFORE the previous group's result is read (the GPU never waits for the host)
@@ -194,6 +197,7 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
     a.key = key; a.row0 = row0;
     a.prev = prev; a.maxdiff = maxdiff;
     a.lit = h->sigmoid_literal;
+    if (h->cur == h->stream2 && h->pcd_geo) a.geo_hint = h->pcd_geo;      // a pass that runs beside the mean-field loop
     if (h->fast_now && !h->multinomial(layer) && a.kind != 2) {
         // fast-binary: the same contraction from the bf16 weight planes and the bf16 shadows of the {0,1} inputs
         // (a state matrix without a valid shadow - real-valued visibles, the first PCD sweep - keeps the fp32 path)
@@ -318,15 +322,22 @@ static int read_flag(bm_dbm *h, float *out) {
 // installed (bm_dbm_set_comm) the residual is all-reduced (max) on the device, in stream order, per sweep;
 // only the host-callback hook (bm_dbm_set_mf_allreduce) costs a host round trip per sweep.
 // the part of `_make_mf` in front of the loop: approximate-inference init, the hoisted X.W0, the step-0 condition
+static bool mf_self_ctl(const bm_dbm *h) {
+    // Self-controlled sweeps (single GPU, Bernoulli layers, grids that fit the residual slots), see mean_field()
+    bool ok = !h->comm && !h->xchg && !h->mf_reduce;
+    for (int i = 0; i < h->L; ++i)
+        ok = ok && !h->multinomial(i) && ((h->n[i + 1] + 31) / 32) * ((h->N + 31) / 32) <= BM_MF_SLOTS;
+    return ok;
+}
 static int mf_prologue(bm_dbm *h, const float *X_dev, bool &hoist) {
     const int L = h->L, N = h->N;
-    // approximate-inference init into the mu_new VARIABLES (:434-446): doubled bottom-up pass
-    for (int i = 0; i < L; ++i) {
-        LayerIn below = (i == 0) ? LayerIn{X_dev, h->V} : LayerIn{h->mu_new[i - 1].p, h->mu_new[i - 1].ld};
-        const float mult = (i == 0 || i < L - 1) ? 2.f : 1.f;
-        layer_update(h, i, N, below, LayerIn{nullptr, 0}, mult, 1.f, 0, h->mu_new[i].p, nullptr, h->mu_new[i].ld,
-                     dkey(h, 0, 0, h->seed, h->call), 0);
-    }
+    static const bool fold = !(bm::dbg("mf_fold") && atoi(bm::dbg("mf_fold")) == 0);   // =0: the separate residual kernels (A/B)
+    // cond at step 0 compares the persistent mu with the init values (:449-452): every init pass leaves max |mu_new - mu| of
+    // its tile in its residual slot (or, where there are no slots, in the atomic cell) - the mean-field passes' own epilogue
+    // path - instead of two more kernels reading both matrices again
+    BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
+    const bool slots = fold && !h->mf_reduce;                  // (the host-callback path reads the atomic cell alone)
+    if (slots && mf_self_ctl(h)) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * (size_t)MAXL * BM_MF_SLOTS * sizeof(float), h->stream));
     // hoisted loop invariant of the sweeps: z0 = X.W0 (raw chain, no activation)
     hoist = L >= 2 && !h->multinomial(0);
     if (hoist) {
@@ -336,19 +347,48 @@ static int mf_prologue(bm_dbm *h, const float *X_dev, bool &hoist) {
         layer_update(h, 0, N, LayerIn{X_dev, h->V}, LayerIn{nullptr, 0}, 1.f, 1.f, 0, h->xw0.p, nullptr, h->xw0.ld,
                      dkey(h, 0, 0, h->seed, h->call), 0, nullptr, nullptr, &e);
     }
-    // cond at step 0 compares the persistent mu with the init values (:449-452)
-    BM_HIP(hipMemsetAsync(h->flag, 0, sizeof(unsigned), h->stream));
-    for (int i = 0; i < L; ++i)
-        hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 256 ? N : 256), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
-                           (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
+    // approximate-inference init into the mu_new VARIABLES (:434-446): doubled bottom-up pass
+    for (int i = 0; i < L; ++i) {
+        LayerIn below = (i == 0) ? LayerIn{X_dev, h->V} : LayerIn{h->mu_new[i - 1].p, h->mu_new[i - 1].ld};
+        const float mult = (i == 0 || i < L - 1) ? 2.f : 1.f;
+        float *blk = slots ? h->mfblk.p + (size_t)i * BM_MF_SLOTS : nullptr;
+        if (i == 0 && hoist && fold) {
+            // the first layer's init is the activation of the chain just stored: sigmoid(2 z0 + hb) elementwise, same bits
+            const int nwg = N < 256 ? N : 256;
+            hipLaunchKernelGGL(mf_init0_kernel, dim3(nwg), dim3(256), 0, h->stream, (const float *)h->xw0.p, h->xw0.ld,
+                               (const float *)h->hb[0].p, (const float *)h->mu[0].p, h->mu[0].ld, h->mu_new[0].p, h->mu_new[0].ld,
+                               N, h->n[1], mult, 1.f, h->sigmoid_literal ? 1 : 0, h->flag, blk);
+            continue;
+        }
+        ActArgs e;
+        memset(&e, 0, sizeof(e));
+        e.maxdiff_blk = blk;
+        layer_update(h, i, N, below, LayerIn{nullptr, 0}, mult, 1.f, 0, h->mu_new[i].p, nullptr, h->mu_new[i].ld,
+                     dkey(h, 0, 0, h->seed, h->call), 0, fold ? h->mu[i].p : nullptr, fold ? h->flag : nullptr, fold ? &e : nullptr);
+    }
+    if (!fold)
+        for (int i = 0; i < L; ++i)
+            hipLaunchKernelGGL(maxabsdiff_kernel, dim3(N < 256 ? N : 256), dim3(256), 0, h->stream, (const float *)h->mu[i].p, h->mu[i].ld,
+                               (const float *)h->mu_new[i].p, h->mu_new[i].ld, N, h->n[i + 1], h->flag);
     return 0;
 }
 
-static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
+// `mid` (optional) is called ONCE, after the part in front of the loop is in the queue and before the first sweep: work for a
+// second stream (the particle sweeps of a training update) is enqueued there - behind the few launches the critical chain starts
+// with, in front of the (up to 2 x max_mf_updates) launches of the loop, so that neither a slow host nor a long loop decides
+// when the second stream starts.
+struct MfMid { int (*fn)(bm_dbm *, void *); void *ctx; bool called; };
+static int mf_mid(bm_dbm *h, MfMid *m) {
+    if (!m || m->called) return 0;
+    m->called = true;
+    return m->fn(h, m->ctx);
+}
+static int mean_field(bm_dbm *h, const float *X_dev, int *out_n, MfMid *mid = nullptr) {
     const int L = h->L, N = h->N;
     constexpr int MF_GROUP = 8;
     bool hoist = false;
     BM_TRY(mf_prologue(h, X_dev, hoist));
+    BM_TRY(mf_mid(h, mid));
     int step = 0;
     Mat *cur = h->mu, *alt = h->mu_alt;
     if (h->mf_reduce) {
@@ -385,11 +425,12 @@ static int mean_field(bm_dbm *h, const float *X_dev, int *out_n) {
         // update of sweep s-1 is evaluated by the first kernel of sweep s (ActArgs::chk_ctl) from the slot set of
         // the other parity; only the LAST sweep of a group needs the one-workgroup control kernel.  Otherwise
         // (communicator installed, Multinomial layers, > BM_MF_SLOTS workgroups possible) one control step per sweep.
-        bool self_ctl = !h->comm && !h->xchg;
-        for (int i = 0; i < L; ++i)
-            self_ctl = self_ctl && !h->multinomial(i) && ((h->n[i + 1] + 31) / 32) * ((N + 31) / 32) <= BM_MF_SLOTS;
+        const bool self_ctl = mf_self_ctl(h);
         const size_t set_sz = (size_t)MAXL * BM_MF_SLOTS;
-        if (self_ctl) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * set_sz * sizeof(float), h->stream));
+        {
+            static const bool fold = !(bm::dbg("mf_fold") && atoi(bm::dbg("mf_fold")) == 0);
+            if (self_ctl && !fold) BM_HIP(hipMemsetAsync(h->mfblk.p, 0, 2 * set_sz * sizeof(float), h->stream));   // (else: mf_prologue)
+        }
         BM_TRY(ctl_step(1));
         // Groups of sweeps are enqueued without host round trips; the loop-control record is copied to a pinned
         // mirror after each group and READ ONE GROUP LATE: group g+1 is already in the queue when the host looks at
@@ -509,26 +550,39 @@ static void particles_update(bm_dbm *h, int k, bool sample, bool update_only_v_a
 
 
 // mean-field on the data rows and PCD sweeps on the particles of one update, concurrently (see bm_dbm::stream2).
-// The particle sweeps are enqueued FIRST (mean_field() blocks the host on its loop control), on the second stream,
-// between a fork event (everything enqueued so far, i.e. the previous parameter update) and a join event the main
-// stream waits for before anything reads the particles.  Same kernels, same RNG streams: results do not change.
+// The particle sweeps go to the second stream, between a fork event (recorded before anything of this update is enqueued: the
+// previous parameter update) and a join event the main stream waits for before anything reads the particles; the host enqueues
+// them from mean_field()'s `mid` hook - after the launches in front of the mean-field loop, before the loop's own.  Same kernels,
+// same RNG streams: results do not change.
 static bool pcd_overlap_ok(const bm_dbm *h) {
     static const bool off = bm::dbg("dbm_overlap") && atoi(bm::dbg("dbm_overlap")) == 0;
     if (off || h->updates_seen < 2) return false;          // the first updates tune their launches undisturbed
     for (int i = 0; i < h->L; ++i) if (h->multinomial(i)) return false;     // one logits row store per layer
     return true;
 }
+static int enqueue_particles_stream2(bm_dbm *h, void *ctx) {
+    const int k = *(const int *)ctx;
+    BM_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    h->cur = h->stream2;
+    particles_update(h, k, true);                                 // :521
+    h->cur = h->stream;
+    BM_HIP(hipEventRecord(h->ev_join, h->stream2));
+    return 0;
+}
 static int mean_field_and_particles(bm_dbm *h, const float *X_dev, int k, int *out_n) {
     const bool ov = pcd_overlap_ok(h);
+    // where the host enqueues the particle sweeps: behind the mean-field's prologue (default) or in front of it (=0); same time
+    // per update on a fast host (profiles/r6_dbm_ab.txt)
+    static const bool late = !(bm::dbg("dbm_pcd_late") && atoi(bm::dbg("dbm_pcd_late")) == 0);
+    MfMid mid{enqueue_particles_stream2, &k, false};
     if (ov) {
-        BM_HIP(hipEventRecord(h->ev_fork, h->stream));
-        BM_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        h->cur = h->stream2;
-        particles_update(h, k, true);                             // :521
-        h->cur = h->stream;
-        BM_HIP(hipEventRecord(h->ev_join, h->stream2));
+        BM_HIP(hipEventRecord(h->ev_fork, h->stream));            // = the previous parameter update
+        if (!late) BM_TRY(mf_mid(h, &mid));
     }
-    const int rc = mean_field(h, X_dev, out_n);                   // :517
+    int rc = mean_field(h, X_dev, out_n, ov ? &mid : nullptr);    // :517
+    if (ov && !mid.called) {                                      // the mean-field failed before its hook ran
+        if (mf_mid(h, &mid) && !rc) rc = 1;
+    }
     // (the join is enqueued even when the mean-field failed: later calls on the main stream must not race the
     //  particle sweeps still running on the second one)
     if (ov) { if (hipStreamWaitEvent(h->stream, h->ev_join, 0) != hipSuccess && !rc) { set_error("hipStreamWaitEvent(join) failed"); return 1; } }
@@ -579,27 +633,29 @@ static void launch_dbm_colsums(bm_dbm *h, const float *X_dev) {
 
 // bias / running-mean / sparsity updates from the (possibly all-reduced) column sums
 static void launch_dbm_biases(bm_dbm *h, float N, float M, float lr, float mom) {
+    static_assert(DBM_BIAS_JOBS == 1 + MAXL, "one job per layer + the visible one");
+    DbmBiasMulti m;
+    memset(&m, 0, sizeof(m));
+    int nmax = h->V;
     {
-        DbmBiasArgs b;
-        memset(&b, 0, sizeof(b));
+        DbmBiasArgs &b = m.job[0];
         b.s_pos = h->sums_p + sums_off(h, 0); b.s_neg = h->sums_p + sums_off(h, 1);
         b.b = h->vb.p; b.db = h->dvb.p; b.n = h->V; b.N = N; b.M = M; b.lr = lr; b.mom = mom;
-        hipLaunchKernelGGL(dbm_bias_kernel, dim3((h->V + 255) / 256), dim3(256), 0, h->stream, b);
     }
     for (int i = 0; i < h->L; ++i) {
-        DbmBiasArgs b;
-        memset(&b, 0, sizeof(b));
+        DbmBiasArgs &b = m.job[1 + i];
         b.s_pos = h->sums_p + sums_off(h, 2 + 2 * i); b.s_neg = h->sums_p + sums_off(h, 3 + 2 * i);
         b.b = h->hb[i].p; b.db = h->dhb[i].p; b.q = h->q[i].p; b.mm = h->mm[i].p; b.pen = h->pen[i].p;
         b.n = h->n[i + 1]; b.layer = i;
         b.N = N; b.M = M; b.lr = lr; b.mom = mom;
         b.damping = h->cfg.sparsity_damping; b.cost = h->cfg.sparsity_cost[i]; b.target = h->cfg.sparsity_target[i];
-        hipLaunchKernelGGL(dbm_bias_kernel, dim3((b.n + 255) / 256), dim3(256), 0, h->stream, b);
+        if (b.n > nmax) nmax = b.n;
     }
+    hipLaunchKernelGGL(dbm_bias_multi_kernel, dim3((nmax + 255) / 256, 1 + h->L), dim3(256), 0, h->stream, m);
 }
 
 // outer products of layer i: fused (update in the epilogue) or raw pos / neg into `grad`
-static void launch_dbm_grad(bm_dbm *h, const float *X_dev, int i, int fused, float N, float M, float lr, float mom) {
+static void launch_dbm_grad(bm_dbm *h, const float *X_dev, int i, int fused, float N, float M, float lr, float mom, hipStream_t st = nullptr) {
     GradArgs g;
     memset(&g, 0, sizeof(g));
     const float *below_pos = (i == 0) ? X_dev : h->mu[i - 1].p;
@@ -618,12 +674,13 @@ static void launch_dbm_grad(bm_dbm *h, const float *X_dev, int i, int fused, flo
     g.ldw = h->W[i].ld; g.ldwt = h->Wt[i].ld;
     g.pen = h->pen[i].p;
     g.N = N; g.M = M; g.l2 = h->cfg.l2; g.lr = lr; g.mom = mom;
-    launch_grad(g, h->stream);
+    launch_grad(g, st ? st : h->stream);
 }
 
 static int recon_msre(bm_dbm *h, const float *X_dev, float *out_msre);
 
-static void launch_dbm_maxnorm(bm_dbm *h, int i, int c_first = 0, int c_end = -1) {
+static void launch_dbm_maxnorm(bm_dbm *h, int i, int c_first = 0, int c_end = -1, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     MaxNormArgs m;
     m.c_first = c_first; m.c_end = c_end < 0 ? h->n[i + 1] : c_end;
     if (m.c_end <= m.c_first) return;
@@ -631,8 +688,8 @@ static void launch_dbm_maxnorm(bm_dbm *h, int i, int c_first = 0, int c_end = -1
     m.max_norm = h->cfg.max_norm; m.norm_out = h->wnorm[i].p;
     m.num = h->mn_fac[i].p; m.den = h->mn_fac[i].p + m.I;
     const int nc = m.c_end - m.c_first;
-    hipLaunchKernelGGL(maxnorm_kernel, dim3((nc + MN_COLS - 1) / MN_COLS), dim3(NT), 0, h->stream, m);
-    hipLaunchKernelGGL(maxnorm_scale_kernel, dim3(((nc + 31) / 32) * ((m.J + 31) / 32)), dim3(256), 0, h->stream, m);
+    hipLaunchKernelGGL(maxnorm_kernel, dim3((nc + MN_COLS - 1) / MN_COLS), dim3(NT), 0, st, m);
+    hipLaunchKernelGGL(maxnorm_scale_kernel, dim3(((nc + 31) / 32) * ((m.J + 31) / 32)), dim3(256), 0, st, m);
 }
 
 // gradients + sparsity + momentum + max-norm (dbm.py:550-621) from the current mu / particles
@@ -640,9 +697,23 @@ static int apply_update(bm_dbm *h, const float *X_dev, float lr, float mom) {
     const float N = (float)h->N, M = (float)h->M;
     launch_dbm_colsums(h, X_dev);
     launch_dbm_biases(h, N, M, lr, mom);
+    // The layers' outer products + max-norm passes are independent of each other (each reads mu / particles and its own
+    // penalty vector, writes its own W / dW / W^T): odd layers go to the second stream, between a fork and a join event, so
+    // that the 104 + 128 tiles of a 784-512-1024 stack share the chip instead of taking turns (once the launches are tuned).
+    static const bool split_off = bm::dbg("dbm_tail_split") && atoi(bm::dbg("dbm_tail_split")) == 0;
+    const bool split = !split_off && h->L >= 2 && h->updates_seen >= 3;
+    if (split) {
+        BM_HIP(hipEventRecord(h->ev_fork, h->stream));
+        BM_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    }
     for (int i = 0; i < h->L; ++i) {
-        launch_dbm_grad(h, X_dev, i, 1, N, M, lr, mom);
-        launch_dbm_maxnorm(h, i);
+        hipStream_t st = (split && (i & 1)) ? h->stream2 : h->stream;
+        launch_dbm_grad(h, X_dev, i, 1, N, M, lr, mom, st);
+        launch_dbm_maxnorm(h, i, 0, -1, st);
+    }
+    if (split) {
+        BM_HIP(hipEventRecord(h->ev_join, h->stream2));
+        BM_HIP(hipStreamWaitEvent(h->stream, h->ev_join, 0));
     }
     BM_CHECK(!h->failed, "bm_dbm: a device allocation failed inside a sweep (row store of a Multinomial layer)");
     BM_HIP(hipGetLastError());
@@ -679,6 +750,7 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
     }
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipStreamCreate(&h->stream2));
+    if (bm::dbg("dbm_pcd_geo")) h->pcd_geo = atoi(bm::dbg("dbm_pcd_geo"));
     h->cur = h->stream;
     BM_HIP(hipEventCreate(&h->ev0));
     BM_HIP(hipEventCreate(&h->ev1));

@@ -83,6 +83,9 @@ struct ActArgs {
     // the bf16 shadow of the states this launch writes (null: none)
     Bf3Range b3;
     uint16_t *states16; int ld16;
+    int geo_hint;                // != 0: this tile geometry (launch_act_as codes) instead of the launch tuner's choice - the caller
+                                 // knows something the tuner's solo timing does not (the DBM's particle sweeps run BESIDE the
+                                 // mean-field passes: the 32 KiB tile shares a CU with them, the tuner's 96 KiB pick takes turns)
     int map_xi;                  // block -> tile map: 0 = the traffic model's XCD grid, 8 / 4 / 2 / 1 that grid, -1 the slab order (launch tuner)
     // Metric fetch of a training iteration (base_rbm.py:496-517, rbm.py:17-22): the h0 pass already holds the pre-activations
     // x.W + hb the free energy needs, so ITS epilogue leaves, per row j, sum_i softplus(z + b) (through `rowacc`) and the same for
@@ -1630,6 +1633,15 @@ __global__ void dbm_bias_kernel(DbmBiasArgs a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < a.n) dbm_bias_update(a, c);
 }
+// every layer's bias update of one DBM update as ONE launch (blockIdx.y = job: the visible layer, then the hidden layers): the
+// three launches of a 2-layer stack were 3 us of work each behind 4 - 8 us of launch latency at the tail of the update
+constexpr int DBM_BIAS_JOBS = 1 + 4;              // 1 + BM_DBM_MAX_LAYERS
+struct DbmBiasMulti { DbmBiasArgs job[DBM_BIAS_JOBS]; };
+__global__ void dbm_bias_multi_kernel(DbmBiasMulti m) {
+    const DbmBiasArgs &a = m.job[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < a.n) dbm_bias_update(a, c);
+}
 
 // Max-norm column rescale (dbm.py:511-513, :603-607):  W[:,c] *= min(||W[:,c]||, c_max) / max(||W[:,c]||, 1e-8)
 // Two kernels.  maxnorm_kernel: one workgroup per 16 columns computes ||.||^2 as the canonical chain
@@ -1865,6 +1877,37 @@ __global__ __launch_bounds__(256) void maxabsdiff_kernel(const float *A, int lda
     if (threadIdx.x == 0) {
         m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
         if (m > 0.f) atomicMax(out, __float_as_uint(m));
+    }
+}
+
+// Approximate-inference init of the FIRST hidden layer from the hoisted chain (dbm.py:434-446 with mean_field()'s X.W0):
+// out = sigmoid(mult * z + bmult * b) with z = the stored raw pre-activation - the arithmetic of act_epilogue, operation by
+// operation, so the result is the bits of the GEMM pass it replaces - and the step-0 residual max |out - prev| of the loop
+// condition (dbm.py:449-452) into this workgroup's slot (gridDim.x <= BM_MF_SLOTS) or one atomic.  Rows over workgroups.
+__global__ __launch_bounds__(256) void mf_init0_kernel(const float *Z, int ldz, const float *bias, const float *prev, int ldp,
+                                                       float *out, int ldo, int rows, int cols, float mult, float bmult, int lit,
+                                                       unsigned *maxdiff, float *blk) {
+    __shared__ float s_m[4];
+    float dm = 0.f;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float *z = Z + (size_t)r * ldz, *p = prev + (size_t)r * ldp;
+        float *o = out + (size_t)r * ldo;
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const float x = mult * z[c];
+            const float b = bmult * bias[c];
+            const float m = lit ? sigmoid_literal(x + b) : sigmoid(x + b);
+            dm = fmaxf(dm, fabsf(m - p[c]));
+            o[c] = m;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dm = fmaxf(dm, __shfl_xor(dm, off));
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = dm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        dm = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (blk && gridDim.x <= BM_MF_SLOTS) blk[blockIdx.x] = dm;
+        else if (dm > 0.f) atomicMax(maxdiff, __float_as_uint(dm));
     }
 }
 
@@ -2249,7 +2292,7 @@ static inline void launch_act(const ActArgs &a, hipStream_t st) {
         hipLaunchKernelGGL(shadow16_kernel, dim3(256), dim3(256), 0, st, (const float *)a.states, a.ldo, a.J, a.I, a.states16, a.ld16);
 }
 static inline void launch_act_f32(const ActArgs &a, hipStream_t st) {
-    const int ov = act_geo_override();
+    const int ov = act_geo_override() ? act_geo_override() : a.geo_hint;
     if (ov) { launch_act_as(ov, a, st); return; }
     static std::mutex mu;
     static std::map<std::array<long long, 6>, ActTune> table;
