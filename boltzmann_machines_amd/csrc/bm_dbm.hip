@@ -41,9 +41,13 @@ struct bm_dbm {
     // small mean-field kernels.  `cur` is the stream layer_update / gibbs_sweep enqueue on.
     hipStream_t stream2 = nullptr, cur = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int pcd_geo = 3;                               // tile of the particle passes while they share the chip with the mean-field
+    int pcd_geo = 0;                               // tile of the particle passes while they share the chip with the mean-field
                                                    // loop (ActArgs::geo_hint; BM355_DEBUG=dbm_pcd_geo=N, 0 = the tuner's choice):
-                                                   // 1.388 -> 1.353 ms per update at 784-512-1024 x 512 (profiles/r6_dbm_ab.txt)
+                                                   // 3 (32 x 32, 32 KiB) where there IS a loop of small latency-bound passes to
+                                                   // share CUs with - two or more layers of <= 2M weights, <= 1024 rows: 1.388 ->
+                                                   // 1.353 ms per update at 784-512-1024 x 512 - and the tuner's pick elsewhere
+                                                   // (3072 x 5000, one layer: 1.21 -> 1.29 .. 1.51 ms with the small tile;
+                                                   // profiles/r6_dbm_ab.txt)
     int updates_seen = 0;                          // the first updates run on one stream (launch tuning measures alone)
     // mean-field loop control mirror: pinned host copies of `ctl`, one per enqueued group of sweeps, so that the next
     // group is enqueued BEFORE the previous group's result is read (the GPU never waits for the host)
@@ -750,7 +754,12 @@ int bm_dbm_create(const bm_dbm_config *cfg, bm_dbm **out) {
     }
     BM_HIP(hipStreamCreate(&h->stream));
     BM_HIP(hipStreamCreate(&h->stream2));
-    if (bm::dbg("dbm_pcd_geo")) h->pcd_geo = atoi(bm::dbg("dbm_pcd_geo"));
+    {
+        bool small = h->L >= 2 && h->N <= 1024 && h->M <= 1024 && cfg->max_mf_updates >= 2;
+        for (int i = 0; i < h->L; ++i) small = small && (long long)h->n[i] * h->n[i + 1] <= (2ll << 20);
+        h->pcd_geo = small ? 3 : 0;
+        if (bm::dbg("dbm_pcd_geo")) h->pcd_geo = atoi(bm::dbg("dbm_pcd_geo"));
+    }
     h->cur = h->stream;
     BM_HIP(hipEventCreate(&h->ev0));
     BM_HIP(hipEventCreate(&h->ev1));
