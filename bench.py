@@ -636,7 +636,7 @@ class Ais(_DbmBase):
 WORKLOADS = {w.name: w for w in (RbmCD, RbmGibbs, Grbm, Dbm, Ais)}
 DEFAULTS = {'rbm': (2000, 100), 'gibbs': (300, 30), 'grbm': (30, 5), 'dbm': (40, 5), 'ais': (2, 1)}
 # the short passes the default run adds behind the headline: (steps, warm-up, untimed precondition seconds)
-OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 20, 5, 0.2), ('ais', 1, 1, 0.0),
+OTHERS = (('gibbs', 100, 10, 0.2), ('grbm', 12, 3, 0.2), ('dbm', 40, 8, 0.3), ('ais', 1, 1, 0.0),
           # the opt-in bf16 x 3 mode only where it gains (AIS 1.9x, the 3072 x 5000 particle sweeps +4 %): at the 784 x 1024 shapes
           # it is slower than fp32 and bm_*_set_fast_binary(1) no longer takes effect there (profiles/r5_{gibbs,dbm}_summary.md)
           ('ais+fast_binary', 1, 1, 0.0), ('grbm+fast_binary', 12, 3, 0.2))
