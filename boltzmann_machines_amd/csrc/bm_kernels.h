@@ -439,8 +439,7 @@ __device__ __forceinline__ float act_epilogue(const ActArgs &a, const PhiloxKey 
                             const float t = z[e] + bs[e];
                             if constexpr (FE) qa2 += softplus(t + delta * a.fe_w[(size_t)fc * a.fe_ldw + i]);    // the PLL partner's row (beta_b == 1)
                             if (a.rowacc_single) qa += HWMATH ? softplus_hw(a.beta_b * t) : softplus(a.beta_b * t);
-                            else qa += HWMATH ? softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t)
-                                              : softplus(a.beta_b * t) - softplus(a.beta_a * t);
+                            else qa += softplus_hw(a.beta_b * t) - softplus_hw(a.beta_a * t);
                         }
                     }
                     // the state of this element as it was just stored by this lane

@@ -100,9 +100,13 @@ __device__ __forceinline__ float softplus(float x) {
 }
 __device__ __forceinline__ float log_sigmoid(float x) { return -softplus(-x); }
 
-// Fast-binary mode only (bm_bf3.h; tolerance parity, never the default path): the same functions on the hardware
-// transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1e-7 relative), a third of the instructions of the
-// bit-pinned forms above - the epilogue, not the bf16 matrix work, bounds those kernels.
+// The same functions on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1e-7 relative), a third of
+// the instructions of the forms above.  sigmoid_hw: fast-binary mode only (bm_bf3.h; tolerance parity, never the default
+// path - a sigmoid decides sampled bits).  softplus_hw: also the AIS log-weight terms of the DEFAULT path (act_epilogue,
+// difference form): those are tolerance-checked sums that feed no state, two softplus per output element against 512 k of
+// matrix work made the epilogue what bounds the AIS passes (round 6, same-box A/B: 242.3 -> 229.9 ms per 300 betas x 20 000
+// chains), and against the float64-accumulating oracle the values move no further than with the polynomial form
+// (tools/ais_accuracy.py; profiles/r6_ais_softplus.txt).
 __device__ __forceinline__ float sigmoid_hw(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.44269504088896341f);      // exp(-x): inf for very negative x -> 0
     return __builtin_amdgcn_rcpf(1.0f + e);
