@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """One-off DBM parity stress (developer tool): random layer counts / sizes / flags, two updates each, against
-the oracle under BM355_DEBUG=act_geo=<n>.  usage: BM355_DEBUG=act_geo=8 python tools/stress_parity_dbm.py [n] [seed]"""
+the oracle under BM355_DEBUG=act_geo=<n>.  usage: BM355_DEBUG=act_geo=8 python tools/stress_parity_dbm.py [n] [seed]
+UPDATES=5 in the environment: five updates per case, so that the paths that start with the third update of a handle (particle
+sweeps on the second stream with their own tile, the layers' outer products on two streams) are compared too."""
 import os, sys
+os.environ.setdefault('OMP_NUM_THREADS', '16')          # the oracle is OpenMP (tests/conftest.py)
+os.environ.setdefault('OMP_WAIT_POLICY', 'passive')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests.test_dbm_parity_gpu import make_pair, data, assert_equal
@@ -25,7 +29,7 @@ for case in range(n):
     k = int(rng.randint(1, 4))
     names = ['vb', 'v'] + [b + ('' if i == 0 else '_%d' % i) for i in range(L) for b in ('W', 'hb', 'mu', 'h', 'q_means')]
     try:
-        for s in range(2):
+        for s in range(int(os.environ.get('UPDATES', '2'))):
             X = data(N, V, case + s)
             n1, _ = eng.train_step(as_device(X), 0.03, 0.6, k)
             n2, _ = twin.train_step(X, 0.03, 0.6, k)
