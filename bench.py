@@ -188,6 +188,9 @@ def pmc_traffic(config):
         if have != mine:
             return (None, '%s is STALE: taken on library sources %s (commit %s), running %s - re-collect with tools/profile.sh'
                     % (name, have or 'unrecorded', d.get('head', 'unrecorded'), mine))
+        if d.get('traffic_bytes_per_update') is None:
+            return (None, '%s holds per-dispatch counters only: the counter passes of this configuration are dominated by the launch '
+                          "tuner's candidate launches (tools/summarize_profile.py)" % name)
         return (float(d['traffic_bytes_per_update']),
                 '%s (rocprofv3 --pmc passes of this command on these library sources, %s / commit %s; not measured in this run)'
                 % (name, mine, d.get('head', '?')))

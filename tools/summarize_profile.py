@@ -86,8 +86,10 @@ for cfg in configs:
             for k, dd in agg(f).items():
                 pmc.setdefault(k, {}).update(dd)
     # steps seen by the counter pass: one marker kernel per step
-    marker = {'rbm': 'grad_kernel', 'gibbs': None, 'grbm': 'maxnorm_kernel', 'dbm': 'dbm_bias_kernel', 'ais': 'ais_init_kernel',
+    marker = {'rbm': 'grad_kernel', 'gibbs': None, 'grbm': 'maxnorm_kernel', 'dbm': 'dbm_bias_multi_kernel', 'ais': 'ais_init_kernel',
               'aisfast': 'ais_init_kernel', 'grbmfast': 'maxnorm_kernel'}[cfg]
+    if marker == 'dbm_bias_multi_kernel' and not any(marker in k for k in ndisp):
+        marker = 'dbm_bias_kernel'                      # libraries before round 6: three bias launches per update
     if marker:
         per = {'dbm_bias_kernel': 3}.get(marker, 1)
         n_steps = max(1, sum(n for k, n in ndisp.items() if marker in k) // per)
@@ -95,6 +97,11 @@ for cfg in configs:
         n_steps = max(1, sum(n for k, n in ndisp.items() if 'act_chain_kernel' in k) +
                       sum(n for k, n in ndisp.items() if 'act_kernel' in k) // 20)
     traffic = (2 * totals['FETCH_SIZE'] + totals['WRITE_SIZE']) * 1024 / n_steps
+    if cfg in ('ais', 'aisfast'):
+        # the counter passes of this configuration run 20 betas of a 1000-beta step behind ~1500 launches of the launch tuner's
+        # candidates (a new process tunes again): their total says nothing about a bench step.  The per-kernel table below is
+        # per dispatch and stands; the per-step figure is withheld (bench.py prints `traffic: null` and why).
+        traffic = None
     prov = provenance()
     lines = ['# rocprofv3 summary %s / %s - `python bench.py --config %s` on 1x MI355X' % (tag, cfg, cfg), '',
              'library sources %s, commit %s' % (prov.get('source_sha16', 'unrecorded'), prov.get('head', 'unrecorded')), '',
@@ -116,7 +123,8 @@ for cfg in configs:
             ('%.0f' % dd['SQ_LDS_BANK_CONFLICT']) if 'SQ_LDS_BANK_CONFLICT' in dd else '-'))
     lines += ['', 'MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); issue-stalled / parked % = the counter / SQ_WAVE_CYCLES',
               '(quad-cycle units, MI355X_MICROARCH.md); MFMA instr = wave instructions per launch.',
-              'HBM-side traffic per bench step (all engine dispatches of the counter pass / %d steps, FETCH doubled + WRITE): %.1f MB' % (n_steps, traffic / 1e6),
+              ('HBM-side traffic per bench step (all engine dispatches of the counter pass / %d steps, FETCH doubled + WRITE): %.1f MB' % (n_steps, traffic / 1e6))
+              if traffic is not None else 'HBM-side traffic per bench step: withheld - the counter passes (20 betas) are dominated by the launch tuner\'s candidate launches; the table is per dispatch',
               '(working sets up to 256 MB are Infinity-Cache resident; these are L2-miss side counters, not DRAM bytes).', '']
     b = os.path.join(src, cfg + '.bench.json')
     if os.path.exists(b) and os.path.getsize(b) > 10:
