@@ -514,7 +514,7 @@ class Dbm(_DbmBase):
         from boltzmann_machines_amd.utils import philox
         V_, N_ = self.DV, self.DN
         self.world = world
-        self.eng = eng = DbmEngine(V_, [self.H1, self.H2], n_particles=N_, batch_size=N_, max_mf_updates=50, mf_tol=1e-7,
+        self.eng = eng = DbmEngine(V_, [self.H1, self.H2], n_particles=N_, batch_size=N_, max_mf_updates=50, mf_tol=float(getattr(args, 'dbm_mf_tol', 1e-7)),
                                    l2=1e-7, max_norm=6., sparsity_target=[0.2, 0.1], sparsity_cost=[1e-4, 5e-5])
         eng.set('W', philox.tf_random_normal((V_, self.H1), 0.01, 1337))
         eng.set('W_1', philox.tf_random_normal((self.H1, self.H2), 0.01, 1111))
@@ -550,7 +550,8 @@ class Dbm(_DbmBase):
             'metric': 'DBM updates/sec (784-512-1024, mean-field + PCD-5, 512 rows + 512 particles per GPU)',
             'value': round(world * args.steps / dt, 2),
             'unit': 'updates/s x GPUs (each update = 512 rows + 512 particles per GPU; weak scaling)',
-            'config': {'workload': '2-layer DBM 784-512-1024 mean-field (<=50 sweeps, tol 1e-7) + PCD-5 fp32 (BASELINE configs[3])',
+            'config': {'workload': '2-layer DBM 784-512-1024 mean-field (<=50 sweeps, tol %g) + PCD-5 fp32 (BASELINE configs[3]%s)'
+                                   % (getattr(args, 'dbm_mf_tol', 1e-7), '' if getattr(args, 'dbm_mf_tol', 1e-7) == 1e-7 else '; NON-BASELINE tolerance'),
                        'layers': [V_, H1, H2], 'batch_per_gpu': N_, 'particles_per_gpu': N_, 'n_gibbs_steps': k,
                        'mean_field_sweeps_executed': T, 'parallelism': 'dp%d' % world,
                        'collective': ('%s: all-reduce(max) of the mean-field residual per sweep + one all-reduce(sum) of '
@@ -984,6 +985,9 @@ def main():
     ap.add_argument('--k', type=int, default=1, help='n_gibbs_steps of CD-k (rbm), sweeps per call (gibbs), AIS transitions per beta')
     ap.add_argument('--ais-runs', type=int, default=20000)
     ap.add_argument('--ais-betas', type=int, default=1000)
+    ap.add_argument('--dbm-mf-tol', type=float, default=1e-7,
+                    help='dbm: mean-field tolerance (BASELINE configs[3]: 1e-7 = the loop runs to its 50-sweep cap; a looser one '
+                         'measures the update with the SHORT loop of a trained model - a developer setting, named in config.workload)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--fast-binary', action='store_true',
                     help='gibbs / ais / grbm / dbm: the opt-in exact-product bf16 x 3 mode (bm_*_set_fast_binary); a NON-default, '

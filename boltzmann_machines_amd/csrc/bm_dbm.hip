@@ -48,6 +48,13 @@ struct bm_dbm {
                                                    // 1.353 ms per update at 784-512-1024 x 512 - and the tuner's pick elsewhere
                                                    // (3072 x 5000, one layer: 1.21 -> 1.29 .. 1.51 ms with the small tile;
                                                    // profiles/r6_dbm_ab.txt)
+    int pcd_geo_now = 0;                           // ... and only while the loop is not SHORT: the small tile makes the particle
+                                                   // chain itself slower (228 against 190 us for PCD-5), and that chain is the
+                                                   // critical path under a loop of 3 sweeps (0.384 against 0.364 ms per update
+                                                   // with the hint; from ~6 sweeps on the hint wins: 0.409 against 0.437 ms at 7).
+                                                   // Decided per update from the previous trip count: MORE than one loop sweep per
+                                                   // particle sweep (BM355_DEBUG=dbm_pcd_ratio=N; the crossover measured at
+                                                   // 784-512-1024 x 512, PCD-5 lies between 5 and 6 sweeps).
     int updates_seen = 0;                          // the first updates run on one stream (launch tuning measures alone)
     // mean-field loop control mirror: pinned host copies of `ctl`, one per enqueued group of sweeps, so that the next
     // group is enqueued BEFORE the previous group's result is read (the GPU never waits for the host)
@@ -201,7 +208,7 @@ static void layer_update(bm_dbm *h, int layer /* hidden layer index, -1 = visibl
     a.key = key; a.row0 = row0;
     a.prev = prev; a.maxdiff = maxdiff;
     a.lit = h->sigmoid_literal;
-    if (h->cur == h->stream2 && h->pcd_geo) a.geo_hint = h->pcd_geo;      // a pass that runs beside the mean-field loop
+    if (h->cur == h->stream2 && h->pcd_geo_now) a.geo_hint = h->pcd_geo_now;   // a pass that runs beside the mean-field loop
     if (h->fast_now && !h->multinomial(layer) && a.kind != 2) {
         // fast-binary: the same contraction from the bf16 weight planes and the bf16 shadows of the {0,1} inputs
         // (a state matrix without a valid shadow - real-valued visibles, the first PCD sweep - keeps the fp32 path)
@@ -567,9 +574,12 @@ static bool pcd_overlap_ok(const bm_dbm *h) {
 static int enqueue_particles_stream2(bm_dbm *h, void *ctx) {
     const int k = *(const int *)ctx;
     BM_HIP(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    static const int min_ratio = bm::dbg("dbm_pcd_ratio") ? atoi(bm::dbg("dbm_pcd_ratio")) : 1;
+    h->pcd_geo_now = (h->pcd_geo && h->mf_pred > min_ratio * k) ? h->pcd_geo : 0;
     h->cur = h->stream2;
     particles_update(h, k, true);                                 // :521
     h->cur = h->stream;
+    h->pcd_geo_now = 0;
     BM_HIP(hipEventRecord(h->ev_join, h->stream2));
     return 0;
 }
