@@ -77,6 +77,29 @@ def test_config3_dbm_784_512_1024_batch512_pcd5(gpu_lib):
     eng.close()
 
 
+def test_config3_dbm_steady_state_updates_bit_exact(gpu_lib):
+    """the same stack over EIGHT updates (mean-field capped at 30 sweeps to keep the oracle in seconds): from the third update of a
+    handle the particle sweeps run on a second stream beside the mean-field loop - with their own 32 x 32 tile once the previous
+    trip count exceeds the number of particle sweeps - and the layers' outer products run on two streams; every
+    variable and the executed sweeps stay the oracle's, bit for bit, after every update"""
+    from boltzmann_machines_amd.engine import as_device
+    V, nh, N = 784, [512, 1024], 512
+    kw = dict(max_mf_updates=30, mf_tol=1e-7, l2=1e-7, max_norm=6., sparsity_target=[0.2, 0.1],
+              sparsity_cost=[1e-4, 5e-5])
+    eng, twin = D.make_pair(V, nh, N, N, **kw)
+    eng.seed(42); twin.set_seed(42)
+    names = ['W', 'W_1', 'vb', 'hb', 'hb_1', 'dW', 'dW_1', 'v', 'h', 'h_1', 'mu', 'mu_1', 'q_means', 'mu_means_1']
+    for s in range(8):
+        X = D.data(N, V, 1 + s)
+        g = eng.train_step(as_device(X), 2e-3, 0.9, 5, want_msre=bool(s & 1))
+        c = twin.train_step(X, 2e-3, 0.9, 5, want_msre=bool(s & 1))
+        assert g[0] == c[0] and g[0] > 5, (s, g, c)
+        if s & 1:
+            np.testing.assert_allclose(g[1], c[1], rtol=1e-5)
+        D.assert_equal(eng, twin, names)
+    eng.close()
+
+
 def test_config3_dbm_reference_arithmetic_batch512(gpu_lib):
     """the same update in the engine's reference arithmetic (bm_dbm_set_sigmoid_literal: tf.sigmoid as float32
     1 / (1 + exp(-x)), layers.py:47-48): bit-exact against the oracle's literal mode incl. the executed sweep count"""
