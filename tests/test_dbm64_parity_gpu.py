@@ -99,6 +99,23 @@ def test_gaussian_visible_f64(gpu_lib):
     eng.close()
 
 
+def test_gaussian_visible_sampled_f64(gpu_lib):
+    """sampled Gaussian visibles: the Normal draw goes through the device's double log / sin / cos, so the particles agree to
+    round-off (1e-11) instead of bit for bit - as in the float64 RBM (tests/test_rbm64_parity_gpu.py); sweep counts equal"""
+    V, nh, N, M = 24, [16, 10], 9, 7
+    eng, twin = make_pair(V, nh, N, M, v_unit=1, sample_v_states=True, max_mf_updates=6, mf_tol=1e-8)
+    sig = np.linspace(0.6, 1.4, V)
+    eng.set('sigma', sig); twin.p['sigma'][...] = sig
+    eng.seed(5); twin.set_seed(5)
+    X = orc.normal(87654321, 78, 0, N * V).astype(np.float64).reshape(N, V)
+    assert eng.train_step(dev(X), 1e-3, 0.9, 1)[0] == twin.train_step(X, 1e-3, 0.9, 1)[0]
+    for nm in ('W', 'W_1', 'vb', 'hb', 'hb_1', 'v', 'mu', 'mu_1'):
+        np.testing.assert_allclose(eng.get(nm), twin.p[nm], rtol=1e-11, atol=1e-13, err_msg=nm)
+    for nm in ('h', 'h_1'):                                     # the hidden bitmaps are draws from means that agree to 1e-11
+        assert np.mean(eng.get(nm) != twin.p[nm]) < 0.02, nm
+    eng.close()
+
+
 def test_inference_ais_and_elbo_f64(gpu_lib):
     from boltzmann_machines_amd._ffi import DeviceArray
     V, nh, N, M = 20, [12, 16], 10, 10
