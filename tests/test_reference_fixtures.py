@@ -52,7 +52,7 @@ def test_ais_slice_in_the_reference_order_of_float32_accumulation(monkeypatch, t
 
 
 @pytest.mark.skipif(not reference_shim.available(), reason='the reference checkout is not on this box')
-@pytest.mark.parametrize('name', ['rbm_reference_test_config', 'rbm_schedules', 'dbm_two_layers', 'rbm_config1_shape',
+@pytest.mark.parametrize('name', ['rbm_reference_test_config', 'rbm_schedules', 'dbm_two_layers', 'dbm_float64', 'rbm_config1_shape',
                                   'dbm_config3_shape_b100'])
 def test_committed_fixture_is_what_the_reference_produces(name, tmp_path, monkeypatch):
     """regenerates a fixture from /root/reference on the TF-1 stand-in and compares it with the committed file"""
